@@ -1,0 +1,388 @@
+// Fused gather + BPR + L2-regulariser loss and gradients, and the dense Adam step.
+//
+// One wavefront per (user, pos, neg) triple: six embedding rows are gathered with
+// coalesced loads, the two dot products are reduced with wave shuffles, the loss term and
+// d loss / d score are formed in registers, and the three gradient rows are scattered.
+// Duplicate rows inside a batch are the norm (popular items), so the scatter has two
+// forms: float atomics (fast, sum order varies run to run) and a deterministic one — the
+// 3B (row, slot) pairs are sorted and one lane group per distinct row adds its
+// contributions in batch order.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+
+#include "idg_common.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;
+constexpr int LDS_SORT_MAX = 8192;  // (key,slot) pairs one workgroup sorts in LDS
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+struct BprArgs {
+  const float* fin;
+  const float* ego;
+  const int64_t* users;
+  const int64_t* pos;
+  const int64_t* neg;
+  int64_t num_users, B, d;
+  float inv_B, reg_scale;  // reg_scale = reg_lambda / B
+  float* coef;             // [B]   d loss0 / d x_i (already / B)
+  float* loss_i;           // [B]
+  float* sq;               // [3,B] squared norms of the ego rows
+  int32_t* keys;           // [3B]  destination row per slot (deterministic form)
+  int32_t* slots;          // [3B]
+  float* g_final;
+  float* g_ego;
+  int atomic;
+};
+
+__global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int lane = threadIdx.x % WAVE;
+  if (i >= a.B) return;
+  const int64_t ru = a.users[i];
+  const int64_t rp = a.num_users + a.pos[i];
+  const int64_t rn = a.num_users + a.neg[i];
+  const float* fu = a.fin + ru * a.d;
+  const float* fp = a.fin + rp * a.d;
+  const float* fn = a.fin + rn * a.d;
+  const float* eu = a.ego + ru * a.d;
+  const float* epp = a.ego + rp * a.d;
+  const float* en = a.ego + rn * a.d;
+  float sp = 0.f, sn = 0.f, qu = 0.f, qp = 0.f, qn = 0.f;
+  for (int64_t f = lane; f < a.d; f += WAVE) {
+    const float u = fu[f], p = fp[f], n = fn[f];
+    sp = __builtin_fmaf(u, p, sp);
+    sn = __builtin_fmaf(u, n, sn);
+    const float x = eu[f], y = epp[f], z = en[f];
+    qu = __builtin_fmaf(x, x, qu);
+    qp = __builtin_fmaf(y, y, qp);
+    qn = __builtin_fmaf(z, z, qn);
+  }
+  sp = wave_sum(sp);
+  sn = wave_sum(sn);
+  qu = wave_sum(qu);
+  qp = wave_sum(qp);
+  qn = wave_sum(qn);
+  const float x = sp - sn;
+  const float sig = 1.0f / (1.0f + expf(-x));
+  const float li = -logf(sig + 1e-7f);  // losses.py:11 (10e-8)
+  const float c = -(sig * (1.0f - sig)) / (sig + 1e-7f) * a.inv_B;
+  if (lane == 0) {
+    a.loss_i[i] = li;
+    a.coef[i] = c;
+    a.sq[i] = qu;
+    a.sq[a.B + i] = qp;
+    a.sq[2 * a.B + i] = qn;
+    if (!a.atomic) {
+      a.keys[3 * i + 0] = (int32_t)ru;
+      a.keys[3 * i + 1] = (int32_t)rp;
+      a.keys[3 * i + 2] = (int32_t)rn;
+      a.slots[3 * i + 0] = (int32_t)(3 * i + 0);
+      a.slots[3 * i + 1] = (int32_t)(3 * i + 1);
+      a.slots[3 * i + 2] = (int32_t)(3 * i + 2);
+    }
+  }
+  if (a.atomic) {
+    for (int64_t f = lane; f < a.d; f += WAVE) {
+      if (a.g_final) {
+        const float u = fu[f], p = fp[f], n = fn[f];
+        atomicAdd(a.g_final + ru * a.d + f, c * (p - n));
+        atomicAdd(a.g_final + rp * a.d + f, c * u);
+        atomicAdd(a.g_final + rn * a.d + f, -c * u);
+      }
+      if (a.g_ego) {
+        atomicAdd(a.g_ego + ru * a.d + f, a.reg_scale * eu[f]);
+        atomicAdd(a.g_ego + rp * a.d + f, a.reg_scale * epp[f]);
+        atomicAdd(a.g_ego + rn * a.d + f, a.reg_scale * en[f]);
+      }
+    }
+  }
+}
+
+// Sort <= LDS_SORT_MAX 64-bit (row << 32 | slot) keys ascending in LDS, one workgroup.
+__global__ __launch_bounds__(1024) void lds_sort_kernel(const int32_t* __restrict__ keys,
+                                                        const int32_t* __restrict__ slots, int n, int n_pow2,
+                                                        int32_t* __restrict__ keys_out,
+                                                        int32_t* __restrict__ slots_out) {
+  extern __shared__ unsigned long long s_k[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n_pow2; i += 1024)
+    s_k[i] = i < n ? (((unsigned long long)(uint32_t)keys[i]) << 32) | (uint32_t)slots[i] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= n_pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n_pow2; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = s_k[i], b = s_k[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            s_k[i] = b;
+            s_k[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += 1024) {
+    keys_out[i] = (int32_t)(s_k[i] >> 32);
+    slots_out[i] = (int32_t)(s_k[i] & 0xffffffffu);
+  }
+}
+
+// One wave per sorted position that starts a run of equal rows.
+__global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int32_t* __restrict__ skeys,
+                                                            const int32_t* __restrict__ sslots) {
+  const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int lane = threadIdx.x % WAVE;
+  const int64_t n3 = 3 * a.B;
+  if (j >= n3) return;
+  const int32_t row = skeys[j];
+  if (j > 0 && skeys[j - 1] == row) return;
+  int64_t e = j + 1;
+  while (e < n3 && skeys[e] == row) ++e;
+  for (int64_t f = lane; f < a.d; f += WAVE) {
+    float acc = 0.f;
+    for (int64_t t = j; t < e; ++t) {
+      const int32_t s = sslots[t];
+      const int64_t i = s / 3;
+      const int kind = s - 3 * (int32_t)i;
+      const float c = a.coef[i];
+      float v;
+      if (kind == 0) {
+        const float p = a.fin[(a.num_users + a.pos[i]) * a.d + f];
+        const float n = a.fin[(a.num_users + a.neg[i]) * a.d + f];
+        v = c * (p - n);
+      } else {
+        const float u = a.fin[a.users[i] * a.d + f];
+        v = kind == 1 ? c * u : -c * u;
+      }
+      acc = t == j ? v : acc + v;
+    }
+    const int64_t o = (int64_t)row * a.d + f;
+    float reg = 0.f;
+    if (a.g_ego) {
+      const float r1 = a.reg_scale * a.ego[o];
+      reg = r1;
+      for (int64_t t = j + 1; t < e; ++t) reg += r1;
+    }
+    if (a.g_final && a.g_final == a.g_ego) {
+      a.g_final[o] += acc + reg;
+    } else {
+      if (a.g_final) a.g_final[o] += acc;
+      if (a.g_ego) a.g_ego[o] += reg;
+    }
+  }
+}
+
+// loss[0] = mean(loss_i); loss[1] = reg_lambda * sum_blocks 0.5 * (sqrt(sum sq))^2 / B
+__global__ __launch_bounds__(1024) void bpr_reduce_kernel(const float* __restrict__ loss_i,
+                                                          const float* __restrict__ sq, int64_t B, float reg_lambda,
+                                                          float* __restrict__ loss) {
+  __shared__ float s[4][1024];
+  const int tid = threadIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = tid; i < B; i += 1024) {
+    acc[0] += loss_i[i];
+    acc[1] += sq[i];
+    acc[2] += sq[B + i];
+    acc[3] += sq[2 * B + i];
+  }
+  for (int q = 0; q < 4; ++q) s[q][tid] = acc[q];
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o)
+      for (int q = 0; q < 4; ++q) s[q][tid] += s[q][tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float fB = (float)B;
+    loss[0] = s[0][0] / fB;
+    float reg = 0.f;
+    for (int q = 1; q < 4; ++q) {
+      const float nrm = sqrtf(s[q][0]);  // embedding.norm(2)
+      reg += 0.5f * (nrm * nrm) / fB;    // 1/2 * norm.pow(2) / B   (losses.py:19)
+    }
+    loss[1] = reg_lambda * reg;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                     int64_t n, float w1, float beta2, float w2, float step_size,
+                                                     float bc2_sqrt, float eps) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    const float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+#define IDG_ADAM1(c)                                                 \
+  M.c = __builtin_fmaf(w1, G.c - M.c, M.c);                          \
+  V.c = __builtin_fmaf(w2 * G.c, G.c, V.c * beta2);                  \
+  P.c = P.c - step_size * (M.c / (sqrtf(V.c) / bc2_sqrt + eps));
+    IDG_ADAM1(x) IDG_ADAM1(y) IDG_ADAM1(z) IDG_ADAM1(w)
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+  // scalar tail
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += BLOCK) {
+      float P = p[i], M = m[i], V = v[i];
+      const float G = g[i];
+      M = __builtin_fmaf(w1, G - M, M);
+      V = __builtin_fmaf(w2 * G, G, V * beta2);
+      P = P - step_size * (M / (sqrtf(V) / bc2_sqrt + eps));
+      p[i] = P;
+      m[i] = M;
+      v[i] = V;
+    }
+  }
+#undef IDG_ADAM1
+}
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct BprWs {
+  size_t coef, loss_i, sq, keys, slots, skeys, sslots, temp, total;
+};
+
+BprWs bpr_layout(int64_t B, size_t cub_temp) {
+  BprWs w;
+  size_t o = 0;
+  w.coef = o;
+  o += align256((size_t)B * 4);
+  w.loss_i = o;
+  o += align256((size_t)B * 4);
+  w.sq = o;
+  o += align256((size_t)B * 12);
+  w.keys = o;
+  o += align256((size_t)B * 12);
+  w.slots = o;
+  o += align256((size_t)B * 12);
+  w.skeys = o;
+  o += align256((size_t)B * 12);
+  w.sslots = o;
+  o += align256((size_t)B * 12);
+  w.temp = o;
+  o += align256(cub_temp);
+  w.total = o;
+  return w;
+}
+
+// Upper bound of rocPRIM's radix-sort scratch for n (int32,int32) pairs; checked against the
+// real request at call time.
+size_t cub_temp_bound(int64_t n3) {
+  if (n3 <= LDS_SORT_MAX) return 0;
+  return (size_t)n3 * 16 + ((size_t)8 << 20);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t idg_bpr_workspace_bytes(int64_t B, int64_t d) {
+  (void)d;
+  if (B <= 0) return 0;
+  return bpr_layout(B, cub_temp_bound(3 * B)).total;
+}
+
+int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                      const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                      float reg_lambda, float* loss, float* g_final, float* g_ego, int deterministic, void* ws,
+                      void* stream) {
+  IDG_REQUIRE(final_panel && ego_panel && users && pos && neg && loss && ws, "idg_bpr_fused_f32: NULL argument");
+  IDG_REQUIRE(B > 0 && d > 0 && num_users >= 0 && n >= num_users, "idg_bpr_fused_f32: bad sizes");
+  IDG_REQUIRE(n < ((int64_t)1 << 31), "idg_bpr_fused_f32: more than 2^31 rows");
+  IDG_REQUIRE(3 * B < ((int64_t)1 << 31), "idg_bpr_fused_f32: batch too large");
+  hipStream_t st = (hipStream_t)stream;
+  const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
+  char* base = reinterpret_cast<char*>(ws);
+  BprArgs a{};
+  a.fin = final_panel;
+  a.ego = ego_panel;
+  a.users = users;
+  a.pos = pos;
+  a.neg = neg;
+  a.num_users = num_users;
+  a.B = B;
+  a.d = d;
+  a.inv_B = 1.0f / (float)B;
+  a.reg_scale = reg_lambda / (float)B;
+  a.coef = reinterpret_cast<float*>(base + w.coef);
+  a.loss_i = reinterpret_cast<float*>(base + w.loss_i);
+  a.sq = reinterpret_cast<float*>(base + w.sq);
+  a.keys = reinterpret_cast<int32_t*>(base + w.keys);
+  a.slots = reinterpret_cast<int32_t*>(base + w.slots);
+  a.g_final = g_final;
+  a.g_ego = g_ego;
+  const bool want_grad = g_final || g_ego;
+  a.atomic = (!deterministic && want_grad) ? 1 : 0;
+  if (!want_grad) a.atomic = 1, a.g_final = a.g_ego = nullptr;  // loss only: skip key emission
+
+  const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  hipLaunchKernelGGL(bpr_triple_kernel, dim3(nb), dim3(BLOCK), 0, st, a);
+
+  if (want_grad && deterministic) {
+    const int64_t n3 = 3 * B;
+    int32_t* skeys = reinterpret_cast<int32_t*>(base + w.skeys);
+    int32_t* sslots = reinterpret_cast<int32_t*>(base + w.sslots);
+    if (n3 <= LDS_SORT_MAX) {
+      int p2 = 1;
+      while (p2 < n3) p2 <<= 1;
+      hipLaunchKernelGGL(lds_sort_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, a.keys, a.slots, (int)n3, p2,
+                         skeys, sslots);
+    } else {
+      int end_bit = 1;
+      while (((int64_t)1 << end_bit) < n) ++end_bit;
+      size_t need = 0;
+      IDG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, a.keys, skeys, a.slots, sslots, (int)n3, 0, end_bit, st));
+      const size_t have = cub_temp_bound(n3);
+      if (need > have)
+        return idg::fail(IDG_E_UNSUPPORTED, "idg_bpr_fused_f32: radix sort wants %zu scratch bytes, layout reserves %zu",
+                         need, have);
+      size_t tb = have;
+      IDG_HIP(hipcub::DeviceRadixSort::SortPairs(base + w.temp, tb, a.keys, skeys, a.slots, sslots, (int)n3, 0, end_bit, st));
+    }
+    const unsigned nb3 = (unsigned)((n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+    hipLaunchKernelGGL(bpr_scatter_kernel, dim3(nb3), dim3(BLOCK), 0, st, a, skeys, sslots);
+  }
+  hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, a.loss_i, a.sq, B, reg_lambda, loss);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
+                      double beta1, double beta2, double eps, int64_t step, void* stream) {
+  IDG_REQUIRE(param && grad && exp_avg && exp_avg_sq, "idg_adam_step_f32: NULL argument");
+  IDG_REQUIRE(count >= 0 && step >= 1, "idg_adam_step_f32: bad count/step");
+  if (count == 0) return IDG_OK;
+  IDG_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+              "idg_adam_step_f32: pointers must be 16-byte aligned");
+  // scalars in double on the host, exactly as torch/optim/adam.py forms them
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)std::sqrt(bc2);
+  const int64_t n4 = count / 4;
+  int64_t nb = (n4 + BLOCK - 1) / BLOCK;
+  nb = std::max<int64_t>(1, std::min<int64_t>(nb, 256 * 8));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n4, count, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size,
+                     bc2_sqrt, (float)eps);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Shared internals of libidgrec.so: error reporting and HIP call checking.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "idgrec.h"
+
+namespace idg {
+
+// Thread-local "last error" string behind idg_last_error().
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* get_error();
+
+inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  set_error("%s", buf);
+  return code;
+}
+
+}  // namespace idg
+
+#define IDG_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return idg::fail(IDG_E_INVALID, __VA_ARGS__);   \
+  } while (0)
+
+#define IDG_HIP(call)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return idg::fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? IDG_E_NODEVICE \
+                                                                             : IDG_E_HIP,  \
+                       "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                       __LINE__);                                                          \
+  } while (0)

@@ -1,0 +1,636 @@
+// Sparse graph handle and the CSR row-block SpMM for gfx950.
+//
+// Work decomposition (all fixed at idg_graph_create, so results are run-to-run identical):
+//   * every CSR row is one "virtual row" (vrow); a row with more than `split_threshold`
+//     stored entries is cut into segments of seg_len(row) entries, each its own vrow that
+//     produces a partial sum; a fix-up kernel adds the partials in segment order.
+//   * consecutive vrows are packed into tiles of <= TILE_NNZ entries and <= TILE_VROWS
+//     vrows.  One 256-thread workgroup per tile stages the tile's (column,value) pairs and
+//     vrow pointers in LDS with coalesced loads, then LPR = d/4 lanes walk one vrow each:
+//     16-byte loads of the dense panel row (one 4*d-byte row per LPR lanes, fully
+//     coalesced), 8 rows in flight per lane group, a strictly sequential fmaf chain per
+//     output element — the order torch's CPU sparse.mm uses, hence bit-identical to it.
+//   * HBM/L2-bound: no MFMA here by design.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "idg_common.h"
+
+namespace {
+
+constexpr int TILE_NNZ = 2048;    // entries staged in LDS per workgroup (16 KiB)
+constexpr int TILE_VROWS = 256;   // vrows per workgroup
+constexpr int BLOCK = 256;
+constexpr int64_t DEFAULT_SPLIT = 256;
+
+struct __attribute__((aligned(16))) Tile {
+  int64_t nnz_begin;
+  int32_t vrow_begin;
+  int16_t n_vrows;  // 1..TILE_VROWS
+  int16_t n_nnz_hi; // unused
+};
+
+struct ColVal {
+  int32_t col;
+  float val;
+};
+
+struct LongRow {
+  int64_t slot_begin;  // first partial slot
+  int32_t row;
+  int32_t n_seg;
+};
+
+struct Epilogue {
+  float* Y;             // [n_rows, ldy]   (nullable)
+  const float* addend;  // acc += addend[r] (nullable)
+  const float* sum_in;  // s = sum_in[r] + acc (nullable -> s = acc)
+  float* sum_out;       // sum_out[r] = s / div (nullable)
+  int64_t ldy;          // leading dimension of Y/addend/sum_in/sum_out
+  float div;            // 1 = no division
+  int accumulate;       // sum_out[r] += instead of =
+};
+
+}  // namespace
+
+struct idg_graph {
+  int device = -1;
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  uint32_t flags = 0;
+  int64_t split_threshold = 0;
+  int64_t n_vrows = 0, n_tiles = 0, n_long = 0, n_slots = 0, n_xl = 0;
+  // device
+  ColVal* d_cv = nullptr;
+  int64_t* d_vptr = nullptr;   // [n_vrows+1]
+  int32_t* d_vtgt = nullptr;   // [n_vrows] >=0 row id, <0 ~partial slot
+  Tile* d_tiles = nullptr;
+  LongRow* d_long = nullptr;
+  int32_t* d_xl = nullptr;     // vrows too long for one tile (EXACT_ORDER only)
+  // host copies for the checker
+  std::vector<int64_t> h_long_rows, h_seg_len;
+};
+
+namespace {
+
+__device__ __forceinline__ float4 fma4(float a, float4 x, float4 acc) {
+  acc.x = __builtin_fmaf(a, x.x, acc.x);
+  acc.y = __builtin_fmaf(a, x.y, acc.y);
+  acc.z = __builtin_fmaf(a, x.z, acc.z);
+  acc.w = __builtin_fmaf(a, x.w, acc.w);
+  return acc;
+}
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, int off, float4 acc) {
+  const int64_t o = r * ep.ldy + off;
+  if (ep.addend) acc = add4(acc, *reinterpret_cast<const float4*>(ep.addend + o));
+  if (ep.Y) *reinterpret_cast<float4*>(ep.Y + o) = acc;
+  if (ep.sum_out) {
+    float4 s = acc;
+    if (ep.sum_in) s = add4(*reinterpret_cast<const float4*>(ep.sum_in + o), acc);
+    if (ep.div != 1.0f) {
+      s.x = s.x / ep.div;
+      s.y = s.y / ep.div;
+      s.z = s.z / ep.div;
+      s.w = s.w / ep.div;
+    }
+    if (ep.accumulate) s = add4(*reinterpret_cast<const float4*>(ep.sum_out + o), s);
+    *reinterpret_cast<float4*>(ep.sum_out + o) = s;
+  }
+}
+
+// Sequential walk of entries [s, e) of a (col,val) list; CV may be LDS or global.
+template <typename CVPtr>
+__device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __restrict__ Xl,
+                                       int64_t ldx, float4 acc) {
+  int j = s;
+  for (; j + 8 <= e; j += 8) {
+    ColVal p[8];
+    float4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = cv[j + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fma4(p[u].val, x[u], acc);
+  }
+  if (j + 4 <= e) {
+    ColVal p[4];
+    float4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = cv[j + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fma4(p[u].val, x[u], acc);
+    j += 4;
+  }
+  for (; j < e; ++j) {
+    ColVal p = cv[j];
+    float4 x = *reinterpret_cast<const float4*>(Xl + (int64_t)p.col * ldx);
+    acc = fma4(p.val, x, acc);
+  }
+  return acc;
+}
+
+// One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
+// every feature block of width 4*LPR (d = NB * 4 * LPR).
+template <int LPR, int NB>
+__global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(const Tile* __restrict__ tiles,
+                                                          const int64_t* __restrict__ vptr,
+                                                          const int32_t* __restrict__ vtgt,
+                                                          const ColVal* __restrict__ cv,
+                                                          const float* __restrict__ X, int64_t ldx,
+                                                          float* __restrict__ partials, int64_t d,
+                                                          Epilogue ep) {
+  __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ int s_ptr[TILE_VROWS + 1];
+  __shared__ int s_tgt[TILE_VROWS];
+
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int nv = t.n_vrows;
+  const int64_t nz0 = t.nnz_begin;
+  for (int i = tid; i <= nv; i += BLOCK) s_ptr[i] = (int)(vptr[t.vrow_begin + i] - nz0);
+  for (int i = tid; i < nv; i += BLOCK) s_tgt[i] = vtgt[t.vrow_begin + i];
+  const int cnt = (int)(vptr[t.vrow_begin + nv] - nz0);
+  {
+    const ColVal* src = cv + nz0;
+    for (int i = tid; i < cnt; i += BLOCK) s_cv[i] = src[i];
+  }
+  __syncthreads();
+
+  constexpr int GROUPS = BLOCK / LPR;
+  const int g = tid / LPR;
+  const int l = tid % LPR;
+  for (int v = g; v < nv; v += GROUPS) {
+    const int s = s_ptr[v], e = s_ptr[v + 1];
+    const int tgt = s_tgt[v];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int off = (b * LPR + l) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = walk(s_cv, s, e, X + off, ldx, acc);
+      if (tgt >= 0) {
+        epilogue_store(ep, tgt, off, acc);
+      } else {
+        *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
+      }
+    }
+  }
+}
+
+// EXACT_ORDER rows longer than a tile: one lane group streams the row from global memory.
+template <int LPR, int NB>
+__global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__ xl,
+                                                     const int64_t* __restrict__ vptr,
+                                                     const int32_t* __restrict__ vtgt,
+                                                     const ColVal* __restrict__ cv,
+                                                     const float* __restrict__ X, int64_t ldx,
+                                                     Epilogue ep) {
+  const int v = xl[blockIdx.x];
+  const int l = threadIdx.x;
+  if (l >= LPR) return;
+  const int64_t s = vptr[v], e = vptr[v + 1];
+  const int tgt = vtgt[v];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int off = (b * LPR + l) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t c = s; c < e; c += (1 << 20)) {
+      const int len = (int)std::min<int64_t>(e - c, 1 << 20);
+      acc = walk(cv + c, 0, len, X + off, ldx, acc);
+    }
+    epilogue_store(ep, tgt, off, acc);
+  }
+}
+
+// Fix-up: one lane group per split row adds its partials in segment order.
+template <int LPR, int NB>
+__global__ __launch_bounds__(BLOCK) void spmm_fixup_kernel(const LongRow* __restrict__ rows, int n_long,
+                                                           const float* __restrict__ partials, int64_t d,
+                                                           Epilogue ep) {
+  constexpr int GROUPS = BLOCK / LPR;
+  const int g = blockIdx.x * GROUPS + threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  if (g >= n_long) return;
+  const LongRow lr = rows[g];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int off = (b * LPR + l) * 4;
+    const float* p = partials + lr.slot_begin * d + off;
+    float4 acc = *reinterpret_cast<const float4*>(p);
+    int sgm = 1;
+    for (; sgm + 8 <= lr.n_seg; sgm += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(p + (int64_t)(sgm + u) * d);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = add4(acc, x[u]);
+    }
+    for (; sgm < lr.n_seg; ++sgm) acc = add4(acc, *reinterpret_cast<const float4*>(p + (int64_t)sgm * d));
+    epilogue_store(ep, lr.row, off, acc);
+  }
+}
+
+// Any d (slow path): 64 lanes stride over the features one float at a time.
+__global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __restrict__ vptr,
+                                                             const int32_t* __restrict__ vtgt,
+                                                             int64_t n_vrows, const ColVal* __restrict__ cv,
+                                                             const float* __restrict__ X, int64_t ldx,
+                                                             float* __restrict__ partials, int64_t d,
+                                                             Epilogue ep) {
+  const int64_t v = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  const int l = threadIdx.x % 64;
+  if (v >= n_vrows) return;
+  const int64_t s = vptr[v], e = vptr[v + 1];
+  const int tgt = vtgt[v];
+  for (int64_t f = l; f < d; f += 64) {
+    float acc = 0.f;
+    for (int64_t j = s; j < e; ++j) acc = __builtin_fmaf(cv[j].val, X[(int64_t)cv[j].col * ldx + f], acc);
+    if (tgt < 0) {
+      partials[(int64_t)(~tgt) * d + f] = acc;
+      continue;
+    }
+    const int64_t o = (int64_t)tgt * ep.ldy + f;
+    if (ep.addend) acc += ep.addend[o];
+    if (ep.Y) ep.Y[o] = acc;
+    if (ep.sum_out) {
+      float sres = ep.sum_in ? ep.sum_in[o] + acc : acc;
+      if (ep.div != 1.0f) sres = sres / ep.div;
+      if (ep.accumulate) sres = ep.sum_out[o] + sres;
+      ep.sum_out[o] = sres;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __restrict__ rows, int n_long,
+                                                              const float* __restrict__ partials, int64_t d,
+                                                              Epilogue ep) {
+  const int g = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  const int l = threadIdx.x % 64;
+  if (g >= n_long) return;
+  const LongRow lr = rows[g];
+  for (int64_t f = l; f < d; f += 64) {
+    const float* p = partials + lr.slot_begin * d + f;
+    float acc = p[0];
+    for (int sgm = 1; sgm < lr.n_seg; ++sgm) acc += p[(int64_t)sgm * d];
+    const int64_t o = (int64_t)lr.row * ep.ldy + f;
+    if (ep.addend) acc += ep.addend[o];
+    if (ep.Y) ep.Y[o] = acc;
+    if (ep.sum_out) {
+      float sres = ep.sum_in ? ep.sum_in[o] + acc : acc;
+      if (ep.div != 1.0f) sres = sres / ep.div;
+      if (ep.accumulate) sres = ep.sum_out[o] + sres;
+      ep.sum_out[o] = sres;
+    }
+  }
+}
+
+template <int LPR, int NB>
+int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials, int64_t d,
+                const Epilogue& ep, hipStream_t st) {
+  if (g->n_tiles > 0)
+    hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB>), dim3((unsigned)g->n_tiles), dim3(BLOCK), 0, st, g->d_tiles,
+                       g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep);
+  if (g->n_xl > 0)
+    hipLaunchKernelGGL((spmm_xl_kernel<LPR, NB>), dim3((unsigned)g->n_xl), dim3(64), 0, st, g->d_xl, g->d_vptr,
+                       g->d_vtgt, g->d_cv, X, ldx, ep);
+  if (g->n_long > 0) {
+    constexpr int GROUPS = BLOCK / LPR;
+    const unsigned nb = (unsigned)((g->n_long + GROUPS - 1) / GROUPS);
+    hipLaunchKernelGGL((spmm_fixup_kernel<LPR, NB>), dim3(nb), dim3(BLOCK), 0, st, g->d_long, (int)g->n_long,
+                       partials, d, ep);
+  }
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, void* ws, const Epilogue& ep,
+                  hipStream_t st) {
+  float* partials = reinterpret_cast<float*>(ws);
+  if (g->n_slots > 0 && !partials) return idg::fail(IDG_E_INVALID, "idg_spmm: workspace is NULL but the graph has split rows");
+  const bool aligned = (ldx % 4 == 0) && (ep.ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
+                       ((uintptr_t)ep.Y % 16 == 0) && ((uintptr_t)ep.addend % 16 == 0) &&
+                       ((uintptr_t)ep.sum_in % 16 == 0) && ((uintptr_t)ep.sum_out % 16 == 0);
+  if (aligned) {
+    switch (d) {
+      case 32: return launch_fast<8, 1>(g, X, ldx, partials, d, ep, st);
+      case 64: return launch_fast<16, 1>(g, X, ldx, partials, d, ep, st);
+      case 128: return launch_fast<32, 1>(g, X, ldx, partials, d, ep, st);
+      case 256: return launch_fast<64, 1>(g, X, ldx, partials, d, ep, st);
+      case 512: return launch_fast<64, 2>(g, X, ldx, partials, d, ep, st);
+      default: break;
+    }
+  }
+  if (g->n_vrows > 0) {
+    const unsigned nb = (unsigned)((g->n_vrows + (BLOCK / 64) - 1) / (BLOCK / 64));
+    hipLaunchKernelGGL(spmm_generic_kernel, dim3(nb), dim3(BLOCK), 0, st, g->d_vptr, g->d_vtgt, g->n_vrows,
+                       g->d_cv, X, ldx, partials, d, ep);
+  }
+  if (g->n_long > 0) {
+    const unsigned nb = (unsigned)((g->n_long + (BLOCK / 64) - 1) / (BLOCK / 64));
+    hipLaunchKernelGGL(fixup_generic_kernel, dim3(nb), dim3(BLOCK), 0, st, g->d_long, (int)g->n_long, partials,
+                       d, ep);
+  }
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int64_t seg_len_for(int64_t len) {
+  // ~sqrt(len) balances the parallel segment pass against the sequential fix-up pass.
+  int64_t s = (int64_t)std::ceil(std::sqrt((double)len));
+  s = (s + 7) / 8 * 8;
+  return std::min<int64_t>(std::max<int64_t>(s, 64), TILE_NNZ);
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  int enter(int dev) {
+    IDG_HIP(hipGetDevice(&prev));
+    if (prev != dev) {
+      IDG_HIP(hipSetDevice(dev));
+      switched = true;
+    }
+    return IDG_OK;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  if (src.empty()) return IDG_OK;
+  IDG_HIP(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(T)));
+  IDG_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return IDG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                     const int32_t* indices, const float* values, uint32_t flags, int64_t split_threshold,
+                     idg_graph** out) {
+  IDG_REQUIRE(out, "idg_graph_create: out is NULL");
+  IDG_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "idg_graph_create: negative size");
+  IDG_REQUIRE(indptr && (nnz == 0 || (indices && values)), "idg_graph_create: NULL CSR array");
+  IDG_REQUIRE(n_rows < ((int64_t)1 << 31) && n_cols < ((int64_t)1 << 31), "idg_graph_create: more than 2^31 rows/cols");
+  IDG_REQUIRE(indptr[0] == 0 && indptr[n_rows] == nnz, "idg_graph_create: indptr[0]=%lld indptr[n]=%lld nnz=%lld",
+              (long long)indptr[0], (long long)indptr[n_rows], (long long)nnz);
+  IDG_REQUIRE(split_threshold >= 0, "idg_graph_create: negative split_threshold");
+  for (int64_t r = 0; r < n_rows; ++r)
+    IDG_REQUIRE(indptr[r + 1] >= indptr[r], "idg_graph_create: indptr not monotone at row %lld", (long long)r);
+  for (int64_t k = 0; k < nnz; ++k)
+    IDG_REQUIRE(indices[k] >= 0 && indices[k] < n_cols, "idg_graph_create: column %d outside [0,%lld) at entry %lld",
+                indices[k], (long long)n_cols, (long long)k);
+  const int ndev = idg_device_count();
+  if (ndev <= 0) return idg::fail(IDG_E_NODEVICE, "idg_graph_create: no HIP device visible (this library has no CPU path)");
+  IDG_REQUIRE(device >= 0 && device < ndev, "idg_graph_create: device %d outside [0,%d)", device, ndev);
+
+  idg_graph* g = new (std::nothrow) idg_graph;
+  if (!g) return idg::fail(IDG_E_NOMEM, "idg_graph_create: out of memory");
+  g->device = device;
+  g->n_rows = n_rows;
+  g->n_cols = n_cols;
+  g->nnz = nnz;
+  g->flags = flags;
+  const bool exact = (flags & IDG_GRAPH_EXACT_ORDER) != 0;
+  int64_t T = split_threshold > 0 ? split_threshold : DEFAULT_SPLIT;
+  T = std::min<int64_t>(T, TILE_NNZ);
+  g->split_threshold = exact ? 0 : T;
+
+  // ---- virtual rows
+  std::vector<int64_t> vptr;
+  std::vector<int32_t> vtgt;
+  std::vector<LongRow> longs;
+  vptr.reserve((size_t)n_rows + 1);
+  vtgt.reserve((size_t)n_rows);
+  vptr.push_back(0);
+  int64_t slots = 0;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    const int64_t s = indptr[r], e = indptr[r + 1], len = e - s;
+    if (exact || len <= T) {
+      vtgt.push_back((int32_t)r);
+      vptr.push_back(e);
+      continue;
+    }
+    const int64_t S = seg_len_for(len);
+    const int64_t nseg = (len + S - 1) / S;
+    if (slots + nseg >= ((int64_t)1 << 31)) {
+      delete g;
+      return idg::fail(IDG_E_UNSUPPORTED, "idg_graph_create: too many row segments");
+    }
+    longs.push_back(LongRow{slots, (int32_t)r, (int32_t)nseg});
+    g->h_long_rows.push_back(r);
+    g->h_seg_len.push_back(S);
+    for (int64_t k = 0; k < nseg; ++k) {
+      vtgt.push_back((int32_t)~(int32_t)(slots + k));
+      vptr.push_back(std::min(e, s + (k + 1) * S));
+    }
+    slots += nseg;
+  }
+  g->n_vrows = (int64_t)vtgt.size();
+  g->n_long = (int64_t)longs.size();
+  g->n_slots = slots;
+
+  // ---- tiles
+  std::vector<Tile> tiles;
+  std::vector<int32_t> xl;
+  {
+    int64_t v = 0;
+    const int64_t nv = g->n_vrows;
+    while (v < nv) {
+      const int64_t len0 = vptr[(size_t)v + 1] - vptr[(size_t)v];
+      if (len0 > TILE_NNZ) {  // only possible with EXACT_ORDER
+        xl.push_back((int32_t)v);
+        ++v;
+        continue;
+      }
+      int64_t w = v;
+      const int64_t nz0 = vptr[(size_t)v];
+      while (w < nv && w - v < TILE_VROWS && vptr[(size_t)w + 1] - nz0 <= TILE_NNZ) ++w;
+      Tile t;
+      t.nnz_begin = nz0;
+      t.vrow_begin = (int32_t)v;
+      t.n_vrows = (int16_t)(w - v);
+      t.n_nnz_hi = 0;
+      tiles.push_back(t);
+      v = w;
+    }
+  }
+  // Heaviest work first: tiles made of row segments (hub rows) feed the fix-up pass, and
+  // a tile's cost grows with its entry count; launch order = descending entry count.
+  std::stable_sort(tiles.begin(), tiles.end(), [&](const Tile& a, const Tile& b) {
+    const int64_t na = vptr[(size_t)a.vrow_begin + a.n_vrows] - a.nnz_begin;
+    const int64_t nb = vptr[(size_t)b.vrow_begin + b.n_vrows] - b.nnz_begin;
+    return na > nb;
+  });
+  g->n_tiles = (int64_t)tiles.size();
+  g->n_xl = (int64_t)xl.size();
+
+  std::vector<ColVal> cv((size_t)nnz);
+  for (int64_t k = 0; k < nnz; ++k) cv[(size_t)k] = ColVal{indices[k], values[k]};
+
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc == IDG_OK) rc = upload(&g->d_cv, cv);
+  if (rc == IDG_OK) rc = upload(&g->d_vptr, vptr);
+  if (rc == IDG_OK) rc = upload(&g->d_vtgt, vtgt);
+  if (rc == IDG_OK) rc = upload(&g->d_tiles, tiles);
+  if (rc == IDG_OK) rc = upload(&g->d_long, longs);
+  if (rc == IDG_OK) rc = upload(&g->d_xl, xl);
+  if (rc != IDG_OK) {
+    idg_graph_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return IDG_OK;
+}
+
+int idg_graph_destroy(idg_graph* g) {
+  if (!g) return IDG_OK;
+  if (g->device >= 0 && idg_device_count() > g->device) {
+    DeviceGuard guard;
+    if (guard.enter(g->device) == IDG_OK) {
+      (void)hipFree(g->d_cv);
+      (void)hipFree(g->d_vptr);
+      (void)hipFree(g->d_vtgt);
+      (void)hipFree(g->d_tiles);
+      (void)hipFree(g->d_long);
+      (void)hipFree(g->d_xl);
+    }
+  }
+  delete g;
+  return IDG_OK;
+}
+
+int idg_graph_info(const idg_graph* g, int64_t info[8]) {
+  IDG_REQUIRE(g && info, "idg_graph_info: NULL argument");
+  info[0] = g->n_rows;
+  info[1] = g->n_cols;
+  info[2] = g->nnz;
+  info[3] = g->n_tiles + g->n_xl;
+  info[4] = g->n_long;
+  info[5] = g->n_slots;
+  info[6] = g->split_threshold;
+  info[7] = g->flags;
+  return IDG_OK;
+}
+
+int idg_graph_long_rows(const idg_graph* g, int64_t* long_rows, int64_t* seg_len) {
+  IDG_REQUIRE(g, "idg_graph_long_rows: NULL handle");
+  for (size_t i = 0; i < g->h_long_rows.size(); ++i) {
+    if (long_rows) long_rows[i] = g->h_long_rows[i];
+    if (seg_len) seg_len[i] = g->h_seg_len[i];
+  }
+  return IDG_OK;
+}
+
+size_t idg_spmm_workspace_bytes(const idg_graph* g, int64_t d) {
+  if (!g || d <= 0) return 0;
+  return (size_t)g->n_slots * (size_t)d * sizeof(float);
+}
+
+int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* addend,
+                 int64_t d, void* ws, void* stream) {
+  IDG_REQUIRE(g && X && Y, "idg_spmm_f32: NULL argument");
+  IDG_REQUIRE(d > 0 && ldx >= d && ldy >= d, "idg_spmm_f32: bad d/ldx/ldy (%lld,%lld,%lld)", (long long)d,
+              (long long)ldx, (long long)ldy);
+  Epilogue ep{};
+  ep.Y = Y;
+  ep.addend = addend;
+  ep.ldy = ldy;
+  ep.div = 1.0f;
+  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream);
+}
+
+size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {
+  if (!g || d <= 0) return 0;
+  // two ping-pong panels + the split-row partials
+  const size_t panel = ((size_t)std::max(g->n_rows, g->n_cols) * (size_t)d * sizeof(float) + 255) / 256 * 256;
+  return 2 * panel + idg_spmm_workspace_bytes(g, d);
+}
+
+static int propagate_common(const idg_graph* g, const float* in, float* out, int K, int include0, int64_t d,
+                            void* ws, hipStream_t st, bool backward, int accumulate) {
+  IDG_REQUIRE(g && in && out && ws, "idg_propagate: NULL argument");
+  IDG_REQUIRE(g->n_rows == g->n_cols, "idg_propagate: graph must be square");
+  IDG_REQUIRE(K >= 1, "idg_propagate: K must be >= 1 (got %d)", K);
+  IDG_REQUIRE(d > 0, "idg_propagate: d must be > 0");
+  IDG_REQUIRE(in != out, "idg_propagate: in-place propagation is not supported");
+  const size_t panel = ((size_t)g->n_rows * (size_t)d * sizeof(float) + 255) / 256 * 256;
+  float* P[2] = {reinterpret_cast<float*>(ws), reinterpret_cast<float*>((char*)ws + panel)};
+  void* partials = (char*)ws + 2 * panel;
+  const float cnt = (float)(K + (include0 ? 1 : 0));
+  const float* X = in;
+  for (int k = 1; k <= K; ++k) {
+    Epilogue ep{};
+    ep.ldy = d;
+    ep.div = 1.0f;
+    const bool last = (k == K);
+    if (!backward) {
+      // forward: running sum lives in `out`; the last layer divides.
+      if (!last) ep.Y = P[(k - 1) & 1];
+      if (k == 1) {
+        if (include0 || last) {
+          ep.sum_in = include0 ? in : nullptr;
+          ep.sum_out = out;
+        }
+      } else {
+        // sum so far = out (include0, or k > 2) or the layer input X_1 (k == 2, no layer 0)
+        ep.sum_in = (include0 || k > 2) ? out : X;
+        ep.sum_out = out;
+      }
+      if (last) ep.div = cnt;
+    } else {
+      // backward Horner step: h <- A.h + g ; the last one scales by 1/cnt.
+      if (!last) {
+        ep.Y = P[(k - 1) & 1];
+        ep.addend = in;
+      } else {
+        ep.sum_in = include0 ? in : nullptr;
+        ep.sum_out = out;
+        ep.div = cnt;
+        ep.accumulate = accumulate;
+      }
+    }
+    int rc = spmm_dispatch(g, X, d, d, partials, ep, st);
+    if (rc != IDG_OK) return rc;
+    X = P[(k - 1) & 1];
+  }
+  return IDG_OK;
+}
+
+int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int K, int include_layer0, int64_t d,
+                           void* ws, void* stream) {
+  return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0);
+}
+
+int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, float* gE0, int K, int include_layer0,
+                               int64_t d, int accumulate, void* ws, void* stream) {
+  IDG_REQUIRE(g, "idg_propagate_mean_bwd_f32: NULL graph");
+  IDG_REQUIRE(g->flags & IDG_GRAPH_SYMMETRIC,
+              "idg_propagate_mean_bwd_f32: graph not flagged IDG_GRAPH_SYMMETRIC (build the transposed handle and "
+              "chain idg_spmm_f32 instead)");
+  return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate);
+}
+
+}  // extern "C"

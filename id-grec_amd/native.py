@@ -1,0 +1,94 @@
+"""ctypes binding of libidgrec.so (C ABI: include/idgrec.h).
+
+Nothing here computes: every function marshals pointers and sizes and raises RuntimeError
+with idg_last_error() when the library reports a failure.  There is deliberately no
+fallback: if the shared library is missing the import of this module fails, and device
+entry points fail on a machine without a gfx950 GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libidgrec.so")
+
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_u32p = C.POINTER(C.c_uint32)
+c_f32p = C.POINTER(C.c_float)
+c_vp = C.c_void_p
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+PROTOTYPES = {
+    "idg_version": (C.c_int, []),
+    "idg_last_error": (C.c_char_p, []),
+    "idg_device_count": (C.c_int, []),
+    "idg_rng_create": (C.c_int, [C.c_uint32, C.POINTER(c_vp)]),
+    "idg_rng_destroy": (C.c_int, [c_vp]),
+    "idg_rng_get_state": (C.c_int, [c_vp, c_u32p, C.POINTER(C.c_int32)]),
+    "idg_rng_set_state": (C.c_int, [c_vp, c_u32p, C.c_int32]),
+    "idg_rng_bytes": (C.c_int, [c_vp, C.c_int64, c_vp]),
+    "idg_rng_randint": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_i64p]),
+    "idg_sample_epoch": (C.c_int, [c_vp, c_i64p, c_i64p, C.c_int64, c_i64p, c_i32p, C.c_int64, C.c_int64,
+                                   c_i64p, c_i64p]),
+    "idg_shuffle_perm": (C.c_int, [c_vp, C.c_int64, c_i64p]),
+    "idg_ratings_open": (C.c_int, [C.c_char_p, C.POINTER(c_vp), c_i64p, c_i64p, c_i64p, c_i64p]),
+    "idg_ratings_read": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p]),
+    "idg_ratings_destroy": (C.c_int, [c_vp]),
+    "idg_build_norm_adj": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int,
+                                     C.POINTER(C.c_double), c_i64p, c_i64p, c_i32p, c_f32p]),
+    "idg_graph_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.c_uint32,
+                                   C.c_int64, C.POINTER(c_vp)]),
+    "idg_graph_destroy": (C.c_int, [c_vp]),
+    "idg_graph_info": (C.c_int, [c_vp, c_i64p]),
+    "idg_graph_long_rows": (C.c_int, [c_vp, c_i64p, c_i64p]),
+    "idg_spmm_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
+    "idg_spmm_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, c_vp]),
+    "idg_propagate_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
+    "idg_propagate_mean_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, c_vp, c_vp]),
+    "idg_propagate_mean_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int, c_vp, c_vp]),
+    "idg_bpr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "idg_bpr_fused_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
+                                    C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp]),
+    "idg_adam_step_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_int64, c_vp]),
+    "idg_score_dense_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp]),
+    "idg_score_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "idg_score_topk_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int,
+                                     C.c_int, c_vp, c_vp, c_vp, c_vp]),
+}
+
+IDG_GRAPH_SYMMETRIC = 1
+IDG_GRAPH_EXACT_ORDER = 2
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libidgrec.so is not built (%s). Run `python id-grec_amd/build.py` (needs hipcc); "
+        "there is no pure-Python or CPU substitute for it." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class IdgError(RuntimeError):
+    def __init__(self, code, where):
+        msg = lib.idg_last_error()
+        msg = msg.decode("utf-8", "replace") if msg else ""
+        super().__init__("%s failed (%d): %s" % (where, code, msg))
+        self.code = code
+
+
+def check(code, where):
+    if code != 0:
+        raise IdgError(code, where)
+
+
+def device_count():
+    return int(lib.idg_device_count())
+
+
+def np_ptr(arr, ctype):
+    """Pointer to a C-contiguous numpy array's buffer (the caller keeps `arr` alive)."""
+    return arr.ctypes.data_as(C.POINTER(ctype))

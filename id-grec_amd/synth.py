@@ -1,0 +1,79 @@
+"""Deterministic synthetic interaction graphs of the shapes BASELINE.json names
+(SURVEY.md §8d).  The real yelp2018 / amazon-book `train.txt` are not distributable, so
+benchmarks and parity tests run on graphs with the same node/edge counts and a comparable
+skew: user degree ~ lognormal(0, 1) rescaled to the target mean (min 1, cap I/2), items drawn
+from a Zipf-like popularity p_i ~ (rank_i + 1)^-0.8 under a fixed random id permutation,
+de-duplicated per user.  The generator is NOT parity-relevant; only its output is.
+"""
+import os
+
+import numpy as np
+
+SHAPES = {
+    # name: (num_users, num_items, train_edges)
+    "tiny": (50, 40, 300),
+    "small": (300, 250, 3600),
+    "medium": (4000, 3000, 120000),
+    "yelp2018": (31668, 38048, 1237259),
+    "amazon-book": (52643, 91599, 2380730),
+    "synth-1M": (1000000, 500000, 20000000),
+    "synth-10M": (10000000, 5000000, 200000000),
+}
+
+
+def generate(num_users, num_items, num_edges, seed=0, zipf_a=0.8):
+    """Returns (users int64[E'], items int64[E']) sorted by (user, item); E' ~ num_edges
+    (duplicates removed, every user keeps >= 1 item)."""
+    rng = np.random.default_rng(seed)
+    U, I, E = int(num_users), int(num_items), int(num_edges)
+    deg = rng.lognormal(0.0, 1.0, U)
+    deg = deg * (E / deg.sum())
+    deg = np.clip(np.rint(deg), 1, max(1, I // 2)).astype(np.int64)
+    # popularity CDF over ranks, ranks mapped to ids by a fixed permutation
+    p = (np.arange(I, dtype=np.float64) + 1.0) ** (-zipf_a)
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    perm = rng.permutation(I)
+    total = int(deg.sum())
+    users = np.repeat(np.arange(U, dtype=np.int64), deg)
+    items = perm[np.searchsorted(cdf, rng.random(total), side="right").clip(0, I - 1)].astype(np.int64)
+    key = np.unique(users * I + items)
+    return key // I, key % I
+
+
+def split_test(users, items, num_users, n_test=1, seed=1):
+    """Hold out up to n_test items per user (never a user's last train item).
+    Returns train (users, items) and test (users, items)."""
+    rng = np.random.default_rng(seed)
+    order = np.lexsort((rng.random(len(users)), users))
+    u_s, i_s = users[order], items[order]
+    start = np.searchsorted(u_s, np.arange(num_users), side="left")
+    cnt = np.diff(np.append(start, len(u_s)))
+    rank = np.arange(len(u_s)) - np.repeat(start, cnt)
+    take = np.minimum(n_test, np.maximum(cnt - 1, 0))
+    is_test = rank < np.repeat(take, cnt)
+    tr = np.lexsort((i_s[~is_test], u_s[~is_test]))
+    te = np.lexsort((i_s[is_test], u_s[is_test]))
+    return (u_s[~is_test][tr], i_s[~is_test][tr]), (u_s[is_test][te], i_s[is_test][te])
+
+
+def write_ratings(path, users, items):
+    """The reference's text format: one line per user, `uid i1 i2 ...` (data_loader.py:48-70)."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    order = np.lexsort((items, users))
+    u, i = users[order], items[order]
+    bounds = np.nonzero(np.diff(u))[0] + 1
+    with open(path, "w") as f:
+        for uu, chunk in zip(u[np.r_[0, bounds]] if len(u) else [], np.split(i, bounds)):
+            f.write(str(int(uu)) + " " + " ".join(map(str, chunk.tolist())) + "\n")
+
+
+def make_dataset(root, name, shape=None, seed=0, n_test=1):
+    """Create <root>/<name>/{train,test}.txt for a named or explicit shape; returns the dir."""
+    U, I, E = SHAPES[name] if shape is None else shape
+    users, items = generate(U, I, E, seed=seed)
+    (tu, ti), (su, si) = split_test(users, items, U, n_test=n_test, seed=seed + 1)
+    d = os.path.join(root, name)
+    write_ratings(os.path.join(d, "train.txt"), tu, ti)
+    write_ratings(os.path.join(d, "test.txt"), su, si)
+    return d

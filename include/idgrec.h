@@ -1,0 +1,217 @@
+/*
+ * idgrec.h — C-ABI of libidgrec.so, the MI355X (gfx950) implementation of ID-GRec's
+ * LightGCN-style hot path: BPR sampler -> K-layer normalised-adjacency SpMM ->
+ * fused gather-BPR loss/grad -> dense Adam, and full-rank scoring + mask + top-K.
+ *
+ * The reference (BlueGhostYi/ID-GRec) is pure Python; the "FFI" a maintainer binds is
+ * ctypes.  Every entry point below names the reference call site
+ * (path:line relative to the reference repo) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = error class (IDG_E_*); the message of the
+ *     last failure on the calling thread is idg_last_error().
+ *   - "host" functions take host pointers and never touch the GPU.
+ *   - "device" functions take DEVICE pointers owned by the caller (torch tensors'
+ *     data_ptr()), are asynchronous on the hipStream_t passed as `void* stream`
+ *     (NULL = the null stream), never allocate, never synchronise.  Scratch memory is
+ *     caller-allocated; sizes come from the matching *_workspace_bytes().
+ *   - opaque handles (idg_rng, idg_ratings, idg_graph) are owned by the library and
+ *     released by the paired *_destroy().
+ *   - no C++ exception crosses this boundary.  There is NO CPU fallback for device
+ *     entry points: without a gfx950 device they fail with IDG_E_NODEVICE.
+ */
+#ifndef IDGREC_H
+#define IDGREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDG_VERSION 100 /* 0.1.0 */
+
+/* error classes */
+#define IDG_OK 0
+#define IDG_E_INVALID (-1)  /* bad argument */
+#define IDG_E_NODEVICE (-2) /* no HIP device / wrong device */
+#define IDG_E_HIP (-3)      /* a HIP runtime call failed */
+#define IDG_E_IO (-4)       /* file could not be read / parsed */
+#define IDG_E_NOMEM (-5)
+#define IDG_E_UNSUPPORTED (-6)
+
+int idg_version(void);
+const char* idg_last_error(void);
+/* number of visible HIP devices (0 when none). Never fails. */
+int idg_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * HOST: NumPy-legacy MT19937 stream  (replaces the global np.random state the reference
+ * seeds in utility/utility_function/tools.py:8-14 and draws from in
+ * utility/utility_data/data_loader.py:120 and utility/utility_function/tools.py:42)
+ * ---------------------------------------------------------------------------------- */
+typedef struct idg_rng idg_rng;
+
+/* np.random.seed(seed) : init_genrand(seed), pos = 624 */
+int idg_rng_create(uint32_t seed, idg_rng** out);
+int idg_rng_destroy(idg_rng* rng);
+/* mirrors np.random.get_state()[1:3] / set_state */
+int idg_rng_get_state(const idg_rng* rng, uint32_t key[624], int32_t* pos);
+int idg_rng_set_state(idg_rng* rng, const uint32_t key[624], int32_t pos);
+/* RandomState.bytes(n): raw little-endian uint32 stream */
+int idg_rng_bytes(idg_rng* rng, int64_t nbytes, uint8_t* out);
+/* `count` successive scalar np.random.randint(0, high) draws (masked rejection) */
+int idg_rng_randint(idg_rng* rng, int64_t high, int64_t count, int64_t* out);
+
+/* Data.sample_data_to_train_all (utility/utility_data/data_loader.py:108-127):
+ * for every train edge i in file order emit [train_user[i], train_item[i], neg] with
+ * neg = randint(0,num_items) re-drawn while neg is in the user's positive set.
+ * pos_indptr[num_users+1] / pos_indices (ascending per user) are the CSR rows of the
+ * train matrix (Data.all_positive).  Users with no positives are skipped (:114-115).
+ * out_triples is [E,3] row-major int64; *out_count = rows written (<= E). */
+int idg_sample_epoch(idg_rng* rng, const int64_t* train_user, const int64_t* train_item, int64_t E,
+                     const int64_t* pos_indptr, const int32_t* pos_indices, int64_t num_users,
+                     int64_t num_items, int64_t* out_triples, int64_t* out_count);
+
+/* np.random.shuffle(np.arange(n)) (utility/utility_function/tools.py:41-42) */
+int idg_shuffle_perm(idg_rng* rng, int64_t n, int64_t* out_perm);
+
+/* ------------------------------------------------------------------------------------
+ * HOST: rating-file parser and adjacency builder
+ * ---------------------------------------------------------------------------------- */
+typedef struct idg_ratings idg_ratings;
+
+/* Data.read_ratings (utility/utility_data/data_loader.py:48-70): parse lines
+ * "uid i1 i2 ..." (space separated ints).  Lines with no items count in n_lines but emit
+ * no edge and do not move the maxima (:59-61).  max_user/max_item are -1 when no edge. */
+int idg_ratings_open(const char* path, idg_ratings** out, int64_t* n_edges, int64_t* n_lines,
+                     int64_t* max_user, int64_t* max_item);
+/* users/items [n_edges] in file order; line_users [n_lines]; pos_length = items per
+ * non-empty line (may be NULL). */
+int idg_ratings_read(const idg_ratings* r, int64_t* users, int64_t* items, int64_t* line_users);
+int idg_ratings_destroy(idg_ratings* r);
+
+/* data_graph.sparse_adjacency_matrix (utility/utility_data/data_graph.py:33-55) and, with
+ * self_loops != 0, sparse_adjacency_matrix_with_self (:7-30): the symmetric bipartite
+ * adjacency A=[[0,R],[R^T,0]] (+I), duplicate (u,i) pairs summed, normalised
+ * D^-1/2 A D^-1/2, as CSR with ascending columns and float32 values.  Arithmetic follows
+ * the reference: float32 products (d_i*a)*d_j without self loops; float64 products rounded
+ * once to float32 with them (the `+ sp.eye` promotes to float64).
+ * dinv (nullable, [U+I]): d^-1/2 per node as the caller computed it (the Python host passes
+ * np.power(deg, -0.5), the reference's own expression, whose SIMD rounding cannot be
+ * restated portably); NULL = correctly rounded 1/sqrt(deg), 0 for isolated nodes.
+ * Two-call protocol: first call with indptr==NULL returns *nnz; second call fills
+ * indptr[U+I+1], indices[nnz], values[nnz]. */
+int idg_build_norm_adj(int64_t num_users, int64_t num_items, int64_t E, const int64_t* users,
+                       const int64_t* items, int self_loops, const double* dinv, int64_t* nnz,
+                       int64_t* indptr, int32_t* indices, float* values);
+
+/* ------------------------------------------------------------------------------------
+ * DEVICE: sparse graph handle
+ * (replaces the coalesced torch sparse COO tensor built in models/LightGCN.py:30-32 via
+ *  utility/utility_function/tools.py:95-109)
+ * ---------------------------------------------------------------------------------- */
+typedef struct idg_graph idg_graph;
+
+#define IDG_GRAPH_SYMMETRIC 1u   /* A == A^T exactly: backward reuses the same CSR */
+#define IDG_GRAPH_EXACT_ORDER 2u /* never split a row: every output element is the
+                                    sequential CSR-order fmaf chain torch CPU computes */
+
+/* CSR arrays are HOST pointers; the handle uploads and owns device copies plus its
+ * row-block tile schedule.  split_threshold: rows with more stored entries than this are
+ * cut into chunks summed in chunk order (0 = library default; ignored with EXACT_ORDER). */
+int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                     const int32_t* indices, const float* values, uint32_t flags,
+                     int64_t split_threshold, idg_graph** out);
+int idg_graph_destroy(idg_graph* g);
+/* info[0..7] = n_rows, n_cols, nnz, n_tiles, n_long_rows, n_long_chunks, split_threshold, flags */
+int idg_graph_info(const idg_graph* g, int64_t info[8]);
+/* The split schedule, so a checker can restate the exact summation order: row
+ * long_rows[i] is summed as consecutive segments of seg_len[i] stored entries, each a
+ * sequential fmaf chain from 0, then the partials are added left to right starting from
+ * the first.  Both arrays hold n_long_rows (info[4]) elements; either may be NULL. */
+int idg_graph_long_rows(const idg_graph* g, int64_t* long_rows, int64_t* seg_len);
+
+/* Y = A.X  (torch.sparse.mm(Graph, X): models/LightGCN.py:44, SimGCL.py:48, XSimGCL.py:51,
+ * NGCF.py:85, SGL.py:48,50).  X [n_cols, d], Y [n_rows, d] row-major fp32 with leading
+ * dimensions ldx/ldy (elements).  If addend != NULL: Y = A.X + addend (addend [n_rows,d],
+ * leading dimension ldy) — the autograd chain rule of the layer mean uses this form.
+ * ws: idg_spmm_workspace_bytes(g, d) bytes of device scratch (may be NULL when that is 0). */
+size_t idg_spmm_workspace_bytes(const idg_graph* g, int64_t d);
+int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                 const float* addend, int64_t d, void* ws, void* stream);
+
+/* LightGCN.aggregate (models/LightGCN.py:36-52) / SimGCL.aggregate(perturbed=False)
+ * (models/SimGCL.py:39-60): out = mean over layers of E_k, E_{k+1} = A.E_k, k < K,
+ * E_0 included iff include_layer0.  Running sum left-to-right then a true division by the
+ * layer count — the order torch.mean(torch.stack(..)) produces on CPU.
+ * E0, out: [n, d] contiguous.  ws: idg_propagate_workspace_bytes(g, d). */
+size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d);
+int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int K,
+                           int include_layer0, int64_t d, void* ws, void* stream);
+/* Backward of the above for a SYMMETRIC graph: gE0 = (1/cnt)(c0.g + A(g + A(g + ... A g))),
+ * the Horner form of autograd's chain through K torch.sparse.mm nodes and the mean.
+ * accumulate != 0: gE0 += (the ego-embedding regulariser's gradient is already there). */
+int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, float* gE0, int K,
+                               int include_layer0, int64_t d, int accumulate, void* ws,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DEVICE: fused gather + BPR + L2-reg loss and gradients
+ * (LightGCN.forward models/LightGCN.py:54-72; losses.get_bpr_loss / get_reg_loss
+ *  utility/utility_function/losses.py:4-21; and their autograd backward)
+ * ---------------------------------------------------------------------------------- */
+/* final/ego: [n, d] panels, rows [0,num_users) users then items.  users/pos/neg: int64[B]
+ * (pos/neg are item ids, NOT offset by num_users).
+ * loss[0] = mean_i -log(sigmoid(<f_u,f_p> - <f_u,f_n>) + 1e-7)
+ * loss[1] = reg_lambda * sum over the three ego blocks of 0.5*||block||_F^2 / B
+ * g_final[n,d] += d loss[0] / d final   (rows scatter-added, duplicates accumulate)
+ * g_ego  [n,d] += d loss[1] / d ego
+ * g_final / g_ego must be zeroed (or hold a gradient to accumulate into) by the caller;
+ * either may be NULL to skip that gradient.  final == ego is the MFBPR case
+ * (models/MFBPR.py:29-42).  deterministic != 0: duplicate rows are summed in batch order
+ * (run-to-run reproducible); 0: float atomics.
+ * ws: idg_bpr_workspace_bytes(B, d). */
+size_t idg_bpr_workspace_bytes(int64_t B, int64_t d);
+int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
+                      int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                      int64_t B, int64_t d, float reg_lambda, float* loss, float* g_final,
+                      float* g_ego, int deterministic, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DEVICE: dense Adam step  (torch.optim.Adam defaults, utility/utility_train/trainer.py:11,56:
+ * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  step is 1-based.  The
+ * hyper-parameters are doubles because torch forms lr/(1-beta1^t) and sqrt(1-beta2^t) in
+ * double on the host before the fp32 kernels see them.
+ * ---------------------------------------------------------------------------------- */
+int idg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      int64_t count, double lr, double beta1, double beta2, double eps,
+                      int64_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DEVICE: full-rank scoring, train-positive masking, top-K
+ * (get_rating_for_test models/LightGCN.py:74-80, MFBPR.py:44-49; batch_test.Test
+ *  utility/utility_train/batch_test.py:59-68)
+ * ---------------------------------------------------------------------------------- */
+/* rating[b, i] = act(<user_panel[users[b]], item_panel[i]>), act = sigmoid if apply_sigmoid.
+ * rating: [Bt, I] row-major.  The dense matrix the reference's evaluator mutates. */
+int idg_score_dense_f32(const float* user_panel, const float* item_panel, const int64_t* users,
+                        int64_t Bt, int64_t I, int64_t d, int apply_sigmoid, float* rating,
+                        void* stream);
+
+/* Fused: never materialises [Bt, I].  Scores as above; entries (b, i) with i in the train
+ * row of users[b] (excl_indptr[num_users+1] int64 / excl_items int32 ascending, DEVICE
+ * pointers, indexed by user id; NULL = no masking) are replaced by -1 (batch_test.py:62-65);
+ * the k best per row are returned sorted by (score desc, item id asc).
+ * out_idx int64 [Bt,k], out_val fp32 [Bt,k] (may be NULL). */
+size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k);
+int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users,
+                       int64_t Bt, int64_t I, int64_t d, const int64_t* excl_indptr,
+                       const int32_t* excl_items, int k, int apply_sigmoid, int64_t* out_idx,
+                       float* out_val, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDGREC_H */

@@ -1,0 +1,137 @@
+"""Host half of libidgrec.so (C++ through the C ABI) against the reference goldens and
+against NumPy's own legacy generator."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import idgrec_amd.host as H
+from idgrec_amd import native
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(os.path.dirname(native.LIB_PATH), "..", "..", "include", "idgrec.h")).read()
+    declared = set(re.findall(r"\b(idg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(native.lib, name), "libidgrec.so does not export %s" % name
+    assert declared == set(native.PROTOTYPES), declared ^ set(native.PROTOTYPES)
+    assert native.lib.idg_version() == 100
+
+
+def test_errors_are_reported_not_thrown():
+    with pytest.raises(native.IdgError) as e:
+        H.Rng(1).randint(0, 3)
+    assert "high must be > 0" in str(e.value)
+    with pytest.raises(native.IdgError):
+        H.parse_ratings("/nonexistent/train.txt")
+
+
+def test_mt19937_stream_matches_numpy(golden_tiny):
+    assert H.Rng(2024).bytes(256) == golden_tiny["rng_bytes"].tobytes()
+    for seed in (0, 1, 2024, 2**32 - 1):
+        assert H.Rng(seed).bytes(4099) == np.random.RandomState(seed).bytes(4099)
+    key, pos = H.Rng(5).get_state()
+    st = np.random.RandomState(5).get_state()
+    assert np.array_equal(key, st[1]) and pos == st[2]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 40, 38048, 65536, 65537, 91599, 5_000_000, 2**32 - 1, 2**32, 2**32 + 5, 2**40])
+def test_randint_masked_rejection(n):
+    rs = np.random.RandomState(7)
+    assert np.array_equal(H.Rng(7).randint(n, 500), np.array([rs.randint(0, n) for _ in range(500)]))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 1000, 65537])
+def test_shuffle_matches_numpy(n):
+    rs = np.random.RandomState(11)
+    p = np.arange(n)
+    rs.shuffle(p)
+    r = H.Rng(11)
+    assert np.array_equal(r.shuffle_perm(n), p)
+    assert r.randint(1000, 5).tolist() == [rs.randint(0, 1000) for _ in range(5)]  # stream position
+
+
+@pytest.mark.parametrize("gname", ["tiny", "small"])
+def test_sampler_and_shuffle_vs_reference(gname, golden_tiny, golden_small):
+    g = golden_tiny if gname == "tiny" else golden_small
+    r = H.Rng(2024)
+    args = (g["train_user"], g["train_item"], g["pos_indptr"], g["pos_indices"], int(g["num_items"]))
+    s1 = r.sample_epoch(*args)
+    p1 = r.shuffle_perm(len(s1))
+    s2 = r.sample_epoch(*args)
+    p2 = r.shuffle_perm(len(s2))
+    assert np.array_equal(s1, g["sample1"]) and np.array_equal(p1, g["perm1"])
+    assert np.array_equal(s2, g["sample2"]) and np.array_equal(p2, g["perm2"])
+
+
+def test_global_stream_is_shared_with_numpy(golden_small):
+    g = golden_small
+    np.random.seed(2024)
+    with H.GlobalStream() as r:
+        s1 = r.sample_epoch(g["train_user"], g["train_item"], g["pos_indptr"], g["pos_indices"], int(g["num_items"]))
+    idx = np.arange(len(s1))
+    np.random.shuffle(idx)  # numpy continues the very same stream
+    assert np.array_equal(s1, g["sample1"]) and np.array_equal(idx, g["perm1"])
+
+
+def test_sampler_skips_users_without_positives():
+    # user 1 has no positives: its edges are skipped and draw nothing (data_loader.py:114-115)
+    indptr = np.array([0, 2, 2, 3], dtype=np.int64)
+    indices = np.array([0, 3, 1], dtype=np.int32)
+    tu = np.array([0, 1, 2, 0], dtype=np.int64)
+    ti = np.array([0, 2, 1, 3], dtype=np.int64)
+    out = H.Rng(3).sample_epoch(tu, ti, indptr, indices, 5)
+    assert out[:, 0].tolist() == [0, 2, 0]
+    assert all(out[k, 2] not in {0: (0, 3), 2: (1,)}[out[k, 0]] for k in range(3))
+    with pytest.raises(native.IdgError):  # a user who saw everything can never get a negative
+        H.Rng(3).sample_epoch(np.array([0]), np.array([0]), np.array([0, 2]), np.array([0, 1], dtype=np.int32), 2)
+
+
+@pytest.mark.parametrize("gname", ["tiny", "small"])
+def test_parser_vs_reference(gname, tmp_path, golden_tiny, golden_small):
+    g = golden_tiny if gname == "tiny" else golden_small
+    for split in ("train", "test"):
+        p = tmp_path / (split + ".txt")
+        p.write_bytes(g[split + "_txt"].tobytes())
+        users, items, lines, mu, mi = H.parse_ratings(p)
+        assert np.array_equal(users, g[split + "_user"]) and np.array_equal(items, g[split + "_item"])
+    assert mu + 1 <= int(g["num_users"]) and mi + 1 <= int(g["num_items"])
+
+
+def test_parser_edge_cases(tmp_path):
+    p = tmp_path / "r.txt"
+    p.write_text("3 1 2\n7\n0 5\n")  # user 7 has no items: counted as a line, emits no edge
+    users, items, lines, mu, mi = H.parse_ratings(p)
+    assert users.tolist() == [3, 3, 0] and items.tolist() == [1, 2, 5]
+    assert lines.tolist() == [3, 7, 0] and (mu, mi) == (3, 5)
+    p.write_text("1 2 x\n")
+    with pytest.raises(native.IdgError):
+        H.parse_ratings(p)
+    p.write_text("")
+    users, items, lines, mu, mi = H.parse_ratings(p)
+    assert len(users) == 0 and (mu, mi) == (-1, -1)
+
+
+@pytest.mark.parametrize("gname", ["tiny", "small"])
+def test_adjacency_vs_reference(gname, golden_tiny, golden_small):
+    g = golden_tiny if gname == "tiny" else golden_small
+    U, I = int(g["num_users"]), int(g["num_items"])
+    ip, ix, dv = H.build_norm_adj(U, I, g["train_user"], g["train_item"])
+    assert np.array_equal(ip, g["adj_indptr"]) and np.array_equal(ix, g["adj_indices"])
+    assert np.array_equal(dv, g["adj_data"])  # bit-exact, incl. the duplicated pair on `tiny`
+    ip, ix, dv = H.build_norm_adj(U, I, g["train_user"], g["train_item"], self_loops=True)
+    assert np.array_equal(ip, g["adjself_indptr"]) and np.array_equal(ix, g["adjself_indices"])
+    assert np.array_equal(dv, g["adjself_data"])
+    # library-default d^-1/2 (correctly rounded) differs from numpy's SIMD power by <= 1 ulp per factor
+    _, _, dv2 = H.build_norm_adj(U, I, g["train_user"], g["train_item"], numpy_power=False)
+    np.testing.assert_allclose(dv2, g["adj_data"], rtol=3e-7)
+
+
+def test_adjacency_isolated_nodes_and_empty():
+    ip, ix, dv = H.build_norm_adj(3, 4, np.array([0, 0, 2]), np.array([1, 3, 1]))
+    assert ip.tolist() == [0, 2, 2, 3, 3, 5, 5, 6]  # user 1, items 0 and 2 are isolated: empty rows
+    assert np.isfinite(dv).all()
+    ip, ix, dv = H.build_norm_adj(2, 2, np.array([], dtype=np.int64), np.array([], dtype=np.int64))
+    assert ip.tolist() == [0, 0, 0, 0, 0] and len(ix) == 0
