@@ -41,7 +41,9 @@ struct BprArgs {
   int32_t* slots;          // [3B]
   float* g_final;
   float* g_ego;
+  const float* upstream;  // device [2]: d total / d loss[0], d total / d loss[1]; NULL = ones
   int atomic;
+  int emit_keys;
 };
 
 __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
     a.sq[i] = qu;
     a.sq[a.B + i] = qp;
     a.sq[2 * a.B + i] = qn;
-    if (!a.atomic) {
+    if (a.emit_keys) {
       a.keys[3 * i + 0] = (int32_t)ru;
       a.keys[3 * i + 1] = (int32_t)rp;
       a.keys[3 * i + 2] = (int32_t)rn;
@@ -91,19 +93,31 @@ __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
       a.slots[3 * i + 2] = (int32_t)(3 * i + 2);
     }
   }
-  if (a.atomic) {
-    for (int64_t f = lane; f < a.d; f += WAVE) {
-      if (a.g_final) {
-        const float u = fu[f], p = fp[f], n = fn[f];
-        atomicAdd(a.g_final + ru * a.d + f, c * (p - n));
-        atomicAdd(a.g_final + rp * a.d + f, c * u);
-        atomicAdd(a.g_final + rn * a.d + f, -c * u);
-      }
-      if (a.g_ego) {
-        atomicAdd(a.g_ego + ru * a.d + f, a.reg_scale * eu[f]);
-        atomicAdd(a.g_ego + rp * a.d + f, a.reg_scale * epp[f]);
-        atomicAdd(a.g_ego + rn * a.d + f, a.reg_scale * en[f]);
-      }
+}
+
+// Backward, atomic form: one wave per triple, float atomics into the gradient rows.
+__global__ __launch_bounds__(BLOCK) void bpr_atomic_kernel(BprArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int lane = threadIdx.x % WAVE;
+  if (i >= a.B) return;
+  const int64_t ru = a.users[i];
+  const int64_t rp = a.num_users + a.pos[i];
+  const int64_t rn = a.num_users + a.neg[i];
+  const float up0 = a.upstream ? a.upstream[0] : 1.0f;
+  const float up1 = a.upstream ? a.upstream[1] : 1.0f;
+  const float c = a.coef[i] * up0;
+  const float rs = a.reg_scale * up1;
+  for (int64_t f = lane; f < a.d; f += WAVE) {
+    if (a.g_final) {
+      const float u = a.fin[ru * a.d + f], p = a.fin[rp * a.d + f], n = a.fin[rn * a.d + f];
+      atomicAdd(a.g_final + ru * a.d + f, c * (p - n));
+      atomicAdd(a.g_final + rp * a.d + f, c * u);
+      atomicAdd(a.g_final + rn * a.d + f, -c * u);
+    }
+    if (a.g_ego) {
+      atomicAdd(a.g_ego + ru * a.d + f, rs * a.ego[ru * a.d + f]);
+      atomicAdd(a.g_ego + rp * a.d + f, rs * a.ego[rp * a.d + f]);
+      atomicAdd(a.g_ego + rn * a.d + f, rs * a.ego[rn * a.d + f]);
     }
   }
 }
@@ -151,13 +165,15 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
   if (j > 0 && skeys[j - 1] == row) return;
   int64_t e = j + 1;
   while (e < n3 && skeys[e] == row) ++e;
+  const float up0 = a.upstream ? a.upstream[0] : 1.0f;
+  const float up1 = a.upstream ? a.upstream[1] : 1.0f;
   for (int64_t f = lane; f < a.d; f += WAVE) {
     float acc = 0.f;
     for (int64_t t = j; t < e; ++t) {
       const int32_t s = sslots[t];
       const int64_t i = s / 3;
       const int kind = s - 3 * (int32_t)i;
-      const float c = a.coef[i];
+      const float c = a.coef[i] * up0;
       float v;
       if (kind == 0) {
         const float p = a.fin[(a.num_users + a.pos[i]) * a.d + f];
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
     const int64_t o = (int64_t)row * a.d + f;
     float reg = 0.f;
     if (a.g_ego) {
-      const float r1 = a.reg_scale * a.ego[o];
+      const float r1 = (a.reg_scale * up1) * a.ego[o];
       reg = r1;
       for (int64_t t = j + 1; t < e; ++t) reg += r1;
     }
@@ -298,18 +314,14 @@ size_t idg_bpr_workspace_bytes(int64_t B, int64_t d) {
   return bpr_layout(B, cub_temp_bound(3 * B)).total;
 }
 
-int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
-                      const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
-                      float reg_lambda, float* loss, float* g_final, float* g_ego, int deterministic, void* ws,
-                      void* stream) {
-  IDG_REQUIRE(final_panel && ego_panel && users && pos && neg && loss && ws, "idg_bpr_fused_f32: NULL argument");
-  IDG_REQUIRE(B > 0 && d > 0 && num_users >= 0 && n >= num_users, "idg_bpr_fused_f32: bad sizes");
-  IDG_REQUIRE(n < ((int64_t)1 << 31), "idg_bpr_fused_f32: more than 2^31 rows");
-  IDG_REQUIRE(3 * B < ((int64_t)1 << 31), "idg_bpr_fused_f32: batch too large");
-  hipStream_t st = (hipStream_t)stream;
-  const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
+static int bpr_args(BprArgs& a, const BprWs& w, const float* final_panel, const float* ego_panel,
+                    int64_t num_users, int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                    int64_t B, int64_t d, float reg_lambda, void* ws, const char* who) {
+  if (!(final_panel && ego_panel && users && pos && neg && ws)) return idg::fail(IDG_E_INVALID, "%s: NULL argument", who);
+  if (!(B > 0 && d > 0 && num_users >= 0 && n >= num_users)) return idg::fail(IDG_E_INVALID, "%s: bad sizes", who);
+  if (n >= ((int64_t)1 << 31)) return idg::fail(IDG_E_INVALID, "%s: more than 2^31 rows", who);
+  if (3 * B >= ((int64_t)1 << 31)) return idg::fail(IDG_E_INVALID, "%s: batch too large", who);
   char* base = reinterpret_cast<char*>(ws);
-  BprArgs a{};
   a.fin = final_panel;
   a.ego = ego_panel;
   a.users = users;
@@ -325,16 +337,46 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
   a.sq = reinterpret_cast<float*>(base + w.sq);
   a.keys = reinterpret_cast<int32_t*>(base + w.keys);
   a.slots = reinterpret_cast<int32_t*>(base + w.slots);
-  a.g_final = g_final;
-  a.g_ego = g_ego;
-  const bool want_grad = g_final || g_ego;
-  a.atomic = (!deterministic && want_grad) ? 1 : 0;
-  if (!want_grad) a.atomic = 1, a.g_final = a.g_ego = nullptr;  // loss only: skip key emission
+  return IDG_OK;
+}
 
+int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                        const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                        float reg_lambda, float* loss, void* ws, void* stream) {
+  IDG_REQUIRE(loss, "idg_bpr_forward_f32: loss is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const BprWs w = bpr_layout(B > 0 ? B : 1, cub_temp_bound(3 * B));
+  BprArgs a{};
+  int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
+                    "idg_bpr_forward_f32");
+  if (rc != IDG_OK) return rc;
+  a.emit_keys = 1;
   const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
   hipLaunchKernelGGL(bpr_triple_kernel, dim3(nb), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, a.loss_i, a.sq, B, reg_lambda, loss);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
 
-  if (want_grad && deterministic) {
+int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                         const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                         float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
+                         void* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const BprWs w = bpr_layout(B > 0 ? B : 1, cub_temp_bound(3 * B));
+  BprArgs a{};
+  int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
+                    "idg_bpr_backward_f32");
+  if (rc != IDG_OK) return rc;
+  if (!g_final && !g_ego) return IDG_OK;
+  a.g_final = g_final;
+  a.g_ego = g_ego;
+  a.upstream = upstream;
+  char* base = reinterpret_cast<char*>(ws);
+  if (!deterministic) {
+    const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+    hipLaunchKernelGGL(bpr_atomic_kernel, dim3(nb), dim3(BLOCK), 0, st, a);
+  } else {
     const int64_t n3 = 3 * B;
     int32_t* skeys = reinterpret_cast<int32_t*>(base + w.skeys);
     int32_t* sslots = reinterpret_cast<int32_t*>(base + w.sslots);
@@ -350,7 +392,7 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
       IDG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, a.keys, skeys, a.slots, sslots, (int)n3, 0, end_bit, st));
       const size_t have = cub_temp_bound(n3);
       if (need > have)
-        return idg::fail(IDG_E_UNSUPPORTED, "idg_bpr_fused_f32: radix sort wants %zu scratch bytes, layout reserves %zu",
+        return idg::fail(IDG_E_UNSUPPORTED, "idg_bpr_backward_f32: radix sort wants %zu scratch bytes, layout reserves %zu",
                          need, have);
       size_t tb = have;
       IDG_HIP(hipcub::DeviceRadixSort::SortPairs(base + w.temp, tb, a.keys, skeys, a.slots, sslots, (int)n3, 0, end_bit, st));
@@ -358,9 +400,18 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
     const unsigned nb3 = (unsigned)((n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
     hipLaunchKernelGGL(bpr_scatter_kernel, dim3(nb3), dim3(BLOCK), 0, st, a, skeys, sslots);
   }
-  hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, a.loss_i, a.sq, B, reg_lambda, loss);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
+}
+
+int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                      const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                      float reg_lambda, float* loss, float* g_final, float* g_ego, int deterministic, void* ws,
+                      void* stream) {
+  int rc = idg_bpr_forward_f32(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, loss, ws, stream);
+  if (rc != IDG_OK) return rc;
+  return idg_bpr_backward_f32(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr,
+                              g_final, g_ego, deterministic, ws, stream);
 }
 
 int idg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,

@@ -1,0 +1,363 @@
+"""Device operators: torch tensors in, torch tensors out, computed by libidgrec.so's HIP
+kernels through the C ABI.  PyTorch only supplies device memory, streams and autograd
+bookkeeping.  Every operator requires CUDA(=HIP) tensors; there is no CPU implementation —
+calling one with CPU tensors raises.
+
+Operator boundary: `spmm(graph, X)` stands where the reference calls
+`torch.sparse.mm(self.Graph, X)` (models/LightGCN.py:44); `propagate_mean` is the whole
+`aggregate()` loop (models/LightGCN.py:36-52); `bpr_loss` is the gather + get_bpr_loss +
+reg_lambda*get_reg_loss of `forward()` (models/LightGCN.py:57-68); `score_topk` is
+get_rating_for_test + mask + torch.topk (utility/utility_train/batch_test.py:59-68).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import native
+from .native import check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "idgrec_amd operators run on MI355X only: got a %s tensor. There is no CPU fallback; "
+                "move the model and inputs to the GPU (device='cuda')." % t.device)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64c(t, name):
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Graph:
+    """Device-resident CSR adjacency + its row-block tile schedule (idg_graph).
+
+    Built from HOST CSR arrays (numpy / scipy).  `symmetric=True` declares A == A^T so the
+    backward pass reuses the same handle (true for the normalised bipartite adjacency,
+    SURVEY §0.6); otherwise the transposed CSR is built once on the host.
+    """
+
+    def __init__(self, indptr, indices, values, n_rows, n_cols, device=None, symmetric=True, exact_order=False,
+                 split_threshold=0, _transpose_of=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("idgrec_amd.Graph needs a HIP device (torch.cuda.is_available() is False); "
+                               "this library has no CPU path.")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("idgrec_amd.Graph: device must be a cuda(HIP) device, got %s" % dev)
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        self.nnz = int(indices.shape[0])
+        self.symmetric = bool(symmetric)
+        flags = (native.IDG_GRAPH_SYMMETRIC if symmetric else 0) | (native.IDG_GRAPH_EXACT_ORDER if exact_order else 0)
+        h = C.c_void_p()
+        check(lib.idg_graph_create(self.device.index, self.n_rows, self.n_cols, self.nnz,
+                                   native.np_ptr(indptr, C.c_int64), native.np_ptr(indices, C.c_int32),
+                                   native.np_ptr(values, C.c_float), flags, int(split_threshold), C.byref(h)),
+              "idg_graph_create")
+        self._h = h
+        self._ws = {}
+        self._T = _transpose_of
+        if not symmetric and _transpose_of is None:
+            import scipy.sparse as sp
+
+            At = sp.csr_matrix((values, indices, indptr), shape=(self.n_rows, self.n_cols)).T.tocsr()
+            At.sort_indices()
+            self._T = Graph(At.indptr, At.indices, At.data, self.n_cols, self.n_rows, device=self.device,
+                            symmetric=False, exact_order=exact_order, split_threshold=split_threshold,
+                            _transpose_of=self)
+
+    @classmethod
+    def from_scipy(cls, mat, **kw):
+        m = mat.tocsr()
+        m.sort_indices()
+        return cls(m.indptr, m.indices, m.data, m.shape[0], m.shape[1], **kw)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.idg_graph_destroy(h)
+
+    @property
+    def T(self):
+        return self if self.symmetric else self._T
+
+    def info(self):
+        a = (C.c_int64 * 8)()
+        check(lib.idg_graph_info(self._h, a), "idg_graph_info")
+        keys = ("n_rows", "n_cols", "nnz", "n_tiles", "n_long_rows", "n_segments", "split_threshold", "flags")
+        return dict(zip(keys, [int(x) for x in a]))
+
+    def long_rows(self):
+        n = self.info()["n_long_rows"]
+        rows = np.empty(n, dtype=np.int64)
+        seg = np.empty(n, dtype=np.int64)
+        check(lib.idg_graph_long_rows(self._h, native.np_ptr(rows, C.c_int64), native.np_ptr(seg, C.c_int64)),
+              "idg_graph_long_rows")
+        return rows, seg
+
+    def _workspace(self, kind, d):
+        key = (kind, int(d))
+        ws = self._ws.get(key)
+        if ws is None:
+            fn = lib.idg_spmm_workspace_bytes if kind == "spmm" else lib.idg_propagate_workspace_bytes
+            nbytes = int(fn(self._h, int(d)))
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    # ---- raw (non-autograd) calls
+    def spmm_raw(self, X, addend=None, out=None):
+        _require_device(X, addend, out)
+        X = _f32c(X, "X")
+        if X.dim() != 2 or X.shape[0] != self.n_cols:
+            raise ValueError("X must be [%d, d], got %s" % (self.n_cols, tuple(X.shape)))
+        d = X.shape[1]
+        Y = torch.empty((self.n_rows, d), dtype=torch.float32, device=X.device) if out is None else out
+        if addend is not None:
+            addend = _f32c(addend, "addend")
+            if addend.shape != Y.shape:
+                raise ValueError("addend shape %s != output shape %s" % (tuple(addend.shape), tuple(Y.shape)))
+        ws = self._workspace("spmm", d)
+        check(lib.idg_spmm_f32(self._h, _ptr(X), d, _ptr(Y), d, _ptr(addend), d, _ptr(ws), _stream()), "idg_spmm_f32")
+        return Y
+
+    def propagate_mean_raw(self, E0, K, include_layer0=True, out=None):
+        _require_device(E0, out)
+        E0 = _f32c(E0, "E0")
+        if E0.shape[0] != self.n_rows:
+            raise ValueError("E0 must have %d rows, got %d" % (self.n_rows, E0.shape[0]))
+        d = E0.shape[1]
+        out = torch.empty_like(E0) if out is None else out
+        ws = self._workspace("prop", d)
+        check(lib.idg_propagate_mean_f32(self._h, _ptr(E0), _ptr(out), int(K), int(bool(include_layer0)), d,
+                                         _ptr(ws), _stream()), "idg_propagate_mean_f32")
+        return out
+
+    def propagate_mean_bwd_raw(self, gout, K, include_layer0=True, out=None, accumulate=False):
+        _require_device(gout, out)
+        gout = _f32c(gout, "gout")
+        d = gout.shape[1]
+        if out is None:
+            if accumulate:
+                raise ValueError("accumulate=True needs an existing `out`")
+            out = torch.empty_like(gout)
+        ws = self._workspace("prop", d)
+        check(lib.idg_propagate_mean_bwd_f32(self._h, _ptr(gout), _ptr(out), int(K), int(bool(include_layer0)), d,
+                                             int(bool(accumulate)), _ptr(ws), _stream()),
+              "idg_propagate_mean_bwd_f32")
+        return out
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, graph):
+        ctx.graph = graph
+        return graph.spmm_raw(X)
+
+    @staticmethod
+    def backward(ctx, gY):
+        return ctx.graph.T.spmm_raw(gY), None
+
+
+def spmm(graph, X):
+    """Y = A.X — the drop-in for torch.sparse.mm(Graph, X) (models/LightGCN.py:44)."""
+    return _SpMM.apply(X, graph)
+
+
+class _PropagateMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, E0, graph, K, include_layer0):
+        ctx.graph, ctx.K, ctx.inc = graph, K, include_layer0
+        return graph.propagate_mean_raw(E0, K, include_layer0)
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.graph.symmetric:
+            raise RuntimeError("propagate_mean backward needs a symmetric graph; chain spmm() instead")
+        return ctx.graph.propagate_mean_bwd_raw(g, ctx.K, ctx.inc), None, None, None
+
+
+def propagate_mean(graph, E0, K, include_layer0=True):
+    """mean_k(A^k E0), k = (0|1)..K — LightGCN.aggregate / SimGCL.aggregate(perturbed=False)."""
+    return _PropagateMean.apply(E0, graph, int(K), bool(include_layer0))
+
+
+# ------------------------------------------------------------------------------------ BPR
+_bpr_ws_cache = {}
+
+
+def _bpr_ws(B, d, device):
+    key = (int(B), int(d), device)
+    ws = _bpr_ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib.idg_bpr_workspace_bytes(int(B), int(d))), dtype=torch.uint8, device=device)
+        _bpr_ws_cache[key] = ws
+    return ws
+
+
+class _BprLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, deterministic):
+        _require_device(final_panel, ego_panel, users, pos, neg)
+        fin = _f32c(final_panel, "final_panel")
+        ego = fin if ego_panel is final_panel else _f32c(ego_panel, "ego_panel")
+        users, pos, neg = _i64c(users, "users"), _i64c(pos, "pos"), _i64c(neg, "neg")
+        n, d = fin.shape
+        B = users.shape[0]
+        loss = torch.empty(2, dtype=torch.float32, device=fin.device)
+        ws = _bpr_ws(B, d, fin.device)
+        check(lib.idg_bpr_forward_f32(_ptr(fin), _ptr(ego), int(num_users), n, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                      float(reg_lambda), _ptr(loss), _ptr(ws), _stream()), "idg_bpr_forward_f32")
+        ctx.save_for_backward(fin, ego, users, pos, neg)
+        ctx.meta = (int(num_users), float(reg_lambda), bool(deterministic), ego_panel is final_panel, ws)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g_bpr, g_reg):
+        fin, ego, users, pos, neg = ctx.saved_tensors
+        num_users, reg_lambda, deterministic, same, ws = ctx.meta
+        n, d = fin.shape
+        B = users.shape[0]
+        up = torch.stack([g_bpr.to(torch.float32).reshape(()), g_reg.to(torch.float32).reshape(())]).contiguous()
+        g_final = torch.zeros_like(fin)
+        g_ego = g_final if same else torch.zeros_like(ego)
+        # ws still holds this batch's coefficients: forward and backward of one step are adjacent on the stream
+        check(lib.idg_bpr_backward_f32(_ptr(fin), _ptr(ego), num_users, n, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                       reg_lambda, _ptr(up), _ptr(g_final), _ptr(g_ego), int(deterministic), _ptr(ws),
+                                       _stream()), "idg_bpr_backward_f32")
+        return g_final, (None if same else g_ego), None, None, None, None, None, None
+
+
+def bpr_loss(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, deterministic=True):
+    """(bpr_loss, reg_lambda * reg_loss) as 0-d tensors, differentiable w.r.t. both panels.
+
+    final_panel / ego_panel: [num_users + num_items, d], users first.  Passing the same
+    tensor twice is the MFBPR case (models/MFBPR.py:29-42)."""
+    if ego_panel is final_panel:
+        out = _BprLossSame.apply(final_panel, users, pos, neg, num_users, reg_lambda, deterministic)
+    else:
+        out = _BprLoss.apply(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, deterministic)
+    return out
+
+
+class _BprLossSame(torch.autograd.Function):
+    """final == ego: one differentiable input (autograd would otherwise see two aliases)."""
+
+    @staticmethod
+    def forward(ctx, panel, users, pos, neg, num_users, reg_lambda, deterministic):
+        return _BprLoss.forward(ctx, panel, panel, users, pos, neg, num_users, reg_lambda, deterministic)
+
+    @staticmethod
+    def backward(ctx, g_bpr, g_reg):
+        g = _BprLoss.backward(ctx, g_bpr, g_reg)
+        return g[0], None, None, None, None, None, None
+
+
+def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, g_final, g_ego, loss=None,
+                  deterministic=True):
+    """No-autograd form: loss[2] plus gradients accumulated into g_final / g_ego (caller zeroes)."""
+    _require_device(final_panel, ego_panel, users, pos, neg, g_final, g_ego)
+    n, d = final_panel.shape
+    B = users.shape[0]
+    loss = torch.empty(2, dtype=torch.float32, device=final_panel.device) if loss is None else loss
+    ws = _bpr_ws(B, d, final_panel.device)
+    check(lib.idg_bpr_fused_f32(_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos),
+                                _ptr(neg), B, d, float(reg_lambda), _ptr(loss), _ptr(g_final), _ptr(g_ego),
+                                int(bool(deterministic)), _ptr(ws), _stream()), "idg_bpr_fused_f32")
+    return loss
+
+
+# ----------------------------------------------------------------------------------- Adam
+def adam_step_raw(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    _require_device(param, grad, exp_avg, exp_avg_sq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("adam_step_raw needs contiguous float32 tensors")
+    check(lib.idg_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
+                                float(beta1), float(beta2), float(eps), int(step), _stream()), "idg_adam_step_f32")
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam's default algorithm (utility/utility_train/trainer.py:11) as one HIP
+    kernel per parameter tensor.  Same constructor signature for the arguments the reference
+    uses; weight decay / amsgrad are not part of the reference path and are rejected."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("idgrec_amd.Adam implements the reference's plain Adam only")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                adam_step_raw(p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], st["step"], b1, b2, group["eps"])
+        return loss
+
+
+# --------------------------------------------------------------------------- scoring/top-K
+def score_dense(user_panel, item_panel, users, apply_sigmoid=True):
+    """rating[Bt, I] = act(user_panel[users] @ item_panel.T) — get_rating_for_test."""
+    _require_device(user_panel, item_panel, users)
+    U, V = _f32c(user_panel, "user_panel"), _f32c(item_panel, "item_panel")
+    users = _i64c(users, "users")
+    Bt, I, d = users.shape[0], V.shape[0], V.shape[1]
+    rating = torch.empty((Bt, I), dtype=torch.float32, device=V.device)
+    check(lib.idg_score_dense_f32(_ptr(U), _ptr(V), _ptr(users), Bt, I, d, int(bool(apply_sigmoid)), _ptr(rating),
+                                  _stream()), "idg_score_dense_f32")
+    return rating
+
+
+def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=None, apply_sigmoid=True,
+               return_values=False):
+    """Top-k item ids per batch user, train positives masked to -1 (batch_test.py:59-68).
+    excl_indptr int64[num_users+1] / excl_items int32: DEVICE CSR of the train matrix."""
+    _require_device(user_panel, item_panel, users, excl_indptr, excl_items)
+    U, V = _f32c(user_panel, "user_panel"), _f32c(item_panel, "item_panel")
+    users = _i64c(users, "users")
+    Bt, I, d = users.shape[0], V.shape[0], V.shape[1]
+    if excl_indptr is not None:
+        if excl_indptr.dtype != torch.int64 or excl_items.dtype != torch.int32:
+            raise TypeError("excl_indptr must be int64 and excl_items int32")
+    idx = torch.empty((Bt, k), dtype=torch.int64, device=V.device)
+    val = torch.empty((Bt, k), dtype=torch.float32, device=V.device) if return_values else None
+    ws = torch.empty(int(lib.idg_score_topk_workspace_bytes(Bt, I, d, int(k))), dtype=torch.uint8, device=V.device)
+    check(lib.idg_score_topk_f32(_ptr(U), _ptr(V), _ptr(users), Bt, I, d, _ptr(excl_indptr), _ptr(excl_items), int(k),
+                                 int(bool(apply_sigmoid)), _ptr(idx), _ptr(val), _ptr(ws), _stream()),
+          "idg_score_topk_f32")
+    return (idx, val) if return_values else idx

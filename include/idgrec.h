@@ -178,6 +178,18 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
                       int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
                       int64_t B, int64_t d, float reg_lambda, float* loss, float* g_final,
                       float* g_ego, int deterministic, void* ws, void* stream);
+/* The same computation as two calls, for callers that sit under an autograd engine:
+ * forward writes loss[2] and keeps per-triple coefficients in ws; backward (same ws, same
+ * inputs) scatters the gradients scaled by upstream[0] (for loss[0]) and upstream[1] (for
+ * loss[1]) — a DEVICE pointer to the two incoming gradient scalars, or NULL for 1, 1. */
+int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
+                        int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                        int64_t B, int64_t d, float reg_lambda, float* loss, void* ws,
+                        void* stream);
+int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
+                         int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                         int64_t B, int64_t d, float reg_lambda, const float* upstream,
+                         float* g_final, float* g_ego, int deterministic, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: dense Adam step  (torch.optim.Adam defaults, utility/utility_train/trainer.py:11,56:
