@@ -69,6 +69,14 @@ if not os.path.exists(LIB_PATH):
         "libidgrec.so is not built (%s). Run `python id-grec_amd/build.py` (needs hipcc); "
         "there is no pure-Python or CPU substitute for it." % LIB_PATH)
 
+# libidgrec.so is handed torch's streams and device pointers, so both must sit on ONE HIP
+# runtime: torch bundles its own libamdhip64 (same SONAME as /opt/rocm's) and whichever copy
+# is mapped first wins.  Import torch first so the library binds to torch's runtime.
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
+    _torch = None
+
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in PROTOTYPES.items():
     _fn = getattr(lib, _name)
