@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — BPR triples/sec of the LightGCN-3 training step on MI355X.
+
+A step = one pass of the hot path over one batch of B sampled triples: K-layer propagation
+of the full graph, fused gather-BPR-loss-grad, K-layer backward propagation, dense Adam —
+exactly the work of one iteration of the reference's loop (trainer.py:42-56), on a synthetic
+graph of the shape BASELINE.json names, inputs resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload yelp2018|amazon-book|synth-1M|synth-10M]
+
+Prints ONE JSON line (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INFINITY_CACHE_BYTES = 256 << 20
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=300)
+    p.add_argument("--warmup", type=int, default=30)
+    p.add_argument("--workload", default="yelp2018")
+    p.add_argument("--dim", type=int, default=64)
+    p.add_argument("--layers", type=int, default=3)
+    p.add_argument("--batch", type=int, default=1024)
+    p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MFBPR"])
+    p.add_argument("--atomic", action="store_true", help="float-atomic scatter instead of the deterministic one")
+    p.add_argument("--split", type=int, default=0, help="row split threshold (0 = library default)")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--seed", type=int, default=2024)
+    return p.parse_args()
+
+
+def spmm_bytes(n, nnz, d):
+    """algorithmic bytes of one Y = A.X."""
+    gather = 4 * (n + 1) + 8 * nnz + 4 * nnz * d + 4 * n * d
+    minimum = 4 * (n + 1) + 8 * nnz + 8 * n * d
+    return gather, minimum
+
+
+def build_workload(args, rank, world):
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    U, I, E = S.SHAPES[args.workload]
+    t0 = time.time()
+    users, items = S.generate(U, I, E, seed=0)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    pos_ptr = np.zeros(U + 1, dtype=np.int64)
+    pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    rng = H.Rng(args.seed)
+    need = (args.steps + args.warmup) * args.batch
+    tri = rng.sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
+    tri = tri[rng.shuffle_perm(len(tri))]
+    while len(tri) < need:  # more steps than one epoch holds: draw further epochs
+        t2 = rng.sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
+        tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
+    return dict(U=U, I=I, E=len(users), indptr=ip, indices=ix, values=dv, triples=tri, prep_s=time.time() - t0)
+
+
+def xavier_uniform_panel(U, I, d, seed):
+    """nn.init.xavier_uniform_ on each table separately (models/LightGCN.py:27-28)."""
+    g = torch.Generator().manual_seed(seed)
+    out = torch.empty(U + I, d)
+    for lo, hi in ((0, U), (U, U + I)):
+        bound = (6.0 / ((hi - lo) + d)) ** 0.5
+        out[lo:hi] = (torch.rand(hi - lo, d, generator=g) * 2 - 1) * bound
+    return out
+
+
+def cpu_baseline(args, wl, W0):
+    """The reference's step restated on stock PyTorch CPU ops (oracle/torch_ref.py), timed on
+    this box's host cores on a bounded number of steps of the same workload."""
+    from oracle.torch_ref import RefStep
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    U, I = wl["U"], wl["I"]
+    ref = RefStep(wl["indptr"], wl["indices"], wl["values"], U, I, W0[:U], W0[U:], n_layers=args.layers,
+                  lr=1e-3, propagate=(args.model == "LightGCN"))
+    tri = torch.from_numpy(wl["triples"])
+    B = args.batch
+    done, t_used = 0, 0.0
+    ref.step(tri[:B, 0], tri[:B, 1], tri[:B, 2])  # untimed warm-up
+    while t_used < args.cpu_seconds and (done + 2) * B <= len(tri):
+        b = tri[(done + 1) * B:(done + 2) * B]
+        t0 = time.perf_counter()
+        ref.step(b[:, 0], b[:, 1], b[:, 2])
+        t_used += time.perf_counter() - t0
+        done += 1
+    return {"value": done * B / t_used, "unit": "triples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of the same %s B=%d workload, torch %s CPU ops (oracle/torch_ref.py), %.1f s"
+                      % (done, args.model, B, torch.__version__, t_used)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path to time.")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group("nccl")
+
+    import idgrec_amd.ops as ops
+    from idgrec_amd.engine import PropagationEngine
+
+    if world > 1:
+        from idgrec_amd.sharded import run_sharded_bench
+
+        return run_sharded_bench(args, rank, world, dist)
+
+    wl = build_workload(args, rank, world)
+    U, I, d, K, B = wl["U"], wl["I"], args.dim, args.layers, args.batch
+    n, nnz = U + I, len(wl["indices"])
+    graph = None
+    if args.model == "LightGCN":
+        graph = ops.Graph(wl["indptr"], wl["indices"], wl["values"], n, n, split_threshold=args.split)
+    W0 = xavier_uniform_panel(U, I, d, args.seed)
+    eng = PropagationEngine(graph, U, I, d, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
+                            deterministic=not args.atomic, params=W0.cuda())
+    tri = torch.from_numpy(wl["triples"]).cuda()
+    tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
+    losses = torch.zeros((args.steps + args.warmup, 2), dtype=torch.float32, device="cuda")
+
+    def batch(i):
+        s = slice(i * B, (i + 1) * B)
+        return tu[s], tp[s], tn[s]
+
+    for i in range(args.warmup):
+        eng.train_step(*batch(i), loss_out=losses[i])
+    torch.cuda.synchronize()
+
+    # timed region: exactly --steps steps
+    eng.events = []
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        eng.train_step(*batch(i), loss_out=losses[i])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    events, eng.events = eng.events, None
+
+    ms_per_step = dt / args.steps * 1e3
+    value = B * args.steps / dt
+    out = {
+        "metric": "BPR triples/sec, %s-%d dim=%d" % (args.model, K, d),
+        "value": value, "unit": "triples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s-shape graph: %d users x %d items, %d train edges, nnz(A)=%d; %s K=%d d=%d B=%d; "
+                               "step = propagate + fused BPR + backward propagate + dense Adam"
+                               % (args.workload, U, I, wl["E"], nnz, args.model, K, d, B),
+                   "batch": B, "dim": d, "layers": K, "scatter": "atomic" if args.atomic else "deterministic"},
+        "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[-1].sum().item())],
+    }
+    if graph is not None:
+        # HIP events recorded on the launch stream around every forward / backward propagation
+        # inside the timed region: 2K SpMM launches per step.
+        spmm_ms = sum(a.elapsed_time(b) for a, b in events) / (len(events) * K)
+        gather, minimum = spmm_bytes(n, nnz, d)
+        achieved = gather / (spmm_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_%s_d%d.json" % (args.workload, d))
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        info = graph.info()
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "spmm_tile_kernel<%d,1> (+ split-row fix-up)" % (d // 4),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "us_per_launch": spmm_ms * 1e3, "launches_timed": len(events) * K,
+            "bytes_gather": gather, "bytes_min": minimum,
+            "frac_bytes_min": minimum / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "cache_resident": bool(4 * n * d < INFINITY_CACHE_BYTES),
+            "tiles": info["n_tiles"], "split_rows": info["n_long_rows"],
+        }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, wl, W0.numpy())
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,35 @@
+"""The CPU-baseline port (oracle/torch_ref.py) must BE the reference's step: bit-identical
+weights after six Adam steps on the golden trajectory (same torch build, same op order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from oracle.torch_ref import RefStep
+
+
+@pytest.mark.parametrize("model", ["lgcn", "mf"])
+def test_port_reproduces_reference_trajectory(model, golden_small):
+    g = golden_small
+    torch.set_num_threads(1)
+    U, I = int(g["num_users"]), int(g["num_items"])
+    pos = [g["pos_indices"][g["pos_indptr"][u]:g["pos_indptr"][u + 1]] for u in range(U)]
+    np.random.seed(2024)
+    s = oracle.sample_epoch(g["train_user"], g["train_item"], pos, I)
+    s = s[oracle.shuffle_perm(len(s))]
+    ref = RefStep(g["adj_indptr"], g["adj_indices"], g["adj_data"], U, I, g["d64_init_user"], g["d64_init_item"],
+                  lr=1e-3 if model == "lgcn" else 1e-4, propagate=(model == "lgcn"))
+    for step in range(6):
+        b = torch.from_numpy(s[step * 128:(step + 1) * 128])
+        vals = ref.step(b[:, 0], b[:, 1], b[:, 2])
+        np.testing.assert_allclose(vals, g["traj_%s_losses" % model][step], rtol=1e-7)
+        np.testing.assert_allclose(ref.user_w.detach().numpy(), g["traj_%s_user" % model][step], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(ref.item_w.detach().numpy(), g["traj_%s_item" % model][step], rtol=1e-6, atol=1e-9)
+
+
+def test_port_rating_matches_reference(golden_small):
+    g = golden_small
+    U, I = int(g["num_users"]), int(g["num_items"])
+    ref = RefStep(g["adj_indptr"], g["adj_indices"], g["adj_data"], U, I, g["d64_init_user"], g["d64_init_item"])
+    R = ref.rating(torch.from_numpy(g["test_dict_users"][:48])).numpy()
+    np.testing.assert_allclose(R, g["d64_lgcn_rating"], rtol=1e-6, atol=1e-7)
