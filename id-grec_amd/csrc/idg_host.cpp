@@ -197,7 +197,7 @@ int idg_shuffle_perm(idg_rng* rng, int64_t n, int64_t* out_perm) {
 // Rating file parser
 // ---------------------------------------------------------------------------------------
 struct idg_ratings {
-  std::vector<int64_t> users, items, line_users;
+  std::vector<int64_t> users, items, line_users, line_counts;
 };
 
 extern "C" {
@@ -256,6 +256,7 @@ int idg_ratings_open(const char* path, idg_ratings** out, int64_t* n_edges, int6
       return idg::fail(IDG_E_IO, "idg_ratings_open: %s line %lld is empty", path, (long long)line_no);
     }
     r->line_users.push_back(user);
+    r->line_counts.push_back(n_items);
     if (n_items > 0) {
       r->users.insert(r->users.end(), (size_t)n_items, user);
       mu = std::max(mu, user);
@@ -272,12 +273,15 @@ int idg_ratings_open(const char* path, idg_ratings** out, int64_t* n_edges, int6
   return IDG_OK;
 }
 
-int idg_ratings_read(const idg_ratings* r, int64_t* users, int64_t* items, int64_t* line_users) {
+int idg_ratings_read(const idg_ratings* r, int64_t* users, int64_t* items, int64_t* line_users,
+                     int64_t* line_counts) {
   IDG_REQUIRE(r, "idg_ratings_read: NULL handle");
   if (users && !r->users.empty()) std::memcpy(users, r->users.data(), r->users.size() * sizeof(int64_t));
   if (items && !r->items.empty()) std::memcpy(items, r->items.data(), r->items.size() * sizeof(int64_t));
   if (line_users && !r->line_users.empty())
     std::memcpy(line_users, r->line_users.data(), r->line_users.size() * sizeof(int64_t));
+  if (line_counts && !r->line_counts.empty())
+    std::memcpy(line_counts, r->line_counts.data(), r->line_counts.size() * sizeof(int64_t));
   return IDG_OK;
 }
 

@@ -56,12 +56,12 @@ class PropagationEngine:
             return self.params
         if force or self._final_version != self.step_count:
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final)
-            self._final_version = self.step_count
+            self._final_version = self.step_count  # invalidated by loss_and_grad() / model.train()
         return self.final
 
-    # ---- one training step; returns the device tensor [bpr_loss, reg_lambda * reg_loss]
+    # ---- forward + backward: losses [bpr, reg_lambda*reg] and d(sum)/dE0 into self.grad
     @torch.no_grad()
-    def train_step(self, users, pos, neg, loss_out=None):
+    def loss_and_grad(self, users, pos, neg, loss_out=None):
         loss = self.loss if loss_out is None else loss_out
         self.grad.zero_()
         if self.graph is not None:
@@ -77,6 +77,13 @@ class PropagationEngine:
         else:
             ops.bpr_fused_raw(self.params, self.params, users, pos, neg, self.U, self.reg_lambda, self.grad,
                               self.grad, loss=loss, deterministic=self.deterministic)
+        self._final_version = -1
+        return loss
+
+    # ---- one whole training step (loss_and_grad + dense Adam), for callers without a torch optimizer
+    @torch.no_grad()
+    def train_step(self, users, pos, neg, loss_out=None):
+        loss = self.loss_and_grad(users, pos, neg, loss_out)
         self.step_count += 1
         ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
                           self.betas[0], self.betas[1], self.eps)

@@ -94,9 +94,10 @@ class GlobalStream:
         return False
 
 
-def parse_ratings(path):
+def parse_ratings(path, counts=False):
     """Native Data.read_ratings (data_loader.py:48-70).
-    Returns (users[E], items[E], line_users[L], max_user, max_item)."""
+    Returns (users[E], items[E], line_users[L], max_user, max_item); with counts=True also
+    line_counts[L] (items per line) as a sixth element."""
     h = C.c_void_p()
     ne, nl, mu, mi = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
     check(lib.idg_ratings_open(str(path).encode(), C.byref(h), C.byref(ne), C.byref(nl), C.byref(mu), C.byref(mi)),
@@ -105,10 +106,13 @@ def parse_ratings(path):
         users = np.empty(ne.value, dtype=np.int64)
         items = np.empty(ne.value, dtype=np.int64)
         lines = np.empty(nl.value, dtype=np.int64)
-        check(lib.idg_ratings_read(h, np_ptr(users, C.c_int64), np_ptr(items, C.c_int64), np_ptr(lines, C.c_int64)),
-              "idg_ratings_read")
+        cnts = np.empty(nl.value, dtype=np.int64)
+        check(lib.idg_ratings_read(h, np_ptr(users, C.c_int64), np_ptr(items, C.c_int64), np_ptr(lines, C.c_int64),
+                                   np_ptr(cnts, C.c_int64)), "idg_ratings_read")
     finally:
         lib.idg_ratings_destroy(h)
+    if counts:
+        return users, items, lines, int(mu.value), int(mi.value), cnts
     return users, items, lines, int(mu.value), int(mi.value)
 
 

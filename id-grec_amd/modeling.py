@@ -1,0 +1,136 @@
+"""Shared machinery of the model plugins in models/*.py.
+
+The reference's models each own two nn.Embedding tables and call torch.cat on them in every
+forward (models/LightGCN.py:38).  `PackedRecommender` keeps the same two nn.Embedding
+modules (same construction order, hence the same initial weights for a given torch seed) but
+backs them with ONE contiguous [num_users + num_items, d] buffer, so the propagation kernels
+read the ego panel in place.  It also provides the fused, autograd-free training step and the
+fused top-K evaluation that the trainer / evaluator use when a model offers them.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .engine import PropagationEngine
+
+
+class _PackedPanel(torch.autograd.Function):
+    """(user_weight, item_weight) -> the [n, d] panel they both live in, without copying."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, storage):
+        ctx.U = user_w.shape[0]
+        return storage.view(storage.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[: ctx.U], g[ctx.U:], None
+
+
+class PackedRecommender(nn.Module):
+    #: number of propagation layers (0 = plain matrix factorisation) and whether layer 0 is averaged in
+    n_layers = 0
+    include_layer0 = True
+
+    def __init__(self, config, dataset, device):
+        super().__init__()
+        self.config, self.dataset, self.device = config, dataset, device
+        self.reg_lambda = float(config["reg_lambda"])
+        d = int(config["embedding_size"])
+        # construction order fixes the torch RNG consumption: normal_(user), normal_(item),
+        # then the two xavier calls (models/LightGCN.py:21-28)
+        self.user_embedding = nn.Embedding(num_embeddings=dataset.num_users, embedding_dim=d)
+        self.item_embedding = nn.Embedding(num_embeddings=dataset.num_items, embedding_dim=d)
+        nn.init.xavier_uniform_(self.user_embedding.weight, gain=1)
+        nn.init.xavier_uniform_(self.item_embedding.weight, gain=1)
+        self.activation = nn.Sigmoid()
+        self.Graph = None
+        self._storage = None
+        self._engine = None
+        self._pack()
+
+    # ------------------------------------------------------------------ packed storage
+    def _pack(self):
+        uw, iw = self.user_embedding.weight, self.item_embedding.weight
+        U = uw.shape[0]
+        storage = torch.cat([uw.data, iw.data]).contiguous()
+        uw.data, iw.data = storage[:U], storage[U:]
+        self._storage = storage
+        self._engine = None
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._pack()  # .to(device) / .float() re-create the tensors: restore the aliasing
+        return out
+
+    def _is_packed(self):
+        uw, iw, st = self.user_embedding.weight, self.item_embedding.weight, self._storage
+        return (st is not None and uw.data_ptr() == st.data_ptr() and uw.device == st.device
+                and iw.data_ptr() == st.data_ptr() + uw.numel() * 4)
+
+    def ego_panel(self):
+        """Differentiable [n, d] view of both tables."""
+        if not self._is_packed():
+            self._pack()
+        return _PackedPanel.apply(self.user_embedding.weight, self.item_embedding.weight, self._storage)
+
+    def train(self, mode=True):
+        if self._engine is not None:
+            self._engine._final_version = -1  # weights may change: drop the cached propagation
+        return super().train(mode)
+
+    # ------------------------------------------------------------------ graph
+    def attach_graph(self, sp_mat):
+        """Upload a scipy adjacency to the model's device as an ops.Graph."""
+        from utility.utility_function import tools
+
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            raise RuntimeError("%s needs an MI355X: device is %s and idgrec_amd has no CPU path "
+                               "(torch.cuda.is_available() = %s)." % (type(self).__name__, dev, torch.cuda.is_available()))
+        self.Graph = tools.convert_sp_mat_to_graph(sp_mat, dev)
+        return self.Graph
+
+    # ------------------------------------------------------------------ fused paths
+    def engine(self):
+        if self._engine is None or self._engine.params.data_ptr() != self._storage.data_ptr():
+            if not self._is_packed():
+                self._pack()
+            ops._require_device(self._storage)
+            self._engine = PropagationEngine(self.Graph if self.n_layers > 0 else None, self.dataset.num_users,
+                                             self.dataset.num_items, self._storage.shape[1], self.n_layers,
+                                             include_layer0=self.include_layer0, reg_lambda=self.reg_lambda,
+                                             params=self._storage)
+        return self._engine
+
+    #: models whose training loss is exactly [bpr, reg] over the mean-propagated panel set this
+    supports_fused_step = False
+
+    def fused_loss_and_grad(self, users, pos, neg, loss_out=None):
+        """Losses [bpr, reg_lambda*reg] (device tensor) and d(sum)/d(weights) written into the
+        two parameters' .grad — the work of forward() + backward() without an autograd graph."""
+        eng = self.engine()
+        loss = eng.loss_and_grad(users, pos, neg, loss_out)
+        U = self.dataset.num_users
+        self.user_embedding.weight.grad = eng.grad[:U]
+        self.item_embedding.weight.grad = eng.grad[U:]
+        return loss
+
+    def final_panels(self):
+        """(users [U,d], items [I,d]) used for scoring, cached while the weights are frozen."""
+        fin = self.engine().propagate()
+        U = self.dataset.num_users
+        return fin[:U], fin[U:]
+
+    def get_rating_for_test(self, user):
+        """sigmoid(E_u[user] . E_i^T) as a dense [B, num_items] matrix (models/LightGCN.py:74-80)."""
+        with torch.no_grad():
+            ue, ie = self.final_panels()
+            return ops.score_dense(ue, ie, user.long(), apply_sigmoid=True)
+
+    def topk_for_test(self, user, k):
+        """Top-k unseen items per user without materialising the rating matrix."""
+        with torch.no_grad():
+            ue, ie = self.final_panels()
+            ip, ix = self.dataset.train_csr_on(ue.device)
+            return ops.score_topk(ue, ie, user.long(), k, ip, ix, apply_sigmoid=True)

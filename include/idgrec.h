@@ -87,9 +87,10 @@ typedef struct idg_ratings idg_ratings;
  * no edge and do not move the maxima (:59-61).  max_user/max_item are -1 when no edge. */
 int idg_ratings_open(const char* path, idg_ratings** out, int64_t* n_edges, int64_t* n_lines,
                      int64_t* max_user, int64_t* max_item);
-/* users/items [n_edges] in file order; line_users [n_lines]; pos_length = items per
- * non-empty line (may be NULL). */
-int idg_ratings_read(const idg_ratings* r, int64_t* users, int64_t* items, int64_t* line_users);
+/* users/items [n_edges] in file order; line_users / line_counts [n_lines] = the user id and
+ * the number of items of every line.  Any output may be NULL. */
+int idg_ratings_read(const idg_ratings* r, int64_t* users, int64_t* items, int64_t* line_users,
+                     int64_t* line_counts);
 int idg_ratings_destroy(idg_ratings* r);
 
 /* data_graph.sparse_adjacency_matrix (utility/utility_data/data_graph.py:33-55) and, with

@@ -1,0 +1,180 @@
+"""GPU end-to-end: the model plugins + trainer + evaluator against what the reference logged
+and learned on the same data and seed (goldens `loop_*` dumped through the reference's own
+universal_trainer), and fused-vs-autograd equivalence of the two step implementations."""
+import io
+import logging
+import re
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _dataset(tmp_path, g, name, **cfg):
+    import utility.utility_data.data_loader as data_loader
+
+    d = tmp_path / name
+    d.mkdir(exist_ok=True)
+    (d / "train.txt").write_bytes(g["train_txt"].tobytes())
+    (d / "test.txt").write_bytes(g["test_txt"].tobytes())
+    config = dict(dataset=name, dataset_path=str(tmp_path) + "/", sparsity_test="0")
+    config.update({k: str(v) for k, v in cfg.items()})
+    return data_loader.Data(str(d), config), config
+
+
+def _numbers(line):
+    return [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:e[-+]?\d+)?", line.replace("Training time: T", ""))]
+
+
+BASE = dict(embedding_size=64, reg_lambda=0.0001, GCN_layer=3, batch_size=256, test_batch_size=64, training_epochs=3,
+            interval=2, top_K="[5, 10]", early_stopping=10)
+
+
+@pytest.mark.parametrize("mname,lr", [("lgcn", 0.001), ("mf", 0.0001)])
+def test_full_loop_vs_reference_run(mname, lr, tmp_path, golden_small):
+    import utility.utility_function.tools as tools
+    import utility.utility_train.trainer as trainer
+    from models.LightGCN import LightGCN
+    from models.MFBPR import MFBPR
+
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", learn_rate=lr, **BASE)
+    stream = io.StringIO()
+    logger = logging.getLogger("gpu_loop_" + mname)
+    logger.setLevel(logging.INFO)
+    logger.handlers = [logging.StreamHandler(stream)]
+    tools.set_seed(2024)
+    model = (LightGCN if mname == "lgcn" else MFBPR)(cfg, data, torch.device("cuda"))
+    # identical initial weights: same torch RNG call order as the reference's constructor
+    assert np.array_equal(model.user_embedding.weight.detach().cpu().numpy(), g["d64_init_user"])
+    assert np.array_equal(model.item_embedding.weight.detach().cpu().numpy(), g["d64_init_item"])
+    trainer.universal_trainer(model, None, cfg, data, torch.device("cuda"), logger)
+    lines = stream.getvalue().splitlines()
+    ref_lines = g["loop_%s_log" % mname].tolist()
+    assert len(lines) == len(ref_lines)
+    for mine, ref in zip(lines, ref_lines):
+        mine = re.sub(r"Training time: [0-9.]+", "Training time: T", mine)
+        a, b = _numbers(mine), _numbers(ref)
+        assert len(a) == len(b), (mine, ref)
+        if "training loss" in ref:
+            # 6-decimal strings; a last-digit flip at a rounding boundary is fp32 noise
+            np.testing.assert_allclose(a, b, rtol=RTOL, atol=1.5e-6)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8)  # recall / ndcg / best epoch
+    np.testing.assert_allclose(model.user_embedding.weight.detach().cpu().numpy(), g["loop_%s_user" % mname],
+                               rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(model.item_embedding.weight.detach().cpu().numpy(), g["loop_%s_item" % mname],
+                               rtol=RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize("mname", ["lgcn", "mf"])
+def test_fused_step_equals_autograd_step(mname, tmp_path, golden_small):
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.LightGCN import LightGCN
+    from models.MFBPR import MFBPR
+
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", learn_rate=0.001, **BASE)
+    batch = torch.from_numpy(g["d64_batch"]).cuda()
+    grads, losses_ = [], []
+    for fused in (False, True):
+        tools.set_seed(2024)
+        model = (LightGCN if mname == "lgcn" else MFBPR)(cfg, data, torch.device("cuda")).to("cuda")
+        if fused:
+            loss = model.fused_loss_and_grad(batch[:, 0].contiguous(), batch[:, 1].contiguous(), batch[:, 2].contiguous())
+            losses_.append(loss.cpu().numpy().copy())
+        else:
+            ll = model(batch[:, 0], batch[:, 1], batch[:, 2])
+            sum(ll).backward()
+            losses_.append(np.array([x.item() for x in ll], dtype=np.float32))
+        grads.append((model.user_embedding.weight.grad.cpu().numpy().copy(),
+                      model.item_embedding.weight.grad.cpu().numpy().copy()))
+    assert np.array_equal(losses_[0], losses_[1])
+    np.testing.assert_allclose(grads[0][0], grads[1][0], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(grads[0][1], grads[1][1], rtol=1e-6, atol=1e-10)
+    key = "d64_lgcn" if mname == "lgcn" else "d64_mf"
+    np.testing.assert_allclose(grads[1][0], g[key + "_grad_user"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(grads[1][1], g[key + "_grad_item"], rtol=RTOL, atol=1e-8)
+
+
+def test_packed_storage_survives_to_and_optimizer(tmp_path, golden_small):
+    from idgrec_amd import ops
+    from models.MFBPR import MFBPR
+
+    data, cfg = _dataset(tmp_path, golden_small, "small", learn_rate=0.001, **BASE)
+    model = MFBPR(cfg, data, torch.device("cuda"))
+    model.to("cuda")
+    assert model._is_packed() and model.user_embedding.weight.is_cuda
+    opt = ops.Adam(model.parameters(), lr=0.01)
+    batch = torch.from_numpy(golden_small["d64_batch"]).cuda()
+    before = model._storage.clone()
+    sum(model(batch[:, 0], batch[:, 1], batch[:, 2])).backward()
+    opt.step()
+    assert model._is_packed() and not torch.equal(before, model._storage)
+    assert torch.equal(model.user_embedding.weight.data, model._storage[: data.num_users])
+
+
+def test_evaluator_fused_vs_dense_path(tmp_path, golden_small):
+    import utility.utility_train.batch_test as batch_test
+    from models.LightGCN import LightGCN
+
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", learn_rate=0.001, **dict(BASE, top_K="[10, 20]"))
+    import utility.utility_function.tools as tools
+
+    tools.set_seed(2024)
+    model = LightGCN(cfg, data, torch.device("cuda")).to("cuda")
+    res = batch_test.Test(data, model, torch.device("cuda"), cfg)  # fused top-K path
+    np.testing.assert_allclose(np.stack([res["recall"], res["precision"], res["ndcg"]]), g["d64_lgcn_test_10_20"],
+                               rtol=1e-6, atol=1e-9)
+    # the dense protocol (get_rating_for_test + mask + torch.topk) gives the same metrics
+    class Dense:
+        def __init__(self, m):
+            self.m = m
+
+        def eval(self):
+            self.m.eval()
+            return self
+
+        def get_rating_for_test(self, u):
+            return self.m.get_rating_for_test(u)
+
+    res2 = batch_test.Test(data, Dense(model), torch.device("cuda"), cfg)
+    np.testing.assert_allclose(res2["recall"], res["recall"], rtol=1e-6, atol=1e-9)
+    R = model.get_rating_for_test(torch.from_numpy(g["test_dict_users"][:48]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(R, g["d64_lgcn_rating"], rtol=1e-5, atol=1e-6)
+
+
+def test_simgcl_runs_and_clean_view_matches_reference(tmp_path, golden_small):
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.SimGCL import SimGCL
+
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", learn_rate=0.001, ssl_lambda=0.5, temperature=0.2, epsilon=0.05, **BASE)
+    tools.set_seed(2024)
+    model = SimGCL(cfg, data, torch.device("cuda")).to("cuda")
+    with torch.no_grad():
+        u, i = model.aggregate(perturbed=False)
+    assert np.array_equal(u.cpu().numpy(), g["d64_simgcl_user"]) and np.array_equal(i.cpu().numpy(), g["d64_simgcl_item"])
+    with torch.no_grad():
+        pu, pi = model.aggregate(perturbed=True)
+    # the perturbation moves every row by exactly eps per layer on the unit sphere: bounded, non-zero
+    delta = (torch.cat([pu, pi]) - torch.cat([u, i])).norm(dim=1)
+    assert float(delta.max()) < 3 * 0.05 and float(delta.median()) > 0.01  # isolated nodes (zero rows) stay put: sign(0) = 0
+    batch = torch.from_numpy(g["d64_batch"]).cuda()
+    opt = ops.Adam(model.parameters(), lr=1e-3)
+    first = None
+    for _ in range(5):
+        ll = model(batch[:, 0], batch[:, 1], batch[:, 2])
+        assert len(ll) == 3 and all(torch.isfinite(x) for x in ll)
+        opt.zero_grad()
+        sum(ll).backward()
+        opt.step()
+        first = first if first is not None else float(sum(ll))
+    assert float(sum(ll)) < first  # five steps on one batch reduce its loss

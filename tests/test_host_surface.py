@@ -1,0 +1,204 @@
+"""Drop-in surface on the CPU: loader, configuration, shuffle / mini-batch, evaluator and
+trainer bookkeeping — everything that is host logic.  Device kernels are not involved: the
+stand-in models below are plain torch modules defined here."""
+import json
+import logging
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import utility.utility_data.data_graph as data_graph
+import utility.utility_data.data_loader as data_loader
+import utility.utility_function.losses as losses
+import utility.utility_function.metrics as metrics
+import utility.utility_function.tools as tools
+import utility.utility_train.batch_test as batch_test
+import utility.utility_train.trainer as trainer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dataset(tmp_path, g, name="small", **cfg):
+    d = tmp_path / name
+    d.mkdir(exist_ok=True)
+    (d / "train.txt").write_bytes(g["train_txt"].tobytes())
+    (d / "test.txt").write_bytes(g["test_txt"].tobytes())
+    config = dict(dataset=name, dataset_path=str(tmp_path) + "/", sparsity_test="0")
+    config.update(cfg)
+    return data_loader.Data(str(d), config), config
+
+
+@pytest.mark.parametrize("gname", ["tiny", "small"])
+def test_data_matches_reference(gname, tmp_path, golden_tiny, golden_small):
+    g = golden_tiny if gname == "tiny" else golden_small
+    data, _ = _dataset(tmp_path, g, gname)
+    assert (data.num_users, data.num_items) == (int(g["num_users"]), int(g["num_items"]))
+    assert (data.num_train, data.num_test) == (int(g["num_train"]), int(g["num_test"]))
+    assert data.get_statistics() == str(g["statistics"])
+    assert np.array_equal(data.train_user, g["train_user"]) and np.array_equal(data.train_item, g["train_item"])
+    assert np.array_equal(data.user_item_net.indptr, g["pos_indptr"])
+    assert np.array_equal(data.user_item_net.indices, g["pos_indices"])
+    assert np.array_equal(data.user_item_net.data, g["pos_data"])
+    assert list(data.test_dict.keys()) == g["test_dict_users"].tolist()
+    assert len(data.all_positive) == data.num_users and data.all_positive[0].dtype == np.int32
+    # the global-stream contract: seed -> sample -> shuffle -> sample -> shuffle
+    tools.set_seed(2024)
+    s1 = data.sample_data_to_train_all()
+    (_, _, _), p1 = tools.shuffle(s1[:, 0], s1[:, 1], s1[:, 2], indices=True)
+    s2 = data.sample_data_to_train_all()
+    _, p2 = tools.shuffle(torch.from_numpy(s2[:, 0]), indices=True)
+    assert np.array_equal(s1, g["sample1"]) and np.array_equal(p1, g["perm1"])
+    assert np.array_equal(s2, g["sample2"]) and np.array_equal(p2, g["perm2"])
+
+
+def test_adjacency_builders_and_cache(tmp_path, golden_tiny):
+    g = golden_tiny
+    data, _ = _dataset(tmp_path, g, "tiny")
+    A = data_graph.sparse_adjacency_matrix(data)
+    assert A.dtype == np.float32 and np.array_equal(A.data, g["adj_data"]) and np.array_equal(A.indices, g["adj_indices"])
+    assert os.path.exists(data.path + "/pre_A.npz")
+    A2 = data_graph.sparse_adjacency_matrix(data)  # second call: cache hit
+    assert (A != A2).nnz == 0
+    As = data_graph.sparse_adjacency_matrix_with_self(data)
+    assert As.dtype == np.float64 and np.array_equal(As.astype(np.float32).data, g["adjself_data"])
+
+
+def test_configuration_files(golden_misc, tmp_path, capsys):
+    ref = json.loads(str(golden_misc["configs"]))
+    for name in ("LightGCN", "MFBPR", "SimGCL"):
+        cfg = tools.read_configuration(os.path.join(ROOT, "configure", name + ".txt"), name)
+        assert cfg == ref[name] and list(cfg) == list(ref[name])  # same keys, values and order
+    p = tmp_path / "bad.txt"
+    p.write_text("a = 1\nno separator here\nb = x = y\nc=3")
+    cfg = tools.read_configuration(str(p), "bad")
+    assert cfg == {"a": "1", "c": "3"}
+    assert capsys.readouterr().out.count("Configuration file format error.") == 2
+    with pytest.raises(IOError):
+        tools.read_configuration(str(tmp_path / "missing.txt"), "missing")
+
+
+def test_parser_defaults_and_bool_quirk():
+    import Parser
+
+    a = Parser.parse_args([])
+    assert (a.seed_flag, a.seed, a.cuda, a.gpu_id, a.model) == (True, 2024, True, 0, "unknown")
+    assert Parser.parse_args(["--cuda", "False"]).cuda is True  # type=bool: any non-empty string is True
+    assert Parser.parse_args(["--model=LightGCN", "--seed", "7"]).model == "LightGCN"
+
+
+def test_mini_batch_and_shuffle_shapes():
+    x, y = np.arange(10), np.arange(10) * 2
+    assert [len(b) for b in tools.mini_batch(x, batch_size=4)] == [4, 4, 2]
+    assert [tuple(map(len, b)) for b in tools.mini_batch(x, y, batch_size=5)] == [(5, 5), (5, 5)]
+    with pytest.raises(ValueError):
+        tools.shuffle(x, y[:3])
+    a, b = tools.shuffle(x, y)
+    assert np.array_equal(b, 2 * a) and sorted(a.tolist()) == list(range(10))
+
+
+def test_metrics_and_losses_vs_reference(golden_misc):
+    g = golden_misc
+    r, test = g["metrics_r"], json.loads(str(g["metrics_test"]))
+    for k in (1, 3, 5):
+        got = [metrics.recall_at_k(r, k, test), metrics.precision_at_k(r, k, test), metrics.ndcg_at_k(r, k, test)]
+        np.testing.assert_allclose(got, g["metrics_k%d" % k], rtol=1e-12)
+    assert np.array_equal(metrics.get_label(test, g["label_pred"]), g["label"])
+    a, b = torch.from_numpy(g["infonce_a"]), torch.from_numpy(g["infonce_b"])
+    np.testing.assert_allclose(losses.get_InfoNCE_loss(a, b, 0.2).item(), g["infonce_02"], rtol=1e-6)
+    np.testing.assert_allclose(losses.get_InfoNCE_loss_all(a, b, torch.cat([b, a]), 0.2).item(), g["infonce_all_02"], rtol=1e-6)
+    np.testing.assert_allclose(losses.get_bpr_loss(a, b, torch.flip(b, [0])).item(), g["bpr_raw"], rtol=1e-6)
+    np.testing.assert_allclose(losses.get_reg_loss(a, b, torch.flip(b, [0])).item(), g["reg_raw"], rtol=1e-6)
+
+
+class _FixedPanels(torch.nn.Module):
+    """Stand-in model: scores from fixed panels with stock torch CPU ops."""
+
+    def __init__(self, users, items):
+        super().__init__()
+        self.u, self.i = torch.from_numpy(users), torch.from_numpy(items)
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def get_rating_for_test(self, user):
+        return torch.sigmoid(self.u[user.long()] @ self.i.t())
+
+
+@pytest.mark.parametrize("topk,key", [("[10, 20]", "d64_lgcn_test_10_20"), ("[20, 40]", "d64_lgcn_test_20_40")])
+def test_evaluator_vs_reference_Test(topk, key, tmp_path, golden_small):
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", top_K=topk, test_batch_size="64")
+    model = _FixedPanels(g["d64_lgcn_user"], g["d64_lgcn_item"])
+    res = batch_test.Test(data, model, torch.device("cpu"), cfg)
+    np.testing.assert_allclose(np.stack([res["recall"], res["precision"], res["ndcg"]]), g[key], rtol=1e-9)
+    assert res["hit"].tolist() == [0.0, 0.0]  # allocated, never filled (batch_test.py:44)
+
+
+def test_general_test_bookkeeping(tmp_path, golden_small, capsys):
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", top_K="[10, 20]", test_batch_size="64", early_stopping="2")
+    model = _FixedPanels(g["d64_lgcn_user"], g["d64_lgcn_item"])
+    best = {'count': 0, 'epoch': 0, 'recall': [0., 0.], 'ndcg': [0., 0.], 'stop': 0}
+    res, best = batch_test.general_test(data, model, "cpu", cfg, 0, best)
+    assert best["epoch"] == 1 and best["count"] == 0 and best["recall"] is res["recall"]
+    res, best = batch_test.general_test(data, model, "cpu", cfg, 10, best)  # no improvement
+    assert best["count"] == 1 and best["stop"] == 0
+    res, best = batch_test.general_test(data, model, "cpu", cfg, 20, best)
+    assert best["stop"] == 99999 and "Early stop" in capsys.readouterr().out
+
+
+class _TinyMF(torch.nn.Module):
+    """Stand-in trainable model (stock torch ops) to exercise the generic trainer path."""
+
+    def __init__(self, U, I):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.u = torch.nn.Parameter(torch.randn(U, 8, generator=g) * 0.1)
+        self.i = torch.nn.Parameter(torch.randn(I, 8, generator=g) * 0.1)
+
+    def forward(self, user, pos, neg):
+        return [losses.get_bpr_loss(self.u[user], self.i[pos], self.i[neg]),
+                1e-4 * losses.get_reg_loss(self.u[user], self.i[pos], self.i[neg])]
+
+    def get_rating_for_test(self, user):
+        return torch.sigmoid(self.u[user.long()] @ self.i.t())
+
+
+def test_universal_trainer_log_format_and_schedule(tmp_path, golden_small):
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", top_K="[5, 10]", test_batch_size="64", batch_size="256",
+                         training_epochs="3", interval="2", early_stopping="10", learn_rate="0.01")
+    stream = io.StringIO()
+    logger = logging.getLogger("test_trainer")
+    logger.setLevel(logging.INFO)
+    logger.handlers = [logging.StreamHandler(stream)]
+    tools.set_seed(2024)
+    model = _TinyMF(data.num_users, data.num_items)
+    w0 = model.u.detach().clone()
+    trainer.universal_trainer(model, None, cfg, data, torch.device("cpu"), logger)
+    lines = stream.getvalue().splitlines()
+    import re
+
+    def shape(line):  # the line with every number masked
+        line = line.replace("Training time: T", "Training time: 0")
+        return re.sub(r"\s+", " ", re.sub(r"[-+]?\d+\.?\d*(?:e[-+]?\d+)?", "#", line)).replace(" ]", "]")
+
+    assert [shape(ln) for ln in lines] == [shape(ln) for ln in g["loop_mf_log"].tolist()]  # same lines, same order
+    assert lines[0].startswith("Epoch:    1 | Training time: ") and " | training loss: " in lines[0]
+    total, parts = lines[0].split("training loss: ")[1].split(" = ")
+    assert abs(float(total) - sum(float(p) for p in parts.split(" + "))) < 2e-6
+    assert lines[1].startswith("Epoch:    1 | Test recall: [") and "| Test NDCG: [" in lines[1]
+    assert lines[-2] == "Model training process completed." and lines[-1].startswith("Best epoch: ")
+    assert not torch.equal(model.u.detach(), w0)
+
+
+def test_models_refuse_cpu_loudly(tmp_path, golden_tiny):
+    """No CPU fallback: on a machine without a HIP device the graph models fail at construction."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from models.LightGCN import LightGCN
+
+    data, cfg = _dataset(tmp_path, golden_tiny, "tiny", embedding_size="64", reg_lambda="1e-4", GCN_layer="3")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        LightGCN(cfg, data, torch.device("cpu"))
