@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--seed", type=int, default=2024)
+    p.add_argument("--force-sharded", action="store_true",
+                   help="run the user-row-sharded path even at world size 1 (exercises the RCCL code path)")
     return p.parse_args()
 
 
@@ -70,16 +72,6 @@ def build_workload(args, rank, world):
         t2 = rng.sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
         tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
     return dict(U=U, I=I, E=len(users), indptr=ip, indices=ix, values=dv, triples=tri, prep_s=time.time() - t0)
-
-
-def xavier_uniform_panel(U, I, d, seed):
-    """nn.init.xavier_uniform_ on each table separately (models/LightGCN.py:27-28)."""
-    g = torch.Generator().manual_seed(seed)
-    out = torch.empty(U + I, d)
-    for lo, hi in ((0, U), (U, U + I)):
-        bound = (6.0 / ((hi - lo) + d)) ** 0.5
-        out[lo:hi] = (torch.rand(hi - lo, d, generator=g) * 2 - 1) * bound
-    return out
 
 
 def cpu_baseline(args, wl, W0):
@@ -120,16 +112,17 @@ def main():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path to time.")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist_
 
         dist = dist_
         dist.init_process_group("nccl")
 
     import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
     from idgrec_amd.engine import PropagationEngine
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         from idgrec_amd.sharded import run_sharded_bench
 
         return run_sharded_bench(args, rank, world, dist)
@@ -140,7 +133,7 @@ def main():
     graph = None
     if args.model == "LightGCN":
         graph = ops.Graph(wl["indptr"], wl["indices"], wl["values"], n, n, split_threshold=args.split)
-    W0 = xavier_uniform_panel(U, I, d, args.seed)
+    W0 = S.xavier_uniform_panel(U, I, d, args.seed)
     eng = PropagationEngine(graph, U, I, d, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
                             deterministic=not args.atomic, params=W0.cuda())
     tri = torch.from_numpy(wl["triples"]).cuda()

@@ -268,6 +268,25 @@ __global__ __launch_bounds__(BLOCK) void adam_kernel(float* __restrict__ p, cons
 #undef IDG_ADAM1
 }
 
+__global__ __launch_bounds__(BLOCK) void lincomb_kernel(float* __restrict__ out, const float* x, float a,
+                                                        const float* y, float b, int64_t n4, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
+    const float4 X = reinterpret_cast<const float4*>(x)[i];
+    float4 R = make_float4(a * X.x, a * X.y, a * X.z, a * X.w);
+    if (y) {
+      const float4 Y = reinterpret_cast<const float4*>(y)[i];
+      R.x = __builtin_fmaf(b, Y.x, R.x);
+      R.y = __builtin_fmaf(b, Y.y, R.y);
+      R.z = __builtin_fmaf(b, Y.z, R.z);
+      R.w = __builtin_fmaf(b, Y.w, R.w);
+    }
+    reinterpret_cast<float4*>(out)[i] = R;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += BLOCK) out[i] = y ? __builtin_fmaf(b, y[i], a * x[i]) : a * x[i];
+}
+
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct BprWs {
@@ -412,6 +431,17 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
   if (rc != IDG_OK) return rc;
   return idg_bpr_backward_f32(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr,
                               g_final, g_ego, deterministic, ws, stream);
+}
+
+int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b, int64_t count, void* stream) {
+  IDG_REQUIRE(out && x && count >= 0, "idg_lincomb_f32: NULL argument / negative count");
+  if (count == 0) return IDG_OK;
+  IDG_REQUIRE(((uintptr_t)out | (uintptr_t)x | (uintptr_t)y) % 16 == 0, "idg_lincomb_f32: pointers must be 16-byte aligned");
+  const int64_t n4 = count / 4;
+  int64_t nb = std::max<int64_t>(1, std::min<int64_t>((n4 + BLOCK - 1) / BLOCK, 256 * 8));
+  hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, out, x, a, y, b, n4, count);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
 }
 
 int idg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,

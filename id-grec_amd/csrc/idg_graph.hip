@@ -562,6 +562,24 @@ int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int6
   return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream);
 }
 
+int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, const float* addend,
+                    const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate, int64_t d, void* ws,
+                    void* stream) {
+  IDG_REQUIRE(g && X && (Y || sum_out), "idg_spmm_ex_f32: NULL argument");
+  IDG_REQUIRE(d > 0 && ldx >= d && ldy >= d, "idg_spmm_ex_f32: bad d/ldx/ldy (%lld,%lld,%lld)", (long long)d,
+              (long long)ldx, (long long)ldy);
+  IDG_REQUIRE(div != 0.0f, "idg_spmm_ex_f32: div must be non-zero");
+  Epilogue ep{};
+  ep.Y = Y;
+  ep.addend = addend;
+  ep.sum_in = sum_in;
+  ep.sum_out = sum_out;
+  ep.ldy = ldy;
+  ep.div = div;
+  ep.accumulate = accumulate;
+  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream);
+}
+
 size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {
   if (!g || d <= 0) return 0;
   // two ping-pong panels + the split-row partials

@@ -55,7 +55,7 @@ class Graph:
     """
 
     def __init__(self, indptr, indices, values, n_rows, n_cols, device=None, symmetric=True, exact_order=False,
-                 split_threshold=0, _transpose_of=None):
+                 split_threshold=0, build_transpose=True, _transpose_of=None):
         if not torch.cuda.is_available():
             raise RuntimeError("idgrec_amd.Graph needs a HIP device (torch.cuda.is_available() is False); "
                                "this library has no CPU path.")
@@ -78,7 +78,7 @@ class Graph:
         self._h = h
         self._ws = {}
         self._T = _transpose_of
-        if not symmetric and _transpose_of is None:
+        if not symmetric and build_transpose and _transpose_of is None:
             import scipy.sparse as sp
 
             At = sp.csr_matrix((values, indices, indptr), shape=(self.n_rows, self.n_cols)).T.tocsr()
@@ -167,6 +167,24 @@ class Graph:
                                              int(bool(accumulate)), _ptr(ws), _stream()),
               "idg_propagate_mean_bwd_f32")
         return out
+
+
+def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False):
+    """idg_spmm_ex_f32: t = A.X (+ addend); Y = t; sum_out (+)= (sum_in + t) / div.  All [*, d] contiguous."""
+    _require_device(X, Y, addend, sum_in, sum_out)
+    d = X.shape[1]
+    for t in (X, Y, addend, sum_in, sum_out):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != d):
+            raise TypeError("spmm_ex_raw needs contiguous float32 [*, %d] panels" % d)
+    ws = graph._workspace("spmm", d)
+    check(lib.idg_spmm_ex_f32(graph._h, _ptr(X), d, _ptr(Y), _ptr(addend), _ptr(sum_in), _ptr(sum_out), d, float(div),
+                              int(bool(accumulate)), d, _ptr(ws), _stream()), "idg_spmm_ex_f32")
+
+
+def lincomb_raw(out, x, a, y=None, b=0.0):
+    """out = a*x + b*y (y may be None)."""
+    _require_device(out, x, y)
+    check(lib.idg_lincomb_f32(_ptr(out), _ptr(x), float(a), _ptr(y), float(b), out.numel(), _stream()), "idg_lincomb_f32")
 
 
 class _SpMM(torch.autograd.Function):
@@ -285,6 +303,22 @@ def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda
     check(lib.idg_bpr_fused_f32(_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos),
                                 _ptr(neg), B, d, float(reg_lambda), _ptr(loss), _ptr(g_final), _ptr(g_ego),
                                 int(bool(deterministic)), _ptr(ws), _stream()), "idg_bpr_fused_f32")
+    return loss
+
+
+def bpr_fwd_bwd_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, upstream, g_final, g_ego, loss,
+                    deterministic=True):
+    """Forward then backward with the two upstream gradient scalars read from the DEVICE tensor
+    `upstream` (the sharded path scales a rank's share of the global batch this way)."""
+    _require_device(final_panel, ego_panel, users, pos, neg, upstream, g_final, g_ego, loss)
+    n, d = final_panel.shape
+    B = users.shape[0]
+    ws = _bpr_ws(B, d, final_panel.device)
+    args = (_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+            float(reg_lambda))
+    check(lib.idg_bpr_forward_f32(*args, _ptr(loss), _ptr(ws), _stream()), "idg_bpr_forward_f32")
+    check(lib.idg_bpr_backward_f32(*args, _ptr(upstream), _ptr(g_final), _ptr(g_ego), int(bool(deterministic)),
+                                   _ptr(ws), _stream()), "idg_bpr_backward_f32")
     return loss
 
 

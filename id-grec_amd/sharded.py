@@ -1,0 +1,324 @@
+"""User-row-sharded LightGCN training step across the GPUs of one node.
+
+The reference is single-device; this is new functionality whose oracle is the single-GPU
+result.  Rank g owns a contiguous, nnz-balanced block of users: their embedding rows (and
+Adam state), the rows R_g of the normalised interaction matrix (U_g x I) and the transposed
+block R_g^T (I x U_g) — both with the GLOBAL d^-1/2 scaling, so the stacked blocks equal the
+single-GPU adjacency.  The item table and its Adam state are replicated.
+
+One propagation layer:      X_U[g] <- R_g . X_I                  (local)
+                            X_I    <- all-reduce_g( R_g^T . X_U[g] )   (RCCL over xGMI)
+so a step costs K all-reduces forward and K + 1 backward of one [I, d] fp32 panel (the extra
+one completes the item-side BPR gradient, whose contributions are spread over the ranks by
+triple ownership).  The item-side product is launched first and its all-reduce overlaps the
+user-side product.  The last backward all-reduce carries the item regulariser gradient too,
+so every rank ends the step with bit-identical item gradients (RCCL all-reduce returns the
+same bits on every rank) and the replicated Adam updates stay coherent without further
+exchange.
+
+The layer loop is written once against two small interfaces — `kernels` (SpMM with fused
+epilogue, fused BPR, Adam, linear combination, allocation) and `comm` (all-reduce) — so the
+world_size-2 gloo tests in tests/ can drive it on CPU with a checker-backed stub while the
+product binds it to the HIP kernels (`HipKernels`) and torch.distributed/RCCL (`TorchComm`).
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------- partitioning
+def partition_users_by_nnz(user_degree, world):
+    """Contiguous user blocks with ~equal stored entries.  Returns bounds[world + 1]."""
+    deg = np.asarray(user_degree, dtype=np.int64)
+    U = len(deg)
+    csum = np.concatenate([[0], np.cumsum(deg)])
+    total = csum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r // world
+        b = int(np.searchsorted(csum, target, side="left"))
+        bounds.append(min(max(b, bounds[-1]), U))
+    bounds.append(U)
+    return np.asarray(bounds, dtype=np.int64)
+
+
+def shard_adjacency(indptr, indices, values, num_users, num_items, u_lo, u_hi):
+    """From the global normalised adjacency CSR ([U+I, U+I], users first) cut
+    R_g   (rows = users [u_lo, u_hi), columns = items 0..I)  and
+    R_g^T (rows = items 0..I, columns = users re-based to 0..u_hi-u_lo).
+    Values are copied, never re-normalised."""
+    U, I = int(num_users), int(num_items)
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices)
+    values = np.asarray(values, dtype=np.float32)
+    # user rows: every column is an item (>= U)
+    s, e = indptr[u_lo], indptr[u_hi]
+    ui_ptr = indptr[u_lo:u_hi + 1] - s
+    ui_idx = (indices[s:e].astype(np.int64) - U).astype(np.int32)
+    ui_val = values[s:e].copy()
+    # item rows: keep the columns that fall in this rank's user block
+    s2, e2 = indptr[U], indptr[U + I]
+    cols = indices[s2:e2].astype(np.int64)
+    keep = (cols >= u_lo) & (cols < u_hi)
+    row_of = np.repeat(np.arange(I, dtype=np.int64), np.diff(indptr[U:U + I + 1]))
+    iu_cnt = np.bincount(row_of[keep], minlength=I)
+    iu_ptr = np.concatenate([[0], np.cumsum(iu_cnt)]).astype(np.int64)
+    iu_idx = (cols[keep] - u_lo).astype(np.int32)
+    iu_val = values[s2:e2][keep].copy()
+    return (ui_ptr, ui_idx, ui_val), (iu_ptr, iu_idx, iu_val)
+
+
+# --------------------------------------------------------------------------- the step
+class ShardedEngine:
+    """One rank's share of the LightGCN step.  Arrays are whatever `kernels` allocates
+    (torch CUDA tensors in the product); row layout of every local panel: this rank's users
+    first ([0, U_g)), then ALL items ([U_g, U_g + I))."""
+
+    def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
+                 reg_lambda=1e-4, lr=1e-3):
+        self.k, self.comm = kernels, comm
+        self.Ug, self.I, self.d, self.K = int(n_local_users), int(num_items), int(dim), int(n_layers)
+        self.c0 = 1 if include_layer0 else 0
+        self.cnt = float(self.K + self.c0)
+        self.reg_lambda, self.lr = float(reg_lambda), float(lr)
+        self.G_ui = kernels.make_graph(*ui_csr, self.Ug, self.I)
+        self.G_iu = kernels.make_graph(*iu_csr, self.I, self.Ug)
+        n = self.Ug + self.I
+        z = kernels.zeros
+        self.P, self.G, self.M, self.V = z((n, dim)), z((n, dim)), z((n, dim)), z((n, dim))
+        self.FIN, self.GF = z((n, dim)), z((n, dim))
+        self.XU = [z((self.Ug, dim)), z((self.Ug, dim))]
+        self.XI = [z((self.I, dim)), z((self.I, dim))]
+        self.loss = z((2,))
+        self.upstream = z((2,))
+        self.step_count = 0
+
+    def _u(self, a):
+        return a[: self.Ug]
+
+    def _i(self, a):
+        return a[self.Ug:]
+
+    # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
+    def propagate(self):
+        k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
+        xu_prev, xi_prev = self._u(self.P), self._i(self.P)
+        fin_u, fin_i = self._u(self.FIN), self._i(self.FIN)
+        for layer in range(1, K + 1):
+            last = layer == K
+            xi_new = self.XI[layer & 1]
+            k.spmm(self.G_iu, xu_prev, Y=xi_new)                       # item-side partial ...
+            work = self.comm.all_reduce_async(xi_new)                  # ... summed over ranks, overlapping:
+            if layer == 1:
+                sum_in = self._u(self.P) if c0 else None
+            else:
+                sum_in = fin_u if (c0 or layer > 2) else xu_prev
+            xu_new = None if last else self.XU[layer & 1]
+            k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0)
+            self.comm.wait(work)
+            scale = 1.0 / cnt if last else 1.0
+            if layer == 1:
+                base = self._i(self.P) if c0 else None
+            else:
+                base = fin_i if (c0 or layer > 2) else xi_prev
+            k.lincomb(fin_i, xi_new, scale, base, scale)
+            xu_prev, xi_prev = xu_new, xi_new
+        return self.FIN
+
+    # ---- backward of the above given GF = d loss / d FIN (item rows still per-rank partials),
+    #      accumulated onto G (which already holds the regulariser gradient, item rows partial)
+    def propagate_backward(self):
+        k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
+        g_u, g_i = self._u(self.GF), self._i(self.GF)
+        self.comm.wait(self.comm.all_reduce_async(g_i))               # complete the item-side gradient
+        h_u, h_i = g_u, g_i
+        for layer in range(K, 1, -1):
+            t_i = self.XI[layer & 1]
+            k.spmm(self.G_iu, h_u, Y=t_i)
+            work = self.comm.all_reduce_async(t_i)
+            t_u = self.XU[layer & 1]
+            k.spmm(self.G_ui, h_i, Y=t_u, addend=g_u)                 # (A h)_U + g_U
+            self.comm.wait(work)
+            k.lincomb(t_i, t_i, 1.0, g_i, 1.0)                        # (A h)_I + g_I
+            h_u, h_i = t_u, t_i
+        # last Horner step, scaled by 1/cnt; regulariser gradients ride along
+        t_i = self.XI[1] if h_i is not self.XI[1] else self.XI[0]
+        k.spmm(self.G_iu, h_u, Y=t_i)
+        k.lincomb(t_i, t_i, 1.0 / cnt, self._i(self.G), 1.0)          # partial/cnt + this rank's item reg grads
+        work = self.comm.all_reduce_async(t_i)
+        k.spmm(self.G_ui, h_i, sum_in=g_u if c0 else None, sum_out=self._u(self.G), div=cnt, accumulate=True)
+        self.comm.wait(work)
+        k.lincomb(self._i(self.G), t_i, 1.0, g_i if c0 else None, 1.0 / cnt)
+        return self.G
+
+    def train_step(self, users_local, pos, neg, global_batch):
+        """users_local: ids re-based to this rank's block; pos/neg: global item ids;
+        global_batch: total triples over all ranks this step (the mean's divisor)."""
+        k = self.k
+        B = len(users_local)
+        self.propagate()
+        k.fill(self.G, 0.0)
+        k.fill(self.GF, 0.0)
+        ratio = float(B) / float(global_batch)
+        if B > 0:
+            k.fill(self.upstream, ratio)
+            k.bpr(self.FIN, self.P, self.Ug, users_local, pos, neg, self.reg_lambda, self.upstream, self.GF, self.G,
+                  self.loss)
+            k.lincomb(self.loss, self.loss, ratio, None, 0.0)         # local mean -> share of the global mean
+        else:
+            k.fill(self.loss, 0.0)
+        loss_work = self.comm.all_reduce_async(self.loss)
+        self.propagate_backward()
+        self.comm.wait(loss_work)
+        self.step_count += 1
+        k.adam(self.P, self.G, self.M, self.V, self.lr, self.step_count)
+        return self.loss
+
+
+# --------------------------------------------------------------------------- product bindings
+class HipKernels:
+    """`kernels` bound to libidgrec.so on the current HIP device."""
+
+    def __init__(self, device=None, deterministic=True):
+        import torch
+
+        from . import ops
+
+        self.torch, self.ops = torch, ops
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.deterministic = deterministic
+
+    def zeros(self, shape):
+        return self.torch.zeros(shape, dtype=self.torch.float32, device=self.device)
+
+    def fill(self, a, v):
+        a.fill_(v)
+
+    def make_graph(self, indptr, indices, values, n_rows, n_cols):
+        # both orientations (R_g and R_g^T) are built explicitly by shard_adjacency
+        return self.ops.Graph(indptr, indices, values, n_rows, n_cols, device=self.device, symmetric=False,
+                              build_transpose=False)
+
+    def spmm(self, graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False):
+        self.ops.spmm_ex_raw(graph, X, Y, addend, sum_in, sum_out, div, accumulate)
+
+    def lincomb(self, out, x, a, y, b):
+        self.ops.lincomb_raw(out, x, a, y, b)
+
+    def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss):
+        self.ops.bpr_fwd_bwd_raw(fin, ego, users, pos, neg, n_users, reg_lambda, upstream, g_final, g_ego, loss,
+                                 self.deterministic)
+
+    def adam(self, p, g, m, v, lr, step):
+        self.ops.adam_step_raw(p, g, m, v, lr, step)
+
+
+class TorchComm:
+    """`comm` on torch.distributed (backend "nccl" == RCCL over xGMI on ROCm).  With the gloo
+    backend (tests: two ranks sharing one GPU, or CPU arrays) device tensors are staged through
+    the host."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.backend = dist.get_backend()
+
+    def all_reduce_async(self, t):
+        import torch
+
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(t)  # shares memory
+        if self.backend == "gloo" and t.is_cuda:
+            host = t.cpu()
+            self.dist.all_reduce(host)
+            t.copy_(host)
+            return None
+        return self.dist.all_reduce(t, async_op=True)
+
+    def wait(self, work):
+        if work is not None:
+            work.wait()
+
+
+class NoComm:
+    """world_size 1."""
+
+    def all_reduce_async(self, t):
+        return None
+
+    def wait(self, work):
+        pass
+
+
+# --------------------------------------------------------------------------- bench driver
+def run_sharded_bench(args, rank, world, dist):
+    """bench.py --gpus N (N > 1): weak scaling — every rank owns a block of the BASELINE-shape
+    user set (U = N x the named shape's users, items fixed), B triples of its own users per
+    step; value = N*B*steps / max-over-ranks time."""
+    import json
+    import time
+
+    import torch
+
+    from . import host as H
+    from . import synth as S
+
+    U1, I, E1 = S.SHAPES[args.workload]
+    U, E = U1 * world, E1 * world
+    users, items = S.generate(U, I, E, seed=0)           # every rank derives the same global graph
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    deg_u = np.bincount(users, minlength=U)
+    bounds = partition_users_by_nnz(deg_u, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    ui, iu = shard_adjacency(ip, ix, dv, U, I, lo, hi)
+    kern = HipKernels(deterministic=not args.atomic)
+    eng = ShardedEngine(kern, TorchComm(dist), ui, iu, hi - lo, I, args.dim, args.layers, True, 1e-4, 1e-3)
+    W0 = S.xavier_uniform_panel(U, I, args.dim, args.seed)  # same initialisation as the single-GPU run
+    eng.P[: hi - lo].copy_(W0[lo:hi])
+    eng.P[hi - lo:].copy_(W0[U:])
+    # this rank's triples: the native sampler over its own users' edges
+    sel = (users >= lo) & (users < hi)
+    lu, li = users[sel] - lo, items[sel]
+    pos_ptr = np.zeros(hi - lo + 1, dtype=np.int64)
+    pos_ptr[1:] = np.cumsum(np.bincount(lu, minlength=hi - lo))
+    rng = H.Rng(args.seed + rank)
+    B = args.batch
+    need = (args.steps + args.warmup) * B
+    tri = np.empty((0, 3), dtype=np.int64)
+    while len(tri) < need:
+        t2 = rng.sample_epoch(lu, li, pos_ptr, li.astype(np.int32), I)
+        tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
+    tri = torch.from_numpy(tri).cuda()
+    tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
+    gB = B * world
+
+    def step(i):
+        s = slice(i * B, (i + 1) * B)
+        return eng.train_step(tu[s], tp[s], tn[s], gB)
+
+    for i in range(args.warmup):
+        step(i)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    if rank == 0:
+        n, nnz = U + I, len(ix)
+        out = {
+            "metric": "BPR triples/sec, LightGCN-%d dim=%d" % (args.layers, args.dim),
+            "value": gB * args.steps / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d x %s-shape user blocks: %d users x %d items, %d train edges, nnz(A)=%d; "
+                                   "LightGCN K=%d d=%d, B=%d per GPU (global %d); user rows sharded, item table "
+                                   "replicated, %d all-reduces of [%d,%d] fp32 per step over RCCL"
+                                   % (world, args.workload, U, I, len(users), nnz, args.layers, args.dim, B, gB,
+                                      2 * args.layers + 1, I, args.dim),
+                       "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "user-row shard x%d" % world},
+            "loss_last": [float(x) for x in eng.loss.cpu()],
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()

@@ -77,3 +77,16 @@ def make_dataset(root, name, shape=None, seed=0, n_test=1):
     write_ratings(os.path.join(d, "train.txt"), tu, ti)
     write_ratings(os.path.join(d, "test.txt"), su, si)
     return d
+
+
+def xavier_uniform_panel(num_users, num_items, d, seed):
+    """[U+I, d] torch CPU tensor: nn.init.xavier_uniform_ applied to the user and the item table
+    separately (models/LightGCN.py:27-28), from torch's CPU generator seeded with `seed`."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    out = torch.empty(num_users + num_items, d)
+    for lo, hi in ((0, num_users), (num_users, num_users + num_items)):
+        bound = (6.0 / ((hi - lo) + d)) ** 0.5
+        out[lo:hi] = (torch.rand(hi - lo, d, generator=g) * 2 - 1) * bound
+    return out

@@ -143,6 +143,14 @@ size_t idg_spmm_workspace_bytes(const idg_graph* g, int64_t d);
 int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
                  const float* addend, int64_t d, void* ws, void* stream);
 
+/* The same product with the whole fused epilogue exposed, for callers that assemble the layer
+ * loop themselves (the user-row-sharded multi-GPU path, where an all-reduce sits between the
+ * layers):  t = A.X (+ addend);  Y = t (if Y);  s = (sum_in ? sum_in + t : t) / div;
+ * sum_out (+)= s (if sum_out; += when accumulate).  All panels share ldy. */
+int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, const float* addend,
+                    const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
+                    int64_t d, void* ws, void* stream);
+
 /* LightGCN.aggregate (models/LightGCN.py:36-52) / SimGCL.aggregate(perturbed=False)
  * (models/SimGCL.py:39-60): out = mean over layers of E_k, E_{k+1} = A.E_k, k < K,
  * E_0 included iff include_layer0.  Running sum left-to-right then a true division by the
@@ -201,6 +209,12 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
 int idg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                       int64_t count, double lr, double beta1, double beta2, double eps,
                       int64_t step, void* stream);
+
+/* out = a*x + b*y over `count` floats (y may be NULL: out = a*x; out may alias x or y).
+ * Glue for the sharded path: adding an all-reduced layer into the running sum, the final
+ * 1/(K+1) scaling, folding the replicated layer-0 term. */
+int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b, int64_t count,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: full-rank scoring, train-positive masking, top-K

@@ -1,0 +1,128 @@
+"""User-row sharding (id-grec_amd/sharded.py): partitioner, shard extraction, and the
+distributed step against the single-device result — world_size 2 over gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(g, K, include0, B, steps, seed=0):
+    U, I = int(g["num_users"]), int(g["num_items"])
+    W0 = np.concatenate([g["d64_init_user"], g["d64_init_item"]])
+    rng = np.random.default_rng(seed)
+    tri = g["sample1"][rng.permutation(len(g["sample1"]))][: B * steps]
+    return dict(indptr=g["adj_indptr"], indices=g["adj_indices"], values=g["adj_data"], W0=W0, triples=tri, U=U, I=I,
+                K=K, B=B, include0=include0)
+
+
+def _single_device_reference(p, steps):
+    """The same steps on one device, by the oracle."""
+    W = p["W0"].copy()
+    m, v = np.zeros_like(W), np.zeros_like(W)
+    adj = (p["indptr"], p["indices"], p["values"])
+    losses = []
+    for s in range(steps):
+        b = p["triples"][s * p["B"]:(s + 1) * p["B"]]
+        fin = oracle.propagate_mean(*adj, W, p["K"], p["include0"])
+        loss, gf, ge = oracle.bpr(fin, W, p["U"], b[:, 0], b[:, 1], b[:, 2], 1e-4)
+        grad = oracle.propagate_mean_bwd(*adj, gf, p["K"], p["include0"]) + ge
+        oracle.adam(W, np.ascontiguousarray(grad), m, v, 1e-3, s + 1)
+        losses.append(loss)
+    return W, fin, grad, np.stack(losses)
+
+
+def _launch(mode, path, steps, world=2):
+    port = _free_port()
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(r), str(world),
+                               str(port), mode, path, str(steps)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [dict(np.load(path + ".out%d.npz" % r)) for r in range(world)]
+
+
+def _check(p, outs, steps, rtol, atol):
+    W, fin, grad, losses = _single_device_reference(p, steps)
+    U = p["U"]
+    for o in outs:
+        lo, hi = int(o["lo"]), int(o["hi"])
+        np.testing.assert_allclose(o["losses"], losses, rtol=rtol)                  # identical on every rank
+        np.testing.assert_allclose(o["FIN"][: hi - lo], fin[lo:hi], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(o["FIN"][hi - lo:], fin[U:], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(o["G"][: hi - lo], grad[lo:hi], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(o["G"][hi - lo:], grad[U:], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(o["P"][: hi - lo], W[lo:hi], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(o["P"][hi - lo:], W[U:], rtol=rtol, atol=atol)
+    # replicated item table: bit-identical across ranks (coherence without an extra exchange)
+    a, b = outs[0], outs[1]
+    assert np.array_equal(a["P"][int(a["hi"]) - int(a["lo"]):], b["P"][int(b["hi"]) - int(b["lo"]):])
+
+
+def test_partition_is_contiguous_and_balanced():
+    import idgrec_amd.sharded as sh
+
+    deg = np.random.default_rng(0).zipf(1.6, 10000).clip(1, 3000)
+    for world in (1, 2, 3, 8):
+        b = sh.partition_users_by_nnz(deg, world)
+        assert b[0] == 0 and b[-1] == len(deg) and (np.diff(b) >= 0).all() and len(b) == world + 1
+        loads = [deg[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(loads) - min(loads) <= 2 * deg.max()
+    assert sh.partition_users_by_nnz(np.zeros(5, dtype=int), 2).tolist()[0::2] == [0, 5]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shards_tile_the_global_adjacency(world, golden_small):
+    import scipy.sparse as sp
+
+    import idgrec_amd.sharded as sh
+
+    g = golden_small
+    U, I = int(g["num_users"]), int(g["num_items"])
+    A = sp.csr_matrix((g["adj_data"], g["adj_indices"], g["adj_indptr"]), shape=(U + I, U + I))
+    b = sh.partition_users_by_nnz(np.diff(g["adj_indptr"][: U + 1]), world)
+    acc_iu = sp.csr_matrix((I, U), dtype=np.float32)
+    for r in range(world):
+        lo, hi = int(b[r]), int(b[r + 1])
+        (p1, i1, v1), (p2, i2, v2) = sh.shard_adjacency(g["adj_indptr"], g["adj_indices"], g["adj_data"], U, I, lo, hi)
+        ui = sp.csr_matrix((v1, i1, p1), shape=(hi - lo, I))
+        assert (ui != A[lo:hi, U:]).nnz == 0                       # R_g: same values, same order
+        iu = sp.csr_matrix((v2, i2, p2), shape=(I, hi - lo))
+        assert (iu != A[U:, lo:hi]).nnz == 0                       # R_g^T
+        assert (iu != ui.T).nnz == 0
+        pad = sp.hstack([sp.csr_matrix((I, lo)), iu, sp.csr_matrix((I, U - hi))]).tocsr()
+        acc_iu = acc_iu + pad
+    assert (acc_iu != A[U:, :U]).nnz == 0
+
+
+@pytest.mark.parametrize("K,include0", [(3, True), (2, False), (1, True)])
+def test_two_ranks_gloo_cpu_match_single_device(K, include0, tmp_path, golden_small):
+    p = _problem(golden_small, K, include0, B=160, steps=3)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("cpu", path, 3)
+    _check(p, outs, 3, rtol=1e-4, atol=2e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,include0", [(3, True), (2, False)])
+def test_two_ranks_hip_kernels_match_single_device(K, include0, tmp_path, golden_small):
+    p = _problem(golden_small, K, include0, B=160, steps=3)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("gpu", path, 3)
+    _check(p, outs, 3, rtol=1e-4, atol=2e-7)
