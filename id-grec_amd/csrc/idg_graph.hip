@@ -3,7 +3,9 @@
 // Work decomposition (all fixed at idg_graph_create, so results are run-to-run identical):
 //   * every CSR row is one "virtual row" (vrow); a row with more than `split_threshold`
 //     stored entries is cut into segments of seg_len(row) entries, each its own vrow that
-//     produces a partial sum; a fix-up kernel adds the partials in segment order.
+//     produces a partial sum; a fix-up kernel adds the partials in a fixed 4-way strided
+//     order (partials q, q+4, q+8, ... summed in order for q = 0..3, the four sums then
+//     added left to right).
 //   * consecutive vrows are packed into tiles of <= TILE_NNZ entries and <= TILE_VROWS
 //     vrows.  One 256-thread workgroup per tile stages the tile's (column,value) pairs and
 //     vrow pointers in LDS with coalesced loads, then LPR = d/4 lanes walk one vrow each:
@@ -15,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -22,10 +25,12 @@
 
 namespace {
 
-constexpr int TILE_NNZ = 2048;    // entries staged in LDS per workgroup (16 KiB)
+constexpr int TILE_NNZ = 2048;    // LDS capacity: entries staged per workgroup (16 KiB)
 constexpr int TILE_VROWS = 256;   // vrows per workgroup
 constexpr int BLOCK = 256;
-constexpr int64_t DEFAULT_SPLIT = 256;
+constexpr int64_t DEFAULT_SPLIT = 128;
+constexpr int DEFAULT_TILE_CAP = 512;  // entries per tile: small tiles even out work per CU (measured, profiles/r01)
+constexpr int FIX_WAYS = 4;            // lane groups that share one split row in the fix-up pass
 
 struct __attribute__((aligned(16))) Tile {
   int64_t nnz_begin;
@@ -63,6 +68,8 @@ struct idg_graph {
   uint32_t flags = 0;
   int64_t split_threshold = 0;
   int64_t n_vrows = 0, n_tiles = 0, n_long = 0, n_slots = 0, n_xl = 0;
+  int variant = 5;  // tuning knob (IDG_SPMM_VARIANT), see launch_fast
+  int64_t tile_cap = DEFAULT_TILE_CAP;  // entries per tile (IDG_TILE_NNZ, <= TILE_NNZ)
   // device
   ColVal* d_cv = nullptr;
   int64_t* d_vptr = nullptr;   // [n_vrows+1]
@@ -107,11 +114,22 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, in
 }
 
 // Sequential walk of entries [s, e) of a (col,val) list; CV may be LDS or global.
-template <typename CVPtr>
+// UNROLL panel rows are in flight per lane group; the fmaf chain stays strictly in order.
+template <int UNROLL, typename CVPtr>
 __device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __restrict__ Xl,
                                        int64_t ldx, float4 acc) {
   int j = s;
-  for (; j + 8 <= e; j += 8) {
+  for (; j + UNROLL <= e; j += UNROLL) {
+    ColVal p[UNROLL];
+    float4 x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) p[u] = cv[j + u];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc = fma4(p[u].val, x[u], acc);
+  }
+  if (UNROLL > 8 && j + 8 <= e) {
     ColVal p[8];
     float4 x[8];
 #pragma unroll
@@ -120,6 +138,7 @@ __device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __re
     for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc = fma4(p[u].val, x[u], acc);
+    j += 8;
   }
   if (j + 4 <= e) {
     ColVal p[4];
@@ -141,9 +160,10 @@ __device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __re
 }
 
 // One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
-// every feature block of width 4*LPR (d = NB * 4 * LPR).
-template <int LPR, int NB>
-__global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(const Tile* __restrict__ tiles,
+// every feature block of width 4*LPR (d = NB * 4 * LPR).  DYNAMIC: lane groups draw the next
+// vrow from an LDS counter instead of a fixed stride (evens out skewed row lengths).
+template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1>
+__global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __restrict__ tiles,
                                                           const int64_t* __restrict__ vptr,
                                                           const int32_t* __restrict__ vtgt,
                                                           const ColVal* __restrict__ cv,
@@ -153,11 +173,14 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(const Tile* __restrict
   __shared__ ColVal s_cv[TILE_NNZ];
   __shared__ int s_ptr[TILE_VROWS + 1];
   __shared__ int s_tgt[TILE_VROWS];
+  __shared__ int s_next;
 
   const Tile t = tiles[blockIdx.x];
   const int tid = threadIdx.x;
   const int nv = t.n_vrows;
   const int64_t nz0 = t.nnz_begin;
+  constexpr int GROUPS = BLOCK / LPR;
+  if (DYNAMIC && tid == 0) s_next = GROUPS;
   for (int i = tid; i <= nv; i += BLOCK) s_ptr[i] = (int)(vptr[t.vrow_begin + i] - nz0);
   for (int i = tid; i < nv; i += BLOCK) s_tgt[i] = vtgt[t.vrow_begin + i];
   const int cnt = (int)(vptr[t.vrow_begin + nv] - nz0);
@@ -167,22 +190,29 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(const Tile* __restrict
   }
   __syncthreads();
 
-  constexpr int GROUPS = BLOCK / LPR;
   const int g = tid / LPR;
   const int l = tid % LPR;
-  for (int v = g; v < nv; v += GROUPS) {
+  int v = g;
+  while (v < nv) {
     const int s = s_ptr[v], e = s_ptr[v + 1];
     const int tgt = s_tgt[v];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int off = (b * LPR + l) * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = walk(s_cv, s, e, X + off, ldx, acc);
+      acc = walk<UNROLL>(s_cv, s, e, X + off, ldx, acc);
       if (tgt >= 0) {
         epilogue_store(ep, tgt, off, acc);
       } else {
         *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
       }
+    }
+    if (DYNAMIC) {
+      int nxt = 0;
+      if (l == 0) nxt = atomicAdd(&s_next, 1);
+      v = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
+    } else {
+      v += GROUPS;
     }
   }
 }
@@ -206,37 +236,47 @@ __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t c = s; c < e; c += (1 << 20)) {
       const int len = (int)std::min<int64_t>(e - c, 1 << 20);
-      acc = walk(cv + c, 0, len, X + off, ldx, acc);
+      acc = walk<8>(cv + c, 0, len, X + off, ldx, acc);
     }
     epilogue_store(ep, tgt, off, acc);
   }
 }
 
-// Fix-up: one lane group per split row adds its partials in segment order.
+// Fix-up: FIX_WAYS lane groups per split row.  Group q adds partials q, q+W, q+2W, ... in that
+// order; the W group sums are then added left to right (q = 0 first).  Fixed, published order.
 template <int LPR, int NB>
-__global__ __launch_bounds__(BLOCK) void spmm_fixup_kernel(const LongRow* __restrict__ rows, int n_long,
-                                                           const float* __restrict__ partials, int64_t d,
-                                                           Epilogue ep) {
-  constexpr int GROUPS = BLOCK / LPR;
-  const int g = blockIdx.x * GROUPS + threadIdx.x / LPR;
+__global__ __launch_bounds__(FIX_WAYS * LPR) void spmm_fixup_kernel(const LongRow* __restrict__ rows, int n_long,
+                                                                    const float* __restrict__ partials, int64_t d,
+                                                                    Epilogue ep) {
+  __shared__ float4 s_part[FIX_WAYS][LPR];
+  const int q = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
-  if (g >= n_long) return;
-  const LongRow lr = rows[g];
+  const LongRow lr = rows[blockIdx.x];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int off = (b * LPR + l) * 4;
     const float* p = partials + lr.slot_begin * d + off;
-    float4 acc = *reinterpret_cast<const float4*>(p);
-    int sgm = 1;
-    for (; sgm + 8 <= lr.n_seg; sgm += 8) {
-      float4 x[8];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < lr.n_seg) {
+      acc = *reinterpret_cast<const float4*>(p + (int64_t)q * d);
+      int sgm = q + FIX_WAYS;
+      for (; sgm + 7 * FIX_WAYS < lr.n_seg; sgm += 8 * FIX_WAYS) {
+        float4 x[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(p + (int64_t)(sgm + u) * d);
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(p + (int64_t)(sgm + u * FIX_WAYS) * d);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc = add4(acc, x[u]);
+        for (int u = 0; u < 8; ++u) acc = add4(acc, x[u]);
+      }
+      for (; sgm < lr.n_seg; sgm += FIX_WAYS) acc = add4(acc, *reinterpret_cast<const float4*>(p + (int64_t)sgm * d));
     }
-    for (; sgm < lr.n_seg; ++sgm) acc = add4(acc, *reinterpret_cast<const float4*>(p + (int64_t)sgm * d));
-    epilogue_store(ep, lr.row, off, acc);
+    if (b > 0) __syncthreads();
+    s_part[q][l] = acc;
+    __syncthreads();
+    if (q == 0) {
+      const int ways = lr.n_seg < FIX_WAYS ? lr.n_seg : FIX_WAYS;
+      for (int w = 1; w < ways; ++w) acc = add4(acc, s_part[w][l]);
+      epilogue_store(ep, lr.row, off, acc);
+    }
   }
 }
 
@@ -280,8 +320,12 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
   const LongRow lr = rows[g];
   for (int64_t f = l; f < d; f += 64) {
     const float* p = partials + lr.slot_begin * d + f;
-    float acc = p[0];
-    for (int sgm = 1; sgm < lr.n_seg; ++sgm) acc += p[(int64_t)sgm * d];
+    float acc = 0.f;
+    for (int q = 0; q < FIX_WAYS && q < lr.n_seg; ++q) {  // same order as spmm_fixup_kernel
+      float a = p[(int64_t)q * d];
+      for (int sgm = q + FIX_WAYS; sgm < lr.n_seg; sgm += FIX_WAYS) a += p[(int64_t)sgm * d];
+      acc = q == 0 ? a : acc + a;
+    }
     const int64_t o = (int64_t)lr.row * ep.ldy + f;
     if (ep.addend) acc += ep.addend[o];
     if (ep.Y) ep.Y[o] = acc;
@@ -297,17 +341,28 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
 template <int LPR, int NB>
 int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials, int64_t d,
                 const Epilogue& ep, hipStream_t st) {
-  if (g->n_tiles > 0)
-    hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB>), dim3((unsigned)g->n_tiles), dim3(BLOCK), 0, st, g->d_tiles,
-                       g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep);
+  if (g->n_tiles > 0) {
+    const dim3 grid((unsigned)g->n_tiles), block(BLOCK);
+#define IDG_TILE(U, DYN, ...)                                                                                \
+  hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, ##__VA_ARGS__>), grid, block, 0, st, g->d_tiles, g->d_vptr, \
+                     g->d_vtgt, g->d_cv, X, ldx, partials, d, ep)
+    switch (g->variant) {
+      case 1: IDG_TILE(8, true); break;
+      case 2: IDG_TILE(16, false); break;
+      case 3: IDG_TILE(16, true); break;
+      case 4: IDG_TILE(4, true); break;
+      case 5: IDG_TILE(8, true, 8); break;
+      case 6: IDG_TILE(6, true, 8); break;
+      default: IDG_TILE(8, false); break;
+    }
+#undef IDG_TILE
+  }
   if (g->n_xl > 0)
     hipLaunchKernelGGL((spmm_xl_kernel<LPR, NB>), dim3((unsigned)g->n_xl), dim3(64), 0, st, g->d_xl, g->d_vptr,
                        g->d_vtgt, g->d_cv, X, ldx, ep);
   if (g->n_long > 0) {
-    constexpr int GROUPS = BLOCK / LPR;
-    const unsigned nb = (unsigned)((g->n_long + GROUPS - 1) / GROUPS);
-    hipLaunchKernelGGL((spmm_fixup_kernel<LPR, NB>), dim3(nb), dim3(BLOCK), 0, st, g->d_long, (int)g->n_long,
-                       partials, d, ep);
+    hipLaunchKernelGGL((spmm_fixup_kernel<LPR, NB>), dim3((unsigned)g->n_long), dim3(FIX_WAYS * LPR), 0, st,
+                       g->d_long, (int)g->n_long, partials, d, ep);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
@@ -412,6 +467,8 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   g->n_cols = n_cols;
   g->nnz = nnz;
   g->flags = flags;
+  if (const char* v = std::getenv("IDG_SPMM_VARIANT")) g->variant = std::atoi(v);
+  if (const char* v = std::getenv("IDG_TILE_NNZ")) g->tile_cap = std::min<int64_t>(std::max(64, std::atoi(v)), TILE_NNZ);
   const bool exact = (flags & IDG_GRAPH_EXACT_ORDER) != 0;
   int64_t T = split_threshold > 0 ? split_threshold : DEFAULT_SPLIT;
   T = std::min<int64_t>(T, TILE_NNZ);
@@ -466,7 +523,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
       }
       int64_t w = v;
       const int64_t nz0 = vptr[(size_t)v];
-      while (w < nv && w - v < TILE_VROWS && vptr[(size_t)w + 1] - nz0 <= TILE_NNZ) ++w;
+      while (w < nv && w - v < TILE_VROWS && (w == v || vptr[(size_t)w + 1] - nz0 <= g->tile_cap)) ++w;
       Tile t;
       t.nnz_begin = nz0;
       t.vrow_begin = (int32_t)v;

@@ -26,7 +26,7 @@ class Rng:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.idg_rng_destroy(h)
 
     def get_state(self):

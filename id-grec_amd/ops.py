@@ -95,7 +95,7 @@ class Graph:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:  # module globals are already gone at interpreter shutdown
             lib.idg_graph_destroy(h)
 
     @property

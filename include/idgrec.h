@@ -121,7 +121,8 @@ typedef struct idg_graph idg_graph;
 
 /* CSR arrays are HOST pointers; the handle uploads and owns device copies plus its
  * row-block tile schedule.  split_threshold: rows with more stored entries than this are
- * cut into chunks summed in chunk order (0 = library default; ignored with EXACT_ORDER). */
+ * cut into segments summed in a fixed published order (0 = library default 128; ignored with
+ * EXACT_ORDER). */
 int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                      const int32_t* indices, const float* values, uint32_t flags,
                      int64_t split_threshold, idg_graph** out);
@@ -129,9 +130,10 @@ int idg_graph_destroy(idg_graph* g);
 /* info[0..7] = n_rows, n_cols, nnz, n_tiles, n_long_rows, n_long_chunks, split_threshold, flags */
 int idg_graph_info(const idg_graph* g, int64_t info[8]);
 /* The split schedule, so a checker can restate the exact summation order: row
- * long_rows[i] is summed as consecutive segments of seg_len[i] stored entries, each a
- * sequential fmaf chain from 0, then the partials are added left to right starting from
- * the first.  Both arrays hold n_long_rows (info[4]) elements; either may be NULL. */
+ * long_rows[i] is cut into consecutive segments of seg_len[i] stored entries, each a
+ * sequential fmaf chain from +0.  Segment partials p_0, p_1, ... are combined 4-way strided:
+ * s_q = p_q + p_{q+4} + p_{q+8} + ... (left to right) for q = 0..3, row = ((s_0 + s_1) + s_2) + s_3
+ * (absent s_q skipped).  Both arrays hold n_long_rows (info[4]) elements; either may be NULL. */
 int idg_graph_long_rows(const idg_graph* g, int64_t* long_rows, int64_t* seg_len);
 
 /* Y = A.X  (torch.sparse.mm(Graph, X): models/LightGCN.py:44, SimGCL.py:48, XSimGCL.py:51,

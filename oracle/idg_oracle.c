@@ -34,21 +34,25 @@ void orc_spmm_f32(int64_t n_rows, const int64_t* indptr, const int32_t* indices,
 }
 
 /* Same product under libidgrec's published split schedule (include/idgrec.h,
- * idg_graph_long_rows): the rows listed in long_rows (ascending) are summed as consecutive
- * segments of seg_len[i] entries, each a fmaf chain from +0, partials added left to right.
- * All other rows are the plain sequential chain.  This is a restatement of the summation
- * ORDER only; the operands are the reference's. */
+ * idg_graph_long_rows): the rows listed in long_rows (ascending) are cut into consecutive
+ * segments of seg_len[i] entries, each a fmaf chain from +0; the segment partials are combined
+ * 4-way strided: s_q = p_q + p_{q+4} + ... for q = 0..3, row = ((s_0 + s_1) + s_2) + s_3.
+ * All other rows are the plain sequential chain.  This restates the summation ORDER only;
+ * the operands are the reference's. */
 void orc_spmm_sched_f32(int64_t n_rows, const int64_t* indptr, const int32_t* indices, const float* values,
                         const float* X, int64_t d, const int64_t* long_rows, const int64_t* seg_len,
                         int64_t n_long, float* Y) {
+  enum { WAYS = 4 };
   int64_t li = 0;
   float* part = (float*)malloc((size_t)d * sizeof(float));
+  float* way = (float*)malloc((size_t)d * WAYS * sizeof(float));
   for (int64_t r = 0; r < n_rows; ++r) {
     float* y = Y + r * d;
     const int64_t s = indptr[r], e = indptr[r + 1];
     if (li < n_long && long_rows[li] == r) {
       const int64_t S = seg_len[li++];
-      for (int64_t b = s, seg = 0; b < e; b += S, ++seg) {
+      int64_t nseg = 0;
+      for (int64_t b = s; b < e; b += S, ++nseg) {
         const int64_t be = b + S < e ? b + S : e;
         for (int64_t f = 0; f < d; ++f) part[f] = 0.0f;
         for (int64_t k = b; k < be; ++k) {
@@ -56,13 +60,15 @@ void orc_spmm_sched_f32(int64_t n_rows, const int64_t* indptr, const int32_t* in
           const float* x = X + (int64_t)indices[k] * d;
           for (int64_t f = 0; f < d; ++f) part[f] = fmaf(v, x[f], part[f]);
         }
-        if (seg == 0)
-          for (int64_t f = 0; f < d; ++f) y[f] = part[f];
+        float* w = way + (nseg % WAYS) * d;
+        if (nseg < WAYS)
+          for (int64_t f = 0; f < d; ++f) w[f] = part[f];
         else
-          for (int64_t f = 0; f < d; ++f) y[f] = y[f] + part[f];
+          for (int64_t f = 0; f < d; ++f) w[f] = w[f] + part[f];
       }
-      if (s == e)
-        for (int64_t f = 0; f < d; ++f) y[f] = 0.0f;
+      for (int64_t f = 0; f < d; ++f) y[f] = nseg > 0 ? way[f] : 0.0f;
+      for (int64_t q = 1; q < WAYS && q < nseg; ++q)
+        for (int64_t f = 0; f < d; ++f) y[f] = y[f] + way[q * d + f];
     } else {
       for (int64_t f = 0; f < d; ++f) y[f] = 0.0f;
       for (int64_t k = s; k < e; ++k) {
@@ -73,6 +79,7 @@ void orc_spmm_sched_f32(int64_t n_rows, const int64_t* indptr, const int32_t* in
     }
   }
   free(part);
+  free(way);
 }
 
 /* LightGCN.aggregate (models/LightGCN.py:36-52) with include_layer0 = 1;

@@ -51,9 +51,14 @@ def random_csr(n_rows, n_cols, avg, seed, hubs=()):
 def test_spmm_bit_exact_vs_reference_torch_cpu(ops, gname, d, golden_tiny, golden_small):
     g = golden_tiny if gname == "tiny" else golden_small
     E0 = np.concatenate([g["d%d_init_user" % d], g["d%d_init_item" % d]])
-    for kw in (dict(exact_order=True), dict()):  # no row of these graphs exceeds the default split
+    for kw in (dict(exact_order=True), dict(split_threshold=2048)):  # no row is split
         Y = ops.spmm(_graph(ops, g, **kw), dev(E0)).cpu().numpy()
         assert np.array_equal(Y, g["d%d_spmm1" % d])
+    # default handle: rows above the default threshold follow the published split order
+    G = _graph(ops, g)
+    Y = ops.spmm(G, dev(E0)).cpu().numpy()
+    assert np.array_equal(Y, oracle.spmm(*_adj(g), E0, *G.long_rows()))
+    np.testing.assert_allclose(Y, g["d%d_spmm1" % d], rtol=1e-5, atol=1e-8)
 
 
 @pytest.mark.parametrize("d", [32, 64, 128, 256, 512, 48, 7])
@@ -118,19 +123,26 @@ def test_propagate_mean_bit_exact_vs_reference_aggregate(ops, gname, d, golden_t
     g = golden_tiny if gname == "tiny" else golden_small
     U = int(g["num_users"])
     E0 = dev(np.concatenate([g["d%d_init_user" % d], g["d%d_init_item" % d]]))
-    G = _graph(ops, g)
+    G = _graph(ops, g, exact_order=True)
     out = ops.propagate_mean(G, E0, 3, True).cpu().numpy()
     assert np.array_equal(out[:U], g["d%d_lgcn_user" % d]) and np.array_equal(out[U:], g["d%d_lgcn_item" % d])
     out = ops.propagate_mean(G, E0, 3, False).cpu().numpy()
     assert np.array_equal(out[:U], g["d%d_simgcl_user" % d]) and np.array_equal(out[U:], g["d%d_simgcl_item" % d])
+    # default handle (hub rows split): within fp32 rounding of the reference
+    out = ops.propagate_mean(_graph(ops, g), E0, 3, True).cpu().numpy()
+    np.testing.assert_allclose(out[:U], g["d%d_lgcn_user" % d], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(out[U:], g["d%d_lgcn_item" % d], rtol=1e-5, atol=1e-8)
 
 
 @pytest.mark.parametrize("K,inc", [(1, True), (1, False), (2, True), (2, False), (4, True), (4, False)])
 def test_propagate_mean_layer_counts(ops, K, inc, golden_small):
     g = golden_small
     E0 = np.concatenate([g["d64_init_user"], g["d64_init_item"]])
-    out = ops.propagate_mean(_graph(ops, g), dev(E0), K, inc).cpu().numpy()
-    assert np.array_equal(out, oracle.propagate_mean(*_adj(g), E0, K, inc))
+    G = _graph(ops, g)
+    out = ops.propagate_mean(G, dev(E0), K, inc).cpu().numpy()
+    assert np.array_equal(out, oracle.propagate_mean(*_adj(g), E0, K, inc, *G.long_rows()))
+    Ge = _graph(ops, g, exact_order=True)
+    assert np.array_equal(ops.propagate_mean(Ge, dev(E0), K, inc).cpu().numpy(), oracle.propagate_mean(*_adj(g), E0, K, inc))
 
 
 @pytest.mark.parametrize("K,inc", [(3, True), (3, False), (1, True), (2, False)])
