@@ -43,7 +43,6 @@ struct BprArgs {
   float* g_ego;
   const float* upstream;  // device [2]: d total / d loss[0], d total / d loss[1]; NULL = ones
   int atomic;
-  int emit_keys;
 };
 
 __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
@@ -84,15 +83,21 @@ __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
     a.sq[i] = qu;
     a.sq[a.B + i] = qp;
     a.sq[2 * a.B + i] = qn;
-    if (a.emit_keys) {
-      a.keys[3 * i + 0] = (int32_t)ru;
-      a.keys[3 * i + 1] = (int32_t)rp;
-      a.keys[3 * i + 2] = (int32_t)rn;
-      a.slots[3 * i + 0] = (int32_t)(3 * i + 0);
-      a.slots[3 * i + 1] = (int32_t)(3 * i + 1);
-      a.slots[3 * i + 2] = (int32_t)(3 * i + 2);
-    }
   }
+}
+
+// (row, slot) keys of the 3B gradient contributions of a batch: depends on the indices only.
+__global__ __launch_bounds__(BLOCK) void bpr_keys_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+                                                         const int64_t* __restrict__ neg, int64_t B, int64_t num_users,
+                                                         int32_t* __restrict__ keys, int32_t* __restrict__ slots) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= B) return;
+  keys[3 * i + 0] = (int32_t)users[i];
+  keys[3 * i + 1] = (int32_t)(num_users + pos[i]);
+  keys[3 * i + 2] = (int32_t)(num_users + neg[i]);
+  slots[3 * i + 0] = (int32_t)(3 * i + 0);
+  slots[3 * i + 1] = (int32_t)(3 * i + 1);
+  slots[3 * i + 2] = (int32_t)(3 * i + 2);
 }
 
 // Backward, atomic form: one wave per triple, float atomics into the gradient rows.
@@ -369,12 +374,49 @@ int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_
   int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
                     "idg_bpr_forward_f32");
   if (rc != IDG_OK) return rc;
-  a.emit_keys = 1;
   const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
   hipLaunchKernelGGL(bpr_triple_kernel, dim3(nb), dim3(BLOCK), 0, st, a);
   hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, a.loss_i, a.sq, B, reg_lambda, loss);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
+}
+
+static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
+                         int64_t n, void* ws, hipStream_t st, const char* who) {
+  if (!(users && pos && neg && ws)) return idg::fail(IDG_E_INVALID, "%s: NULL argument", who);
+  if (!(B > 0 && num_users >= 0 && n >= num_users)) return idg::fail(IDG_E_INVALID, "%s: bad sizes", who);
+  if (n >= ((int64_t)1 << 31) || 3 * B >= ((int64_t)1 << 31)) return idg::fail(IDG_E_INVALID, "%s: sizes exceed int32 keys", who);
+  const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
+  char* base = reinterpret_cast<char*>(ws);
+  int32_t* keys = reinterpret_cast<int32_t*>(base + w.keys);
+  int32_t* slots = reinterpret_cast<int32_t*>(base + w.slots);
+  int32_t* skeys = reinterpret_cast<int32_t*>(base + w.skeys);
+  int32_t* sslots = reinterpret_cast<int32_t*>(base + w.sslots);
+  hipLaunchKernelGGL(bpr_keys_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, pos, neg, B,
+                     num_users, keys, slots);
+  const int64_t n3 = 3 * B;
+  if (n3 <= LDS_SORT_MAX) {
+    int p2 = 1;
+    while (p2 < n3) p2 <<= 1;
+    hipLaunchKernelGGL(lds_sort_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, keys, slots, (int)n3, p2, skeys, sslots);
+  } else {
+    int end_bit = 1;
+    while (((int64_t)1 << end_bit) < n) ++end_bit;
+    size_t need = 0;
+    IDG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, skeys, slots, sslots, (int)n3, 0, end_bit, st));
+    const size_t have = cub_temp_bound(n3);
+    if (need > have)
+      return idg::fail(IDG_E_UNSUPPORTED, "%s: radix sort wants %zu scratch bytes, layout reserves %zu", who, need, have);
+    size_t tb = have;
+    IDG_HIP(hipcub::DeviceRadixSort::SortPairs(base + w.temp, tb, keys, skeys, slots, sslots, (int)n3, 0, end_bit, st));
+  }
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
+                     int64_t n, void* ws, void* stream) {
+  return bpr_sort_plan(users, pos, neg, B, num_users, n, ws, (hipStream_t)stream, "idg_bpr_plan_f32");
 }
 
 int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
@@ -396,26 +438,13 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
     const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
     hipLaunchKernelGGL(bpr_atomic_kernel, dim3(nb), dim3(BLOCK), 0, st, a);
   } else {
-    const int64_t n3 = 3 * B;
-    int32_t* skeys = reinterpret_cast<int32_t*>(base + w.skeys);
-    int32_t* sslots = reinterpret_cast<int32_t*>(base + w.sslots);
-    if (n3 <= LDS_SORT_MAX) {
-      int p2 = 1;
-      while (p2 < n3) p2 <<= 1;
-      hipLaunchKernelGGL(lds_sort_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, a.keys, a.slots, (int)n3, p2,
-                         skeys, sslots);
-    } else {
-      int end_bit = 1;
-      while (((int64_t)1 << end_bit) < n) ++end_bit;
-      size_t need = 0;
-      IDG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, a.keys, skeys, a.slots, sslots, (int)n3, 0, end_bit, st));
-      const size_t have = cub_temp_bound(n3);
-      if (need > have)
-        return idg::fail(IDG_E_UNSUPPORTED, "idg_bpr_backward_f32: radix sort wants %zu scratch bytes, layout reserves %zu",
-                         need, have);
-      size_t tb = have;
-      IDG_HIP(hipcub::DeviceRadixSort::SortPairs(base + w.temp, tb, a.keys, skeys, a.slots, sslots, (int)n3, 0, end_bit, st));
+    if (deterministic != IDG_BPR_PLANNED) {
+      rc = bpr_sort_plan(users, pos, neg, B, num_users, n, ws, st, "idg_bpr_backward_f32");
+      if (rc != IDG_OK) return rc;
     }
+    const int64_t n3 = 3 * B;
+    const int32_t* skeys = reinterpret_cast<const int32_t*>(base + w.skeys);
+    const int32_t* sslots = reinterpret_cast<const int32_t*>(base + w.sslots);
     const unsigned nb3 = (unsigned)((n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
     hipLaunchKernelGGL(bpr_scatter_kernel, dim3(nb3), dim3(BLOCK), 0, st, a, skeys, sslots);
   }

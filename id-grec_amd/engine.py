@@ -37,6 +37,7 @@ class PropagationEngine:
         self.loss = torch.zeros(2, **f32)
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
+        self._side = None   # side stream for index-only work
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
     # ---- views handed to nn.Embedding
@@ -63,20 +64,34 @@ class PropagationEngine:
     @torch.no_grad()
     def loss_and_grad(self, users, pos, neg, loss_out=None):
         loss = self.loss if loss_out is None else loss_out
+        det = int(self.deterministic)
+        plan_done = None
+        if self.deterministic and self.graph is not None:
+            # the (row, slot) sort needs only the indices: run it on a side stream under the forward propagation
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(main)  # the previous step's scatter has consumed the old plan
+            with torch.cuda.stream(self._side):
+                ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d)
+                plan_done = self._side.record_event()
+            det = 2
         self.grad.zero_()
         if self.graph is not None:
             ev = self._mark()
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final)
             self._mark(ev)
             self.g_final.zero_()
+            if plan_done is not None:
+                torch.cuda.current_stream().wait_event(plan_done)
             ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
-                              self.grad, loss=loss, deterministic=self.deterministic)
+                              self.grad, loss=loss, deterministic=det)
             ev = self._mark()
             self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True)
             self._mark(ev)
         else:
             ops.bpr_fused_raw(self.params, self.params, users, pos, neg, self.U, self.reg_lambda, self.grad,
-                              self.grad, loss=loss, deterministic=self.deterministic)
+                              self.grad, loss=loss, deterministic=det)
         self._final_version = -1
         return loss
 

@@ -292,9 +292,21 @@ class _BprLossSame(torch.autograd.Function):
         return g[0], None, None, None, None, None, None
 
 
+def bpr_plan_raw(users, pos, neg, num_users, n, d):
+    """Sort this batch's (row, slot) pairs into the BPR workspace (idg_bpr_plan_f32) on the CURRENT
+    stream.  Index-only work: run it on a side stream while the propagation is in flight, then call
+    bpr_fused_raw(..., deterministic=2)."""
+    _require_device(users, pos, neg)
+    B = users.shape[0]
+    ws = _bpr_ws(B, d, users.device)
+    check(lib.idg_bpr_plan_f32(_ptr(users), _ptr(pos), _ptr(neg), B, int(num_users), int(n), _ptr(ws), _stream()),
+          "idg_bpr_plan_f32")
+
+
 def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, g_final, g_ego, loss=None,
                   deterministic=True):
-    """No-autograd form: loss[2] plus gradients accumulated into g_final / g_ego (caller zeroes)."""
+    """No-autograd form: loss[2] plus gradients accumulated into g_final / g_ego (caller zeroes).
+    deterministic: False/0 float atomics, True/1 sort in-call, 2 plan already built (bpr_plan_raw)."""
     _require_device(final_panel, ego_panel, users, pos, neg, g_final, g_ego)
     n, d = final_panel.shape
     B = users.shape[0]
@@ -302,7 +314,7 @@ def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda
     ws = _bpr_ws(B, d, final_panel.device)
     check(lib.idg_bpr_fused_f32(_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos),
                                 _ptr(neg), B, d, float(reg_lambda), _ptr(loss), _ptr(g_final), _ptr(g_ego),
-                                int(bool(deterministic)), _ptr(ws), _stream()), "idg_bpr_fused_f32")
+                                int(deterministic), _ptr(ws), _stream()), "idg_bpr_fused_f32")
     return loss
 
 

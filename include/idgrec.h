@@ -193,6 +193,12 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
  * forward writes loss[2] and keeps per-triple coefficients in ws; backward (same ws, same
  * inputs) scatters the gradients scaled by upstream[0] (for loss[0]) and upstream[1] (for
  * loss[1]) — a DEVICE pointer to the two incoming gradient scalars, or NULL for 1, 1. */
+/* deterministic = IDG_BPR_PLANNED: the sorted (row, slot) plan of THIS batch is already in ws,
+ * put there by idg_bpr_plan_f32 (which depends on the indices only, so a caller can run it on
+ * a second stream while the forward propagation is still in flight). */
+#define IDG_BPR_PLANNED 2
+int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
+                     int64_t num_users, int64_t n, void* ws, void* stream);
 int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
                         int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
                         int64_t B, int64_t d, float reg_lambda, float* loss, void* ws,

@@ -22,16 +22,18 @@ n, nnz = U + I, len(ix)
 X = torch.randn(n, d, device="cuda") * 0.1
 gather = 4 * (n + 1) + 8 * nnz + 4 * nnz * d + 4 * n * d
 configs = []
-VARS = [int(x) for x in os.environ.get("VARS", "1,4,5,6").split(",")]
-SPLITS = [int(x) for x in os.environ.get("SPLITS", "128,96,64").split(",")]
-CAPS = [int(x) for x in os.environ.get("CAPS", "1024,768,512").split(",")]
+VARS = [int(x) for x in os.environ.get("VARS", "5").split(",")]
+SPLITS = [int(x) for x in os.environ.get("SPLITS", "128").split(",")]
+CAPS = [int(x) for x in os.environ.get("CAPS", "512,1024").split(",")]
+BANDS = [int(x) for x in os.environ.get("BANDS", "1,2,4,8").split(",")]
 for var in VARS:
     for split in SPLITS:
         for cap in CAPS:
-            configs.append((var, split, cap))
+            for bands in BANDS:
+                configs.append((var, split, cap, bands))
 graphs = []
-for var, split, cap in configs:
-    os.environ["IDG_SPMM_VARIANT"], os.environ["IDG_TILE_NNZ"] = str(var), str(cap)
+for var, split, cap, bands in configs:
+    os.environ["IDG_SPMM_VARIANT"], os.environ["IDG_TILE_NNZ"], os.environ["IDG_XCD_BANDS"] = str(var), str(cap), str(bands)
     graphs.append(ops.Graph(ip, ix, dv, n, n, split_threshold=split))
 ref = None
 Y = torch.empty_like(X)
@@ -51,5 +53,6 @@ print("%s d=%d n=%d nnz=%d gather=%.1f MB" % (wl, d, n, nnz, gather / 1e6))
 for c, G in zip(configs, graphs):
     t = np.median(times[c])
     info = G.info()
-    print("variant=%d split=%4d cap=%4d tiles=%5d long=%4d segs=%5d : %7.1f us (min %6.1f)  %6.2f TB/s gather"
-          % (c[0], c[1], c[2], info["n_tiles"], info["n_long_rows"], info["n_segments"], t, min(times[c]), gather / t / 1e6))
+    print("variant=%d split=%4d cap=%4d bands=%d tiles=%5d long=%4d segs=%5d : %7.1f us (min %6.1f)  %6.2f TB/s gather"
+          % (c[0], c[1], c[2], c[3], info["n_tiles"], info["n_long_rows"], info["n_segments"], t, min(times[c]),
+             gather / t / 1e6))
