@@ -42,6 +42,7 @@ struct BprArgs {
   float* g_final;
   float* g_ego;
   const float* upstream;  // device [2]: d total / d loss[0], d total / d loss[1]; NULL = ones
+  uint32_t* touched;      // bitmap of g_final rows written; when set, rows are STORED, not accumulated
   int atomic;
 };
 
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
   while (e < n3 && skeys[e] == row) ++e;
   const float up0 = a.upstream ? a.upstream[0] : 1.0f;
   const float up1 = a.upstream ? a.upstream[1] : 1.0f;
+  if (a.touched && a.g_final && lane == 0) atomicOr(a.touched + (row >> 5), 1u << (row & 31));
   for (int64_t f = lane; f < a.d; f += WAVE) {
     float acc = 0.f;
     for (int64_t t = j; t < e; ++t) {
@@ -200,7 +202,10 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
     if (a.g_final && a.g_final == a.g_ego) {
       a.g_final[o] += acc + reg;
     } else {
-      if (a.g_final) a.g_final[o] += acc;
+      if (a.g_final) {
+        if (a.touched) a.g_final[o] = acc;  // one wave owns a row: a plain store, no zero-fill needed
+        else a.g_final[o] += acc;
+      }
       if (a.g_ego) a.g_ego[o] += reg;
     }
   }
@@ -422,8 +427,10 @@ int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* ne
 int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
                          const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
                          float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
-                         void* ws, void* stream) {
+                         uint32_t* touched, void* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  IDG_REQUIRE(!touched || (deterministic && g_final && g_final != g_ego),
+              "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter into a g_final distinct from g_ego");
   const BprWs w = bpr_layout(B > 0 ? B : 1, cub_temp_bound(3 * B));
   BprArgs a{};
   int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
@@ -433,6 +440,7 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
   a.g_final = g_final;
   a.g_ego = g_ego;
   a.upstream = upstream;
+  a.touched = touched;
   char* base = reinterpret_cast<char*>(ws);
   if (!deterministic) {
     const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
@@ -454,12 +462,12 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
 
 int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
                       const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
-                      float reg_lambda, float* loss, float* g_final, float* g_ego, int deterministic, void* ws,
-                      void* stream) {
+                      float reg_lambda, float* loss, float* g_final, float* g_ego, int deterministic,
+                      uint32_t* touched, void* ws, void* stream) {
   int rc = idg_bpr_forward_f32(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, loss, ws, stream);
   if (rc != IDG_OK) return rc;
   return idg_bpr_backward_f32(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr,
-                              g_final, g_ego, deterministic, ws, stream);
+                              g_final, g_ego, deterministic, touched, ws, stream);
 }
 
 int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b, int64_t count, void* stream) {

@@ -59,6 +59,7 @@ struct Epilogue {
   int64_t ldy;          // leading dimension of Y/addend/sum_in/sum_out
   float div;            // 1 = no division
   int accumulate;       // sum_out[r] += instead of =
+  const uint32_t* mask; // row bitmap of addend / sum_in: rows with a 0 bit are zero and are not read (nullable)
 };
 
 }  // namespace
@@ -97,13 +98,18 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+__device__ __forceinline__ bool mask_bit(const uint32_t* __restrict__ mask, int64_t r) {
+  return (mask[r >> 5] >> (r & 31)) & 1u;
+}
+
 __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, int off, float4 acc) {
   const int64_t o = r * ep.ldy + off;
-  if (ep.addend) acc = add4(acc, *reinterpret_cast<const float4*>(ep.addend + o));
+  const bool live = ep.mask == nullptr || mask_bit(ep.mask, r);  // x + 0 == x: skipping a zero row is exact
+  if (ep.addend && live) acc = add4(acc, *reinterpret_cast<const float4*>(ep.addend + o));
   if (ep.Y) *reinterpret_cast<float4*>(ep.Y + o) = acc;
   if (ep.sum_out) {
     float4 s = acc;
-    if (ep.sum_in) s = add4(*reinterpret_cast<const float4*>(ep.sum_in + o), acc);
+    if (ep.sum_in && live) s = add4(*reinterpret_cast<const float4*>(ep.sum_in + o), acc);
     if (ep.div != 1.0f) {
       s.x = s.x / ep.div;
       s.y = s.y / ep.div;
@@ -157,6 +163,35 @@ __device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __re
     ColVal p = cv[j];
     float4 x = *reinterpret_cast<const float4*>(Xl + (int64_t)p.col * ldx);
     acc = fma4(p.val, x, acc);
+  }
+  return acc;
+}
+
+// The same walk over a panel whose all-zero rows are flagged in a bitmap: entries that point at a
+// zero row are skipped (fmaf(v, +0, acc) == acc for the finite, non-negative-zero operands here),
+// so only live rows are fetched.  Used by the first backward layer, whose input has <= 3B live rows.
+template <int UNROLL, typename CVPtr>
+__device__ __forceinline__ float4 walk_masked(CVPtr cv, int s, int e, const float* __restrict__ Xl, int64_t ldx,
+                                              const uint32_t* __restrict__ mask, float4 acc) {
+  int j = s;
+  for (; j + UNROLL <= e; j += UNROLL) {
+    ColVal p[UNROLL];
+    bool live[UNROLL];
+    float4 x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) p[u] = cv[j + u];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) live[u] = mask_bit(mask, p[u].col);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (live[u]) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (live[u]) acc = fma4(p[u].val, x[u], acc);
+  }
+  for (; j < e; ++j) {
+    ColVal p = cv[j];
+    if (mask_bit(mask, p.col)) acc = fma4(p.val, *reinterpret_cast<const float4*>(Xl + (int64_t)p.col * ldx), acc);
   }
   return acc;
 }
@@ -219,6 +254,86 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   }
 }
 
+// Sparse-input form of the tile kernel: the gathered panel has few live rows (bitmap x_mask).
+// The staged entry list is flagged in parallel (one bitmap probe per entry, no dependent chains),
+// prefix-scanned and compacted in LDS, the vrow pointers are remapped, and the ordinary sequential
+// walk then runs over the live entries only.  Dropping a dead entry is exact (fmaf(v, +0, acc) ==
+// acc), the survivors keep their order, so results are bit-identical to the dense form.
+template <int LPR, int NB>
+__global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __restrict__ tiles,
+                                                                 const int64_t* __restrict__ vptr,
+                                                                 const int32_t* __restrict__ vtgt,
+                                                                 const ColVal* __restrict__ cv,
+                                                                 const float* __restrict__ X, int64_t ldx,
+                                                                 float* __restrict__ partials, int64_t d, Epilogue ep,
+                                                                 const uint32_t* __restrict__ x_mask) {
+  __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ int s_pre[TILE_NNZ + 1];  // s_pre[i] = live entries among [0, i)
+  __shared__ int s_ptr[TILE_VROWS + 1];
+  __shared__ int s_tgt[TILE_VROWS];
+  __shared__ int s_wave[BLOCK / 64 + 1];
+  __shared__ int s_next;
+
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int lane = tid % 64, wave = tid / 64;
+  const int nv = t.n_vrows;
+  const int64_t nz0 = t.nnz_begin;
+  constexpr int GROUPS = BLOCK / LPR;
+  if (tid == 0) s_next = GROUPS;
+  for (int i = tid; i <= nv; i += BLOCK) s_ptr[i] = (int)(vptr[t.vrow_begin + i] - nz0);
+  for (int i = tid; i < nv; i += BLOCK) s_tgt[i] = vtgt[t.vrow_begin + i];
+  const int cnt = (int)(vptr[t.vrow_begin + nv] - nz0);
+  const ColVal* src = cv + nz0;
+  // flag + ordered compaction, BLOCK entries per round
+  int base = 0;
+  for (int i0 = 0; i0 < cnt; i0 += BLOCK) {
+    const int i = i0 + tid;
+    ColVal e{};
+    bool live = false;
+    if (i < cnt) {
+      e = src[i];
+      live = mask_bit(x_mask, e.col);
+    }
+    const unsigned long long m = __ballot(live);
+    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    int total = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) total += s_wave[w];
+    if (i < cnt) s_pre[i] = before + in_wave;
+    if (live) s_cv[before + in_wave] = e;
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) s_pre[cnt] = base;
+  __syncthreads();
+
+  const int g = tid / LPR;
+  const int l = tid % LPR;
+  int v = g;
+  while (v < nv) {
+    const int s = s_pre[s_ptr[v]], e = s_pre[s_ptr[v + 1]];
+    const int tgt = s_tgt[v];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int off = (b * LPR + l) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = walk<8>(s_cv, s, e, X + off, ldx, acc);
+      if (tgt >= 0) {
+        epilogue_store(ep, tgt, off, acc);
+      } else {
+        *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
+      }
+    }
+    int nxt = 0;
+    if (l == 0) nxt = atomicAdd(&s_next, 1);
+    v = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
+  }
+}
+
 // EXACT_ORDER rows longer than a tile: one lane group streams the row from global memory.
 template <int LPR, int NB>
 __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__ xl,
@@ -226,7 +341,7 @@ __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__
                                                      const int32_t* __restrict__ vtgt,
                                                      const ColVal* __restrict__ cv,
                                                      const float* __restrict__ X, int64_t ldx,
-                                                     Epilogue ep) {
+                                                     Epilogue ep, const uint32_t* __restrict__ x_mask) {
   const int v = xl[blockIdx.x];
   const int l = threadIdx.x;
   if (l >= LPR) return;
@@ -238,7 +353,7 @@ __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t c = s; c < e; c += (1 << 20)) {
       const int len = (int)std::min<int64_t>(e - c, 1 << 20);
-      acc = walk<8>(cv + c, 0, len, X + off, ldx, acc);
+      acc = x_mask ? walk_masked<8>(cv + c, 0, len, X + off, ldx, x_mask, acc) : walk<8>(cv + c, 0, len, X + off, ldx, acc);
     }
     epilogue_store(ep, tgt, off, acc);
   }
@@ -288,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
                                                              int64_t n_vrows, const ColVal* __restrict__ cv,
                                                              const float* __restrict__ X, int64_t ldx,
                                                              float* __restrict__ partials, int64_t d,
-                                                             Epilogue ep) {
+                                                             Epilogue ep, const uint32_t* __restrict__ x_mask) {
   const int64_t v = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
   const int l = threadIdx.x % 64;
   if (v >= n_vrows) return;
@@ -296,16 +411,18 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
   const int tgt = vtgt[v];
   for (int64_t f = l; f < d; f += 64) {
     float acc = 0.f;
-    for (int64_t j = s; j < e; ++j) acc = __builtin_fmaf(cv[j].val, X[(int64_t)cv[j].col * ldx + f], acc);
+    for (int64_t j = s; j < e; ++j)
+      if (!x_mask || mask_bit(x_mask, cv[j].col)) acc = __builtin_fmaf(cv[j].val, X[(int64_t)cv[j].col * ldx + f], acc);
     if (tgt < 0) {
       partials[(int64_t)(~tgt) * d + f] = acc;
       continue;
     }
     const int64_t o = (int64_t)tgt * ep.ldy + f;
-    if (ep.addend) acc += ep.addend[o];
+    const bool live = ep.mask == nullptr || mask_bit(ep.mask, tgt);
+    if (ep.addend && live) acc += ep.addend[o];
     if (ep.Y) ep.Y[o] = acc;
     if (ep.sum_out) {
-      float sres = ep.sum_in ? ep.sum_in[o] + acc : acc;
+      float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
       if (ep.div != 1.0f) sres = sres / ep.div;
       if (ep.accumulate) sres = ep.sum_out[o] + sres;
       ep.sum_out[o] = sres;
@@ -329,10 +446,11 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
       acc = q == 0 ? a : acc + a;
     }
     const int64_t o = (int64_t)lr.row * ep.ldy + f;
-    if (ep.addend) acc += ep.addend[o];
+    const bool live = ep.mask == nullptr || mask_bit(ep.mask, lr.row);
+    if (ep.addend && live) acc += ep.addend[o];
     if (ep.Y) ep.Y[o] = acc;
     if (ep.sum_out) {
-      float sres = ep.sum_in ? ep.sum_in[o] + acc : acc;
+      float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
       if (ep.div != 1.0f) sres = sres / ep.div;
       if (ep.accumulate) sres = ep.sum_out[o] + sres;
       ep.sum_out[o] = sres;
@@ -342,7 +460,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
 
 template <int LPR, int NB>
 int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials, int64_t d,
-                const Epilogue& ep, hipStream_t st) {
+                const Epilogue& ep, const uint32_t* x_mask, hipStream_t st) {
   if (g->n_tiles > 0) {
     const dim3 grid((unsigned)g->n_tiles), block(BLOCK);
     // Band placement pays while the gathered panel lives in L2 / Infinity Cache (measured: 17.8 and
@@ -352,7 +470,10 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
 #define IDG_TILE(U, DYN, ...)                                                                                \
   hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, ##__VA_ARGS__>), grid, block, 0, st, tile_order, g->d_vptr, \
                      g->d_vtgt, g->d_cv, X, ldx, partials, d, ep)
-    switch (g->variant) {
+    if (x_mask) {  // sparse-input form (first backward layer)
+      hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                         g->d_cv, X, ldx, partials, d, ep, x_mask);
+    } else switch (g->variant) {
       case 1: IDG_TILE(8, true); break;
       case 2: IDG_TILE(16, false); break;
       case 3: IDG_TILE(16, true); break;
@@ -365,7 +486,7 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
   }
   if (g->n_xl > 0)
     hipLaunchKernelGGL((spmm_xl_kernel<LPR, NB>), dim3((unsigned)g->n_xl), dim3(64), 0, st, g->d_xl, g->d_vptr,
-                       g->d_vtgt, g->d_cv, X, ldx, ep);
+                       g->d_vtgt, g->d_cv, X, ldx, ep, x_mask);
   if (g->n_long > 0) {
     hipLaunchKernelGGL((spmm_fixup_kernel<LPR, NB>), dim3((unsigned)g->n_long), dim3(FIX_WAYS * LPR), 0, st,
                        g->d_long, (int)g->n_long, partials, d, ep);
@@ -375,7 +496,7 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
 }
 
 int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, void* ws, const Epilogue& ep,
-                  hipStream_t st) {
+                  hipStream_t st, const uint32_t* x_mask = nullptr) {
   float* partials = reinterpret_cast<float*>(ws);
   if (g->n_slots > 0 && !partials) return idg::fail(IDG_E_INVALID, "idg_spmm: workspace is NULL but the graph has split rows");
   const bool aligned = (ldx % 4 == 0) && (ep.ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
@@ -383,18 +504,18 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
                        ((uintptr_t)ep.sum_in % 16 == 0) && ((uintptr_t)ep.sum_out % 16 == 0);
   if (aligned) {
     switch (d) {
-      case 32: return launch_fast<8, 1>(g, X, ldx, partials, d, ep, st);
-      case 64: return launch_fast<16, 1>(g, X, ldx, partials, d, ep, st);
-      case 128: return launch_fast<32, 1>(g, X, ldx, partials, d, ep, st);
-      case 256: return launch_fast<64, 1>(g, X, ldx, partials, d, ep, st);
-      case 512: return launch_fast<64, 2>(g, X, ldx, partials, d, ep, st);
+      case 32: return launch_fast<8, 1>(g, X, ldx, partials, d, ep, x_mask, st);
+      case 64: return launch_fast<16, 1>(g, X, ldx, partials, d, ep, x_mask, st);
+      case 128: return launch_fast<32, 1>(g, X, ldx, partials, d, ep, x_mask, st);
+      case 256: return launch_fast<64, 1>(g, X, ldx, partials, d, ep, x_mask, st);
+      case 512: return launch_fast<64, 2>(g, X, ldx, partials, d, ep, x_mask, st);
       default: break;
     }
   }
   if (g->n_vrows > 0) {
     const unsigned nb = (unsigned)((g->n_vrows + (BLOCK / 64) - 1) / (BLOCK / 64));
     hipLaunchKernelGGL(spmm_generic_kernel, dim3(nb), dim3(BLOCK), 0, st, g->d_vptr, g->d_vtgt, g->n_vrows,
-                       g->d_cv, X, ldx, partials, d, ep);
+                       g->d_cv, X, ldx, partials, d, ep, x_mask);
   }
   if (g->n_long > 0) {
     const unsigned nb = (unsigned)((g->n_long + (BLOCK / 64) - 1) / (BLOCK / 64));
@@ -695,7 +816,8 @@ size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {
 }
 
 static int propagate_common(const idg_graph* g, const float* in, float* out, int K, int include0, int64_t d,
-                            void* ws, hipStream_t st, bool backward, int accumulate) {
+                            void* ws, hipStream_t st, bool backward, int accumulate,
+                            const uint32_t* in_mask = nullptr) {
   IDG_REQUIRE(g && in && out && ws, "idg_propagate: NULL argument");
   IDG_REQUIRE(g->n_rows == g->n_cols, "idg_propagate: graph must be square");
   IDG_REQUIRE(K >= 1, "idg_propagate: K must be >= 1 (got %d)", K);
@@ -726,7 +848,9 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
       }
       if (last) ep.div = cnt;
     } else {
-      // backward Horner step: h <- A.h + g ; the last one scales by 1/cnt.
+      // backward Horner step: h <- A.h + g ; the last one scales by 1/cnt.  `in_mask` flags the
+      // live rows of g: the first product gathers from g itself, every step adds g.
+      ep.mask = in_mask;
       if (!last) {
         ep.Y = P[(k - 1) & 1];
         ep.addend = in;
@@ -737,7 +861,7 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
         ep.accumulate = accumulate;
       }
     }
-    int rc = spmm_dispatch(g, X, d, d, partials, ep, st);
+    int rc = spmm_dispatch(g, X, d, d, partials, ep, st, (backward && k == 1) ? in_mask : nullptr);
     if (rc != IDG_OK) return rc;
     X = P[(k - 1) & 1];
   }
@@ -749,13 +873,13 @@ int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int 
   return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0);
 }
 
-int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, float* gE0, int K, int include_layer0,
-                               int64_t d, int accumulate, void* ws, void* stream) {
+int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask, float* gE0, int K,
+                               int include_layer0, int64_t d, int accumulate, void* ws, void* stream) {
   IDG_REQUIRE(g, "idg_propagate_mean_bwd_f32: NULL graph");
   IDG_REQUIRE(g->flags & IDG_GRAPH_SYMMETRIC,
               "idg_propagate_mean_bwd_f32: graph not flagged IDG_GRAPH_SYMMETRIC (build the transposed handle and "
               "chain idg_spmm_f32 instead)");
-  return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate);
+  return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate, gout_mask);
 }
 
 }  // extern "C"

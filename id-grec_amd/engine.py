@@ -34,6 +34,7 @@ class PropagationEngine:
         self.exp_avg_sq = torch.zeros((self.n, self.d), **f32)
         self.final = torch.empty((self.n, self.d), **f32) if graph is not None else None
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
+        self.touched = torch.zeros((self.n + 31) // 32, dtype=torch.int32, device=dev) if graph is not None else None
         self.loss = torch.zeros(2, **f32)
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
@@ -81,13 +82,21 @@ class PropagationEngine:
             ev = self._mark()
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final)
             self._mark(ev)
-            self.g_final.zero_()
+            if det:
+                # deterministic scatter: reached rows of g_final are stored and flagged in a bitmap; the
+                # backward propagation reads flagged rows only, so g_final itself is never zero-filled
+                self.touched.zero_()
+                touched = self.touched
+            else:
+                self.g_final.zero_()
+                touched = None
             if plan_done is not None:
                 torch.cuda.current_stream().wait_event(plan_done)
             ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
-                              self.grad, loss=loss, deterministic=det)
+                              self.grad, loss=loss, deterministic=det, touched=touched)
             ev = self._mark()
-            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True)
+            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True,
+                                              mask=touched)
             self._mark(ev)
         else:
             ops.bpr_fused_raw(self.params, self.params, users, pos, neg, self.U, self.reg_lambda, self.grad,

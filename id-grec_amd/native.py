@@ -48,15 +48,16 @@ PROTOTYPES = {
     "idg_lincomb_f32": (C.c_int, [c_vp, c_vp, C.c_float, c_vp, C.c_float, C.c_int64, c_vp]),
     "idg_propagate_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
     "idg_propagate_mean_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, c_vp, c_vp]),
-    "idg_propagate_mean_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int, c_vp, c_vp]),
+    "idg_propagate_mean_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int, c_vp,
+                                             c_vp]),
     "idg_bpr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "idg_bpr_fused_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
-                                    C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp]),
+                                    C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "idg_bpr_plan_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_bpr_forward_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                       C.c_float, c_vp, c_vp, c_vp]),
     "idg_bpr_backward_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
-                                       C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp]),
+                                       C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "idg_adam_step_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_int64, c_vp]),
     "idg_score_dense_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp]),

@@ -154,8 +154,9 @@ class Graph:
                                          _ptr(ws), _stream()), "idg_propagate_mean_f32")
         return out
 
-    def propagate_mean_bwd_raw(self, gout, K, include_layer0=True, out=None, accumulate=False):
-        _require_device(gout, out)
+    def propagate_mean_bwd_raw(self, gout, K, include_layer0=True, out=None, accumulate=False, mask=None):
+        """mask: int32/uint32 bitmap tensor of gout's live rows (see idg_propagate_mean_bwd_f32), or None."""
+        _require_device(gout, out, mask)
         gout = _f32c(gout, "gout")
         d = gout.shape[1]
         if out is None:
@@ -163,7 +164,7 @@ class Graph:
                 raise ValueError("accumulate=True needs an existing `out`")
             out = torch.empty_like(gout)
         ws = self._workspace("prop", d)
-        check(lib.idg_propagate_mean_bwd_f32(self._h, _ptr(gout), _ptr(out), int(K), int(bool(include_layer0)), d,
+        check(lib.idg_propagate_mean_bwd_f32(self._h, _ptr(gout), _ptr(mask), _ptr(out), int(K), int(bool(include_layer0)), d,
                                              int(bool(accumulate)), _ptr(ws), _stream()),
               "idg_propagate_mean_bwd_f32")
         return out
@@ -262,8 +263,8 @@ class _BprLoss(torch.autograd.Function):
         g_ego = g_final if same else torch.zeros_like(ego)
         # ws still holds this batch's coefficients: forward and backward of one step are adjacent on the stream
         check(lib.idg_bpr_backward_f32(_ptr(fin), _ptr(ego), num_users, n, _ptr(users), _ptr(pos), _ptr(neg), B, d,
-                                       reg_lambda, _ptr(up), _ptr(g_final), _ptr(g_ego), int(deterministic), _ptr(ws),
-                                       _stream()), "idg_bpr_backward_f32")
+                                       reg_lambda, _ptr(up), _ptr(g_final), _ptr(g_ego), int(deterministic), None,
+                                       _ptr(ws), _stream()), "idg_bpr_backward_f32")
         return g_final, (None if same else g_ego), None, None, None, None, None, None
 
 
@@ -304,9 +305,11 @@ def bpr_plan_raw(users, pos, neg, num_users, n, d):
 
 
 def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, g_final, g_ego, loss=None,
-                  deterministic=True):
+                  deterministic=True, touched=None):
     """No-autograd form: loss[2] plus gradients accumulated into g_final / g_ego (caller zeroes).
-    deterministic: False/0 float atomics, True/1 sort in-call, 2 plan already built (bpr_plan_raw)."""
+    deterministic: False/0 float atomics, True/1 sort in-call, 2 plan already built (bpr_plan_raw).
+    touched: zeroed int32 bitmap [ceil(n/32)]; if given, reached g_final rows are stored + flagged and
+    g_final needs no zero-fill (feed the bitmap to Graph.propagate_mean_bwd_raw(mask=...))."""
     _require_device(final_panel, ego_panel, users, pos, neg, g_final, g_ego)
     n, d = final_panel.shape
     B = users.shape[0]
@@ -314,7 +317,7 @@ def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda
     ws = _bpr_ws(B, d, final_panel.device)
     check(lib.idg_bpr_fused_f32(_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos),
                                 _ptr(neg), B, d, float(reg_lambda), _ptr(loss), _ptr(g_final), _ptr(g_ego),
-                                int(deterministic), _ptr(ws), _stream()), "idg_bpr_fused_f32")
+                                int(deterministic), _ptr(touched), _ptr(ws), _stream()), "idg_bpr_fused_f32")
     return loss
 
 
@@ -329,7 +332,7 @@ def bpr_fwd_bwd_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lamb
     args = (_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos), _ptr(neg), B, d,
             float(reg_lambda))
     check(lib.idg_bpr_forward_f32(*args, _ptr(loss), _ptr(ws), _stream()), "idg_bpr_forward_f32")
-    check(lib.idg_bpr_backward_f32(*args, _ptr(upstream), _ptr(g_final), _ptr(g_ego), int(bool(deterministic)),
+    check(lib.idg_bpr_backward_f32(*args, _ptr(upstream), _ptr(g_final), _ptr(g_ego), int(bool(deterministic)), None,
                                    _ptr(ws), _stream()), "idg_bpr_backward_f32")
     return loss
 

@@ -164,9 +164,13 @@ int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int 
 /* Backward of the above for a SYMMETRIC graph: gE0 = (1/cnt)(c0.g + A(g + A(g + ... A g))),
  * the Horner form of autograd's chain through K torch.sparse.mm nodes and the mean.
  * accumulate != 0: gE0 += (the ego-embedding regulariser's gradient is already there). */
-int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, float* gE0, int K,
-                               int include_layer0, int64_t d, int accumulate, void* ws,
-                               void* stream);
+/* gout_mask (nullable): bitmap, bit r of word r/32 set iff row r of gout is live.  Rows with a
+ * clear bit are taken as zero and never read — a training batch touches <= 3B rows of gout, so
+ * the first backward product skips most of its gathers (exact: fmaf(v, 0, acc) == acc) and gout
+ * needs no zero-fill.  Produced by idg_bpr_backward_f32's `touched` argument. */
+int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask,
+                               float* gE0, int K, int include_layer0, int64_t d, int accumulate,
+                               void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: fused gather + BPR + L2-reg loss and gradients
@@ -179,6 +183,10 @@ int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, float* gE0
  * loss[1] = reg_lambda * sum over the three ego blocks of 0.5*||block||_F^2 / B
  * g_final[n,d] += d loss[0] / d final   (rows scatter-added, duplicates accumulate)
  * g_ego  [n,d] += d loss[1] / d ego
+ * touched (nullable, deterministic forms only, g_final != g_ego): a zeroed bitmap of ceil(n/32)
+ * words; the rows of g_final this batch reaches are then STORED (not accumulated) and their
+ * bits set, every other row of g_final is left untouched and must not be read — hand the
+ * bitmap to idg_propagate_mean_bwd_f32.
  * g_final / g_ego must be zeroed (or hold a gradient to accumulate into) by the caller;
  * either may be NULL to skip that gradient.  final == ego is the MFBPR case
  * (models/MFBPR.py:29-42).  deterministic != 0: duplicate rows are summed in batch order
@@ -188,7 +196,7 @@ size_t idg_bpr_workspace_bytes(int64_t B, int64_t d);
 int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
                       int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
                       int64_t B, int64_t d, float reg_lambda, float* loss, float* g_final,
-                      float* g_ego, int deterministic, void* ws, void* stream);
+                      float* g_ego, int deterministic, uint32_t* touched, void* ws, void* stream);
 /* The same computation as two calls, for callers that sit under an autograd engine:
  * forward writes loss[2] and keeps per-triple coefficients in ws; backward (same ws, same
  * inputs) scatters the gradients scaled by upstream[0] (for loss[0]) and upstream[1] (for
@@ -206,7 +214,8 @@ int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_
 int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
                          int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
                          int64_t B, int64_t d, float reg_lambda, const float* upstream,
-                         float* g_final, float* g_ego, int deterministic, void* ws, void* stream);
+                         float* g_final, float* g_ego, int deterministic, uint32_t* touched, void* ws,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: dense Adam step  (torch.optim.Adam defaults, utility/utility_train/trainer.py:11,56:

@@ -161,6 +161,55 @@ def test_propagate_mean_backward(ops, K, inc, golden_small):
     np.testing.assert_allclose(base.cpu().numpy(), ref + 0.5, rtol=RTOL, atol=1e-6)
 
 
+@pytest.mark.parametrize("K,inc,d", [(3, True, 64), (2, False, 64), (1, True, 256), (3, True, 48)])
+def test_masked_backward_is_bit_identical_and_never_reads_dead_rows(ops, K, inc, d, golden_small):
+    """A batch reaches <= 3B rows of d loss / d final.  With the touched-row bitmap the backward
+    propagation must (a) give the same bits as the dense computation on a zero-filled panel and
+    (b) never read an unflagged row — those hold NaN here."""
+    g = golden_small
+    n = int(g["num_users"]) + int(g["num_items"])
+    rng = np.random.default_rng(d + K)
+    live = np.zeros(n, dtype=bool)
+    live[rng.choice(n, 60, replace=False)] = True
+    dense = np.zeros((n, d), dtype=np.float32)
+    dense[live] = rng.standard_normal((int(live.sum()), d)).astype(np.float32)
+    poisoned = np.where(live[:, None], dense, np.float32(np.nan))
+    words = np.zeros((n + 31) // 32, dtype=np.uint32)
+    for r in np.nonzero(live)[0]:
+        words[r >> 5] |= np.uint32(1) << np.uint32(r & 31)
+    for kw in (dict(), dict(exact_order=True), dict(split_threshold=64)):
+        G = _graph(ops, g, **kw)
+        ref = G.propagate_mean_bwd_raw(dev(dense), K, inc)
+        got = G.propagate_mean_bwd_raw(dev(poisoned), K, inc, mask=dev(words.view(np.int32)))
+        assert torch.equal(ref, got)
+        base = torch.full((n, d), 0.25, device="cuda")
+        G.propagate_mean_bwd_raw(dev(poisoned), K, inc, out=base, accumulate=True, mask=dev(words.view(np.int32)))
+        assert torch.equal(base, ref + 0.25) or torch.allclose(base, ref + 0.25, rtol=1e-6, atol=1e-7)
+
+
+def test_bpr_touched_bitmap_and_stored_rows(ops, golden_small):
+    g = golden_small
+    U = int(g["num_users"])
+    n = U + int(g["num_items"])
+    batch = dev(g["d64_batch"])
+    u, p, ng = batch[:, 0].contiguous(), batch[:, 1].contiguous(), batch[:, 2].contiguous()
+    fin = dev(np.concatenate([g["d64_lgcn_user"], g["d64_lgcn_item"]]))
+    ego = dev(np.concatenate([g["d64_init_user"], g["d64_init_item"]]))
+    gf0, ge0 = torch.zeros_like(fin), torch.zeros_like(ego)
+    l0 = ops.bpr_fused_raw(fin, ego, u, p, ng, U, 1e-4, gf0, ge0, deterministic=True).clone()
+    gf1 = torch.full_like(fin, float("nan"))  # never zero-filled
+    ge1 = torch.zeros_like(ego)
+    touched = torch.zeros((n + 31) // 32, dtype=torch.int32, device="cuda")
+    l1 = ops.bpr_fused_raw(fin, ego, u, p, ng, U, 1e-4, gf1, ge1, deterministic=True, touched=touched)
+    assert torch.equal(l0, l1) and torch.equal(ge0, ge1)
+    bits = touched.cpu().numpy().view(np.uint32)
+    flagged = np.array([(bits[r >> 5] >> (r & 31)) & 1 for r in range(n)], dtype=bool)
+    rows = set(u.cpu().tolist()) | {U + x for x in p.cpu().tolist()} | {U + x for x in ng.cpu().tolist()}
+    assert set(np.nonzero(flagged)[0].tolist()) == rows
+    assert torch.equal(gf1[torch.from_numpy(flagged).cuda()], gf0[torch.from_numpy(flagged).cuda()])
+    assert torch.isnan(gf1[torch.from_numpy(~flagged).cuda()]).all()
+
+
 # ------------------------------------------------------------------------------------- BPR
 @pytest.mark.parametrize("gname", ["tiny", "small"])
 @pytest.mark.parametrize("deterministic", [True, False])
