@@ -14,6 +14,8 @@
 // folds them into the sorted best-64 held one per lane.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "idg_common.h"
 
 namespace {
@@ -31,7 +33,8 @@ template <bool SIGMOID>
 __global__ __launch_bounds__(BLOCK) void score_dense_kernel(const float* __restrict__ U,
                                                             const float* __restrict__ V,
                                                             const int64_t* __restrict__ users, int64_t Bt,
-                                                            int64_t I, int64_t d, float* __restrict__ rating) {
+                                                            int64_t I, int64_t d, float* __restrict__ rating,
+                                                            int64_t ld) {
   const int lane = threadIdx.x % WAVE;
   const int wave = threadIdx.x / WAVE;
   const int i = lane & 31;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(BLOCK) void score_dense_kernel(const float* __restr
         if (b < Bt) {
           float s = acc[r];
           if (SIGMOID) s = sigmoidf_(s);
-          rating[b * I + j0 + i] = s;
+          rating[b * ld + j0 + i] = s;
         }
       }
     }
@@ -141,12 +144,17 @@ __device__ __forceinline__ void wave_sort128_desc(unsigned long long& k0, unsign
   }
 }
 
-// one wave per batch row
-__global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restrict__ rating, int64_t Bt, int64_t I,
+// One wave per batch row, streaming `n_items` scores of the row (item ids item_lo + 0..n_items-1).
+// 16-byte loads, the next 256 scores prefetched while the current ones are filtered.  A row's
+// running best-64 can be carried across launches through `state` (item-chunked evaluation keeps
+// the score scratch bounded for any catalogue size).
+__global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restrict__ rating, int64_t ld, int64_t Bt,
+                                                          int64_t item_lo, int64_t n_items,
                                                           const int64_t* __restrict__ users,
                                                           const int64_t* __restrict__ excl_indptr,
                                                           const int32_t* __restrict__ excl_items, int k,
-                                                          int64_t* __restrict__ out_idx,
+                                                          unsigned long long* __restrict__ state, int load_state,
+                                                          int final_pass, int64_t* __restrict__ out_idx,
                                                           float* __restrict__ out_val) {
   __shared__ unsigned long long s_pend[BLOCK / WAVE][128];
   const int wave = threadIdx.x / WAVE;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restric
   const int64_t b = (int64_t)blockIdx.x * (BLOCK / WAVE) + wave;
   if (b >= Bt) return;
   unsigned long long* pend = s_pend[wave];
-  const float* row = rating + b * I;
+  const float* row = rating + b * ld;
   const int32_t* ex_b = nullptr;
   int ex_n = 0;
   if (excl_indptr) {
@@ -162,25 +170,23 @@ __global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restric
     ex_b = excl_items + excl_indptr[u];
     ex_n = (int)(excl_indptr[u + 1] - excl_indptr[u]);
   }
-  unsigned long long best = 0;  // sorted descending across lanes; 0 = empty (below every real key)
-  unsigned long long tau = 0;
+  unsigned long long best = load_state ? state[b * WAVE + lane] : 0ull;  // sorted descending across lanes; 0 = empty
+  unsigned long long tau = shfl_u64(best, k - 1);
   int n_pend = 0;
 
   auto flush = [&](int take) {
-    // fold `take` (<= 64) pending keys from the tail of the buffer into `best`
+    __builtin_amdgcn_wave_barrier();
     unsigned long long a = lane < take ? pend[n_pend - take + lane] : 0ull;
     n_pend -= take;
     wave_sort128_desc(best, a, lane);
     tau = shfl_u64(best, k - 1);
   };
-
-  for (int64_t base = 0; base < I; base += WAVE) {
-    const int64_t item = base + lane;
+  auto offer = [&](float sc, int64_t local, bool valid) {
     bool pass = false;
     unsigned long long key = 0;
-    if (item < I) {
-      float s = row[item];
-      key = make_key(s, (uint32_t)item);
+    if (valid) {
+      const uint32_t item = (uint32_t)(item_lo + local);
+      key = make_key(sc, item);
       pass = key > tau;
       if (pass && ex_n > 0) {
         int lo = 0, hi = ex_n;
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restric
           else hi = mid;
         }
         if (lo < ex_n && ex_b[lo] == (int32_t)item) {
-          key = make_key(-1.0f, (uint32_t)item);  // batch_test.py:65
+          key = make_key(-1.0f, item);  // batch_test.py:65
           pass = key > tau;
         }
       }
@@ -201,8 +207,36 @@ __global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restric
       n_pend += __popcll(m);
       if (n_pend >= 64) flush(64);
     }
+  };
+
+  const bool vec = ((ld % 4) == 0) && (((uintptr_t)rating % 16) == 0);
+  if (vec) {
+    const int64_t n4 = n_items / 4;  // whole float4 groups
+    float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
+    if (lane < n4) cur = reinterpret_cast<const float4*>(row)[lane];
+    for (int64_t g0 = 0; g0 < n4; g0 += WAVE) {
+      const int64_t gi = g0 + lane;
+      if (gi + WAVE < n4) nxt = reinterpret_cast<const float4*>(row)[gi + WAVE];
+      const bool valid = gi < n4;
+      offer(cur.x, gi * 4 + 0, valid);
+      offer(cur.y, gi * 4 + 1, valid);
+      offer(cur.z, gi * 4 + 2, valid);
+      offer(cur.w, gi * 4 + 3, valid);
+      cur = nxt;
+    }
+    const int64_t tail = n4 * 4 + lane;
+    offer(tail < n_items ? row[tail] : 0.f, tail, tail < n_items);
+  } else {
+    for (int64_t base = 0; base < n_items; base += WAVE) {
+      const int64_t local = base + lane;
+      offer(local < n_items ? row[local] : 0.f, local, local < n_items);
+    }
   }
   if (n_pend > 0) flush(n_pend);
+  if (!final_pass) {
+    state[b * WAVE + lane] = best;
+    return;
+  }
   if (lane < k) {
     out_idx[b * k + lane] = (int64_t)key_item(best);
     if (out_val) out_val[b * k + lane] = key_score(best);
@@ -213,43 +247,74 @@ __global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restric
 
 extern "C" {
 
+static int launch_dense(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt, int64_t n_items,
+                        int64_t d, int apply_sigmoid, float* rating, int64_t ld, hipStream_t st) {
+  const dim3 grid((unsigned)((n_items + (BLOCK / WAVE) * ITEMS_PER_WAVE - 1) / ((BLOCK / WAVE) * ITEMS_PER_WAVE)),
+                  (unsigned)((Bt + 31) / 32));
+  if (apply_sigmoid)
+    hipLaunchKernelGGL(score_dense_kernel<true>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, n_items, d,
+                       rating, ld);
+  else
+    hipLaunchKernelGGL(score_dense_kernel<false>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, n_items, d,
+                       rating, ld);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
 int idg_score_dense_f32(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt,
                         int64_t I, int64_t d, int apply_sigmoid, float* rating, void* stream) {
   IDG_REQUIRE(user_panel && item_panel && users && rating, "idg_score_dense_f32: NULL argument");
   IDG_REQUIRE(Bt > 0 && I > 0 && d > 0, "idg_score_dense_f32: bad sizes");
-  const dim3 grid((unsigned)((I + (BLOCK / WAVE) * ITEMS_PER_WAVE - 1) / ((BLOCK / WAVE) * ITEMS_PER_WAVE)),
-                  (unsigned)((Bt + 31) / 32));
-  if (apply_sigmoid)
-    hipLaunchKernelGGL(score_dense_kernel<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, user_panel, item_panel,
-                       users, Bt, I, d, rating);
-  else
-    hipLaunchKernelGGL(score_dense_kernel<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, user_panel, item_panel,
-                       users, Bt, I, d, rating);
-  IDG_HIP(hipGetLastError());
-  return IDG_OK;
+  return launch_dense(user_panel, item_panel, users, Bt, I, d, apply_sigmoid, rating, I, (hipStream_t)stream);
+}
+
+// Items are processed in windows of at most this many, so the score scratch is Bt x min(I, window)
+// floats however large the catalogue is; a row's running best-64 is carried between windows.
+static inline int64_t item_window() {
+  if (const char* v = std::getenv("IDG_ITEM_WINDOW")) {  // testing knob: exercise the windowed path on small catalogues
+    const long long w = std::atoll(v);
+    if (w >= 32) return (int64_t)w / 4 * 4;
+  }
+  return (int64_t)1 << 16;
+}
+
+static inline size_t topk_scratch_floats(int64_t Bt, int64_t I) {
+  const int64_t ITEM_WINDOW = item_window();
+  const int64_t w = I < ITEM_WINDOW ? I : ITEM_WINDOW;
+  return (size_t)Bt * (size_t)((w + 3) / 4 * 4);
 }
 
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   (void)d;
   (void)k;
   if (Bt <= 0 || I <= 0) return 0;
-  return (size_t)Bt * (size_t)I * sizeof(float);
+  const size_t scores = (topk_scratch_floats(Bt, I) * sizeof(float) + 255) / 256 * 256;
+  return scores + (size_t)Bt * WAVE * sizeof(unsigned long long);
 }
 
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt,
                        int64_t I, int64_t d, const int64_t* excl_indptr, const int32_t* excl_items, int k,
                        int apply_sigmoid, int64_t* out_idx, float* out_val, void* ws, void* stream) {
-  IDG_REQUIRE(out_idx && ws, "idg_score_topk_f32: NULL argument");
+  IDG_REQUIRE(user_panel && item_panel && users && out_idx && ws, "idg_score_topk_f32: NULL argument");
+  IDG_REQUIRE(Bt > 0 && I > 0 && d > 0, "idg_score_topk_f32: bad sizes");
   IDG_REQUIRE(k >= 1 && k <= 64, "idg_score_topk_f32: k=%d outside [1,64]", k);
   IDG_REQUIRE(k <= I, "idg_score_topk_f32: k=%d exceeds the item count %lld", k, (long long)I);
-  IDG_REQUIRE((excl_indptr == nullptr) == (excl_items == nullptr) || excl_indptr,
-              "idg_score_topk_f32: excl_items given without excl_indptr");
+  IDG_REQUIRE(I < ((int64_t)1 << 32), "idg_score_topk_f32: more than 2^32 items");
+  IDG_REQUIRE((excl_indptr == nullptr) == (excl_items == nullptr), "idg_score_topk_f32: excl_indptr and excl_items go together");
+  hipStream_t st = (hipStream_t)stream;
   float* rating = reinterpret_cast<float*>(ws);
-  int rc = idg_score_dense_f32(user_panel, item_panel, users, Bt, I, d, apply_sigmoid, rating, stream);
-  if (rc != IDG_OK) return rc;
+  const size_t scores = (topk_scratch_floats(Bt, I) * sizeof(float) + 255) / 256 * 256;
+  unsigned long long* state = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + scores);
   const unsigned nb = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(nb), dim3(BLOCK), 0, (hipStream_t)stream, rating, Bt, I, users,
-                     excl_indptr, excl_items, k, out_idx, out_val);
+  const int64_t ITEM_WINDOW = item_window();
+  for (int64_t lo = 0; lo < I; lo += ITEM_WINDOW) {
+    const int64_t n_items = I - lo < ITEM_WINDOW ? I - lo : ITEM_WINDOW;
+    const int64_t ld = (n_items + 3) / 4 * 4;  // rows start 16-byte aligned
+    int rc = launch_dense(user_panel, item_panel + lo * d, users, Bt, n_items, d, apply_sigmoid, rating, ld, st);
+    if (rc != IDG_OK) return rc;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(nb), dim3(BLOCK), 0, st, rating, ld, Bt, lo, n_items, users, excl_indptr,
+                       excl_items, k, state, lo > 0 ? 1 : 0, lo + n_items >= I ? 1 : 0, out_idx, out_val);
+  }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }

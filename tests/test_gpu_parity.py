@@ -369,6 +369,19 @@ def test_topk_masked_vs_reference_contract(ops, k, golden_small):
     assert np.array_equal(idx, oracle.topk_reference(R, k))
 
 
+def test_topk_item_windows_carry_state(ops, golden_small, monkeypatch):
+    """Catalogues larger than the item window are scored window by window with the running best
+    list carried between launches: same answer as one pass."""
+    g = golden_small
+    users_np = g["test_dict_users"][:70]
+    args = (dev(g["d64_lgcn_user"]), dev(g["d64_lgcn_item"]), dev(users_np), 20, dev(g["pos_indptr"]), dev(g["pos_indices"]))
+    whole_idx, whole_val = ops.score_topk(*args, return_values=True)
+    for w in ("32", "64", "100"):
+        monkeypatch.setenv("IDG_ITEM_WINDOW", w)
+        idx, val = ops.score_topk(*args, return_values=True)
+        assert torch.equal(idx, whole_idx) and torch.equal(val, whole_val)
+
+
 def test_topk_ties_saturated_sigmoid_and_masked_fill(ops):
     # sigmoid saturates to exactly 1.0f: ties broken by lowest item id (SURVEY §0.8)
     Uu = np.full((3, 64), 1.0, dtype=np.float32)
