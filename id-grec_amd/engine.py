@@ -30,8 +30,7 @@ class PropagationEngine:
         self.params = torch.empty((self.n, self.d), **f32) if params is None else params
         assert self.params.is_cuda and self.params.is_contiguous() and self.params.shape == (self.n, self.d)
         self.grad = torch.zeros((self.n, self.d), **f32)      # d loss / d E0
-        self.exp_avg = torch.zeros((self.n, self.d), **f32)
-        self.exp_avg_sq = torch.zeros((self.n, self.d), **f32)
+        self.exp_avg = self.exp_avg_sq = None                 # Adam moments: allocated by the first train_step()
         self.final = torch.empty((self.n, self.d), **f32) if graph is not None else None
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
         self.touched = torch.zeros((self.n + 31) // 32, dtype=torch.int32, device=dev) if graph is not None else None
@@ -108,6 +107,8 @@ class PropagationEngine:
     @torch.no_grad()
     def train_step(self, users, pos, neg, loss_out=None):
         loss = self.loss_and_grad(users, pos, neg, loss_out)
+        if self.exp_avg is None:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.params), torch.zeros_like(self.params)
         self.step_count += 1
         ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
                           self.betas[0], self.betas[1], self.eps)

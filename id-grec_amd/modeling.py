@@ -47,6 +47,7 @@ class PackedRecommender(nn.Module):
         self.Graph = None
         self._storage = None
         self._engine = None
+        self._eval_cache = None
         self._pack()
 
     # ------------------------------------------------------------------ packed storage
@@ -57,6 +58,7 @@ class PackedRecommender(nn.Module):
         uw.data, iw.data = storage[:U], storage[U:]
         self._storage = storage
         self._engine = None
+        self._eval_cache = None
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
@@ -75,8 +77,7 @@ class PackedRecommender(nn.Module):
         return _PackedPanel.apply(self.user_embedding.weight, self.item_embedding.weight, self._storage)
 
     def train(self, mode=True):
-        if self._engine is not None:
-            self._engine._final_version = -1  # weights may change: drop the cached propagation
+        self._eval_cache = None  # weights may change: drop the cached evaluation panels
         return super().train(mode)
 
     # ------------------------------------------------------------------ graph
@@ -110,6 +111,7 @@ class PackedRecommender(nn.Module):
         """Losses [bpr, reg_lambda*reg] (device tensor) and d(sum)/d(weights) written into the
         two parameters' .grad — the work of forward() + backward() without an autograd graph."""
         eng = self.engine()
+        self._eval_cache = None
         loss = eng.loss_and_grad(users, pos, neg, loss_out)
         U = self.dataset.num_users
         self.user_embedding.weight.grad = eng.grad[:U]
@@ -117,8 +119,15 @@ class PackedRecommender(nn.Module):
         return loss
 
     def final_panels(self):
-        """(users [U,d], items [I,d]) used for scoring, cached while the weights are frozen."""
-        fin = self.engine().propagate()
+        """(users [U,d'], items [I,d']) used for scoring, cached while the weights are frozen.
+        Default: the layer-mean propagation of the packed panel; encoders with their own
+        aggregate() (NGCF) override `_eval_panels`."""
+        if self._eval_cache is None:
+            self._eval_cache = self._eval_panels()
+        return self._eval_cache
+
+    def _eval_panels(self):
+        fin = self.engine().propagate(force=True)
         U = self.dataset.num_users
         return fin[:U], fin[U:]
 

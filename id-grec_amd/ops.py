@@ -227,6 +227,9 @@ _bpr_ws_cache = {}
 
 
 def _bpr_ws(B, d, device):
+    """Scratch of the fused BPR calls.  One buffer per (batch size, width, device): the forward and
+    backward calls of a step (and the side-stream plan) must see the SAME buffer.  Callers that run
+    two BPR steps concurrently on different streams need their own workspace (not done here)."""
     key = (int(B), int(d), device)
     ws = _bpr_ws_cache.get(key)
     if ws is None:

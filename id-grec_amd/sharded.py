@@ -86,7 +86,7 @@ class ShardedEngine:
         self.P, self.G, self.M, self.V = z((n, dim)), z((n, dim)), z((n, dim)), z((n, dim))
         self.FIN, self.GF = z((n, dim)), z((n, dim))
         self.XU = [z((self.Ug, dim)), z((self.Ug, dim))]
-        self.XI = [z((self.I, dim)), z((self.I, dim))]
+        self.XI = [z((self.I, dim)), z((self.I, dim)), z((self.I, dim))]
         self.loss = z((2,))
         self.upstream = z((2,))
         self.step_count = 0
@@ -99,28 +99,40 @@ class ShardedEngine:
 
     # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
     def propagate(self):
+        """Layer k: P_I(k) = R^T X_U(k-1) (local partial) -> all-reduce -> X_I(k);  X_U(k) = R X_I(k-1).
+        P_I(k+1) needs only X_U(k), not X_I(k): it is launched BEFORE waiting for all-reduce k, so the
+        collectives queue back to back on the communicator while the SpMMs keep the GPU busy."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
-        xu_prev, xi_prev = self._u(self.P), self._i(self.P)
         fin_u, fin_i = self._u(self.FIN), self._i(self.FIN)
+        xu_prev, xi_prev = self._u(self.P), self._i(self.P)
+        pending = None  # (work, xi_new, layer) of the all-reduce whose result has not been folded in yet
+
+        def finish(pending):
+            work, xi_new, layer, xi_before = pending
+            self.comm.wait(work)
+            scale = 1.0 / cnt if layer == K else 1.0
+            if layer == 1:
+                base = self._i(self.P) if c0 else None
+            else:
+                base = fin_i if (c0 or layer > 2) else xi_before
+            k.lincomb(fin_i, xi_new, scale, base, scale)
+
         for layer in range(1, K + 1):
             last = layer == K
-            xi_new = self.XI[layer & 1]
-            k.spmm(self.G_iu, xu_prev, Y=xi_new)                       # item-side partial ...
-            work = self.comm.all_reduce_async(xi_new)                  # ... summed over ranks, overlapping:
+            xi_new = self.XI[layer % 3]
+            k.spmm(self.G_iu, xu_prev, Y=xi_new)                       # item-side partial of this layer
+            if pending is not None:
+                finish(pending)                                        # X_I(layer-1) is needed from here on
+            work = self.comm.all_reduce_async(xi_new)
             if layer == 1:
                 sum_in = self._u(self.P) if c0 else None
             else:
                 sum_in = fin_u if (c0 or layer > 2) else xu_prev
             xu_new = None if last else self.XU[layer & 1]
             k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0)
-            self.comm.wait(work)
-            scale = 1.0 / cnt if last else 1.0
-            if layer == 1:
-                base = self._i(self.P) if c0 else None
-            else:
-                base = fin_i if (c0 or layer > 2) else xi_prev
-            k.lincomb(fin_i, xi_new, scale, base, scale)
+            pending = (work, xi_new, layer, xi_prev)
             xu_prev, xi_prev = xu_new, xi_new
+        finish(pending)
         return self.FIN
 
     # ---- backward of the above given GF = d loss / d FIN (item rows still per-rank partials),

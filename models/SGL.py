@@ -1,0 +1,118 @@
+"""SGL (Wu et al., SIGIR'21) on MI355X: LightGCN encoder on the full graph plus two
+edge-dropped views rebuilt every epoch, InfoNCE between the views (reference: models/SGL.py,
+including its own epoch loop `SGL_trainer`).  Every view is a device graph handle; the
+per-epoch sub-graph normalisation runs in the native adjacency builder instead of SciPy."""
+from time import time
+
+import torch
+
+import utility.utility_data.data_graph as data_graph
+import utility.utility_function.losses as losses
+import utility.utility_function.tools as tools
+import utility.utility_train.batch_test as batch_test
+from idgrec_amd import ops
+from idgrec_amd.modeling import PackedRecommender
+
+
+class SGL(PackedRecommender):
+    include_layer0 = True
+
+    def __init__(self, config, dataset, device):
+        super(SGL, self).__init__(config, dataset, device)
+        self.n_layers = int(config['GCN_layer'])
+        self.ssl_lambda = float(config['ssl_lambda'])
+        self.temperature = float(config['temperature'])
+        self.attach_graph(data_graph.sparse_adjacency_matrix(dataset))
+
+    def aggregate(self, graph):
+        """graph: one handle for every layer, or a list with one handle per layer ('rw')."""
+        ego = self.ego_panel()
+        if isinstance(graph, list):
+            x, total = ego, ego
+            for layer in range(self.n_layers):
+                x = ops.spmm(graph[layer], x)
+                total = total + x
+            final = total / float(self.n_layers + 1)
+        else:
+            final = ops.propagate_mean(graph, ego, self.n_layers, include_layer0=True)
+        return torch.split(final, [self.dataset.num_users, self.dataset.num_items])
+
+    def forward(self, user, positive, negative, sub_graph_1, sub_graph_2):
+        ego = self.ego_panel()
+        final = ops.propagate_mean(self.Graph, ego, self.n_layers, include_layer0=True)
+        user_1, item_1 = self.aggregate(sub_graph_1)
+        user_2, item_2 = self.aggregate(sub_graph_2)
+        bpr_loss, reg_loss = ops.bpr_loss(final, ego, user, positive, negative, self.dataset.num_users,
+                                          self.reg_lambda)
+        user_index, item_index = user.long(), positive.long()  # no torch.unique here (models/SGL.py:85-86)
+        ssl = losses.get_InfoNCE_loss(user_1[user_index], user_2[user_index], self.temperature) \
+            + losses.get_InfoNCE_loss(item_1[item_index], item_2[item_index], self.temperature)
+        return [bpr_loss, reg_loss, self.ssl_lambda * ssl]
+
+
+class Trainer():
+    def __init__(self, args, config, dataset, device, logger):
+        self.model = SGL(config, dataset, device)
+        self.args, self.config, self.dataset = args, config, dataset
+        self.device, self.logger = device, logger
+        self.aug_type = config['aug_type']
+        self.ssl_ratio = float(config['ssl_ratio'])
+
+    def train(self):
+        self.SGL_trainer()
+
+    def _view(self):
+        mat = tools.create_adj_mat(self.dataset.user_item_net, self.aug_type, self.ssl_ratio)
+        return tools.convert_sp_mat_to_graph(mat, self.device)
+
+    def _views(self):
+        if self.aug_type in ['nd', 'ed']:
+            return self._view(), self._view()
+        layers = int(self.config['GCN_layer'])  # 'rw': a fresh graph per layer, interleaved draw order as the reference
+        pairs = [(self._view(), self._view()) for _ in range(layers)]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
+
+    def SGL_trainer(self):
+        """The reference's own loop for this model (models/SGL.py:115-199): sub-graphs per epoch,
+        no early-stop break, one more evaluation after the last epoch."""
+        cfg, model, device = self.config, self.model, self.device
+        model.to(device)
+        Optim = ops.Adam(model.parameters(), lr=float(cfg['learn_rate']))
+        batch_size = int(cfg['batch_size'])
+        top_k = eval(cfg['top_K'])
+        best_results = {'count': 0, 'epoch': 0, 'recall': [0. for _ in top_k], 'ndcg': [0. for _ in top_k]}
+        best_results['stop'] = 0
+        for epoch in range(int(cfg['training_epochs'])):
+            print('-' * 100)
+            start_time = time()
+            sub_graph_1, sub_graph_2 = self._views()
+            model.train()
+            triples = torch.from_numpy(self.dataset.sample_data_to_train_all()).to(device)
+            users, pos_items, neg_items = tools.shuffle(triples[:, 0], triples[:, 1], triples[:, 2])
+            num_batch = len(users) // batch_size + 1
+            step_losses = torch.zeros((num_batch, 3), dtype=torch.float32, device=device)
+            for batch_i, (b_u, b_p, b_n) in enumerate(tools.mini_batch(users, pos_items, neg_items, batch_size=batch_size)):
+                loss_list = model(b_u, b_p, b_n, sub_graph_1, sub_graph_2)
+                step_losses[batch_i] = torch.stack([l.detach() for l in loss_list])
+                Optim.zero_grad()
+                sum(loss_list).backward()
+                Optim.step()
+            total_loss_list = [0.] * 3
+            for row in step_losses.double().cpu().numpy():
+                for i, v in enumerate(row):
+                    total_loss_list[i] += float(v)
+            end_time = time()
+            loss_strs = str(round(sum(total_loss_list) / num_batch, 6)) \
+                + " = " + " + ".join([str(round(i / num_batch, 6)) for i in total_loss_list])
+            print("\t Epoch: %4d| train time: %.3f | train_loss: %s" % (epoch + 1, end_time - start_time, loss_strs))
+            self.logger.info("Epoch: %4d | Training time: %.3f | training loss: %s"
+                             % (epoch + 1, end_time - start_time, loss_strs))
+            if epoch % int(cfg['interval']) == 0:
+                result, best_results = batch_test.general_test(self.dataset, model, device, cfg, epoch, best_results)
+                self.logger.info("Epoch: %4d | Test recall: %s | Test NDCG: %s" % (epoch + 1, result['recall'], result['ndcg']))
+        print("\t Model training process completed.")
+        self.logger.info('Model training process completed.')
+        result, best_results = batch_test.general_test(self.dataset, model, device, cfg, int(cfg['training_epochs']),
+                                                       best_results)
+        self.logger.info("Best epoch: %4d | Best recall: %s | Best NDCG: %s"
+                         % (best_results['epoch'], best_results['recall'], best_results['ndcg']))

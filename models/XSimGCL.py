@@ -1,0 +1,61 @@
+"""XSimGCL (Yu et al.) on MI355X: ONE perturbed propagation per step serves both the
+recommendation loss and the contrast between layer `cl_layer` and the final mean (reference:
+models/XSimGCL.py).  Layers chain the SpMM operator with the noise
+`X += sign(X) * normalize(U[0,1)) * eps` in between; evaluation uses the unperturbed encoder
+(mean of layers 1..K), which is the fused propagate-mean operator."""
+import torch
+
+import utility.utility_data.data_graph as data_graph
+import utility.utility_function.losses as losses
+import utility.utility_train.trainer as trainer
+from idgrec_amd import ops
+from idgrec_amd.modeling import PackedRecommender
+
+
+class XSimGCL(PackedRecommender):
+    include_layer0 = False
+
+    def __init__(self, config, dataset, device):
+        super(XSimGCL, self).__init__(config, dataset, device)
+        self.n_layers = int(config['GCN_layer'])
+        self.ssl_lambda = float(config['ssl_lambda'])
+        self.epsilon = float(config['epsilon'])
+        self.temperature = float(config['temperature'])
+        self.cl_layer = int(config['cl_layer'])
+        self.attach_graph(data_graph.sparse_adjacency_matrix(dataset))
+
+    def aggregate(self, perturbed=False):
+        U, I = self.dataset.num_users, self.dataset.num_items
+        ego = self.ego_panel()
+        if not perturbed:
+            return torch.split(ops.propagate_mean(self.Graph, ego, self.n_layers, include_layer0=False), [U, I])
+        x, total, view = ego, None, ego
+        for layer in range(self.n_layers):
+            x = ops.spmm(self.Graph, x)
+            x = x + torch.sign(x) * torch.nn.functional.normalize(torch.rand_like(x), dim=-1) * self.epsilon
+            total = x if total is None else total + x
+            if layer == self.cl_layer - 1:
+                view = x
+        final = total / float(self.n_layers)
+        return torch.split(final, [U, I]) + torch.split(view, [U, I])
+
+    def forward(self, user, positive, negative):
+        ego = self.ego_panel()
+        all_user, all_item, user_cl, item_cl = self.aggregate(perturbed=True)
+        final = torch.cat([all_user, all_item])
+        bpr_loss, reg_loss = ops.bpr_loss(final, ego, user, positive, negative, self.dataset.num_users,
+                                          self.reg_lambda)
+        user_index, item_index = torch.unique(user), torch.unique(positive)
+        ssl = losses.get_InfoNCE_loss(user_cl[user_index], all_user[user_index], self.temperature) \
+            + losses.get_InfoNCE_loss(item_cl[item_index], all_item[item_index], self.temperature)
+        return [bpr_loss, reg_loss, self.ssl_lambda * ssl]
+
+
+class Trainer():
+    def __init__(self, args, config, dataset, device, logger):
+        self.model = XSimGCL(config, dataset, device)
+        self.args, self.config, self.dataset = args, config, dataset
+        self.device, self.logger = device, logger
+
+    def train(self):
+        trainer.universal_trainer(self.model, self.args, self.config, self.dataset, self.device, self.logger)

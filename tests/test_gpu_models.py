@@ -179,3 +179,135 @@ def test_simgcl_runs_and_clean_view_matches_reference(tmp_path, golden_small):
         opt.step()
         first = first if first is not None else float(sum(ll))
     assert float(sum(ll)) < first  # five steps on one batch reduce its loss
+
+
+# ----------------------------------------------------------------- next models
+@pytest.fixture(scope="module")
+def golden_next():
+    import os
+
+    return dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "next_small.npz")))
+
+
+def _cfg(name, **kw):
+    import os
+
+    import utility.utility_function.tools as tools
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = tools.read_configuration(os.path.join(root, "configure", name + ".txt"), name)
+    cfg.update({k: str(v) for k, v in kw.items()})
+    return cfg
+
+
+def _data_with(tmp_path, g, cfg):
+    import utility.utility_data.data_loader as data_loader
+
+    d = tmp_path / "small"
+    d.mkdir(exist_ok=True)
+    (d / "train.txt").write_bytes(g["train_txt"].tobytes())
+    (d / "test.txt").write_bytes(g["test_txt"].tobytes())
+    cfg.update(dataset="small", dataset_path=str(tmp_path) + "/")
+    return data_loader.Data(str(d), cfg)
+
+
+def test_ngcf_vs_reference(tmp_path, golden_small, golden_next):
+    import utility.utility_function.tools as tools
+    from models.NGCF import NGCF
+
+    g, nx = golden_small, golden_next
+    cfg = _cfg("NGCF", mess_drop_prob="[0.0, 0.0, 0.0]")  # the goldens were taken with message dropout off
+    data = _data_with(tmp_path, g, cfg)
+    tools.set_seed(2024)
+    m = NGCF(cfg, data, torch.device("cuda")).to("cuda")
+    assert np.array_equal(m.user_embedding.weight.detach().cpu().numpy(), nx["ngcf_init_user"])
+    for k, v in m.weight_dict.items():  # same torch RNG order as the reference's constructor
+        assert np.array_equal(v.detach().cpu().numpy(), nx["ngcf_" + k]), k
+    m.eval()
+    au, ai = m.aggregate()
+    np.testing.assert_allclose(au.detach().cpu().numpy(), nx["ngcf_user"], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(ai.detach().cpu().numpy(), nx["ngcf_item"], rtol=RTOL, atol=1e-6)
+    b = torch.from_numpy(nx["batch"]).cuda()
+    ll = m(b[:, 0], b[:, 1], b[:, 2])
+    np.testing.assert_allclose([x.item() for x in ll], nx["ngcf_loss"], rtol=RTOL)
+    sum(ll).backward()
+    np.testing.assert_allclose(m.user_embedding.weight.grad.cpu().numpy(), nx["ngcf_grad_user"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(m.item_embedding.weight.grad.cpu().numpy(), nx["ngcf_grad_item"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(m.weight_dict["W_gcn_0"].grad.cpu().numpy(), nx["ngcf_grad_W_gcn_0"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(m.weight_dict["b_bi_2"].grad.cpu().numpy(), nx["ngcf_grad_b_bi_2"], rtol=1e-3, atol=1e-7)
+    R = m.get_rating_for_test(torch.from_numpy(g["test_dict_users"][:32]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(R, nx["ngcf_rating"], rtol=1e-4, atol=1e-5)
+    idx = m.topk_for_test(torch.from_numpy(g["test_dict_users"][:32]).cuda(), 10)  # d' = 256 scoring path
+    assert idx.shape == (32, 10)
+
+
+def test_sgl_three_views_vs_reference(tmp_path, golden_small, golden_next):
+    import scipy.sparse as sp
+
+    import utility.utility_function.tools as tools
+    from models.SGL import SGL
+
+    g, nx = golden_small, golden_next
+    cfg = _cfg("SGL")
+    data = _data_with(tmp_path, g, cfg)
+    tools.set_seed(2024)
+    m = SGL(cfg, data, torch.device("cuda")).to("cuda")
+    n = data.num_users + data.num_items
+    subs = [tools.convert_sp_mat_to_graph(sp.csr_matrix((nx[k + "_data"], nx[k + "_indices"], nx[k + "_indptr"]), shape=(n, n)),
+                                          torch.device("cuda")) for k in ("sgl_sub1", "sgl_sub2")]
+    b = torch.from_numpy(nx["batch"]).cuda()
+    ll = m(b[:, 0], b[:, 1], b[:, 2], subs[0], subs[1])
+    np.testing.assert_allclose([x.item() for x in ll], nx["sgl_loss"], rtol=RTOL)
+    sum(ll).backward()
+    np.testing.assert_allclose(m.user_embedding.weight.grad.cpu().numpy(), nx["sgl_grad_user"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(m.item_embedding.weight.grad.cpu().numpy(), nx["sgl_grad_item"], rtol=1e-3, atol=1e-8)
+    # per-layer graph lists ('rw') give the same encoder when every layer uses the same graph
+    u1, i1 = m.aggregate(subs[0])
+    u2, i2 = m.aggregate([subs[0]] * 3)
+    assert torch.allclose(u1, u2, rtol=1e-6, atol=1e-8) and torch.allclose(i1, i2, rtol=1e-6, atol=1e-8)
+
+
+def test_sgl_trainer_loop_runs(tmp_path, golden_small):
+    import utility.utility_function.tools as tools
+    from models.SGL import Trainer
+
+    cfg = _cfg("SGL", training_epochs=2, batch_size=512, test_batch_size=64, top_K="[5, 10]")
+    data = _data_with(tmp_path, golden_small, cfg)
+    stream = io.StringIO()
+    logger = logging.getLogger("sgl_loop")
+    logger.setLevel(logging.INFO)
+    logger.handlers = [logging.StreamHandler(stream)]
+    tools.set_seed(2024)
+    Trainer(None, cfg, data, torch.device("cuda"), logger).train()
+    lines = stream.getvalue().splitlines()
+    assert [ln.split("|")[0].strip() for ln in lines[:4]] == ["Epoch:    1", "Epoch:    1", "Epoch:    2", "Epoch:    2"]
+    assert lines[0].count(" + ") == 2 and lines[-2] == "Model training process completed." and lines[-1].startswith("Best epoch:")
+
+
+def test_xsimgcl_encoder_and_training(tmp_path, golden_small, golden_next):
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.XSimGCL import XSimGCL
+
+    g, nx = golden_small, golden_next
+    cfg = _cfg("XSimGCL")
+    data = _data_with(tmp_path, g, cfg)
+    tools.set_seed(2024)
+    m = XSimGCL(cfg, data, torch.device("cuda")).to("cuda")
+    with torch.no_grad():
+        u, i = m.aggregate(perturbed=False)
+    np.testing.assert_allclose(u.cpu().numpy(), nx["xsimgcl_user"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(i.cpu().numpy(), nx["xsimgcl_item"], rtol=1e-5, atol=1e-8)
+    out = m.aggregate(perturbed=True)
+    assert len(out) == 4 and out[2].shape == u.shape
+    b = torch.from_numpy(nx["batch"]).cuda()
+    opt = ops.Adam(m.parameters(), lr=1e-3)
+    vals = []
+    for _ in range(5):
+        ll = m(b[:, 0], b[:, 1], b[:, 2])
+        assert len(ll) == 3 and all(torch.isfinite(x) for x in ll)
+        opt.zero_grad()
+        sum(ll).backward()
+        opt.step()
+        vals.append(float(sum(ll).detach()))
+    assert vals[-1] < vals[0]

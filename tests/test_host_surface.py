@@ -202,3 +202,29 @@ def test_models_refuse_cpu_loudly(tmp_path, golden_tiny):
     data, cfg = _dataset(tmp_path, golden_tiny, "tiny", embedding_size="64", reg_lambda="1e-4", GCN_layer="3")
     with pytest.raises(RuntimeError, match="MI355X"):
         LightGCN(cfg, data, torch.device("cpu"))
+
+
+def test_sgl_create_adj_mat_vs_reference(tmp_path, golden_small):
+    """Same python `random` state -> same kept edges -> bit-identical normalised sub-graphs."""
+    import random
+
+    import numpy as np
+
+    nxt = dict(np.load(os.path.join(ROOT, "tests", "golden", "next_small.npz")))
+    data, _ = _dataset(tmp_path, golden_small, "small")
+    random.seed(7)
+    for name in ("sgl_sub1", "sgl_sub2"):
+        A = tools.create_adj_mat(data.user_item_net, "ed", 0.1).tocsr()
+        A.sort_indices()
+        assert A.dtype == np.float32
+        assert np.array_equal(A.indptr, nxt[name + "_indptr"]) and np.array_equal(A.indices, nxt[name + "_indices"])
+        assert np.array_equal(A.data, nxt[name + "_data"])
+    with pytest.raises(NotImplementedError):
+        tools.create_adj_mat(data.user_item_net, "nd", 0.1)
+
+
+def test_next_model_configs(golden_misc):
+    ref = json.loads(str(golden_misc["configs"]))
+    for name in ("NGCF", "SGL", "XSimGCL"):
+        cfg = tools.read_configuration(os.path.join(ROOT, "configure", name + ".txt"), name)
+        assert cfg == ref[name] and list(cfg) == list(ref[name])

@@ -87,6 +87,30 @@ def mini_batch(*tensors, **kwargs):
             yield tuple(x[lo:lo + size] for x in tensors)
 
 
+def create_adj_mat(inter_graph, aug_type, ssl_rate):
+    """SGL's augmented graph (tools.py:67-92): keep int((1 - ssl_rate) * E) interactions chosen with
+    python's `random.sample` (never seeded by the reference), rebuild the symmetric bipartite
+    adjacency on the kept edges and normalise it — natively, through idg_build_norm_adj.
+    Returns a scipy CSR float32 matrix like the reference."""
+    import random
+
+    import scipy.sparse as sp
+
+    num_users, num_items = inter_graph.get_shape()
+    user_index, item_index = inter_graph.nonzero()
+    if aug_type == 'nd':
+        raise NotImplementedError("The method does not implemented.")
+    if aug_type not in ('ed', 'rw'):
+        raise ValueError("unknown aug_type %r" % (aug_type,))
+    edge_number = inter_graph.count_nonzero()
+    keep_index = random.sample(range(edge_number), k=int((1 - ssl_rate) * edge_number))
+    keep_users = np.array(user_index)[keep_index]
+    keep_items = np.array(item_index)[keep_index]
+    indptr, indices, values = _host.build_norm_adj(num_users, num_items, keep_users, keep_items)
+    n = num_users + num_items
+    return sp.csr_matrix((values, indices, indptr), shape=(n, n))
+
+
 def convert_sp_mat_to_graph(sp_mat, device, symmetric=True):
     """scipy matrix -> device graph handle for idgrec_amd.ops.spmm / propagate_mean.  Stands
     where the reference builds its coalesced torch sparse tensor (models/LightGCN.py:31-32)."""
