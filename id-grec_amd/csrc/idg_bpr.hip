@@ -128,35 +128,99 @@ __global__ __launch_bounds__(BLOCK) void bpr_atomic_kernel(BprArgs a) {
   }
 }
 
-// Sort <= LDS_SORT_MAX 64-bit (row << 32 | slot) keys ascending in LDS, one workgroup.
+// Sort <= LDS_SORT_MAX packed (row, slot) keys ascending, one 1024-thread workgroup.
+// Element i = e * 1024 + tid lives in register e of thread tid.  Bitonic network; the partner of
+// element i at distance j is i ^ j:  j >= 1024 -> another register of the same thread (no traffic),
+// 64 <= j < 1024 -> another wave (one LDS exchange), j < 64 -> another lane (wave shuffle).
+// Of the 78 phases of a 4096-key sort only 18 touch LDS.  KeyT is uint32 when row and slot bits
+// fit in 32 (every reference configuration), else uint64.
+template <typename KeyT>
+__device__ __forceinline__ KeyT shfl_xor_key(KeyT v, int m);
+template <>
+__device__ __forceinline__ uint32_t shfl_xor_key<uint32_t>(uint32_t v, int m) {
+  return __shfl_xor(v, m, WAVE);
+}
+template <>
+__device__ __forceinline__ unsigned long long shfl_xor_key<unsigned long long>(unsigned long long v, int m) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = __shfl_xor(lo, m, WAVE);
+  hi = __shfl_xor(hi, m, WAVE);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <typename KeyT, int E>
 __global__ __launch_bounds__(1024) void lds_sort_kernel(const int32_t* __restrict__ keys,
-                                                        const int32_t* __restrict__ slots, int n, int n_pow2,
-                                                        int32_t* __restrict__ keys_out,
+                                                        const int32_t* __restrict__ slots, int n, int p2,
+                                                        int slot_bits, int32_t* __restrict__ keys_out,
                                                         int32_t* __restrict__ slots_out) {
-  extern __shared__ unsigned long long s_k[];
+  __shared__ KeyT s_k[1024 * E];
   const int tid = threadIdx.x;
-  for (int i = tid; i < n_pow2; i += 1024)
-    s_k[i] = i < n ? (((unsigned long long)(uint32_t)keys[i]) << 32) | (uint32_t)slots[i] : ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= n_pow2; k <<= 1) {
+  KeyT v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = e * 1024 + tid;
+    v[e] = i < n ? (KeyT)(((KeyT)(uint32_t)keys[i] << slot_bits) | (KeyT)(uint32_t)slots[i]) : (KeyT)~(KeyT)0;
+  }
+  auto cmpx = [](KeyT a, KeyT o, bool take_min) { return take_min ? (a < o ? a : o) : (a < o ? o : a); };
+  for (int k = 2; k <= p2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n_pow2; i += 1024) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = s_k[i], b = s_k[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            s_k[i] = b;
-            s_k[ixj] = a;
-          }
+      if (j >= 1024) {
+        // partner register e ^ (j / 1024): static indexing needs the distance as a constant
+#define IDG_INTHREAD(JE)                                                                  \
+  if (E > JE) {                                                                           \
+    _Pragma("unroll") for (int e = 0; e < E; ++e) if ((e & JE) == 0 && (e | JE) < E) {    \
+      const int i = e * 1024 + tid;                                                       \
+      const bool up = (i & k) == 0;                                                       \
+      const KeyT a = v[e], b = v[e | JE];                                                 \
+      const bool sw = (a > b) == up;                                                      \
+      v[e] = sw ? b : a;                                                                  \
+      v[e | JE] = sw ? a : b;                                                             \
+    }                                                                                     \
+  }
+        const int je = j >> 10;
+        if (je == 1) { IDG_INTHREAD(1) } else if (je == 2) { IDG_INTHREAD(2) } else if (je == 4) { IDG_INTHREAD(4) }
+#undef IDG_INTHREAD
+      } else if (j >= WAVE) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s_k[e * 1024 + tid] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = e * 1024 + tid;
+          const KeyT o = s_k[i ^ j];
+          v[e] = cmpx(v[e], o, ((i & j) == 0) == ((i & k) == 0));
+        }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = e * 1024 + tid;
+          const KeyT o = shfl_xor_key<KeyT>(v[e], j);
+          v[e] = cmpx(v[e], o, ((i & j) == 0) == ((i & k) == 0));
         }
       }
-      __syncthreads();
     }
   }
-  for (int i = tid; i < n; i += 1024) {
-    keys_out[i] = (int32_t)(s_k[i] >> 32);
-    slots_out[i] = (int32_t)(s_k[i] & 0xffffffffu);
+  const KeyT slot_mask = (KeyT)(((KeyT)1 << slot_bits) - 1);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = e * 1024 + tid;
+    if (i < n) {
+      keys_out[i] = (int32_t)(v[e] >> slot_bits);
+      slots_out[i] = (int32_t)(v[e] & slot_mask);
+    }
+  }
+}
+
+template <typename KeyT>
+static void launch_lds_sort(const int32_t* keys, const int32_t* slots, int n3, int p2, int slot_bits, int32_t* skeys,
+                            int32_t* sslots, hipStream_t st) {
+  const int E = p2 <= 1024 ? 1 : p2 / 1024;
+  switch (E) {
+    case 1: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 1>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2 < 64 ? 64 : p2, slot_bits, skeys, sslots); break;
+    case 2: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 2>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots); break;
+    case 4: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 4>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots); break;
+    default: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 8>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots); break;
   }
 }
 
@@ -403,7 +467,13 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
   if (n3 <= LDS_SORT_MAX) {
     int p2 = 1;
     while (p2 < n3) p2 <<= 1;
-    hipLaunchKernelGGL(lds_sort_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, keys, slots, (int)n3, p2, skeys, sslots);
+    int slot_bits = 1, row_bits = 1;
+    while (((int64_t)1 << slot_bits) < n3) ++slot_bits;
+    while (((int64_t)1 << row_bits) < n) ++row_bits;
+    if (slot_bits + row_bits <= 31)  // top bit kept clear so the all-ones padding key sorts last
+      launch_lds_sort<uint32_t>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);
+    else
+      launch_lds_sort<unsigned long long>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);
   } else {
     int end_bit = 1;
     while (((int64_t)1 << end_bit) < n) ++end_bit;

@@ -60,6 +60,11 @@ struct Epilogue {
   float div;            // 1 = no division
   int accumulate;       // sum_out[r] += instead of =
   const uint32_t* mask; // row bitmap of addend / sum_in: rows with a 0 bit are zero and are not read (nullable)
+  // SimGCL / XSimGCL perturbation applied to t = A.X before anything else (models/SimGCL.py:50-51):
+  //   t += sign(t) * normalize(u, dim=-1) * noise_eps,  u ~ U[0,1)^d from Philox4x32-10(seed; row, block, stream)
+  float noise_eps;      // 0 = off
+  uint64_t noise_seed;
+  uint64_t noise_stream;
 };
 
 }  // namespace
@@ -98,8 +103,59 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+// Philox4x32-10 (Salmon et al. 2011): counter-based, so a row's noise depends only on
+// (seed, stream, row, feature block) — independent of tiling, launch order and split schedule.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += 0x9E3779B9u;
+    key.y += 0xBB67AE85u;
+  }
+  return ctr;
+}
+
+// 4 uniforms in [0,1) for features [4*fblock, 4*fblock+4) of row r
+__device__ __forceinline__ float4 noise4(const Epilogue& ep, int64_t r, int fblock);
+
 __device__ __forceinline__ bool mask_bit(const uint32_t* __restrict__ mask, int64_t r) {
   return (mask[r >> 5] >> (r & 31)) & 1u;
+}
+
+__device__ __forceinline__ float4 noise4(const Epilogue& ep, int64_t r, int fblock) {
+  const uint4 c = make_uint4((uint32_t)r, (uint32_t)((uint64_t)r >> 32), (uint32_t)fblock, (uint32_t)ep.noise_stream);
+  const uint2 k = make_uint2((uint32_t)ep.noise_seed, (uint32_t)(ep.noise_seed >> 32) ^ (uint32_t)(ep.noise_stream >> 32));
+  const uint4 x = philox4x32_10(c, k);
+  const float sc = 1.0f / 16777216.0f;  // 24 random bits -> [0, 1), like torch.rand
+  return make_float4((x.x >> 8) * sc, (x.y >> 8) * sc, (x.z >> 8) * sc, (x.w >> 8) * sc);
+}
+
+// t += sign(t) * u / max(||u||_2, 1e-12) * eps over the WHOLE row: the LPR lanes of the group hold
+// NB feature blocks each; the row norm is reduced across them with shuffles.
+template <int LPR, int NB>
+__device__ __forceinline__ float noise_row_scale(const Epilogue& ep, int64_t r, int l) {
+  float ss = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float4 u = noise4(ep, r, b * LPR + l);
+    ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, LPR);
+  return ep.noise_eps / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+__device__ __forceinline__ float sgn(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }
+
+__device__ __forceinline__ float4 perturb(const Epilogue& ep, int64_t r, int fblock, float scale, float4 t) {
+  const float4 u = noise4(ep, r, fblock);
+  t.x += sgn(t.x) * u.x * scale;
+  t.y += sgn(t.y) * u.y * scale;
+  t.z += sgn(t.z) * u.z * scale;
+  t.w += sgn(t.w) * u.w * scale;
+  return t;
 }
 
 __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, int off, float4 acc) {
@@ -199,7 +255,7 @@ __device__ __forceinline__ float4 walk_masked(CVPtr cv, int s, int e, const floa
 // One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
 // every feature block of width 4*LPR (d = NB * 4 * LPR).  DYNAMIC: lane groups draw the next
 // vrow from an LDS counter instead of a fixed stride (evens out skewed row lengths).
-template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1>
+template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, bool NOISE = false>
 __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __restrict__ tiles,
                                                           const int64_t* __restrict__ vptr,
                                                           const int32_t* __restrict__ vtgt,
@@ -233,12 +289,15 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   while (v < nv) {
     const int s = s_ptr[v], e = s_ptr[v + 1];
     const int tgt = s_tgt[v];
+    float nscale = 0.f;
+    if (NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int off = (b * LPR + l) * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       acc = walk<UNROLL>(s_cv, s, e, X + off, ldx, acc);
       if (tgt >= 0) {
+        if (NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
         epilogue_store(ep, tgt, off, acc);
       } else {
         *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
@@ -323,6 +382,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       acc = walk<8>(s_cv, s, e, X + off, ldx, acc);
       if (tgt >= 0) {
+        if (ep.noise_eps != 0.f) acc = perturb(ep, tgt, b * LPR + l, noise_row_scale<LPR, NB>(ep, tgt, l), acc);
         epilogue_store(ep, tgt, off, acc);
       } else {
         *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
@@ -355,6 +415,7 @@ __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__
       const int len = (int)std::min<int64_t>(e - c, 1 << 20);
       acc = x_mask ? walk_masked<8>(cv + c, 0, len, X + off, ldx, x_mask, acc) : walk<8>(cv + c, 0, len, X + off, ldx, acc);
     }
+    if (ep.noise_eps != 0.f) acc = perturb(ep, tgt, b * LPR + l, noise_row_scale<LPR, NB>(ep, tgt, l), acc);
     epilogue_store(ep, tgt, off, acc);
   }
 }
@@ -392,6 +453,7 @@ __global__ __launch_bounds__(FIX_WAYS * LPR) void spmm_fixup_kernel(const LongRo
     if (q == 0) {
       const int ways = lr.n_seg < FIX_WAYS ? lr.n_seg : FIX_WAYS;
       for (int w = 1; w < ways; ++w) acc = add4(acc, s_part[w][l]);
+      if (ep.noise_eps != 0.f) acc = perturb(ep, lr.row, b * LPR + l, noise_row_scale<LPR, NB>(ep, lr.row, l), acc);
       epilogue_store(ep, lr.row, off, acc);
     }
   }
@@ -473,6 +535,8 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
     if (x_mask) {  // sparse-input form (first backward layer)
       hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
                          g->d_cv, X, ldx, partials, d, ep, x_mask);
+    } else if (ep.noise_eps != 0.f) {  // perturbed layers: own instantiation (Philox + row-norm shuffles)
+      IDG_TILE(8, true, 1, true);
     } else switch (g->variant) {
       case 1: IDG_TILE(8, true); break;
       case 2: IDG_TILE(16, false); break;
@@ -512,6 +576,9 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
       default: break;
     }
   }
+  if (ep.noise_eps != 0.f)
+    return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: the noise epilogue needs d in {32,64,128,256,512} and 16-byte aligned panels (d=%lld)",
+                     (long long)d);
   if (g->n_vrows > 0) {
     const unsigned nb = (unsigned)((g->n_vrows + (BLOCK / 64) - 1) / (BLOCK / 64));
     hipLaunchKernelGGL(spmm_generic_kernel, dim3(nb), dim3(BLOCK), 0, st, g->d_vptr, g->d_vtgt, g->n_vrows,
@@ -808,6 +875,20 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
   return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream);
 }
 
+int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t d, float eps,
+                       uint64_t seed, uint64_t stream_id, void* ws, void* stream) {
+  IDG_REQUIRE(g && X && Y, "idg_spmm_noise_f32: NULL argument");
+  IDG_REQUIRE(d > 0 && ldx >= d && ldy >= d, "idg_spmm_noise_f32: bad d/ldx/ldy");
+  Epilogue ep{};
+  ep.Y = Y;
+  ep.ldy = ldy;
+  ep.div = 1.0f;
+  ep.noise_eps = eps;
+  ep.noise_seed = seed;
+  ep.noise_stream = stream_id;
+  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream);
+}
+
 size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {
   if (!g || d <= 0) return 0;
   // two ping-pong panels + the split-row partials
@@ -817,7 +898,8 @@ size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {
 
 static int propagate_common(const idg_graph* g, const float* in, float* out, int K, int include0, int64_t d,
                             void* ws, hipStream_t st, bool backward, int accumulate,
-                            const uint32_t* in_mask = nullptr) {
+                            const uint32_t* in_mask = nullptr, float noise_eps = 0.f, uint64_t noise_seed = 0,
+                            uint64_t noise_stream = 0) {
   IDG_REQUIRE(g && in && out && ws, "idg_propagate: NULL argument");
   IDG_REQUIRE(g->n_rows == g->n_cols, "idg_propagate: graph must be square");
   IDG_REQUIRE(K >= 1, "idg_propagate: K must be >= 1 (got %d)", K);
@@ -833,6 +915,11 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
     ep.ldy = d;
     ep.div = 1.0f;
     const bool last = (k == K);
+    if (!backward && noise_eps != 0.f) {
+      ep.noise_eps = noise_eps;
+      ep.noise_seed = noise_seed;
+      ep.noise_stream = noise_stream * 64 + (uint64_t)k;  // a fresh stream per layer
+    }
     if (!backward) {
       // forward: running sum lives in `out`; the last layer divides.
       if (!last) ep.Y = P[(k - 1) & 1];
@@ -871,6 +958,11 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
 int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int K, int include_layer0, int64_t d,
                            void* ws, void* stream) {
   return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0);
+}
+
+int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out, int K, int include_layer0, int64_t d,
+                                 float eps, uint64_t seed, uint64_t stream_id, void* ws, void* stream) {
+  return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0, nullptr, eps, seed, stream_id);
 }
 
 int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask, float* gE0, int K,

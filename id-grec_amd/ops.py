@@ -188,6 +188,85 @@ def lincomb_raw(out, x, a, y=None, b=0.0):
     check(lib.idg_lincomb_f32(_ptr(out), _ptr(x), float(a), _ptr(y), float(b), out.numel(), _stream()), "idg_lincomb_f32")
 
 
+_noise_stream = [0]
+
+
+def _next_noise_stream():
+    """(seed, stream id) of the next perturbation: the seed follows torch's device generator
+    (tools.set_seed -> torch.cuda.manual_seed), the stream id counts perturbed layers drawn so far."""
+    _noise_stream[0] += 1
+    return int(torch.cuda.initial_seed()) & 0xFFFFFFFFFFFFFFFF, _noise_stream[0]
+
+
+def reset_noise_stream(value=0):
+    _noise_stream[0] = int(value)
+
+
+class _SpMMNoise(torch.autograd.Function):
+    """Y = A.X, Y += sign(Y) * normalize(U[0,1)) * eps.  d Y / d X = A (sign has zero gradient)."""
+
+    @staticmethod
+    def forward(ctx, X, graph, eps):
+        _require_device(X)
+        X = _f32c(X, "X")
+        ctx.graph = graph
+        d = X.shape[1]
+        Y = torch.empty((graph.n_rows, d), dtype=torch.float32, device=X.device)
+        seed, stream_id = _next_noise_stream()
+        ws = graph._workspace("spmm", d)
+        check(lib.idg_spmm_noise_f32(graph._h, _ptr(X), d, _ptr(Y), d, d, float(eps), C.c_uint64(seed),
+                                     C.c_uint64(stream_id), _ptr(ws), _stream()), "idg_spmm_noise_f32")
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        return ctx.graph.T.spmm_raw(gY), None, None
+
+
+def spmm_perturbed(graph, X, eps):
+    """One SimGCL/XSimGCL layer: torch.sparse.mm followed by the in-place noise (models/XSimGCL.py:51-54)."""
+    return _SpMMNoise.apply(X, graph, float(eps))
+
+
+class _PropagateViews(torch.autograd.Function):
+    """(clean, view_1, ..., view_n): the unperturbed layer mean and n independently perturbed ones.
+    Every output has the same Jacobian w.r.t. E0 — (1/cnt) sum_k A^k — so backward adds the incoming
+    gradients and propagates ONCE (autograd over separate passes would propagate n + 1 times)."""
+
+    @staticmethod
+    def forward(ctx, E0, graph, K, include_layer0, eps, n_views):
+        _require_device(E0)
+        E0 = _f32c(E0, "E0")
+        ctx.graph, ctx.K, ctx.inc = graph, K, include_layer0
+        d = E0.shape[1]
+        outs = [graph.propagate_mean_raw(E0, K, include_layer0)]
+        ws = graph._workspace("prop", d)
+        for _ in range(n_views):
+            out = torch.empty_like(E0)
+            seed, stream_id = _next_noise_stream()
+            check(lib.idg_propagate_mean_noise_f32(graph._h, _ptr(E0), _ptr(out), int(K), int(bool(include_layer0)), d,
+                                                   float(eps), C.c_uint64(seed), C.c_uint64(stream_id), _ptr(ws),
+                                                   _stream()), "idg_propagate_mean_noise_f32")
+            outs.append(out)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        total = None
+        for g in grads:
+            if g is None:
+                continue
+            total = g if total is None else total + g
+        if total is None:
+            return None, None, None, None, None, None
+        return ctx.graph.propagate_mean_bwd_raw(total.contiguous(), ctx.K, ctx.inc), None, None, None, None, None
+
+
+def propagate_views(graph, E0, K, include_layer0, eps, n_views=2):
+    """SimGCL's three encoder passes of one step (models/SimGCL.py:63-65) as one differentiable op."""
+    return _PropagateViews.apply(E0, graph, int(K), bool(include_layer0), float(eps), int(n_views))
+
+
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, graph):

@@ -153,6 +153,12 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
                     const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
                     int64_t d, void* ws, void* stream);
 
+/* One perturbed layer (models/XSimGCL.py:51-54): Y = A.X;  Y += sign(Y) * normalize(u, dim=-1) * eps,
+ * u ~ U[0,1)^d from Philox4x32-10(seed; stream_id, row, feature block).  d in {32,...,512}. */
+int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                       int64_t d, float eps, uint64_t seed, uint64_t stream_id, void* ws,
+                       void* stream);
+
 /* LightGCN.aggregate (models/LightGCN.py:36-52) / SimGCL.aggregate(perturbed=False)
  * (models/SimGCL.py:39-60): out = mean over layers of E_k, E_{k+1} = A.E_k, k < K,
  * E_0 included iff include_layer0.  Running sum left-to-right then a true division by the
@@ -161,6 +167,17 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
 size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d);
 int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int K,
                            int include_layer0, int64_t d, void* ws, void* stream);
+/* SimGCL.aggregate(perturbed=True) (models/SimGCL.py:47-56): as idg_propagate_mean_f32, but after
+ * every product X <- A.X the layer is perturbed in place, X += sign(X) * normalize(u, dim=-1) * eps
+ * with u ~ U[0,1)^d, before it enters the running sum and feeds the next layer.  u comes from
+ * Philox4x32-10 keyed by (seed, stream_id, layer, row, feature block): reproducible for a given
+ * (seed, stream_id), independent of the tile schedule; like the reference's device generator it
+ * matches a CPU run statistically, not bit for bit.  d in {32, 64, 128, 256, 512}.
+ * The gradient w.r.t. E0 is idg_propagate_mean_bwd_f32's (sign() has zero gradient, u is constant). */
+int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out, int K,
+                                 int include_layer0, int64_t d, float eps, uint64_t seed,
+                                 uint64_t stream_id, void* ws, void* stream);
+
 /* Backward of the above for a SYMMETRIC graph: gE0 = (1/cnt)(c0.g + A(g + A(g + ... A g))),
  * the Horner form of autograd's chain through K torch.sparse.mm nodes and the mean.
  * accumulate != 0: gE0 += (the ego-embedding regulariser's gradient is already there). */

@@ -1,10 +1,11 @@
 """SimGCL (Yu et al., SIGIR'22) on MI355X: LightGCN encoder without layer 0 in the mean, two
 noise-perturbed views per step, InfoNCE between the views (reference: models/SimGCL.py).
 
-The clean view is the fused propagate-mean operator; each perturbed view chains the SpMM
-operator K times with the noise `X += sign(X) * normalize(U[0,1)) * eps` applied between
-layers (models/SimGCL.py:49-51).  The noise comes from the device generator, as in the
-reference, so perturbed views agree with a CPU run statistically, not bit for bit.
+The clean view is the fused propagate-mean operator; each perturbed view is the same chain with
+the noise `X += sign(X) * normalize(U[0,1)) * eps` (models/SimGCL.py:49-51) fused into every
+layer's SpMM epilogue (Philox4x32-10, seeded from torch's device seed).  Like the reference's
+device generator it agrees with a CPU run statistically, not bit for bit.  The three passes
+share one backward propagation (identical Jacobian).
 """
 import torch
 
@@ -31,23 +32,19 @@ class SimGCL(PackedRecommender):
         if not perturbed:
             final = ops.propagate_mean(self.Graph, ego, self.n_layers, include_layer0=False)
         else:
-            x, total = ego, None
-            for _ in range(self.n_layers):
-                x = ops.spmm(self.Graph, x)
-                noise = torch.nn.functional.normalize(torch.rand_like(x), dim=-1)
-                x = x + torch.sign(x) * noise * self.epsilon
-                total = x if total is None else total + x
-            final = total / float(self.n_layers)
+            final = ops.propagate_views(self.Graph, ego, self.n_layers, False, self.epsilon, n_views=1)[1]
         return torch.split(final, [self.dataset.num_users, self.dataset.num_items])
 
     def forward(self, user, positive, negative):
+        U, I = self.dataset.num_users, self.dataset.num_items
         ego = self.ego_panel()
-        clean = ops.propagate_mean(self.Graph, ego, self.n_layers, include_layer0=False)
-        user_1, item_1 = self.aggregate(perturbed=True)
-        user_2, item_2 = self.aggregate(perturbed=True)
+        # clean pass + two perturbed passes (models/SimGCL.py:63-65): noise fused into the SpMM epilogue,
+        # one shared backward propagation
+        clean, view_1, view_2 = ops.propagate_views(self.Graph, ego, self.n_layers, False, self.epsilon, n_views=2)
+        user_1, item_1 = torch.split(view_1, [U, I])
+        user_2, item_2 = torch.split(view_2, [U, I])
 
-        bpr_loss, reg_loss = ops.bpr_loss(clean, ego, user, positive, negative, self.dataset.num_users,
-                                          self.reg_lambda)
+        bpr_loss, reg_loss = ops.bpr_loss(clean, ego, user, positive, negative, U, self.reg_lambda)
 
         user_index = torch.unique(user)
         item_index = torch.unique(positive)

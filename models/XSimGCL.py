@@ -31,8 +31,7 @@ class XSimGCL(PackedRecommender):
             return torch.split(ops.propagate_mean(self.Graph, ego, self.n_layers, include_layer0=False), [U, I])
         x, total, view = ego, None, ego
         for layer in range(self.n_layers):
-            x = ops.spmm(self.Graph, x)
-            x = x + torch.sign(x) * torch.nn.functional.normalize(torch.rand_like(x), dim=-1) * self.epsilon
+            x = ops.spmm_perturbed(self.Graph, x, self.epsilon)  # SpMM + fused noise epilogue
             total = x if total is None else total + x
             if layer == self.cl_layer - 1:
                 view = x

@@ -428,3 +428,55 @@ def test_yelp_shape_full_size(ops):
     lhs = (Z.double() * Y.double()).sum().item()
     rhs = (G.spmm_raw(Z).double() * dev(X).double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
+# ------------------------------------------------------------------------- noise epilogue
+def test_noise_epilogue_statistics_and_reproducibility(ops, golden_small):
+    """X' = X + sign(X) * normalize(u) * eps, u ~ U[0,1)^d (models/SimGCL.py:50-51): every row moves
+    by exactly eps (unit-norm direction), componentwise in the direction of sign(X), the noise is
+    uniform, reproducible for a given (seed, stream) and independent of the split schedule."""
+    g = golden_small
+    n = int(g["num_users"]) + int(g["num_items"])
+    E0 = dev(np.concatenate([g["d64_init_user"], g["d64_init_item"]]))
+    eps = 0.05
+    torch.cuda.manual_seed(1234)
+    G = _graph(ops, g)
+    clean = G.spmm_raw(E0)
+    ops.reset_noise_stream(0)
+    Y1 = ops.spmm_perturbed(G, E0, eps)
+    ops.reset_noise_stream(0)
+    Y2 = ops.spmm_perturbed(_graph(ops, g, exact_order=True), E0, eps)   # different tile / split schedule
+    Y3 = ops.spmm_perturbed(G, E0, eps)                                   # next stream id
+    delta = Y1 - clean
+    live = clean.abs().sum(1) > 0
+    np.testing.assert_allclose(delta[live].norm(dim=1).cpu().numpy(), eps, rtol=2e-4)       # ||normalize(u)|| = 1
+    assert torch.all(delta * torch.sign(clean) >= 0)                                         # moves away from zero
+    assert torch.count_nonzero(delta[~live]) == 0                                            # sign(0) = 0
+    assert torch.allclose(Y1, Y2, rtol=1e-5, atol=1e-7)                                      # schedule independent
+    assert not torch.allclose(Y1, Y3)
+    # recover u up to the row norm: uniform on [0,1) => mean 1/2, var 1/12 after un-normalising
+    u_dir = (delta[live] / eps / torch.sign(clean[live]).clamp(min=1)).abs()
+    ratio = u_dir / u_dir.mean(dim=1, keepdim=True)                                          # E[u]/mean(u) ~ 1
+    assert abs(float(ratio.mean()) - 1.0) < 1e-3 and 0.30 < float(ratio.std()) < 0.36 * 2    # sqrt(1/12)/0.5 = 0.577
+    # d = 256 and the fused K-layer form
+    for d in (256,):
+        X = torch.randn(n, d, device="cuda") * 0.1
+        P = ops.propagate_views(G, X, 3, False, eps, n_views=2)
+        assert len(P) == 3 and torch.equal(P[0], G.propagate_mean_raw(X, 3, False))
+        assert not torch.allclose(P[1], P[2]) and float((P[1] - P[0]).norm(dim=1).max()) < 3 * eps
+
+
+def test_propagate_views_single_backward(ops, golden_small):
+    g = golden_small
+    n = int(g["num_users"]) + int(g["num_items"])
+    E0 = dev(np.concatenate([g["d64_init_user"], g["d64_init_item"]])).requires_grad_(True)
+    G = _graph(ops, g)
+    clean, v1, v2 = ops.propagate_views(G, E0, 3, False, 0.05, n_views=2)
+    g0, g1, g2 = (torch.randn(n, 64, device="cuda") for _ in range(3))
+    (clean * g0).sum().backward(retain_graph=True)
+    ref0 = E0.grad.clone()
+    E0.grad = None
+    ((clean * g0).sum() + (v1 * g1).sum() + (v2 * g2).sum()).backward()
+    want = G.propagate_mean_bwd_raw(g0 + g1 + g2, 3, False)
+    assert torch.allclose(E0.grad, want, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(ref0, G.propagate_mean_bwd_raw(g0, 3, False), rtol=1e-5, atol=1e-7)
