@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
   while (e < n3 && skeys[e] == row) ++e;
   const float up0 = a.upstream ? a.upstream[0] : 1.0f;
   const float up1 = a.upstream ? a.upstream[1] : 1.0f;
-  if (a.touched && a.g_final && lane == 0) atomicOr(a.touched + (row >> 5), 1u << (row & 31));
+  if (a.touched && lane == 0) atomicOr(a.touched + (row >> 5), 1u << (row & 31));
   for (int64_t f = lane; f < a.d; f += WAVE) {
     float acc = 0.f;
     for (int64_t t = j; t < e; ++t) {
@@ -270,7 +270,10 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
         if (a.touched) a.g_final[o] = acc;  // one wave owns a row: a plain store, no zero-fill needed
         else a.g_final[o] += acc;
       }
-      if (a.g_ego) a.g_ego[o] += reg;
+      if (a.g_ego) {
+        if (a.touched) a.g_ego[o] = reg;
+        else a.g_ego[o] += reg;
+      }
     }
   }
 }
@@ -499,8 +502,8 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
                          float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
                          uint32_t* touched, void* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  IDG_REQUIRE(!touched || (deterministic && g_final && g_final != g_ego),
-              "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter into a g_final distinct from g_ego");
+  IDG_REQUIRE(!touched || (deterministic && g_final != g_ego),
+              "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter and g_final distinct from g_ego");
   const BprWs w = bpr_layout(B > 0 ? B : 1, cub_temp_bound(3 * B));
   BprArgs a{};
   int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,

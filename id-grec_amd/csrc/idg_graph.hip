@@ -172,7 +172,7 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, in
       s.z = s.z / ep.div;
       s.w = s.w / ep.div;
     }
-    if (ep.accumulate) s = add4(*reinterpret_cast<const float4*>(ep.sum_out + o), s);
+    if (ep.accumulate && live) s = add4(*reinterpret_cast<const float4*>(ep.sum_out + o), s);
     *reinterpret_cast<float4*>(ep.sum_out + o) = s;
   }
 }
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
     if (ep.sum_out) {
       float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
       if (ep.div != 1.0f) sres = sres / ep.div;
-      if (ep.accumulate) sres = ep.sum_out[o] + sres;
+      if (ep.accumulate && live) sres = ep.sum_out[o] + sres;
       ep.sum_out[o] = sres;
     }
   }
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
     if (ep.sum_out) {
       float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
       if (ep.div != 1.0f) sres = sres / ep.div;
-      if (ep.accumulate) sres = ep.sum_out[o] + sres;
+      if (ep.accumulate && live) sres = ep.sum_out[o] + sres;
       ep.sum_out[o] = sres;
     }
   }

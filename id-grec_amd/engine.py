@@ -33,7 +33,10 @@ class PropagationEngine:
         self.exp_avg = self.exp_avg_sq = None                 # Adam moments: allocated by the first train_step()
         self.final = torch.empty((self.n, self.d), **f32) if graph is not None else None
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
-        self.touched = torch.zeros((self.n + 31) // 32, dtype=torch.int32, device=dev) if graph is not None else None
+        words = (self.n + 31) // 32
+        self._touched = [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(2)] if graph is not None else None
+        self.touched = self._touched[0] if graph is not None else None
+        self._parity = 0
         self.loss = torch.zeros(2, **f32)
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
@@ -73,18 +76,24 @@ class PropagationEngine:
                 self._side = torch.cuda.Stream(device=self.device)
             self._side.wait_stream(main)  # the previous step's scatter has consumed the old plan
             with torch.cuda.stream(self._side):
+                self.touched = self._touched[self._parity]  # this step's (already clear) bitmap
+                self._parity ^= 1
+                self._touched[self._parity].zero_()         # clear the next step's, off the critical path
                 ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d)
                 plan_done = self._side.record_event()
             det = 2
-        self.grad.zero_()
+        if not (self.graph is not None and det):
+            self.grad.zero_()
         if self.graph is not None:
             ev = self._mark()
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final)
             self._mark(ev)
             if det:
-                # deterministic scatter: reached rows of g_final are stored and flagged in a bitmap; the
-                # backward propagation reads flagged rows only, so g_final itself is never zero-filled
-                self.touched.zero_()
+                # deterministic scatter: the rows a batch reaches are stored (g_final and the regulariser
+                # gradient in self.grad alike) and flagged in a bitmap; the backward propagation reads
+                # flagged rows only, so neither panel is ever zero-filled
+                if plan_done is None:
+                    self.touched.zero_()
                 touched = self.touched
             else:
                 self.g_final.zero_()

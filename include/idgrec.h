@@ -184,7 +184,9 @@ int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out
 /* gout_mask (nullable): bitmap, bit r of word r/32 set iff row r of gout is live.  Rows with a
  * clear bit are taken as zero and never read — a training batch touches <= 3B rows of gout, so
  * the first backward product skips most of its gathers (exact: fmaf(v, 0, acc) == acc) and gout
- * needs no zero-fill.  Produced by idg_bpr_backward_f32's `touched` argument. */
+ * needs no zero-fill.  With accumulate != 0 the same bitmap governs gE0: flagged rows are added
+ * to, every other row is overwritten (gE0 needs no zero-fill either).  Produced by
+ * idg_bpr_backward_f32's `touched` argument. */
 int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask,
                                float* gE0, int K, int include_layer0, int64_t d, int accumulate,
                                void* ws, void* stream);
@@ -201,9 +203,9 @@ int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint
  * g_final[n,d] += d loss[0] / d final   (rows scatter-added, duplicates accumulate)
  * g_ego  [n,d] += d loss[1] / d ego
  * touched (nullable, deterministic forms only, g_final != g_ego): a zeroed bitmap of ceil(n/32)
- * words; the rows of g_final this batch reaches are then STORED (not accumulated) and their
- * bits set, every other row of g_final is left untouched and must not be read — hand the
- * bitmap to idg_propagate_mean_bwd_f32.
+ * words; the rows of g_final AND g_ego this batch reaches (the same rows) are then STORED (not
+ * accumulated) and their bits set, every other row of both panels is left untouched and must
+ * not be read — hand the bitmap to idg_propagate_mean_bwd_f32, which reads flagged rows only.
  * g_final / g_ego must be zeroed (or hold a gradient to accumulate into) by the caller;
  * either may be NULL to skip that gradient.  final == ego is the MFBPR case
  * (models/MFBPR.py:29-42).  deterministic != 0: duplicate rows are summed in batch order
