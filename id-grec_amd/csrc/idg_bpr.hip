@@ -101,6 +101,18 @@ __global__ __launch_bounds__(BLOCK) void bpr_keys_kernel(const int64_t* __restri
   slots[3 * i + 2] = (int32_t)(3 * i + 2);
 }
 
+// Bitmap of the <= 3B panel rows a batch reads and writes (users, num_users + pos, num_users + neg).
+__global__ __launch_bounds__(BLOCK) void bpr_touch_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+                                                          const int64_t* __restrict__ neg, int64_t B, int64_t num_users,
+                                                          uint32_t* __restrict__ bitmap) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= B) return;
+  const int64_t r0 = users[i], r1 = num_users + pos[i], r2 = num_users + neg[i];
+  atomicOr(bitmap + (r0 >> 5), 1u << (r0 & 31));
+  atomicOr(bitmap + (r1 >> 5), 1u << (r1 & 31));
+  atomicOr(bitmap + (r2 >> 5), 1u << (r2 & 31));
+}
+
 // Backward, atomic form: one wave per triple, float atomics into the gradient rows.
 __global__ __launch_bounds__(BLOCK) void bpr_atomic_kernel(BprArgs a) {
   const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
@@ -488,6 +500,16 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
     size_t tb = have;
     IDG_HIP(hipcub::DeviceRadixSort::SortPairs(base + w.temp, tb, keys, skeys, slots, sslots, (int)n3, 0, end_bit, st));
   }
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
+                       uint32_t* bitmap, void* stream) {
+  IDG_REQUIRE(users && pos && neg && bitmap, "idg_bpr_touch_rows: NULL argument");
+  IDG_REQUIRE(B > 0 && num_users >= 0, "idg_bpr_touch_rows: bad sizes");
+  hipLaunchKernelGGL(bpr_touch_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, users,
+                     pos, neg, B, num_users, bitmap);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }

@@ -84,6 +84,7 @@ struct idg_graph {
   Tile* d_tiles = nullptr;         // heaviest-first order
   Tile* d_tiles_banded = nullptr;  // XCD column-band placement (used when the gathered panel is cache resident)
   LongRow* d_long = nullptr;
+  int32_t* d_slot_row = nullptr;   // partial slot -> the row it belongs to
   int32_t* d_xl = nullptr;     // vrows too long for one tile (EXACT_ORDER only)
   // host copies for the checker
   std::vector<int64_t> h_long_rows, h_seg_len;
@@ -394,6 +395,77 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   }
 }
 
+// Output-row-restricted form: only rows flagged in `out_mask` are produced (the last forward layer
+// of a training step feeds nothing but the layer mean at the <= 3B rows of the batch).  A tile
+// without a flagged row exits before staging its entries; otherwise the flagged vrows run the
+// ordinary walk, so the produced rows are bit-identical to the full product.
+template <int LPR, int NB>
+__global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __restrict__ tiles,
+                                                               const int64_t* __restrict__ vptr,
+                                                               const int32_t* __restrict__ vtgt,
+                                                               const int32_t* __restrict__ slot_row,
+                                                               const ColVal* __restrict__ cv,
+                                                               const float* __restrict__ X, int64_t ldx,
+                                                               float* __restrict__ partials, int64_t d, Epilogue ep,
+                                                               const uint32_t* __restrict__ out_mask) {
+  __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ int s_ptr[TILE_VROWS + 1];
+  __shared__ int s_tgt[TILE_VROWS];
+  __shared__ int s_live[TILE_VROWS];  // compacted list of flagged vrows
+  __shared__ int s_nlive;
+  __shared__ int s_next;
+
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int nv = t.n_vrows;
+  const int64_t nz0 = t.nnz_begin;
+  constexpr int GROUPS = BLOCK / LPR;
+  if (tid == 0) {
+    s_nlive = 0;
+    s_next = GROUPS;
+  }
+  __syncthreads();
+  for (int i = tid; i <= nv; i += BLOCK) s_ptr[i] = (int)(vptr[t.vrow_begin + i] - nz0);
+  for (int i = tid; i < nv; i += BLOCK) {
+    const int tg = vtgt[t.vrow_begin + i];
+    s_tgt[i] = tg;
+    const int row = tg >= 0 ? tg : slot_row[~tg];
+    if (mask_bit(out_mask, row)) s_live[atomicAdd(&s_nlive, 1)] = i;  // order inside a tile is irrelevant
+  }
+  __syncthreads();
+  const int nlive = s_nlive;
+  if (nlive == 0) return;
+  const int cnt = s_ptr[nv];
+  {
+    const ColVal* src = cv + nz0;
+    for (int i = tid; i < cnt; i += BLOCK) s_cv[i] = src[i];
+  }
+  __syncthreads();
+
+  const int g = tid / LPR;
+  const int l = tid % LPR;
+  int q = g;
+  while (q < nlive) {
+    const int v = s_live[q];
+    const int s = s_ptr[v], e = s_ptr[v + 1];
+    const int tgt = s_tgt[v];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int off = (b * LPR + l) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = walk<8>(s_cv, s, e, X + off, ldx, acc);
+      if (tgt >= 0) {
+        epilogue_store(ep, tgt, off, acc);
+      } else {
+        *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
+      }
+    }
+    int nxt = 0;
+    if (l == 0) nxt = atomicAdd(&s_next, 1);
+    q = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
+  }
+}
+
 // EXACT_ORDER rows longer than a tile: one lane group streams the row from global memory.
 template <int LPR, int NB>
 __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__ xl,
@@ -425,11 +497,12 @@ __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__
 template <int LPR, int NB>
 __global__ __launch_bounds__(FIX_WAYS * LPR) void spmm_fixup_kernel(const LongRow* __restrict__ rows, int n_long,
                                                                     const float* __restrict__ partials, int64_t d,
-                                                                    Epilogue ep) {
+                                                                    Epilogue ep, const uint32_t* __restrict__ out_mask) {
   __shared__ float4 s_part[FIX_WAYS][LPR];
   const int q = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
   const LongRow lr = rows[blockIdx.x];
+  if (out_mask && !mask_bit(out_mask, lr.row)) return;  // row not requested (block-uniform)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int off = (b * LPR + l) * 4;
@@ -522,7 +595,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
 
 template <int LPR, int NB>
 int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials, int64_t d,
-                const Epilogue& ep, const uint32_t* x_mask, hipStream_t st) {
+                const Epilogue& ep, const uint32_t* x_mask, const uint32_t* out_mask, hipStream_t st) {
   if (g->n_tiles > 0) {
     const dim3 grid((unsigned)g->n_tiles), block(BLOCK);
     // Band placement pays while the gathered panel lives in L2 / Infinity Cache (measured: 17.8 and
@@ -532,7 +605,10 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
 #define IDG_TILE(U, DYN, ...)                                                                                \
   hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, ##__VA_ARGS__>), grid, block, 0, st, tile_order, g->d_vptr, \
                      g->d_vtgt, g->d_cv, X, ldx, partials, d, ep)
-    if (x_mask) {  // sparse-input form (first backward layer)
+    if (out_mask) {  // only flagged output rows (last forward layer of a training step)
+      hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                         g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, out_mask);
+    } else if (x_mask) {  // sparse-input form (first backward layer)
       hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
                          g->d_cv, X, ldx, partials, d, ep, x_mask);
     } else if (ep.noise_eps != 0.f) {  // perturbed layers: own instantiation (Philox + row-norm shuffles)
@@ -553,14 +629,14 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
                        g->d_vtgt, g->d_cv, X, ldx, ep, x_mask);
   if (g->n_long > 0) {
     hipLaunchKernelGGL((spmm_fixup_kernel<LPR, NB>), dim3((unsigned)g->n_long), dim3(FIX_WAYS * LPR), 0, st,
-                       g->d_long, (int)g->n_long, partials, d, ep);
+                       g->d_long, (int)g->n_long, partials, d, ep, out_mask);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }
 
 int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, void* ws, const Epilogue& ep,
-                  hipStream_t st, const uint32_t* x_mask = nullptr) {
+                  hipStream_t st, const uint32_t* x_mask = nullptr, const uint32_t* out_mask = nullptr) {
   float* partials = reinterpret_cast<float*>(ws);
   if (g->n_slots > 0 && !partials) return idg::fail(IDG_E_INVALID, "idg_spmm: workspace is NULL but the graph has split rows");
   const bool aligned = (ldx % 4 == 0) && (ep.ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
@@ -568,14 +644,17 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
                        ((uintptr_t)ep.sum_in % 16 == 0) && ((uintptr_t)ep.sum_out % 16 == 0);
   if (aligned) {
     switch (d) {
-      case 32: return launch_fast<8, 1>(g, X, ldx, partials, d, ep, x_mask, st);
-      case 64: return launch_fast<16, 1>(g, X, ldx, partials, d, ep, x_mask, st);
-      case 128: return launch_fast<32, 1>(g, X, ldx, partials, d, ep, x_mask, st);
-      case 256: return launch_fast<64, 1>(g, X, ldx, partials, d, ep, x_mask, st);
-      case 512: return launch_fast<64, 2>(g, X, ldx, partials, d, ep, x_mask, st);
+      case 32: return launch_fast<8, 1>(g, X, ldx, partials, d, ep, x_mask, out_mask, st);
+      case 64: return launch_fast<16, 1>(g, X, ldx, partials, d, ep, x_mask, out_mask, st);
+      case 128: return launch_fast<32, 1>(g, X, ldx, partials, d, ep, x_mask, out_mask, st);
+      case 256: return launch_fast<64, 1>(g, X, ldx, partials, d, ep, x_mask, out_mask, st);
+      case 512: return launch_fast<64, 2>(g, X, ldx, partials, d, ep, x_mask, out_mask, st);
       default: break;
     }
   }
+  if (out_mask)
+    return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: row-restricted output needs d in {32,64,128,256,512} and 16-byte aligned panels (d=%lld)",
+                     (long long)d);
   if (ep.noise_eps != 0.f)
     return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: the noise epilogue needs d in {32,64,128,256,512} and 16-byte aligned panels (d=%lld)",
                      (long long)d);
@@ -672,6 +751,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   std::vector<int64_t> vptr;
   std::vector<int32_t> vtgt;
   std::vector<LongRow> longs;
+  std::vector<int32_t> slot_row;
   vptr.reserve((size_t)n_rows + 1);
   vtgt.reserve((size_t)n_rows);
   vptr.push_back(0);
@@ -693,6 +773,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
     g->h_long_rows.push_back(r);
     g->h_seg_len.push_back(S);
     for (int64_t k = 0; k < nseg; ++k) {
+      slot_row.push_back((int32_t)r);
       vtgt.push_back((int32_t)~(int32_t)(slots + k));
       vptr.push_back(std::min(e, s + (k + 1) * S));
     }
@@ -790,6 +871,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK) rc = upload(&g->d_tiles, tiles_plain);
   if (rc == IDG_OK && banded) rc = upload(&g->d_tiles_banded, tiles_banded);
   if (rc == IDG_OK) rc = upload(&g->d_long, longs);
+  if (rc == IDG_OK) rc = upload(&g->d_slot_row, slot_row);
   if (rc == IDG_OK) rc = upload(&g->d_xl, xl);
   if (rc != IDG_OK) {
     idg_graph_destroy(g);
@@ -810,6 +892,7 @@ int idg_graph_destroy(idg_graph* g) {
       (void)hipFree(g->d_tiles);
       (void)hipFree(g->d_tiles_banded);
       (void)hipFree(g->d_long);
+      (void)hipFree(g->d_slot_row);
       (void)hipFree(g->d_xl);
     }
   }
@@ -899,7 +982,7 @@ size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {
 static int propagate_common(const idg_graph* g, const float* in, float* out, int K, int include0, int64_t d,
                             void* ws, hipStream_t st, bool backward, int accumulate,
                             const uint32_t* in_mask = nullptr, float noise_eps = 0.f, uint64_t noise_seed = 0,
-                            uint64_t noise_stream = 0) {
+                            uint64_t noise_stream = 0, const uint32_t* out_rows = nullptr) {
   IDG_REQUIRE(g && in && out && ws, "idg_propagate: NULL argument");
   IDG_REQUIRE(g->n_rows == g->n_cols, "idg_propagate: graph must be square");
   IDG_REQUIRE(K >= 1, "idg_propagate: K must be >= 1 (got %d)", K);
@@ -948,16 +1031,18 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
         ep.accumulate = accumulate;
       }
     }
-    int rc = spmm_dispatch(g, X, d, d, partials, ep, st, (backward && k == 1) ? in_mask : nullptr);
+    int rc = spmm_dispatch(g, X, d, d, partials, ep, st, (backward && k == 1) ? in_mask : nullptr,
+                           (!backward && last) ? out_rows : nullptr);
     if (rc != IDG_OK) return rc;
     X = P[(k - 1) & 1];
   }
   return IDG_OK;
 }
 
-int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int K, int include_layer0, int64_t d,
-                           void* ws, void* stream) {
-  return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0);
+int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, const uint32_t* out_rows, int K,
+                           int include_layer0, int64_t d, void* ws, void* stream) {
+  return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0, nullptr, 0.f, 0, 0,
+                          out_rows);
 }
 
 int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out, int K, int include_layer0, int64_t d,

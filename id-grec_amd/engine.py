@@ -34,8 +34,8 @@ class PropagationEngine:
         self.final = torch.empty((self.n, self.d), **f32) if graph is not None else None
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
         words = (self.n + 31) // 32
-        self._touched = [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(2)] if graph is not None else None
-        self.touched = self._touched[0] if graph is not None else None
+        self._slots = [self._Slot(words, dev), self._Slot(words, dev)] if graph is not None else None
+        self.touched = None
         self._parity = 0
         self.loss = torch.zeros(2, **f32)
         self.step_count = 0
@@ -63,52 +63,99 @@ class PropagationEngine:
             self._final_version = self.step_count  # invalidated by loss_and_grad() / model.train()
         return self.final
 
+    # ---- index-only preparation of a batch on the side stream (row bitmap + sorted scatter plan)
+    class _Slot:
+        def __init__(self, words, device):
+            self.bitmap = torch.zeros(words, dtype=torch.int32, device=device)
+            self.ws = None
+            self.key = None
+            self.rows_done = self.plan_done = None
+            self.free = None  # recorded on the main stream when the step that used this slot is done
+
+    def _prepare(self, slot, users, pos, neg):
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        B = users.shape[0]
+        if slot.ws is None or slot.ws_B != B:
+            slot.ws, slot.ws_B = ops.bpr_workspace(B, self.d, self.device), B
+        if slot.free is not None:
+            self._side.wait_event(slot.free)   # the step that last used this slot has consumed it
+        else:
+            self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            slot.bitmap.zero_()
+            ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap)
+            slot.rows_done = self._side.record_event()       # needed by the last forward layer
+            ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws)
+            slot.plan_done = self._side.record_event()       # needed by the gradient scatter
+        slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
+
+    def _take_slot(self):
+        """Next slot of the two-entry ring (the other one may hold the batch about to be processed)."""
+        for i, slot in enumerate(self._slots):  # a slot whose batch has been consumed (or never filled)
+            if slot.key is None:
+                self._parity = i ^ 1
+                return slot
+        slot = self._slots[self._parity]          # both hold unconsumed prefetches: recycle the older one
+        self._parity ^= 1
+        return slot
+
+    def prefetch(self, users, pos, neg):
+        """Optional one-batch lookahead: prepare the NEXT batch's row bitmap and scatter plan now, so
+        they are ready long before its step starts (otherwise the step prepares them itself and the
+        main stream waits a few microseconds for the side stream)."""
+        if self.deterministic and self.graph is not None:
+            self._prepare(self._take_slot(), users, pos, neg)
+
     # ---- forward + backward: losses [bpr, reg_lambda*reg] and d(sum)/dE0 into self.grad
     @torch.no_grad()
     def loss_and_grad(self, users, pos, neg, loss_out=None):
         loss = self.loss if loss_out is None else loss_out
-        det = int(self.deterministic)
-        plan_done = None
-        if self.deterministic and self.graph is not None:
-            # the (row, slot) sort needs only the indices: run it on a side stream under the forward propagation
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            self._side.wait_stream(main)  # the previous step's scatter has consumed the old plan
-            with torch.cuda.stream(self._side):
-                self.touched = self._touched[self._parity]  # this step's (already clear) bitmap
-                self._parity ^= 1
-                self._touched[self._parity].zero_()         # clear the next step's, off the critical path
-                ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d)
-                plan_done = self._side.record_event()
-            det = 2
-        if not (self.graph is not None and det):
+        main = torch.cuda.current_stream()
+        if self.graph is None:
             self.grad.zero_()
-        if self.graph is not None:
+            ops.bpr_fused_raw(self.params, self.params, users, pos, neg, self.U, self.reg_lambda, self.grad,
+                              self.grad, loss=loss, deterministic=int(self.deterministic))
+            self._final_version = -1
+            return loss
+        if not self.deterministic:
+            self.grad.zero_()
+            self.g_final.zero_()
             ev = self._mark()
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final)
             self._mark(ev)
-            if det:
-                # deterministic scatter: the rows a batch reaches are stored (g_final and the regulariser
-                # gradient in self.grad alike) and flagged in a bitmap; the backward propagation reads
-                # flagged rows only, so neither panel is ever zero-filled
-                if plan_done is None:
-                    self.touched.zero_()
-                touched = self.touched
-            else:
-                self.g_final.zero_()
-                touched = None
-            if plan_done is not None:
-                torch.cuda.current_stream().wait_event(plan_done)
             ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
-                              self.grad, loss=loss, deterministic=det, touched=touched)
+                              self.grad, loss=loss, deterministic=0)
             ev = self._mark()
-            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True,
-                                              mask=touched)
+            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True)
             self._mark(ev)
-        else:
-            ops.bpr_fused_raw(self.params, self.params, users, pos, neg, self.U, self.reg_lambda, self.grad,
-                              self.grad, loss=loss, deterministic=det)
+            self._final_version = -1
+            return loss
+        # deterministic path.  The batch's rows are flagged in a bitmap and its (row, slot) pairs sorted —
+        # index-only work done on a side stream (by prefetch() during the previous step, or right now).
+        key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), users.shape[0])
+        slot = next((sl for sl in self._slots if sl.key == key), None)
+        if slot is None:  # not prefetched: prepare it now (the main stream then waits for the side stream)
+            slot = self._take_slot()
+            self._prepare(slot, users, pos, neg)
+        slot.key = None
+        self.touched = slot.bitmap
+        ev = self._mark()
+        # the BPR kernel reads the layer mean at the batch rows only: the last layer is restricted to them
+        main.wait_event(slot.rows_done)
+        self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
+        self._mark(ev)
+        main.wait_event(slot.plan_done)
+        # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
+        # propagation reads flagged rows only: neither panel is ever zero-filled
+        ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
+                          self.grad, loss=loss, deterministic=2, touched=slot.bitmap, ws=slot.ws)
+        ev = self._mark()
+        self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True,
+                                          mask=slot.bitmap)
+        self._mark(ev)
+        slot.free = main.record_event()
         self._final_version = -1
         return loss
 

@@ -118,6 +118,11 @@ class PackedRecommender(nn.Module):
         self.item_embedding.weight.grad = eng.grad[U:]
         return loss
 
+    def prefetch_batch(self, users, pos, neg):
+        """One-batch lookahead for the fused step (row bitmap + scatter plan on the side stream)."""
+        if self.supports_fused_step and self.n_layers > 0:
+            self.engine().prefetch(users, pos, neg)
+
     def final_panels(self):
         """(users [U,d'], items [I,d']) used for scoring, cached while the weights are frozen.
         Default: the layer-mean propagation of the packed panel; encoders with their own

@@ -142,16 +142,18 @@ class Graph:
         check(lib.idg_spmm_f32(self._h, _ptr(X), d, _ptr(Y), d, _ptr(addend), d, _ptr(ws), _stream()), "idg_spmm_f32")
         return Y
 
-    def propagate_mean_raw(self, E0, K, include_layer0=True, out=None):
-        _require_device(E0, out)
+    def propagate_mean_raw(self, E0, K, include_layer0=True, out=None, out_rows=None):
+        """out_rows: int32 bitmap tensor of the rows of the result that will be read (others are left
+        untouched), or None for the whole panel."""
+        _require_device(E0, out, out_rows)
         E0 = _f32c(E0, "E0")
         if E0.shape[0] != self.n_rows:
             raise ValueError("E0 must have %d rows, got %d" % (self.n_rows, E0.shape[0]))
         d = E0.shape[1]
         out = torch.empty_like(E0) if out is None else out
         ws = self._workspace("prop", d)
-        check(lib.idg_propagate_mean_f32(self._h, _ptr(E0), _ptr(out), int(K), int(bool(include_layer0)), d,
-                                         _ptr(ws), _stream()), "idg_propagate_mean_f32")
+        check(lib.idg_propagate_mean_f32(self._h, _ptr(E0), _ptr(out), _ptr(out_rows), int(K), int(bool(include_layer0)),
+                                         d, _ptr(ws), _stream()), "idg_propagate_mean_f32")
         return out
 
     def propagate_mean_bwd_raw(self, gout, K, include_layer0=True, out=None, accumulate=False, mask=None):
@@ -305,6 +307,11 @@ def propagate_mean(graph, E0, K, include_layer0=True):
 _bpr_ws_cache = {}
 
 
+def bpr_workspace(B, d, device):
+    """A private BPR scratch buffer (callers that pipeline batches keep one per in-flight batch)."""
+    return torch.empty(int(lib.idg_bpr_workspace_bytes(int(B), int(d))), dtype=torch.uint8, device=device)
+
+
 def _bpr_ws(B, d, device):
     """Scratch of the fused BPR calls.  One buffer per (batch size, width, device): the forward and
     backward calls of a step (and the side-stream plan) must see the SAME buffer.  Callers that run
@@ -375,19 +382,26 @@ class _BprLossSame(torch.autograd.Function):
         return g[0], None, None, None, None, None, None
 
 
-def bpr_plan_raw(users, pos, neg, num_users, n, d):
+def bpr_touch_rows_raw(users, pos, neg, num_users, bitmap):
+    """Set the bits of the panel rows this batch touches (idg_bpr_touch_rows); bitmap: zeroed int32 [ceil(n/32)]."""
+    _require_device(users, pos, neg, bitmap)
+    check(lib.idg_bpr_touch_rows(_ptr(users), _ptr(pos), _ptr(neg), users.shape[0], int(num_users), _ptr(bitmap),
+                                 _stream()), "idg_bpr_touch_rows")
+
+
+def bpr_plan_raw(users, pos, neg, num_users, n, d, ws=None):
     """Sort this batch's (row, slot) pairs into the BPR workspace (idg_bpr_plan_f32) on the CURRENT
     stream.  Index-only work: run it on a side stream while the propagation is in flight, then call
     bpr_fused_raw(..., deterministic=2)."""
     _require_device(users, pos, neg)
     B = users.shape[0]
-    ws = _bpr_ws(B, d, users.device)
+    ws = _bpr_ws(B, d, users.device) if ws is None else ws
     check(lib.idg_bpr_plan_f32(_ptr(users), _ptr(pos), _ptr(neg), B, int(num_users), int(n), _ptr(ws), _stream()),
           "idg_bpr_plan_f32")
 
 
 def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, g_final, g_ego, loss=None,
-                  deterministic=True, touched=None):
+                  deterministic=True, touched=None, ws=None):
     """No-autograd form: loss[2] plus gradients accumulated into g_final / g_ego (caller zeroes).
     deterministic: False/0 float atomics, True/1 sort in-call, 2 plan already built (bpr_plan_raw).
     touched: zeroed int32 bitmap [ceil(n/32)]; if given, reached g_final rows are stored + flagged and
@@ -396,7 +410,7 @@ def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda
     n, d = final_panel.shape
     B = users.shape[0]
     loss = torch.empty(2, dtype=torch.float32, device=final_panel.device) if loss is None else loss
-    ws = _bpr_ws(B, d, final_panel.device)
+    ws = _bpr_ws(B, d, final_panel.device) if ws is None else ws
     check(lib.idg_bpr_fused_f32(_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos),
                                 _ptr(neg), B, d, float(reg_lambda), _ptr(loss), _ptr(g_final), _ptr(g_ego),
                                 int(deterministic), _ptr(touched), _ptr(ws), _stream()), "idg_bpr_fused_f32")

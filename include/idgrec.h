@@ -165,8 +165,13 @@ int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y
  * layer count — the order torch.mean(torch.stack(..)) produces on CPU.
  * E0, out: [n, d] contiguous.  ws: idg_propagate_workspace_bytes(g, d). */
 size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d);
-int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, int K,
-                           int include_layer0, int64_t d, void* ws, void* stream);
+/* out_rows (nullable): bitmap of the rows of `out` the caller will read.  The LAST layer's product
+ * feeds nothing but the mean, so with a bitmap it is evaluated for the flagged rows only (bit-
+ * identical values there; every other row of `out` is left untouched).  A training step reads the
+ * mean at the <= 3B rows of its batch: idg_bpr_touch_rows builds that bitmap from the indices. */
+int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out,
+                           const uint32_t* out_rows, int K, int include_layer0, int64_t d, void* ws,
+                           void* stream);
 /* SimGCL.aggregate(perturbed=True) (models/SimGCL.py:47-56): as idg_propagate_mean_f32, but after
  * every product X <- A.X the layer is perturbed in place, X += sign(X) * normalize(u, dim=-1) * eps
  * with u ~ U[0,1)^d, before it enters the running sum and feeds the next layer.  u comes from
@@ -223,6 +228,10 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
 /* deterministic = IDG_BPR_PLANNED: the sorted (row, slot) plan of THIS batch is already in ws,
  * put there by idg_bpr_plan_f32 (which depends on the indices only, so a caller can run it on
  * a second stream while the forward propagation is still in flight). */
+/* bitmap[(r >> 5)] |= 1 << (r & 31) for r in {users[i], num_users + pos[i], num_users + neg[i]}: the
+ * panel rows a batch touches.  bitmap: ceil(n/32) words, zeroed by the caller.  Index-only work. */
+int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
+                       int64_t num_users, uint32_t* bitmap, void* stream);
 #define IDG_BPR_PLANNED 2
 int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      int64_t num_users, int64_t n, void* ws, void* stream);

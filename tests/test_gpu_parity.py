@@ -190,6 +190,36 @@ def test_masked_backward_is_bit_identical_and_never_reads_dead_rows(ops, K, inc,
         assert torch.allclose(base, want, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("K,inc,d,kw", [(3, True, 64, {}), (1, False, 64, {}), (2, True, 256, {}), (3, True, 64, dict(split_threshold=64)),
+                                        (3, False, 64, dict(exact_order=True))])
+def test_forward_restricted_to_batch_rows(ops, K, inc, d, kw, golden_small):
+    """With a row bitmap the last layer is evaluated for the flagged rows only: identical bits there;
+    with K = 1 nothing else is written at all."""
+    g = golden_small
+    U = int(g["num_users"])
+    n = U + int(g["num_items"])
+    rng = np.random.default_rng(K * 7 + d)
+    users, pos, neg = rng.integers(0, U, 40), rng.integers(0, n - U, 40), rng.integers(0, n - U, 40)
+    hub = int(np.argmax(np.diff(g["adj_indptr"])))  # make sure a split (hub) row is requested too
+    pos[0] = hub - U if hub >= U else pos[0]
+    bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device="cuda")
+    ops.bpr_touch_rows_raw(dev(users), dev(pos), dev(neg), U, bitmap)
+    rows = sorted(set(users.tolist()) | {U + x for x in pos.tolist()} | {U + x for x in neg.tolist()})
+    bits = bitmap.cpu().numpy().view(np.uint32)
+    assert [r for r in range(n) if (bits[r >> 5] >> (r & 31)) & 1] == rows
+    E0 = torch.randn(n, d, device="cuda") * 0.1
+    G = _graph(ops, g, **kw)
+    full = G.propagate_mean_raw(E0, K, inc)
+    part = torch.full((n, d), float("nan"), device="cuda")
+    G.propagate_mean_raw(E0, K, inc, out=part, out_rows=bitmap)
+    idx = torch.tensor(rows, device="cuda")
+    assert torch.equal(part[idx], full[idx])
+    if K == 1:
+        rest = torch.ones(n, dtype=torch.bool, device="cuda")
+        rest[idx] = False
+        assert torch.isnan(part[rest]).all()
+
+
 def test_bpr_touched_bitmap_and_stored_rows(ops, golden_small):
     g = golden_small
     U = int(g["num_users"])

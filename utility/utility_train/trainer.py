@@ -51,12 +51,14 @@ def universal_trainer(model, args, config, dataset, device, logger):
         num_batch = len(users) // batch_size + 1  # the reference's divisor, also when batch_size | E
 
         step_losses = None
-        batches = tools.mini_batch(users, pos_items, neg_items, batch_size=batch_size)
+        batches = list(tools.mini_batch(users, pos_items, neg_items, batch_size=batch_size))
         for batch_i, (b_users, b_pos, b_neg) in tqdm(enumerate(batches), desc='Training epoch ' + str(epoch + 1),
                                                        total=int(num_batch)):
             if fused:
                 if step_losses is None:
                     step_losses = torch.zeros((num_batch, 2), dtype=torch.float32, device=device)
+                if batch_i + 1 < len(batches):
+                    model.prefetch_batch(*batches[batch_i + 1])  # index-only work of the next step, off the critical path
                 model.fused_loss_and_grad(b_users, b_pos, b_neg, loss_out=step_losses[batch_i])
                 Optim.step()
                 continue
