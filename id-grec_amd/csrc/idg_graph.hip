@@ -941,8 +941,8 @@ int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int6
 }
 
 int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, const float* addend,
-                    const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate, int64_t d, void* ws,
-                    void* stream) {
+                    const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
+                    const uint32_t* out_rows, int64_t d, void* ws, void* stream) {
   IDG_REQUIRE(g && X && (Y || sum_out), "idg_spmm_ex_f32: NULL argument");
   IDG_REQUIRE(d > 0 && ldx >= d && ldy >= d, "idg_spmm_ex_f32: bad d/ldx/ldy (%lld,%lld,%lld)", (long long)d,
               (long long)ldx, (long long)ldy);
@@ -955,7 +955,7 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
   ep.ldy = ldy;
   ep.div = div;
   ep.accumulate = accumulate;
-  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream);
+  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, nullptr, out_rows);
 }
 
 int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t d, float eps,

@@ -41,6 +41,7 @@ class PropagationEngine:
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
         self._side = None   # side stream for index-only work
+        self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
     # ---- views handed to nn.Embedding
@@ -141,20 +142,19 @@ class PropagationEngine:
             self._prepare(slot, users, pos, neg)
         slot.key = None
         self.touched = slot.bitmap
-        ev = self._mark()
         # the BPR kernel reads the layer mean at the batch rows only: the last layer is restricted to them
         main.wait_event(slot.rows_done)
-        self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
-        self._mark(ev)
+        if self.events is None:
+            self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
+        else:
+            self._forward_layer_by_layer(slot.bitmap)
         main.wait_event(slot.plan_done)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled
         ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
                           self.grad, loss=loss, deterministic=2, touched=slot.bitmap, ws=slot.ws)
-        ev = self._mark()
         self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True,
                                           mask=slot.bitmap)
-        self._mark(ev)
         slot.free = main.record_event()
         self._final_version = -1
         return loss
@@ -169,6 +169,32 @@ class PropagationEngine:
         ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
                           self.betas[0], self.betas[1], self.eps)
         return loss
+
+    def _forward_layer_by_layer(self, out_rows):
+        """The same forward as idg_propagate_mean_f32, one idg_spmm_ex_f32 call per layer, with a HIP
+        event pair around every launch so bench.py can time the dense launches on their own.
+        self.events collects ("dense" | "rows", start, end)."""
+        K, c0 = self.K, 1 if self.inc else 0
+        if self._pp is None:
+            self._pp = [torch.empty_like(self.params), torch.empty_like(self.params)]
+        X = self.params
+        for k in range(1, K + 1):
+            last = k == K
+            if k == 1:
+                sum_in = self.params if c0 else None
+                sum_out = self.final if (c0 or last) else None
+            else:
+                sum_in = self.final if (c0 or k > 2) else X
+                sum_out = self.final
+            Y = None if last else self._pp[(k - 1) & 1]
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            ops.spmm_ex_raw(self.graph, X, Y=Y, sum_in=sum_in, sum_out=sum_out, div=float(K + c0) if last else 1.0,
+                            out_rows=out_rows if last else None)
+            b.record()
+            self.events.append(("rows" if last else "dense", a, b))
+            X = Y
 
     def _mark(self, start=None):
         if self.events is None:

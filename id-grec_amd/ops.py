@@ -172,16 +172,16 @@ class Graph:
         return out
 
 
-def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False):
+def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False, out_rows=None):
     """idg_spmm_ex_f32: t = A.X (+ addend); Y = t; sum_out (+)= (sum_in + t) / div.  All [*, d] contiguous."""
-    _require_device(X, Y, addend, sum_in, sum_out)
+    _require_device(X, Y, addend, sum_in, sum_out, out_rows)
     d = X.shape[1]
     for t in (X, Y, addend, sum_in, sum_out):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != d):
             raise TypeError("spmm_ex_raw needs contiguous float32 [*, %d] panels" % d)
     ws = graph._workspace("spmm", d)
     check(lib.idg_spmm_ex_f32(graph._h, _ptr(X), d, _ptr(Y), _ptr(addend), _ptr(sum_in), _ptr(sum_out), d, float(div),
-                              int(bool(accumulate)), d, _ptr(ws), _stream()), "idg_spmm_ex_f32")
+                              int(bool(accumulate)), _ptr(out_rows), d, _ptr(ws), _stream()), "idg_spmm_ex_f32")
 
 
 def lincomb_raw(out, x, a, y=None, b=0.0):

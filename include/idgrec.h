@@ -148,10 +148,11 @@ int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int6
 /* The same product with the whole fused epilogue exposed, for callers that assemble the layer
  * loop themselves (the user-row-sharded multi-GPU path, where an all-reduce sits between the
  * layers):  t = A.X (+ addend);  Y = t (if Y);  s = (sum_in ? sum_in + t : t) / div;
- * sum_out (+)= s (if sum_out; += when accumulate).  All panels share ldy. */
+ * sum_out (+)= s (if sum_out; += when accumulate).  All panels share ldy.  out_rows (nullable):
+ * bitmap of the output rows to produce; the others are left untouched. */
 int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, const float* addend,
                     const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
-                    int64_t d, void* ws, void* stream);
+                    const uint32_t* out_rows, int64_t d, void* ws, void* stream);
 
 /* One perturbed layer (models/XSimGCL.py:51-54): Y = A.X;  Y += sign(Y) * normalize(u, dim=-1) * eps,
  * u ~ U[0,1)^d from Philox4x32-10(seed; stream_id, row, feature block).  d in {32,...,512}. */
