@@ -76,6 +76,11 @@ struct idg_graph {
   int64_t split_threshold = 0;
   int64_t n_vrows = 0, n_tiles = 0, n_long = 0, n_slots = 0, n_xl = 0;
   int variant = 5;  // tuning knob (IDG_SPMM_VARIANT), see launch_fast
+  // Split-row partials are combined by a separate fix-up launch by default.  IDG_FUSED_FIX=1 combines them
+  // inside the tile kernels instead (last-arriver form, below): correct and bit-identical, but measured
+  // 13 us/step SLOWER on the hub-heavy benchmark graph (one lane group serially adds a hub's ~126 partials
+  // at the kernel's tail); it can pay on graphs with few, short split rows, where the launch is pure overhead.
+  bool no_fused_fix = true;
   int64_t tile_cap = DEFAULT_TILE_CAP;  // entries per tile (IDG_TILE_NNZ, <= TILE_NNZ)
   // device
   ColVal* d_cv = nullptr;
@@ -85,6 +90,8 @@ struct idg_graph {
   Tile* d_tiles_banded = nullptr;  // XCD column-band placement (used when the gathered panel is cache resident)
   LongRow* d_long = nullptr;
   int32_t* d_slot_row = nullptr;   // partial slot -> the row it belongs to
+  int32_t* d_slot_long = nullptr;  // partial slot -> index into d_long
+  int* d_long_cnt = nullptr;       // arrival tickets of the in-kernel split-row combine (zero between launches)
   int32_t* d_xl = nullptr;     // vrows too long for one tile (EXACT_ORDER only)
   // host copies for the checker
   std::vector<int64_t> h_long_rows, h_seg_len;
@@ -253,6 +260,101 @@ __device__ __forceinline__ float4 walk_masked(CVPtr cv, int s, int e, const floa
   return acc;
 }
 
+// ---- split rows combined inside the tile kernel (no separate fix-up launch) ---------------
+// A lane group that finishes a segment stores its partial WRITE-THROUGH (sc1), its wave drains
+// vmcnt(0), the group leader draws a ticket from the row's arrival counter (relaxed, agent
+// scope); the group that draws the last ticket acquires (agent scope: drops this CU's stale L1
+// lines) and adds all the row's partials in the published 4-way strided order, then runs the
+// epilogue.  This is the split-K "last arriver reduces" form of the hardware guide (write-through
+// slabs + drained ticket; the reducer reads the slabs with sc1 loads — an acquire fence instead
+// invalidates the CU's L1, where the hot panel rows live, once per split row: measured slower);
+// results do not depend on which group arrives last, so
+// they are bit-identical to the separate fix-up pass.  The reducer resets the counter for the
+// next launch (launches on one stream are serial; counters are zero at graph creation).
+struct FixCtx {
+  const LongRow* rows;
+  const int32_t* slot_long;
+  int* cnt;
+  uint32_t part_bytes;  // 0 = not fused: plain partial stores + spmm_fixup_kernel
+};
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+template <int LPR, int NB, bool NOISE>
+__device__ __forceinline__ void combine_if_last(const Epilogue& ep, const float* __restrict__ partials, int64_t d,
+                                                const FixCtx& fx, int slot, int l) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through partial stores have completed
+  const int li = fx.slot_long[slot];
+  int old = 0;
+  if (l == 0) old = __hip_atomic_fetch_add(fx.cnt + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __shfl(old, (int)(threadIdx.x % 64) / LPR * LPR, 64);
+  const LongRow lr = fx.rows[li];
+  if (old != lr.n_seg - 1) return;
+  if (l == 0) __hip_atomic_store(fx.cnt + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // every load of the handed-off partials is an sc1 (agent-scope, L1-bypassing) buffer load
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the ticket
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(partials), 0, (int)fx.part_bytes, 0x00020000);
+  auto ld = [&](int64_t elem) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(prs, (unsigned)(elem * 4), 0, 16);  // aux 16 = sc1
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+  };
+  float nscale = 0.f;
+  if (NOISE) nscale = noise_row_scale<LPR, NB>(ep, lr.row, l);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int off = (b * LPR + l) * 4;
+    const int64_t p = lr.slot_begin * d + off;
+    float4 sq[FIX_WAYS];
+#pragma unroll
+    for (int q = 0; q < FIX_WAYS; ++q) sq[q] = q < lr.n_seg ? ld(p + (int64_t)q * d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = FIX_WAYS;
+    for (; j + FIX_WAYS <= lr.n_seg; j += FIX_WAYS) {
+      float4 x[FIX_WAYS];
+#pragma unroll
+      for (int q = 0; q < FIX_WAYS; ++q) x[q] = ld(p + (int64_t)(j + q) * d);
+#pragma unroll
+      for (int q = 0; q < FIX_WAYS; ++q) sq[q] = add4(sq[q], x[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < FIX_WAYS; ++q)
+      if (j + q < lr.n_seg) sq[q] = add4(sq[q], ld(p + (int64_t)(j + q) * d));
+    float4 row = sq[0];
+#pragma unroll
+    for (int q = 1; q < FIX_WAYS; ++q)
+      if (q < lr.n_seg) row = add4(row, sq[q]);
+    if (NOISE) row = perturb(ep, lr.row, b * LPR + l, nscale, row);
+    epilogue_store(ep, lr.row, off, row);
+  }
+}
+
+// One virtual row: the sequential walk over its staged entries, then either the epilogue (whole
+// row) or the partial store + combine protocol (segment of a split row).
+template <int LPR, int NB, int UNROLL, bool NOISE>
+__device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tgt, int l, const float* __restrict__ X,
+                                        int64_t ldx, float* __restrict__ partials, int64_t d, const Epilogue& ep,
+                                        const FixCtx& fx) {
+  float nscale = 0.f;
+  if (NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int off = (b * LPR + l) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = walk<UNROLL>(s_cv, s, e, X + off, ldx, acc);
+    if (tgt >= 0) {
+      if (NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
+      epilogue_store(ep, tgt, off, acc);
+    } else if (fx.part_bytes) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)fx.part_bytes, 0x00020000);
+      u32x4 u;
+      u.x = __float_as_uint(acc.x), u.y = __float_as_uint(acc.y), u.z = __float_as_uint(acc.z), u.w = __float_as_uint(acc.w);
+      __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (unsigned)(((int64_t)(~tgt) * d + off) * 4), 0, 16);  // aux 16 = sc1
+    } else {
+      *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
+    }
+  }
+  if (tgt < 0 && fx.part_bytes) combine_if_last<LPR, NB, NOISE>(ep, partials, d, fx, ~tgt, l);
+}
+
 // One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
 // every feature block of width 4*LPR (d = NB * 4 * LPR).  DYNAMIC: lane groups draw the next
 // vrow from an LDS counter instead of a fixed stride (evens out skewed row lengths).
@@ -263,7 +365,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
                                                           const ColVal* __restrict__ cv,
                                                           const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ partials, int64_t d,
-                                                          Epilogue ep) {
+                                                          Epilogue ep, FixCtx fx) {
   __shared__ ColVal s_cv[TILE_NNZ];
   __shared__ int s_ptr[TILE_VROWS + 1];
   __shared__ int s_tgt[TILE_VROWS];
@@ -288,22 +390,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    const int s = s_ptr[v], e = s_ptr[v + 1];
-    const int tgt = s_tgt[v];
-    float nscale = 0.f;
-    if (NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int off = (b * LPR + l) * 4;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = walk<UNROLL>(s_cv, s, e, X + off, ldx, acc);
-      if (tgt >= 0) {
-        if (NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
-        epilogue_store(ep, tgt, off, acc);
-      } else {
-        *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
-      }
-    }
+    do_vrow<LPR, NB, UNROLL, NOISE>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
     if (DYNAMIC) {
       int nxt = 0;
       if (l == 0) nxt = atomicAdd(&s_next, 1);
@@ -326,7 +413,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
                                                                  const ColVal* __restrict__ cv,
                                                                  const float* __restrict__ X, int64_t ldx,
                                                                  float* __restrict__ partials, int64_t d, Epilogue ep,
-                                                                 const uint32_t* __restrict__ x_mask) {
+                                                                 FixCtx fx, const uint32_t* __restrict__ x_mask) {
   __shared__ ColVal s_cv[TILE_NNZ];
   __shared__ int s_pre[TILE_NNZ + 1];  // s_pre[i] = live entries among [0, i)
   __shared__ int s_ptr[TILE_VROWS + 1];
@@ -375,20 +462,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    const int s = s_pre[s_ptr[v]], e = s_pre[s_ptr[v + 1]];
-    const int tgt = s_tgt[v];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int off = (b * LPR + l) * 4;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = walk<8>(s_cv, s, e, X + off, ldx, acc);
-      if (tgt >= 0) {
-        if (ep.noise_eps != 0.f) acc = perturb(ep, tgt, b * LPR + l, noise_row_scale<LPR, NB>(ep, tgt, l), acc);
-        epilogue_store(ep, tgt, off, acc);
-      } else {
-        *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
-      }
-    }
+    do_vrow<LPR, NB, 8, false>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
     v = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
@@ -407,7 +481,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
                                                                const ColVal* __restrict__ cv,
                                                                const float* __restrict__ X, int64_t ldx,
                                                                float* __restrict__ partials, int64_t d, Epilogue ep,
-                                                               const uint32_t* __restrict__ out_mask) {
+                                                               FixCtx fx, const uint32_t* __restrict__ out_mask) {
   __shared__ ColVal s_cv[TILE_NNZ];
   __shared__ int s_ptr[TILE_VROWS + 1];
   __shared__ int s_tgt[TILE_VROWS];
@@ -447,19 +521,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   int q = g;
   while (q < nlive) {
     const int v = s_live[q];
-    const int s = s_ptr[v], e = s_ptr[v + 1];
-    const int tgt = s_tgt[v];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int off = (b * LPR + l) * 4;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = walk<8>(s_cv, s, e, X + off, ldx, acc);
-      if (tgt >= 0) {
-        epilogue_store(ep, tgt, off, acc);
-      } else {
-        *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
-      }
-    }
+    do_vrow<LPR, NB, 8, false>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
     q = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
@@ -596,6 +658,12 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
 template <int LPR, int NB>
 int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials, int64_t d,
                 const Epilogue& ep, const uint32_t* x_mask, const uint32_t* out_mask, hipStream_t st) {
+  // split rows: combined inside the tile kernels when the partial buffer is addressable through one
+  // buffer descriptor (< 2 GiB); otherwise plain partial stores + the separate fix-up launch
+  FixCtx fx{g->d_long, g->d_slot_long, g->d_long_cnt, 0u};
+  const int64_t part_bytes = g->n_slots * d * (int64_t)sizeof(float);
+  const bool fused_fix = g->n_long > 0 && part_bytes < ((int64_t)1 << 31) && !g->no_fused_fix;
+  if (fused_fix) fx.part_bytes = (uint32_t)part_bytes;
   if (g->n_tiles > 0) {
     const dim3 grid((unsigned)g->n_tiles), block(BLOCK);
     // Band placement pays while the gathered panel lives in L2 / Infinity Cache (measured: 17.8 and
@@ -604,13 +672,13 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
     const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : g->d_tiles;
 #define IDG_TILE(U, DYN, ...)                                                                                \
   hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, ##__VA_ARGS__>), grid, block, 0, st, tile_order, g->d_vptr, \
-                     g->d_vtgt, g->d_cv, X, ldx, partials, d, ep)
+                     g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx)
     if (out_mask) {  // only flagged output rows (last forward layer of a training step)
       hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                         g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, out_mask);
+                         g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask);
     } else if (x_mask) {  // sparse-input form (first backward layer)
       hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                         g->d_cv, X, ldx, partials, d, ep, x_mask);
+                         g->d_cv, X, ldx, partials, d, ep, fx, x_mask);
     } else if (ep.noise_eps != 0.f) {  // perturbed layers: own instantiation (Philox + row-norm shuffles)
       IDG_TILE(8, true, 1, true);
     } else switch (g->variant) {
@@ -618,16 +686,16 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       case 2: IDG_TILE(16, false); break;
       case 3: IDG_TILE(16, true); break;
       case 4: IDG_TILE(4, true); break;
-      case 5: IDG_TILE(8, true, 8); break;
       case 6: IDG_TILE(6, true, 8); break;
-      default: IDG_TILE(8, false); break;
+      case 0: IDG_TILE(8, false); break;
+      default: IDG_TILE(8, true, 8); break;
     }
 #undef IDG_TILE
   }
   if (g->n_xl > 0)
     hipLaunchKernelGGL((spmm_xl_kernel<LPR, NB>), dim3((unsigned)g->n_xl), dim3(64), 0, st, g->d_xl, g->d_vptr,
                        g->d_vtgt, g->d_cv, X, ldx, ep, x_mask);
-  if (g->n_long > 0) {
+  if (g->n_long > 0 && !fused_fix) {
     hipLaunchKernelGGL((spmm_fixup_kernel<LPR, NB>), dim3((unsigned)g->n_long), dim3(FIX_WAYS * LPR), 0, st,
                        g->d_long, (int)g->n_long, partials, d, ep, out_mask);
   }
@@ -741,6 +809,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   g->nnz = nnz;
   g->flags = flags;
   if (const char* v = std::getenv("IDG_SPMM_VARIANT")) g->variant = std::atoi(v);
+  if (const char* v = std::getenv("IDG_FUSED_FIX")) g->no_fused_fix = std::atoi(v) == 0;
   if (const char* v = std::getenv("IDG_TILE_NNZ")) g->tile_cap = std::min<int64_t>(std::max(64, std::atoi(v)), TILE_NNZ);
   const bool exact = (flags & IDG_GRAPH_EXACT_ORDER) != 0;
   int64_t T = split_threshold > 0 ? split_threshold : DEFAULT_SPLIT;
@@ -751,7 +820,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   std::vector<int64_t> vptr;
   std::vector<int32_t> vtgt;
   std::vector<LongRow> longs;
-  std::vector<int32_t> slot_row;
+  std::vector<int32_t> slot_row, slot_long;
   vptr.reserve((size_t)n_rows + 1);
   vtgt.reserve((size_t)n_rows);
   vptr.push_back(0);
@@ -774,6 +843,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
     g->h_seg_len.push_back(S);
     for (int64_t k = 0; k < nseg; ++k) {
       slot_row.push_back((int32_t)r);
+      slot_long.push_back((int32_t)longs.size() - 1);
       vtgt.push_back((int32_t)~(int32_t)(slots + k));
       vptr.push_back(std::min(e, s + (k + 1) * S));
     }
@@ -872,6 +942,8 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK && banded) rc = upload(&g->d_tiles_banded, tiles_banded);
   if (rc == IDG_OK) rc = upload(&g->d_long, longs);
   if (rc == IDG_OK) rc = upload(&g->d_slot_row, slot_row);
+  if (rc == IDG_OK) rc = upload(&g->d_slot_long, slot_long);
+  if (rc == IDG_OK) rc = upload(&g->d_long_cnt, std::vector<int>(longs.size(), 0));
   if (rc == IDG_OK) rc = upload(&g->d_xl, xl);
   if (rc != IDG_OK) {
     idg_graph_destroy(g);
@@ -893,6 +965,8 @@ int idg_graph_destroy(idg_graph* g) {
       (void)hipFree(g->d_tiles_banded);
       (void)hipFree(g->d_long);
       (void)hipFree(g->d_slot_row);
+      (void)hipFree(g->d_slot_long);
+      (void)hipFree(g->d_long_cnt);
       (void)hipFree(g->d_xl);
     }
   }

@@ -70,8 +70,10 @@ def test_spmm_all_widths_exact_order(ops, d):
     assert np.array_equal(Y, oracle.spmm(indptr, indices, values, X))
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("d,thr", [(64, 0), (64, 64), (256, 100), (48, 64)])
-def test_spmm_split_rows_follow_published_schedule(ops, d, thr):
+def test_spmm_split_rows_follow_published_schedule(ops, d, thr, fused, monkeypatch):
+    monkeypatch.setenv("IDG_FUSED_FIX", fused)  # separate fix-up launch (default) / in-kernel last-arriver combine
     # hub rows far above the split threshold, incl. one longer than a whole tile (2048)
     indptr, indices, values = random_csr(900, 6000, 12, seed=5, hubs=[(0, 5000), (17, 2049), (899, 700), (450, 257)])
     X = np.random.default_rng(2).standard_normal((6000, d)).astype(np.float32)
@@ -433,7 +435,13 @@ def test_topk_ties_saturated_sigmoid_and_masked_fill(ops):
 
 
 # ------------------------------------------------------------ full-size (BASELINE) properties
-def test_yelp_shape_full_size(ops):
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_yelp_shape_full_size(ops, fused, monkeypatch):
+    monkeypatch.setenv("IDG_FUSED_FIX", fused)
+    _yelp_shape_full_size(ops)
+
+
+def _yelp_shape_full_size(ops):
     """LightGCN-3 d=64 on the yelp2018-shaped graph (BASELINE.json configs[1]): exact-order
     result bit-identical to the oracle over the whole panel; split schedule within fp32
     rounding; linearity and symmetry (<y, A x> == <A y, x>) as size-independent checks."""
