@@ -21,13 +21,11 @@ SHAPES = {
 }
 
 
-def generate(num_users, num_items, num_edges, seed=0, zipf_a=0.8):
-    """Returns (users int64[E'], items int64[E']) sorted by (user, item); E' ~ num_edges
-    (duplicates removed, every user keeps >= 1 item)."""
+def _draw(num_users, num_items, target, seed, zipf_a):
     rng = np.random.default_rng(seed)
-    U, I, E = int(num_users), int(num_items), int(num_edges)
+    U, I = int(num_users), int(num_items)
     deg = rng.lognormal(0.0, 1.0, U)
-    deg = deg * (E / deg.sum())
+    deg = deg * (target / deg.sum())
     deg = np.clip(np.rint(deg), 1, max(1, I // 2)).astype(np.int64)
     # popularity CDF over ranks, ranks mapped to ids by a fixed permutation
     p = (np.arange(I, dtype=np.float64) + 1.0) ** (-zipf_a)
@@ -39,6 +37,24 @@ def generate(num_users, num_items, num_edges, seed=0, zipf_a=0.8):
     items = perm[np.searchsorted(cdf, rng.random(total), side="right").clip(0, I - 1)].astype(np.int64)
     key = np.unique(users * I + items)
     return key // I, key % I
+
+
+def generate(num_users, num_items, num_edges, seed=0, zipf_a=0.8, match_edges=True):
+    """Returns (users int64[E'], items int64[E']) sorted by (user, item), duplicates removed, every user
+    keeps >= 1 item.  Popular items collide, so a plain draw of num_edges pairs loses ~5 % to
+    de-duplication; with match_edges the draw is repeated (same seed) with a corrected target until
+    E' is within 0.5 % of num_edges (graphs up to 5e7 edges; larger ones take the first draw)."""
+    E = int(num_edges)
+    target = float(E)
+    users, items = _draw(num_users, num_items, target, seed, zipf_a)
+    if not match_edges or E > 50_000_000:
+        return users, items
+    for _ in range(4):
+        if abs(len(users) - E) <= 0.005 * E:
+            break
+        target *= E / max(len(users), 1)
+        users, items = _draw(num_users, num_items, target, seed, zipf_a)
+    return users, items
 
 
 def split_test(users, items, num_users, n_test=1, seed=1):
