@@ -66,10 +66,18 @@ def build_workload(args, rank, world):
     pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
     rng = H.Rng(args.seed)
     need = (args.steps + args.warmup) * args.batch
-    tri = rng.sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
+    items32 = items.astype(np.int32)
+    if len(users) > 8 * need:
+        # a handful of steps on a huge graph: draw negatives for a uniform subset of the edges only (same
+        # triple distribution as slicing a shuffled epoch) instead of sampling all E edges
+        pick = np.sort(np.random.default_rng(args.seed).choice(len(users), size=2 * need, replace=False))
+        su, si = users[pick], items[pick]
+    else:
+        su, si = users, items
+    tri = rng.sample_epoch(su, si, pos_ptr, items32, I)
     tri = tri[rng.shuffle_perm(len(tri))]
     while len(tri) < need:  # more steps than one epoch holds: draw further epochs
-        t2 = rng.sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
+        t2 = rng.sample_epoch(su, si, pos_ptr, items32, I)
         tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
     return dict(U=U, I=I, E=len(users), indptr=ip, indices=ix, values=dv, triples=tri, prep_s=time.time() - t0)
 
