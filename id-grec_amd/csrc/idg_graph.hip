@@ -37,7 +37,7 @@ struct __attribute__((aligned(16))) Tile {
   int64_t nnz_begin;
   int32_t vrow_begin;
   int16_t n_vrows;  // 1..TILE_VROWS
-  int16_t n_nnz_hi; // unused
+  int16_t pad_;
 };
 
 struct ColVal {
@@ -873,7 +873,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
       t.nnz_begin = nz0;
       t.vrow_begin = (int32_t)v;
       t.n_vrows = (int16_t)(w - v);
-      t.n_nnz_hi = 0;
+      t.pad_ = 0;
       tiles.push_back(t);
       v = w;
     }
