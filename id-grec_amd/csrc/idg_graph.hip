@@ -329,7 +329,7 @@ __device__ __forceinline__ void combine_if_last(const Epilogue& ep, const float*
 
 // One virtual row: the sequential walk over its staged entries, then either the epilogue (whole
 // row) or the partial store + combine protocol (segment of a split row).
-template <int LPR, int NB, int UNROLL, bool NOISE>
+template <int LPR, int NB, int UNROLL, bool NOISE, bool FUSED>
 __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tgt, int l, const float* __restrict__ X,
                                         int64_t ldx, float* __restrict__ partials, int64_t d, const Epilogue& ep,
                                         const FixCtx& fx) {
@@ -343,7 +343,7 @@ __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tg
     if (tgt >= 0) {
       if (NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
       epilogue_store(ep, tgt, off, acc);
-    } else if (fx.part_bytes) {
+    } else if (FUSED) {
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)fx.part_bytes, 0x00020000);
       u32x4 u;
       u.x = __float_as_uint(acc.x), u.y = __float_as_uint(acc.y), u.z = __float_as_uint(acc.z), u.w = __float_as_uint(acc.w);
@@ -352,13 +352,13 @@ __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tg
       *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
     }
   }
-  if (tgt < 0 && fx.part_bytes) combine_if_last<LPR, NB, NOISE>(ep, partials, d, fx, ~tgt, l);
+  if (FUSED && tgt < 0) combine_if_last<LPR, NB, NOISE>(ep, partials, d, fx, ~tgt, l);
 }
 
 // One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
 // every feature block of width 4*LPR (d = NB * 4 * LPR).  DYNAMIC: lane groups draw the next
 // vrow from an LDS counter instead of a fixed stride (evens out skewed row lengths).
-template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, bool NOISE = false>
+template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, bool NOISE = false, bool FUSED = false>
 __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __restrict__ tiles,
                                                           const int64_t* __restrict__ vptr,
                                                           const int32_t* __restrict__ vtgt,
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, UNROLL, NOISE>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
+    do_vrow<LPR, NB, UNROLL, NOISE, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
     if (DYNAMIC) {
       int nxt = 0;
       if (l == 0) nxt = atomicAdd(&s_next, 1);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
 // prefix-scanned and compacted in LDS, the vrow pointers are remapped, and the ordinary sequential
 // walk then runs over the live entries only.  Dropping a dead entry is exact (fmaf(v, +0, acc) ==
 // acc), the survivors keep their order, so results are bit-identical to the dense form.
-template <int LPR, int NB>
+template <int LPR, int NB, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __restrict__ tiles,
                                                                  const int64_t* __restrict__ vptr,
                                                                  const int32_t* __restrict__ vtgt,
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, 8, false>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx);
+    do_vrow<LPR, NB, 8, false, FUSED>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
     v = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
 // of a training step feeds nothing but the layer mean at the <= 3B rows of the batch).  A tile
 // without a flagged row exits before staging its entries; otherwise the flagged vrows run the
 // ordinary walk, so the produced rows are bit-identical to the full product.
-template <int LPR, int NB>
+template <int LPR, int NB, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __restrict__ tiles,
                                                                const int64_t* __restrict__ vptr,
                                                                const int32_t* __restrict__ vtgt,
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   int q = g;
   while (q < nlive) {
     const int v = s_live[q];
-    do_vrow<LPR, NB, 8, false>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
+    do_vrow<LPR, NB, 8, false, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
     q = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
@@ -670,25 +670,35 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
     // 36.9 MB panels -16 %); beyond it the two bands differ too much in miss cost (384 MB panel +9 %).
     const bool cache_resident = (int64_t)g->n_cols * d * 4 <= BAND_PANEL_BYTES;
     const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : g->d_tiles;
-#define IDG_TILE(U, DYN, ...)                                                                                \
-  hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, ##__VA_ARGS__>), grid, block, 0, st, tile_order, g->d_vptr, \
-                     g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx)
+#define IDG_TILE(U, DYN, MINW, NOISE)                                                                          \
+  do {                                                                                                         \
+    if (fused_fix)                                                                                             \
+      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, 1, NOISE, true>), grid, block, 0, st, tile_order,  \
+                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx);                          \
+    else                                                                                                       \
+      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, NOISE, false>), grid, block, 0, st,          \
+                         tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx);              \
+  } while (0)
     if (out_mask) {  // only flagged output rows (last forward layer of a training step)
-      hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                         g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask);
+      if (fused_fix)
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask);
+      else
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask);
     } else if (x_mask) {  // sparse-input form (first backward layer)
-      hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                         g->d_cv, X, ldx, partials, d, ep, fx, x_mask);
+      if (fused_fix)
+        hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask);
+      else
+        hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, false>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask);
     } else if (ep.noise_eps != 0.f) {  // perturbed layers: own instantiation (Philox + row-norm shuffles)
       IDG_TILE(8, true, 1, true);
     } else switch (g->variant) {
-      case 1: IDG_TILE(8, true); break;
-      case 2: IDG_TILE(16, false); break;
-      case 3: IDG_TILE(16, true); break;
-      case 4: IDG_TILE(4, true); break;
-      case 6: IDG_TILE(6, true, 8); break;
-      case 0: IDG_TILE(8, false); break;
-      default: IDG_TILE(8, true, 8); break;
+      case 0: IDG_TILE(8, false, 1, false); break;
+      case 1: IDG_TILE(8, true, 1, false); break;
+      default: IDG_TILE(8, true, 8, false); break;
     }
 #undef IDG_TILE
   }
