@@ -138,23 +138,37 @@ class ShardedEngine:
     # ---- backward of the above given GF = d loss / d FIN (item rows still per-rank partials),
     #      accumulated onto G (which already holds the regulariser gradient, item rows partial)
     def propagate_backward(self):
+        """Horner steps h <- A.h + g, k = K..2, then gE0 = (A.h + c0.g)/cnt.  In block form
+        (A.h)_U = R_g h_I (local), (A.h)_I = all-reduce(R_g^T h_U).  As in the forward pass the item-side
+        partial of a step needs only the LOCAL h_U, so it is launched before waiting for the previous
+        all-reduce; the user-side product is what waits for it."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
         g_u, g_i = self._u(self.GF), self._i(self.GF)
-        self.comm.wait(self.comm.all_reduce_async(g_i))               # complete the item-side gradient
-        h_u, h_i = g_u, g_i
+        first = self.comm.all_reduce_async(g_i)               # completes the item-side gradient g_I
+        h_u = g_u
+        pending = ("g", first, g_i)                           # h_I of the coming step, not yet usable
+
+        def finish(p):                                        # -> h_I usable
+            kind, work, buf = p
+            self.comm.wait(work)
+            if kind == "t":
+                k.lincomb(buf, buf, 1.0, g_i, 1.0)            # (A h)_I + g_I
+            return buf
+
         for layer in range(K, 1, -1):
-            t_i = self.XI[layer & 1]
-            k.spmm(self.G_iu, h_u, Y=t_i)
+            t_i = self.XI[layer % 3]
+            k.spmm(self.G_iu, h_u, Y=t_i)                     # partial of (A h)_I: needs h_U only
+            h_i = finish(pending)                             # previous all-reduce (+ g_I) -> h_I
             work = self.comm.all_reduce_async(t_i)
             t_u = self.XU[layer & 1]
-            k.spmm(self.G_ui, h_i, Y=t_u, addend=g_u)                 # (A h)_U + g_U
-            self.comm.wait(work)
-            k.lincomb(t_i, t_i, 1.0, g_i, 1.0)                        # (A h)_I + g_I
-            h_u, h_i = t_u, t_i
+            k.spmm(self.G_ui, h_i, Y=t_u, addend=g_u)         # (A h)_U + g_U
+            pending = ("t", work, t_i)
+            h_u = t_u
         # last Horner step, scaled by 1/cnt; regulariser gradients ride along
-        t_i = self.XI[1] if h_i is not self.XI[1] else self.XI[0]
+        t_i = self.XI[1]  # 3-buffer rotation: never the buffer of the all-reduce still in flight (layer 2 -> XI[2])
         k.spmm(self.G_iu, h_u, Y=t_i)
-        k.lincomb(t_i, t_i, 1.0 / cnt, self._i(self.G), 1.0)          # partial/cnt + this rank's item reg grads
+        h_i = finish(pending)
+        k.lincomb(t_i, t_i, 1.0 / cnt, self._i(self.G), 1.0)  # partial/cnt + this rank's item reg grads
         work = self.comm.all_reduce_async(t_i)
         k.spmm(self.G_ui, h_i, sum_in=g_u if c0 else None, sum_out=self._u(self.G), div=cnt, accumulate=True)
         self.comm.wait(work)

@@ -311,3 +311,26 @@ def test_xsimgcl_encoder_and_training(tmp_path, golden_small, golden_next):
         opt.step()
         vals.append(float(sum(ll).detach()))
     assert vals[-1] < vals[0]
+
+
+def test_training_is_bit_reproducible_run_to_run(tmp_path, golden_small):
+    """Side stream, one-batch lookahead, sorted scatter: two identical trainings must end with identical
+    bits (weights and every logged loss)."""
+    import utility.utility_function.tools as tools
+    import utility.utility_train.trainer as trainer
+    from models.LightGCN import LightGCN
+
+    outs = []
+    for run in range(2):
+        data, cfg = _dataset(tmp_path, golden_small, "small", learn_rate=0.001, **dict(BASE, training_epochs=4, interval=2))
+        stream = io.StringIO()
+        logger = logging.getLogger("repro_%d" % run)
+        logger.setLevel(logging.INFO)
+        logger.handlers = [logging.StreamHandler(stream)]
+        tools.set_seed(2024)
+        model = LightGCN(cfg, data, torch.device("cuda"))
+        trainer.universal_trainer(model, None, cfg, data, torch.device("cuda"), logger)
+        lines = [re.sub(r"Training time: [0-9.]+", "T", ln) for ln in stream.getvalue().splitlines()]
+        outs.append((lines, model.user_embedding.weight.detach().clone(), model.item_embedding.weight.detach().clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
