@@ -7,11 +7,13 @@
 // so every lane reads one contiguous 128-byte run per 64-deep k chunk and nothing is
 // transposed or staged through LDS.
 //
-// Top-K is a wave-level streaming select over one user's scores: a 64-bit key
+// Top-K is a wave-level streaming select over one user's scores, fused behind the MFMA tiles
+// (scores go MFMA accumulator -> LDS slab -> select; never to global memory): a 64-bit key
 // (order-preserving score bits << 32 | ~item) makes "larger key" mean "better score, then
-// lower item id", candidates above the running k-th key are appended to a small LDS buffer
-// with ballot compaction, and every 64 candidates a 128-key bitonic network (shuffles only)
-// folds them into the sorted best-64 held one per lane.
+// lower item id"; a user's running list sits in registers (lane = rank), the steady state is
+// two float compares per 128 scores, and the occasional candidate above the k-th key is
+// inserted with a one-lane DPP shift.  One 128-key bitonic network (shuffles only) per user
+// and catalogue chunk fills the list at the start.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -144,102 +146,236 @@ __device__ __forceinline__ void wave_sort128_desc(unsigned long long& k0, unsign
   }
 }
 
-// One wave per batch row, streaming `n_items` scores of the row (item ids item_lo + 0..n_items-1).
-// 16-byte loads, the next 256 scores prefetched while the current ones are filtered.  A row's
-// running best-64 can be carried across launches through `state` (item-chunked evaluation keeps
-// the score scratch bounded for any catalogue size).
-__global__ __launch_bounds__(BLOCK) void topk_rows_kernel(const float* __restrict__ rating, int64_t ld, int64_t Bt,
-                                                          int64_t item_lo, int64_t n_items,
-                                                          const int64_t* __restrict__ users,
-                                                          const int64_t* __restrict__ excl_indptr,
-                                                          const int32_t* __restrict__ excl_items, int k,
-                                                          unsigned long long* __restrict__ state, int load_state,
-                                                          int final_pass, int64_t* __restrict__ out_idx,
-                                                          float* __restrict__ out_val) {
-  __shared__ unsigned long long s_pend[BLOCK / WAVE][128];
-  const int wave = threadIdx.x / WAVE;
-  const int lane = threadIdx.x % WAVE;
-  const int64_t b = (int64_t)blockIdx.x * (BLOCK / WAVE) + wave;
-  if (b >= Bt) return;
-  unsigned long long* pend = s_pend[wave];
-  const float* row = rating + b * ld;
-  const int32_t* ex_b = nullptr;
-  int ex_n = 0;
-  if (excl_indptr) {
-    const int64_t u = users[b];
-    ex_b = excl_items + excl_indptr[u];
-    ex_n = (int)(excl_indptr[u + 1] - excl_indptr[u]);
-  }
-  unsigned long long best = load_state ? state[b * WAVE + lane] : 0ull;  // sorted descending across lanes; 0 = empty
-  unsigned long long tau = shfl_u64(best, k - 1);
-  int n_pend = 0;
+// ---- fused scoring + masking + top-K -----------------------------------------------------
+// One 256-thread workgroup owns 64 batch users and one chunk of the catalogue, walked in slabs
+// of 128 items.  Per slab: (A) every wave computes the 64 x 32 scores of its 32-item column tile
+// with 2 x 32 v_mfma_f32_32x32x2_f32 per 64-deep k chunk and writes them to an LDS slab;
+// (B) every wave runs the streaming select for its 16 users straight out of LDS.  A user's
+// running best list lives in REGISTERS (lane L = rank L, 16 users x one 64-bit key per lane)
+// and its k-th key in scalar registers, so the steady state costs two LDS reads and two float
+// compares per user and slab; the rare candidate above the k-th key is inserted by a one-lane
+// shift.  The LDS slab (33 KB) is the only shared memory, which leaves room for 4 workgroups
+// per CU.  Scores never reach global memory.  Chunks of one user are merged by
+// topk_merge_kernel.
+// Selection is on RAW scores (sigmoid is monotone, it is applied to the k winners only):
+// order = (raw score descending, item id ascending) — a valid tie order for torch.topk.
+// Masked train positives rank as -1: below every sigmoid output, and among raw scores as the
+// value -1 itself (batch_test.py:65).
+constexpr int FT_USERS = 64;
+constexpr int FT_SLAB = 128;
+constexpr int FT_LD = FT_SLAB + 4;
+constexpr int FT_UPW = FT_USERS / (BLOCK / WAVE);  // users per wave
 
-  auto flush = [&](int take) {
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long a = lane < take ? pend[n_pend - take + lane] : 0ull;
-    n_pend -= take;
-    wave_sort128_desc(best, a, lane);
-    tau = shfl_u64(best, k - 1);
-  };
-  auto offer = [&](float sc, int64_t local, bool valid) {
-    bool pass = false;
-    unsigned long long key = 0;
-    if (valid) {
-      const uint32_t item = (uint32_t)(item_lo + local);
-      key = make_key(sc, item);
-      pass = key > tau;
-      if (pass && ex_n > 0) {
-        int lo = 0, hi = ex_n;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (ex_b[mid] < (int32_t)item) lo = mid + 1;
-          else hi = mid;
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// value of lane - 1 (lane 0 receives an unspecified value)
+__device__ __forceinline__ unsigned long long from_lane_below(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// `list` is descending over the lanes; the wave-uniform key c (different from every key in it) takes
+// its place and everything below moves down one lane (the last key falls off).
+__device__ __forceinline__ void list_insert(unsigned long long& list, unsigned long long c, int lane) {
+  const unsigned long long up = from_lane_below(list);
+  if (list < c) list = (lane == 0 || up > c) ? c : up;
+}
+// Feed the keys of this wave's lanes (0 = no candidate) that beat the k-th key into the list.
+__device__ __forceinline__ void list_offer(unsigned long long& list, unsigned long long& tau, unsigned long long key,
+                                           int k, int lane) {
+  unsigned long long m = __ballot(key > tau);
+  while (m) {
+    const int src = __builtin_ctzll(m);
+    list_insert(list, readlane_u64(key, src), lane);
+    tau = readlane_u64(list, k - 1);
+    m = (m & (m - 1)) & __ballot(key > tau);
+  }
+}
+__device__ __forceinline__ float tau_floor(unsigned long long tau) { return tau ? key_score(tau) : -__builtin_inff(); }
+
+template <bool SIGMOID>
+__global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float* __restrict__ U,
+                                                                 const float* __restrict__ V,
+                                                                 const int64_t* __restrict__ users, int64_t Bt,
+                                                                 int64_t I, int64_t d, int64_t chunk_items,
+                                                                 const int64_t* __restrict__ excl_indptr,
+                                                                 const int32_t* __restrict__ excl_items, int k,
+                                                                 unsigned long long* __restrict__ partial) {
+  __shared__ float s_score[FT_USERS * FT_LD];
+
+  const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t b0 = (int64_t)blockIdx.y * FT_USERS;
+  const int64_t c_lo = (int64_t)blockIdx.x * chunk_items;
+  const int64_t c_hi = c_lo + chunk_items < I ? c_lo + chunk_items : I;
+  const int n_chunks = gridDim.x;
+  const int64_t bu0 = b0 + i < Bt ? b0 + i : Bt - 1;
+  const int64_t bu1 = b0 + 32 + i < Bt ? b0 + 32 + i : Bt - 1;
+  const float* urow0 = U + users[bu0] * d;
+  const float* urow1 = U + users[bu1] * d;
+  const bool d4 = (d % 4 == 0);
+  // Exclusion lists are ascending: lane uu (< 16) keeps a cursor into the list of user 16*wave+uu, parked
+  // at the first train item >= c_lo; every slab it advances past the items that fall inside the slab,
+  // and those entries of the LDS score slab are overwritten before selection (batch_test.py:62-65).
+  int64_t my_ex_cur = 0, my_ex_end = 0;
+  if (excl_indptr && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) {
+    const int64_t uid = users[b0 + FT_UPW * wave + lane];
+    int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
+    my_ex_end = hi;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
+      else hi = mid;
+    }
+    my_ex_cur = lo;
+  }
+  unsigned long long best[FT_UPW], tau[FT_UPW];  // per user of this wave: list (lane = rank) and its k-th key
+#pragma unroll
+  for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull, tau[uu] = 0ull;
+
+  for (int64_t slab = c_lo; slab < c_hi; slab += FT_SLAB) {
+    // ---- (A) scores of this wave's 32-item column tile for both 32-user row tiles
+    {
+      const int64_t j = slab + 32 * wave + i;
+      const float* vrow = V + (j < I ? j : I - 1) * d;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+      // 16 features of each operand at a time (same product order as score_dense_kernel: MFMA q of a 64-deep
+      // chunk pairs feature kc+q with feature kc+32+q) keeps the operand registers at 48
+#pragma unroll 1
+      for (int64_t kq = 0; kq < (d + 63) / 64 * 64; kq += 32) {
+        const int64_t k0 = (kq / 64) * 64 + 32 * h + (kq % 64) / 2;  // kq%64 in {0, 32} -> offset {0, 16}
+        float a0[16], a1[16], bb[16];
+        if (d4 && k0 + 16 <= d) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 x = *reinterpret_cast<const float4*>(urow0 + k0 + 4 * q);
+            const float4 y = *reinterpret_cast<const float4*>(urow1 + k0 + 4 * q);
+            const float4 z = *reinterpret_cast<const float4*>(vrow + k0 + 4 * q);
+            a0[4 * q + 0] = x.x, a0[4 * q + 1] = x.y, a0[4 * q + 2] = x.z, a0[4 * q + 3] = x.w;
+            a1[4 * q + 0] = y.x, a1[4 * q + 1] = y.y, a1[4 * q + 2] = y.z, a1[4 * q + 3] = y.w;
+            bb[4 * q + 0] = z.x, bb[4 * q + 1] = z.y, bb[4 * q + 2] = z.z, bb[4 * q + 3] = z.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const bool in = k0 + q < d;
+            a0[q] = in ? urow0[k0 + q] : 0.f;
+            a1[q] = in ? urow1[k0 + q] : 0.f;
+            bb[q] = in ? vrow[k0 + q] : 0.f;
+          }
         }
-        if (lo < ex_n && ex_b[lo] == (int32_t)item) {
-          key = make_key(-1.0f, item);  // batch_test.py:65
-          pass = key > tau;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bb[q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bb[q], acc1, 0, 0, 0);
+        }
+      }
+      // C/D map: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+      __syncthreads();  // every wave is done selecting from the previous slab
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        s_score[row * FT_LD + 32 * wave + i] = acc0[r];
+        s_score[(32 + row) * FT_LD + 32 * wave + i] = acc1[r];
+      }
+    }
+    __syncthreads();
+    // ---- (B) wave w owns users 16w .. 16w+15 of the block: mask their train items, then select
+    const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
+    if (excl_indptr) {
+      const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
+      // all 16 users' next <= 64 train items are fetched with independent coalesced loads first ...
+      int32_t nxt[FT_UPW];
+#pragma unroll
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, uu);
+        const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, uu);
+        nxt[uu] = cur + lane < end ? excl_items[cur + lane] : 0x7fffffff;
+      }
+      // ... then the ones inside this slab overwrite their scores and move the cursor
+#pragma unroll
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        bool in = nxt[uu] < (int32_t)slab_end;
+        if (in) s_score[(FT_UPW * wave + uu) * FT_LD + (nxt[uu] - (int32_t)slab)] = masked;
+        int n_in = __popcll(__ballot(in));
+        int64_t adv = n_in;
+        while (n_in == WAVE) {  // more than 64 train items inside one 128-item slab: keep going (rare)
+          const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, uu) + adv;
+          const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, uu);
+          const int32_t v = cur + lane < end ? excl_items[cur + lane] : 0x7fffffff;
+          in = v < (int32_t)slab_end;
+          if (in) s_score[(FT_UPW * wave + uu) * FT_LD + (v - (int32_t)slab)] = masked;
+          n_in = __popcll(__ballot(in));
+          adv += n_in;
+        }
+        if (lane == uu) my_ex_cur += adv;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const bool in0 = slab + lane < c_hi, in1 = slab + 64 + lane < c_hi;
+    if (slab == c_lo) {
+      // first slab of the chunk: one 128-key sorting network per user fills its list
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        const int u = FT_UPW * wave + uu;
+        unsigned long long k0 = in0 ? make_key(s_score[u * FT_LD + lane], (uint32_t)(slab + lane)) : 0ull;
+        unsigned long long k1 = in1 ? make_key(s_score[u * FT_LD + 64 + lane], (uint32_t)(slab + 64 + lane)) : 0ull;
+        wave_sort128_desc(k0, k1, lane);
+        const unsigned long long t = readlane_u64(k0, k - 1);
+#pragma unroll
+        for (int q = 0; q < FT_UPW; ++q) {
+          best[q] = q == uu ? k0 : best[q];
+          tau[q] = q == uu ? t : tau[q];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        const int u = FT_UPW * wave + uu;
+        const float s0 = s_score[u * FT_LD + lane], s1 = s_score[u * FT_LD + 64 + lane];
+        // columns past the chunk hold scores of a clamped item: the exact key test below drops them
+        const float floor_ = tau_floor(tau[uu]);  // score of the k-th key (-inf while the list is short)
+        if (__ballot(s0 >= floor_) | __ballot(s1 >= floor_)) {
+          list_offer(best[uu], tau[uu], in0 ? make_key(s0, (uint32_t)(slab + lane)) : 0ull, k, lane);
+          list_offer(best[uu], tau[uu], in1 ? make_key(s1, (uint32_t)(slab + 64 + lane)) : 0ull, k, lane);
         }
       }
     }
-    const unsigned long long m = __ballot(pass);
-    if (m) {
-      if (pass) pend[n_pend + __popcll(m & ((1ull << lane) - 1ull))] = key;
-      n_pend += __popcll(m);
-      if (n_pend >= 64) flush(64);
-    }
-  };
-
-  const bool vec = ((ld % 4) == 0) && (((uintptr_t)rating % 16) == 0);
-  if (vec) {
-    const int64_t n4 = n_items / 4;  // whole float4 groups
-    float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
-    if (lane < n4) cur = reinterpret_cast<const float4*>(row)[lane];
-    for (int64_t g0 = 0; g0 < n4; g0 += WAVE) {
-      const int64_t gi = g0 + lane;
-      if (gi + WAVE < n4) nxt = reinterpret_cast<const float4*>(row)[gi + WAVE];
-      const bool valid = gi < n4;
-      offer(cur.x, gi * 4 + 0, valid);
-      offer(cur.y, gi * 4 + 1, valid);
-      offer(cur.z, gi * 4 + 2, valid);
-      offer(cur.w, gi * 4 + 3, valid);
-      cur = nxt;
-    }
-    const int64_t tail = n4 * 4 + lane;
-    offer(tail < n_items ? row[tail] : 0.f, tail, tail < n_items);
-  } else {
-    for (int64_t base = 0; base < n_items; base += WAVE) {
-      const int64_t local = base + lane;
-      offer(local < n_items ? row[local] : 0.f, local, local < n_items);
-    }
   }
-  if (n_pend > 0) flush(n_pend);
-  if (!final_pass) {
-    state[b * WAVE + lane] = best;
-    return;
+  // ---- publish this chunk's list per user
+#pragma unroll
+  for (int uu = 0; uu < FT_UPW; ++uu) {
+    const int64_t b = b0 + FT_UPW * wave + uu;
+    if (b < Bt) partial[(b * n_chunks + blockIdx.x) * 64 + lane] = best[uu];
+  }
+}
+
+// one wave per batch row: fold the per-chunk lists (each holds its chunk's true top-k in lanes < k),
+// emit ids and values
+template <bool SIGMOID>
+__global__ __launch_bounds__(BLOCK) void topk_merge_kernel(const unsigned long long* __restrict__ partial, int64_t Bt,
+                                                           int n_chunks, int k, int64_t* __restrict__ out_idx,
+                                                           float* __restrict__ out_val) {
+  const int lane = threadIdx.x % WAVE;
+  const int64_t b = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  if (b >= Bt) return;
+  unsigned long long best = partial[(b * n_chunks) * 64 + lane];
+  unsigned long long tau = readlane_u64(best, k - 1);
+  for (int c = 1; c < n_chunks; ++c) {
+    const unsigned long long a = partial[(b * n_chunks + c) * 64 + lane];
+    list_offer(best, tau, lane < k ? a : 0ull, k, lane);
   }
   if (lane < k) {
     out_idx[b * k + lane] = (int64_t)key_item(best);
-    if (out_val) out_val[b * k + lane] = key_score(best);
+    if (out_val) {
+      float s = key_score(best);
+      if (SIGMOID) s = s == -__builtin_inff() ? -1.0f : sigmoidf_(s);
+      out_val[b * k + lane] = s;
+    }
   }
 }
 
@@ -268,28 +404,29 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
   return launch_dense(user_panel, item_panel, users, Bt, I, d, apply_sigmoid, rating, I, (hipStream_t)stream);
 }
 
-// Items are processed in windows of at most this many, so the score scratch is Bt x min(I, window)
-// floats however large the catalogue is; a row's running best-64 is carried between windows.
-static inline int64_t item_window() {
-  if (const char* v = std::getenv("IDG_ITEM_WINDOW")) {  // testing knob: exercise the windowed path on small catalogues
-    const long long w = std::atoll(v);
-    if (w >= 32) return (int64_t)w / 4 * 4;
-  }
-  return (int64_t)1 << 16;
-}
-
-static inline size_t topk_scratch_floats(int64_t Bt, int64_t I) {
-  const int64_t ITEM_WINDOW = item_window();
-  const int64_t w = I < ITEM_WINDOW ? I : ITEM_WINDOW;
-  return (size_t)Bt * (size_t)((w + 3) / 4 * 4);
+// Fused path geometry: 64 users per workgroup, the catalogue cut into n_chunks so that the grid has
+// roughly three workgroups per CU (what its register budget allows); scratch = one best-64 list per (user, chunk).
+static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items) {
+  const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
+  int64_t nc = (768 + user_tiles - 1) / user_tiles;
+  const int64_t max_nc = (I + 1023) / 1024;
+  if (const char* v = std::getenv("IDG_TOPK_CHUNKS"))
+    if (*v) nc = std::atoll(v);  // testing knob
+  nc = nc < 1 ? 1 : (nc > max_nc ? max_nc : nc);
+  int64_t ci = ((I + nc - 1) / nc + FT_SLAB - 1) / FT_SLAB * FT_SLAB;
+  nc = (I + ci - 1) / ci;
+  *n_chunks = (int)nc;
+  *chunk_items = ci;
 }
 
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   (void)d;
   (void)k;
   if (Bt <= 0 || I <= 0) return 0;
-  const size_t scores = (topk_scratch_floats(Bt, I) * sizeof(float) + 255) / 256 * 256;
-  return scores + (size_t)Bt * WAVE * sizeof(unsigned long long);
+  int nc;
+  int64_t ci;
+  fused_geometry(Bt, I, &nc, &ci);
+  return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long);
 }
 
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt,
@@ -302,18 +439,20 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   IDG_REQUIRE(I < ((int64_t)1 << 32), "idg_score_topk_f32: more than 2^32 items");
   IDG_REQUIRE((excl_indptr == nullptr) == (excl_items == nullptr), "idg_score_topk_f32: excl_indptr and excl_items go together");
   hipStream_t st = (hipStream_t)stream;
-  float* rating = reinterpret_cast<float*>(ws);
-  const size_t scores = (topk_scratch_floats(Bt, I) * sizeof(float) + 255) / 256 * 256;
-  unsigned long long* state = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + scores);
-  const unsigned nb = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
-  const int64_t ITEM_WINDOW = item_window();
-  for (int64_t lo = 0; lo < I; lo += ITEM_WINDOW) {
-    const int64_t n_items = I - lo < ITEM_WINDOW ? I - lo : ITEM_WINDOW;
-    const int64_t ld = (n_items + 3) / 4 * 4;  // rows start 16-byte aligned
-    int rc = launch_dense(user_panel, item_panel + lo * d, users, Bt, n_items, d, apply_sigmoid, rating, ld, st);
-    if (rc != IDG_OK) return rc;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(nb), dim3(BLOCK), 0, st, rating, ld, Bt, lo, n_items, users, excl_indptr,
-                       excl_items, k, state, lo > 0 ? 1 : 0, lo + n_items >= I ? 1 : 0, out_idx, out_val);
+  int nc;
+  int64_t ci;
+  fused_geometry(Bt, I, &nc, &ci);
+  unsigned long long* partial = reinterpret_cast<unsigned long long*>(ws);
+  const dim3 grid((unsigned)nc, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
+  const unsigned nbm = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  if (apply_sigmoid) {
+    hipLaunchKernelGGL(score_topk_fused_kernel<true>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
+                       Bt, I, d, ci, excl_indptr, excl_items, k, partial);
+    hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, k, out_idx, out_val);
+  } else {
+    hipLaunchKernelGGL(score_topk_fused_kernel<false>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
+                       Bt, I, d, ci, excl_indptr, excl_items, k, partial);
+    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, k, out_idx, out_val);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;

@@ -273,11 +273,16 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
                         int64_t Bt, int64_t I, int64_t d, int apply_sigmoid, float* rating,
                         void* stream);
 
-/* Fused: never materialises [Bt, I].  Scores as above; entries (b, i) with i in the train
- * row of users[b] (excl_indptr[num_users+1] int64 / excl_items int32 ascending, DEVICE
- * pointers, indexed by user id; NULL = no masking) are replaced by -1 (batch_test.py:62-65);
- * the k best per row are returned sorted by (score desc, item id asc).
- * out_idx int64 [Bt,k], out_val fp32 [Bt,k] (may be NULL). */
+/* Fused: scores go from the MFMA accumulators through an LDS slab into the selection and are never
+ * written to global memory.  Entries (b, i) with i in the train row of users[b] (excl_indptr
+ * [num_users+1] int64 / excl_items int32 ascending, DEVICE pointers, indexed by user id; NULL = no
+ * masking) rank as the value -1 (batch_test.py:62-65).  The k best per row are returned sorted by
+ * (raw score descending, item id ascending) — sigmoid is monotone, so this is one of the orders
+ * torch.topk may return on the sigmoid values; out_val holds act(score), -1 for masked entries.
+ * out_idx int64 [Bt,k], out_val fp32 [Bt,k] (may be NULL).  k <= 64.
+ * ws: idg_score_topk_workspace_bytes (one 64-key list per user and item chunk: 512 B x Bt x chunks).
+ * Throughput wants Bt large — hand over EVERY test user in one call (there is no [Bt, I] matrix to
+ * bound): the catalogue is only cut into chunks when Bt/64 workgroups cannot fill the chip. */
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k);
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users,
                        int64_t Bt, int64_t I, int64_t d, const int64_t* excl_indptr,

@@ -21,6 +21,10 @@ cols = [torch.cat([ix[ip[u]:ip[u + 1]] for u in b.tolist()]).long() if False els
 def mine():
     return [ops.score_topk(Ue, Ie, b, k, ip, ix) for b in batches]
 
+all_users = torch.arange(U, device="cuda")
+def mine_one_call():
+    return [ops.score_topk(Ue, Ie, all_users, k, ip, ix)]
+
 def stock():
     out = []
     for b, r in zip(batches, rows):
@@ -30,7 +34,7 @@ def stock():
         out.append(torch.topk(rating, k)[1])
     return out
 
-for name, fn in (("idg_score_topk_f32", mine), ("stock torch ops", stock)):
+for name, fn in (("idg_score_topk_f32", mine), ("idg_score_topk 1 call", mine_one_call), ("stock torch ops", stock)):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3): fn()
@@ -39,4 +43,6 @@ for name, fn in (("idg_score_topk_f32", mine), ("stock torch ops", stock)):
     print("%-20s %s: %7.2f ms per full evaluation of %d users (%.1f Musers*items/s, %.1f TFLOP/s)" % (name, wl, dt * 1e3, U, U * I / dt / 1e6, 2 * U * I * d / dt / 1e12))
 a, b = mine(), stock()
 same = sum(int((x == y).all(dim=1).sum()) for x, y in zip(a, b))
+c = mine_one_call()[0]
+print("one call == batched:", bool((torch.cat(a) == c).all()))
 print("rows with identical top-%d lists: %d / %d" % (k, same, U))

@@ -398,24 +398,76 @@ def test_topk_masked_vs_reference_contract(ops, k, golden_small):
     assert ok, msg
     np.testing.assert_allclose(val, np.take_along_axis(ref, idx, 1), rtol=1e-5, atol=1e-6)
     assert (np.diff(val, axis=1) <= 0).all()  # sorted descending
-    # exact (score desc, item asc) order against the kernel's own dense scores
-    R = ops.score_dense(dev(g["d64_lgcn_user"]), dev(g["d64_lgcn_item"]), dev(users_np)).cpu().numpy()
+    # exact (raw score desc, item asc) order against the kernel's own dense raw scores
+    R = ops.score_dense(dev(g["d64_lgcn_user"]), dev(g["d64_lgcn_item"]), dev(users_np), apply_sigmoid=False).cpu().numpy()
+    for b, u in enumerate(users_np):
+        R[b, ix[ip[u]:ip[u + 1]]] = -np.inf
+    assert np.array_equal(idx, oracle.topk_reference(R, k))
+    # raw-score mode: masked entries compete as the value -1 (they can beat negative scores)
+    idx2, val2 = ops.score_topk(dev(g["d64_lgcn_user"]), dev(g["d64_lgcn_item"]), dev(users_np), k, dev(ip), dev(ix),
+                                apply_sigmoid=False, return_values=True)
+    R2 = ops.score_dense(dev(g["d64_lgcn_user"]), dev(g["d64_lgcn_item"]), dev(users_np), apply_sigmoid=False).cpu().numpy()
+    for b, u in enumerate(users_np):
+        R2[b, ix[ip[u]:ip[u + 1]]] = -1
+    assert np.array_equal(idx2.cpu().numpy(), oracle.topk_reference(R2, k))
+    np.testing.assert_array_equal(val2.cpu().numpy(), np.take_along_axis(R2, idx2.cpu().numpy(), 1))
+
+
+@pytest.mark.parametrize("d", [64, 256, 40])
+def test_topk_is_independent_of_item_chunking(ops, d, golden_small, monkeypatch):
+    """The catalogue is cut into chunks across workgroups and the per-chunk best lists are merged:
+    any chunk count gives the same answer (incl. ragged last slabs and d not a multiple of 64)."""
+    g = golden_small
+    rng = np.random.default_rng(d)
+    U, I = int(g["num_users"]), 1500
+    Ue = rng.standard_normal((U, d)).astype(np.float32) * 0.4
+    Ie = rng.standard_normal((I, d)).astype(np.float32) * 0.4
+    users_np = rng.integers(0, U, 150)
+    ip = np.zeros(U + 1, dtype=np.int64)
+    ip[1:] = np.cumsum(rng.integers(0, 30, U))
+    ix = np.concatenate([np.sort(rng.choice(I, int(c), replace=False)) for c in np.diff(ip)]).astype(np.int32)
+    args = (dev(Ue), dev(Ie), dev(users_np), 20, dev(ip), dev(ix))
+    outs = []
+    for nc in ("1", "2", "3", "12"):
+        monkeypatch.setenv("IDG_TOPK_CHUNKS", nc)
+        outs.append(ops.score_topk(*args, return_values=True))
+    for idx, val in outs[1:]:
+        assert torch.equal(idx, outs[0][0]) and torch.equal(val, outs[0][1])
+    R = oracle.score(Ue, Ie, users_np, apply_sigmoid=True)
     for b, u in enumerate(users_np):
         R[b, ix[ip[u]:ip[u + 1]]] = -1
-    assert np.array_equal(idx, oracle.topk_reference(R, k))
+    ok, msg = oracle.topk_is_valid(R, outs[0][0].cpu().numpy(), 20, tol=3e-6)
+    assert ok, msg
 
 
-def test_topk_item_windows_carry_state(ops, golden_small, monkeypatch):
-    """Catalogues larger than the item window are scored window by window with the running best
-    list carried between launches: same answer as one pass."""
-    g = golden_small
-    users_np = g["test_dict_users"][:70]
-    args = (dev(g["d64_lgcn_user"]), dev(g["d64_lgcn_item"]), dev(users_np), 20, dev(g["pos_indptr"]), dev(g["pos_indices"]))
-    whole_idx, whole_val = ops.score_topk(*args, return_values=True)
-    for w in ("32", "64", "100"):
-        monkeypatch.setenv("IDG_ITEM_WINDOW", w)
-        idx, val = ops.score_topk(*args, return_values=True)
-        assert torch.equal(idx, whole_idx) and torch.equal(val, whole_val)
+@pytest.mark.parametrize("d", [64, 100])
+def test_topk_dense_exclusion_runs_and_batch_independence(ops, d):
+    """More than 64 train items inside one 128-item slab (the cursor's refill loop), rows that mask
+    almost the whole catalogue, and: a user's list does not depend on which users share its launch."""
+    rng = np.random.default_rng(7 + d)
+    U, I, k = 333, 2100, 20
+    Ue = rng.standard_normal((U, d)).astype(np.float32) * 0.5
+    Ie = rng.standard_normal((I, d)).astype(np.float32) * 0.5
+    rows = []
+    for u in range(U):
+        if u % 5 == 0:
+            rows.append(np.sort(rng.choice(np.arange(128 * (u % 7), 128 * (u % 7) + 256), 200, replace=False)))
+        elif u % 11 == 0:
+            rows.append(np.sort(rng.choice(I, I - 25, replace=False)))
+        else:
+            rows.append(np.sort(rng.choice(I, int(rng.integers(0, 40)), replace=False)))
+    ip = np.zeros(U + 1, dtype=np.int64)
+    ip[1:] = np.cumsum([len(r) for r in rows])
+    ix = np.concatenate(rows).astype(np.int32)
+    users_np = rng.permutation(U)
+    args = (dev(Ue), dev(Ie))
+    whole = ops.score_topk(*args, dev(users_np), k, dev(ip), dev(ix)).cpu().numpy()
+    R = ops.score_dense(*args, dev(users_np), apply_sigmoid=False).cpu().numpy()
+    for b, u in enumerate(users_np):
+        R[b, ix[ip[u]:ip[u + 1]]] = -np.inf
+    assert np.array_equal(whole, oracle.topk_reference(R, k))
+    parts = [ops.score_topk(*args, dev(users_np[lo:lo + 50]), k, dev(ip), dev(ix)).cpu().numpy() for lo in range(0, U, 50)]
+    assert np.array_equal(np.concatenate(parts), whole)
 
 
 def test_topk_ties_saturated_sigmoid_and_masked_fill(ops):

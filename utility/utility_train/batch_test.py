@@ -5,8 +5,11 @@ reference's signatures, result dictionaries and early-stopping bookkeeping
 For every batch of test users the reference materialises sigmoid(E_u E_i^T) [B, I], writes -1
 over the training positives through Python index lists, and calls torch.topk
 (batch_test.py:59-68).  Models that provide `topk_for_test` get all of that from one fused
-call (MFMA scoring + masking from the device-resident train CSR + wave-level top-K); any
-other model goes through its own `get_rating_for_test` and the same mask / topk steps.
+call (MFMA scoring + masking from the device-resident train CSR + wave-level top-K) issued
+ONCE for every test user — the fused kernel has no [B, I] matrix to bound, and a user's
+list does not depend on who shares its launch — and the lists are then cut into the
+reference's `test_batch_size` batches so the metric sums keep their order.  Any other model
+goes through its own `get_rating_for_test` and the same mask / topk steps per batch.
 """
 import numpy as np
 import torch
@@ -62,9 +65,16 @@ def _evaluate(dataset, model, device, config, users):
     num_batch = len(users) // test_batch + 1
     batches = []
     with torch.no_grad():
+        fused = _topk_for_users(dataset, model, device, users, max(topK)) if hasattr(model, "topk_for_test") and len(users) else None
+        lo = 0
         for batch_users in mini_batch(users, batch_size=test_batch):
             truth = [dataset.test_dict[u] for u in batch_users]
-            batches.append((_topk_for_users(dataset, model, device, batch_users, max(topK)), truth))
+            if fused is not None:
+                top = fused[lo:lo + len(batch_users)]
+                lo += len(batch_users)
+            else:
+                top = _topk_for_users(dataset, model, device, batch_users, max(topK))
+            batches.append((top, truth))
     assert num_batch == len(batches)  # as the reference: breaks when test_batch_size divides #users
     for part in batches:
         res = test_one_batch(part, topK)
