@@ -3,10 +3,14 @@
 // Work decomposition (all fixed at idg_graph_create, so results are run-to-run identical):
 //   * every CSR row is one "virtual row" (vrow); a row with more than `split_threshold`
 //     stored entries is cut into segments of seg_len(row) entries, each its own vrow that
-//     produces a partial sum; a fix-up kernel adds the partials in a fixed 4-way strided
-//     order (partials q, q+4, q+8, ... summed in order for q = 0..3, the four sums then
-//     added left to right).
-//   * consecutive vrows are packed into tiles of <= TILE_NNZ entries and <= TILE_VROWS
+//     produces a partial sum; the partials are added in a fixed 4-way strided order
+//     (partials q, q+4, q+8, ... summed in order for q = 0..3, the four sums then added left
+//     to right).  All segments of a row of <= CHUNK_NNZ entries sit in ONE tile: their
+//     partials live in LDS and the workgroup combines them itself ("local" rows).  A longer
+//     row is first cut into chunks of CHUNK_NNZ entries; each chunk is such a local row whose
+//     sum goes to a global partial slot, and the chunk sums are combined in the same 4-way
+//     order by the fix-up kernel (or by the last workgroup to arrive, IDG_FUSED_FIX).
+//   * consecutive vrows are packed into tiles of <= tile_cap entries and <= TILE_VROWS
 //     vrows.  One 256-thread workgroup per tile stages the tile's (column,value) pairs and
 //     vrow pointers in LDS with coalesced loads, then LPR = d/4 lanes walk one vrow each:
 //     16-byte loads of the dense panel row (one 4*d-byte row per LPR lanes, fully
@@ -16,7 +20,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -25,7 +31,10 @@
 
 namespace {
 
-constexpr int TILE_NNZ = 2048;    // LDS capacity: entries staged per workgroup (16 KiB)
+constexpr int TILE_NNZ = 1024;    // LDS capacity: entries staged per workgroup (8 KiB)
+constexpr int CHUNK_NNZ = 512;    // longest row (or piece of a row) whose segments are combined inside one workgroup
+constexpr int LSLOTS = 8;         // LDS partial slots per tile = segments of local rows a tile may hold
+constexpr int32_t LOCAL_CODE = INT32_MIN;  // vtgt of a local segment: LOCAL_CODE + its LDS slot
 constexpr int TILE_VROWS = 256;   // vrows per workgroup
 constexpr int BLOCK = 256;
 constexpr int64_t DEFAULT_SPLIT = 128;
@@ -37,7 +46,16 @@ struct __attribute__((aligned(16))) Tile {
   int64_t nnz_begin;
   int32_t vrow_begin;
   int16_t n_vrows;  // 1..TILE_VROWS
-  int16_t pad_;
+  int16_t n_local;  // local rows (LocalRow entries) of this tile
+  int32_t local_begin;
+  int32_t pad_[3];
+};
+
+struct LocalRow {
+  int32_t tgt;    // >= 0: output row; < 0: ~global partial slot (a chunk of a longer row)
+  int32_t vrow;   // first segment (global vrow index); segments are consecutive vrows
+  int16_t n_seg;  // 2..LSLOTS
+  int16_t lslot;  // first LDS partial slot
 };
 
 struct ColVal {
@@ -50,6 +68,11 @@ struct LongRow {
   int32_t row;
   int32_t n_seg;
 };
+
+// what follows the product in the epilogue, beyond addend / running sum / divide
+constexpr int EPI_PLAIN = 0;
+constexpr int EPI_NOISE = 1;  // SimGCL / XSimGCL perturbation of t = A.X
+constexpr int EPI_ADAM = 2;   // the value stored to sum_out is a finished gradient: apply the Adam update to its row
 
 struct Epilogue {
   float* Y;             // [n_rows, ldy]   (nullable)
@@ -65,6 +88,12 @@ struct Epilogue {
   float noise_eps;      // 0 = off
   uint64_t noise_seed;
   uint64_t noise_stream;
+  // EPI_ADAM (last backward product of a training step): rows of the parameter / moment panels, same layout
+  // as sum_out; constants as idg_adam_step_f32 derives them (torch.optim.Adam defaults, trainer.py:11)
+  float* adam_p;
+  float* adam_m;
+  float* adam_v;
+  float adam_w1, adam_beta2, adam_w2, adam_step_size, adam_bc2_sqrt, adam_eps;
 };
 
 }  // namespace
@@ -74,18 +103,19 @@ struct idg_graph {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   uint32_t flags = 0;
   int64_t split_threshold = 0;
-  int64_t n_vrows = 0, n_tiles = 0, n_long = 0, n_slots = 0, n_xl = 0;
+  int64_t n_vrows = 0, n_tiles = 0, n_long = 0, n_slots = 0, n_xl = 0, n_local = 0, n_split = 0;
   int variant = 5;  // tuning knob (IDG_SPMM_VARIANT), see launch_fast
-  // Split-row partials are combined by a separate fix-up launch by default.  IDG_FUSED_FIX=1 combines them
-  // inside the tile kernels instead (last-arriver form, below): correct and bit-identical, but measured
-  // 13 us/step SLOWER on the hub-heavy benchmark graph (one lane group serially adds a hub's ~126 partials
-  // at the kernel's tail); it can pay on graphs with few, short split rows, where the launch is pure overhead.
-  bool no_fused_fix = true;
+  // Rows of more than CHUNK_NNZ entries leave one global partial per chunk.  By default the workgroup that
+  // delivers a row's last chunk adds them up (last-arriver form, below): no second launch.  IDG_FUSED_FIX=0
+  // selects the separate fix-up launch instead (same bits; measured 6 us per product slower on the benchmark
+  // graphs now that only ~1 % of the rows and a few hundred partials go through the protocol).
+  bool no_fused_fix = false;
   int64_t tile_cap = DEFAULT_TILE_CAP;  // entries per tile (IDG_TILE_NNZ, <= TILE_NNZ)
   // device
   ColVal* d_cv = nullptr;
   int64_t* d_vptr = nullptr;   // [n_vrows+1]
-  int32_t* d_vtgt = nullptr;   // [n_vrows] >=0 row id, <0 ~partial slot
+  int32_t* d_vtgt = nullptr;   // [n_vrows] >=0 row id, <0 ~partial slot, < LOCAL_CODE + LSLOTS: LDS slot of a local segment
+  LocalRow* d_local = nullptr; // local rows, grouped by tile
   Tile* d_tiles = nullptr;         // heaviest-first order
   Tile* d_tiles_banded = nullptr;  // XCD column-band placement (used when the gathered panel is cache resident)
   LongRow* d_long = nullptr;
@@ -94,7 +124,7 @@ struct idg_graph {
   int* d_long_cnt = nullptr;       // arrival tickets of the in-kernel split-row combine (zero between launches)
   int32_t* d_xl = nullptr;     // vrows too long for one tile (EXACT_ORDER only)
   // host copies for the checker
-  std::vector<int64_t> h_long_rows, h_seg_len;
+  std::vector<int64_t> h_long_rows, h_seg_len, h_chunk_len;
 };
 
 namespace {
@@ -166,6 +196,7 @@ __device__ __forceinline__ float4 perturb(const Epilogue& ep, int64_t r, int fbl
   return t;
 }
 
+template <int EPI = EPI_PLAIN>
 __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, int off, float4 acc) {
   const int64_t o = r * ep.ldy + off;
   const bool live = ep.mask == nullptr || mask_bit(ep.mask, r);  // x + 0 == x: skipping a zero row is exact
@@ -182,6 +213,20 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, in
     }
     if (ep.accumulate && live) s = add4(*reinterpret_cast<const float4*>(ep.sum_out + o), s);
     *reinterpret_cast<float4*>(ep.sum_out + o) = s;
+    if (EPI == EPI_ADAM) {  // same arithmetic, operation for operation, as adam_kernel (idg_bpr.hip)
+      float4 P = *reinterpret_cast<const float4*>(ep.adam_p + o);
+      float4 M = *reinterpret_cast<const float4*>(ep.adam_m + o);
+      float4 V = *reinterpret_cast<const float4*>(ep.adam_v + o);
+#define IDG_ADAM1(c)                                                       \
+  M.c = __builtin_fmaf(ep.adam_w1, s.c - M.c, M.c);                        \
+  V.c = __builtin_fmaf(ep.adam_w2 * s.c, s.c, V.c * ep.adam_beta2);        \
+  P.c = P.c - ep.adam_step_size * (M.c / (sqrtf(V.c) / ep.adam_bc2_sqrt + ep.adam_eps));
+      IDG_ADAM1(x) IDG_ADAM1(y) IDG_ADAM1(z) IDG_ADAM1(w)
+#undef IDG_ADAM1
+      *reinterpret_cast<float4*>(ep.adam_p + o) = P;
+      *reinterpret_cast<float4*>(ep.adam_m + o) = M;
+      *reinterpret_cast<float4*>(ep.adam_v + o) = V;
+    }
   }
 }
 
@@ -280,7 +325,7 @@ struct FixCtx {
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-template <int LPR, int NB, bool NOISE>
+template <int LPR, int NB, int EPI>
 __device__ __forceinline__ void combine_if_last(const Epilogue& ep, const float* __restrict__ partials, int64_t d,
                                                 const FixCtx& fx, int slot, int l) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through partial stores have completed
@@ -299,7 +344,7 @@ __device__ __forceinline__ void combine_if_last(const Epilogue& ep, const float*
     return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
   };
   float nscale = 0.f;
-  if (NOISE) nscale = noise_row_scale<LPR, NB>(ep, lr.row, l);
+  if (EPI == EPI_NOISE) nscale = noise_row_scale<LPR, NB>(ep, lr.row, l);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int off = (b * LPR + l) * 4;
@@ -322,27 +367,44 @@ __device__ __forceinline__ void combine_if_last(const Epilogue& ep, const float*
 #pragma unroll
     for (int q = 1; q < FIX_WAYS; ++q)
       if (q < lr.n_seg) row = add4(row, sq[q]);
-    if (NOISE) row = perturb(ep, lr.row, b * LPR + l, nscale, row);
-    epilogue_store(ep, lr.row, off, row);
+    if (EPI == EPI_NOISE) row = perturb(ep, lr.row, b * LPR + l, nscale, row);
+    epilogue_store<EPI>(ep, lr.row, off, row);
   }
 }
 
 // One virtual row: the sequential walk over its staged entries, then either the epilogue (whole
 // row) or the partial store + combine protocol (segment of a split row).
-template <int LPR, int NB, int UNROLL, bool NOISE, bool FUSED>
+__device__ __forceinline__ bool is_local(int tgt) { return tgt < LOCAL_CODE + LSLOTS; }
+
+// Wave lane of this lane group's first lane, rebuilt from the hardware lane counter where it is used (two
+// VALU ops per vrow) instead of living in a register across the gather loop.
+template <int LPR>
+__device__ __forceinline__ int group_leader() {
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  return lane & ~(LPR - 1);
+}
+
+template <int LPR, int NB, int UNROLL, int EPI, bool FUSED>
 __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tgt, int l, const float* __restrict__ X,
                                         int64_t ldx, float* __restrict__ partials, int64_t d, const Epilogue& ep,
-                                        const FixCtx& fx) {
+                                        const FixCtx& fx, float4* s_part) {
   float nscale = 0.f;
-  if (NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
+  if (EPI == EPI_NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int off = (b * LPR + l) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc = walk<UNROLL>(s_cv, s, e, X + off, ldx, acc);
+    acc = walk<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, acc);
+    // the store addresses are rebuilt from the lane id once per vrow: hoisting them out of the vrow loop as
+    // 64-bit per-lane pairs costs the registers that keep the kernel at 64 VGPRs (8 waves/SIMD)
+    int lo = l;
+    asm volatile("" : "+v"(lo));
+    const int off = (b * LPR + lo) * 4;
     if (tgt >= 0) {
-      if (NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
-      epilogue_store(ep, tgt, off, acc);
+      if (EPI == EPI_NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
+      epilogue_store<EPI>(ep, tgt, off, acc);
+    } else if (is_local(tgt)) {
+      s_part[(tgt - LOCAL_CODE) * (NB * LPR) + b * LPR + lo] = acc;
     } else if (FUSED) {
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)fx.part_bytes, 0x00020000);
       u32x4 u;
@@ -352,21 +414,68 @@ __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tg
       *reinterpret_cast<float4*>(partials + (int64_t)(~tgt) * d + off) = acc;
     }
   }
-  if (FUSED && tgt < 0) combine_if_last<LPR, NB, NOISE>(ep, partials, d, fx, ~tgt, l);
+  if (FUSED && tgt < 0 && !is_local(tgt)) combine_if_last<LPR, NB, EPI>(ep, partials, d, fx, ~tgt, l);
+}
+
+// After a tile's vrows are done (and a barrier): lane group j adds the LDS partials of the tile's
+// j-th local row in the published 4-way order (n_seg <= 8: s_q = p_q [+ p_{q+4}], then s_0 + s_1 + s_2 + s_3)
+// and either runs the epilogue (whole row) or hands the sum on as the global partial of a chunk.
+template <int LPR, int NB, int EPI, bool FUSED>
+__device__ __forceinline__ void combine_local(const Tile& t, const LocalRow* __restrict__ locals, const float4* s_part,
+                                              int g, int l, float* __restrict__ partials, int64_t d, const Epilogue& ep,
+                                              const FixCtx& fx, const uint32_t* __restrict__ out_mask,
+                                              const int32_t* __restrict__ slot_row) {
+  constexpr int GROUPS = BLOCK / LPR;
+  constexpr int W = NB * LPR;
+  for (int j = g; j < t.n_local; j += GROUPS) {
+    const LocalRow lr = locals[t.local_begin + j];
+    if (out_mask && !mask_bit(out_mask, lr.tgt >= 0 ? lr.tgt : slot_row[~lr.tgt])) continue;  // row not requested
+    float nscale = 0.f;
+    if (EPI == EPI_NOISE && lr.tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, lr.tgt, l);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int off = (b * LPR + l) * 4;
+      const float4* p = s_part + lr.lslot * W + b * LPR + l;
+      float4 sq[FIX_WAYS];
+#pragma unroll
+      for (int q = 0; q < FIX_WAYS; ++q) sq[q] = q < lr.n_seg ? p[q * W] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < FIX_WAYS; ++q)
+        if (q + FIX_WAYS < lr.n_seg) sq[q] = add4(sq[q], p[(q + FIX_WAYS) * W]);
+      float4 row = sq[0];
+#pragma unroll
+      for (int q = 1; q < FIX_WAYS; ++q)
+        if (q < lr.n_seg) row = add4(row, sq[q]);
+      if (lr.tgt >= 0) {
+        if (EPI == EPI_NOISE) row = perturb(ep, lr.tgt, b * LPR + l, nscale, row);
+        epilogue_store<EPI>(ep, lr.tgt, off, row);
+      } else if (FUSED) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)fx.part_bytes, 0x00020000);
+        u32x4 u;
+        u.x = __float_as_uint(row.x), u.y = __float_as_uint(row.y), u.z = __float_as_uint(row.z), u.w = __float_as_uint(row.w);
+        __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (unsigned)(((int64_t)(~lr.tgt) * d + off) * 4), 0, 16);  // aux 16 = sc1
+      } else {
+        *reinterpret_cast<float4*>(partials + (int64_t)(~lr.tgt) * d + off) = row;
+      }
+    }
+    if (FUSED && lr.tgt < 0) combine_if_last<LPR, NB, EPI>(ep, partials, d, fx, ~lr.tgt, l);
+  }
 }
 
 // One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
 // every feature block of width 4*LPR (d = NB * 4 * LPR).  DYNAMIC: lane groups draw the next
 // vrow from an LDS counter instead of a fixed stride (evens out skewed row lengths).
-template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, bool NOISE = false, bool FUSED = false>
+template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, int EPI = EPI_PLAIN, bool FUSED = false>
 __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __restrict__ tiles,
                                                           const int64_t* __restrict__ vptr,
                                                           const int32_t* __restrict__ vtgt,
                                                           const ColVal* __restrict__ cv,
                                                           const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ partials, int64_t d,
-                                                          Epilogue ep, FixCtx fx) {
+                                                          Epilogue ep, FixCtx fx,
+                                                          const LocalRow* __restrict__ locals) {
   __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ float4 s_part[LSLOTS * NB * LPR];
   __shared__ int s_ptr[TILE_VROWS + 1];
   __shared__ int s_tgt[TILE_VROWS];
   __shared__ int s_next;
@@ -390,14 +499,18 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, UNROLL, NOISE, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
+    do_vrow<LPR, NB, UNROLL, EPI, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
     if (DYNAMIC) {
       int nxt = 0;
       if (l == 0) nxt = atomicAdd(&s_next, 1);
-      v = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
+      v = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
     } else {
       v += GROUPS;
     }
+  }
+  if (t.n_local > 0) {  // block-uniform
+    __syncthreads();
+    combine_local<LPR, NB, EPI, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, nullptr, nullptr);
   }
 }
 
@@ -413,8 +526,10 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
                                                                  const ColVal* __restrict__ cv,
                                                                  const float* __restrict__ X, int64_t ldx,
                                                                  float* __restrict__ partials, int64_t d, Epilogue ep,
-                                                                 FixCtx fx, const uint32_t* __restrict__ x_mask) {
+                                                                 FixCtx fx, const uint32_t* __restrict__ x_mask,
+                                                                 const LocalRow* __restrict__ locals) {
   __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ float4 s_part[LSLOTS * NB * LPR];
   __shared__ int s_pre[TILE_NNZ + 1];  // s_pre[i] = live entries among [0, i)
   __shared__ int s_ptr[TILE_VROWS + 1];
   __shared__ int s_tgt[TILE_VROWS];
@@ -462,10 +577,15 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, 8, false, FUSED>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx);
+    do_vrow<LPR, NB, 8, EPI_PLAIN, FUSED>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx,
+                                      s_part);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
-    v = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
+    v = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
+  }
+  if (t.n_local > 0) {
+    __syncthreads();
+    combine_local<LPR, NB, EPI_PLAIN, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, nullptr, nullptr);
   }
 }
 
@@ -481,8 +601,10 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
                                                                const ColVal* __restrict__ cv,
                                                                const float* __restrict__ X, int64_t ldx,
                                                                float* __restrict__ partials, int64_t d, Epilogue ep,
-                                                               FixCtx fx, const uint32_t* __restrict__ out_mask) {
+                                                               FixCtx fx, const uint32_t* __restrict__ out_mask,
+                                                               const LocalRow* __restrict__ locals) {
   __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ float4 s_part[LSLOTS * NB * LPR];
   __shared__ int s_ptr[TILE_VROWS + 1];
   __shared__ int s_tgt[TILE_VROWS];
   __shared__ int s_live[TILE_VROWS];  // compacted list of flagged vrows
@@ -503,8 +625,15 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   for (int i = tid; i < nv; i += BLOCK) {
     const int tg = vtgt[t.vrow_begin + i];
     s_tgt[i] = tg;
+    if (is_local(tg)) continue;  // segments of a local row are flagged through the row, below
     const int row = tg >= 0 ? tg : slot_row[~tg];
     if (mask_bit(out_mask, row)) s_live[atomicAdd(&s_nlive, 1)] = i;  // order inside a tile is irrelevant
+  }
+  for (int j = tid; j < t.n_local; j += BLOCK) {
+    const LocalRow lr = locals[t.local_begin + j];
+    if (!mask_bit(out_mask, lr.tgt >= 0 ? lr.tgt : slot_row[~lr.tgt])) continue;
+    const int at = atomicAdd(&s_nlive, (int)lr.n_seg);
+    for (int q = 0; q < lr.n_seg; ++q) s_live[at + q] = lr.vrow - t.vrow_begin + q;
   }
   __syncthreads();
   const int nlive = s_nlive;
@@ -521,10 +650,14 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   int q = g;
   while (q < nlive) {
     const int v = s_live[q];
-    do_vrow<LPR, NB, 8, false, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx);
+    do_vrow<LPR, NB, 8, EPI_PLAIN, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
-    q = __shfl(nxt, (threadIdx.x % 64) / LPR * LPR, 64);
+    q = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
+  }
+  if (t.n_local > 0) {
+    __syncthreads();
+    combine_local<LPR, NB, EPI_PLAIN, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, out_mask, slot_row);
   }
 }
 
@@ -589,8 +722,24 @@ __global__ __launch_bounds__(FIX_WAYS * LPR) void spmm_fixup_kernel(const LongRo
       const int ways = lr.n_seg < FIX_WAYS ? lr.n_seg : FIX_WAYS;
       for (int w = 1; w < ways; ++w) acc = add4(acc, s_part[w][l]);
       if (ep.noise_eps != 0.f) acc = perturb(ep, lr.row, b * LPR + l, noise_row_scale<LPR, NB>(ep, lr.row, l), acc);
-      epilogue_store(ep, lr.row, off, acc);
+      if (ep.adam_p)
+        epilogue_store<EPI_ADAM>(ep, lr.row, off, acc);
+      else
+        epilogue_store<EPI_PLAIN>(ep, lr.row, off, acc);
     }
+  }
+}
+
+__device__ __forceinline__ void generic_epilogue(const Epilogue& ep, int64_t r, int64_t f, float acc) {
+  const int64_t o = r * ep.ldy + f;
+  const bool live = ep.mask == nullptr || mask_bit(ep.mask, r);
+  if (ep.addend && live) acc += ep.addend[o];
+  if (ep.Y) ep.Y[o] = acc;
+  if (ep.sum_out) {
+    float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
+    if (ep.div != 1.0f) sres = sres / ep.div;
+    if (ep.accumulate && live) sres = ep.sum_out[o] + sres;
+    ep.sum_out[o] = sres;
   }
 }
 
@@ -606,6 +755,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
   if (v >= n_vrows) return;
   const int64_t s = vptr[v], e = vptr[v + 1];
   const int tgt = vtgt[v];
+  if (is_local(tgt)) return;  // spmm_generic_local_kernel
   for (int64_t f = l; f < d; f += 64) {
     float acc = 0.f;
     for (int64_t j = s; j < e; ++j)
@@ -614,16 +764,35 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
       partials[(int64_t)(~tgt) * d + f] = acc;
       continue;
     }
-    const int64_t o = (int64_t)tgt * ep.ldy + f;
-    const bool live = ep.mask == nullptr || mask_bit(ep.mask, tgt);
-    if (ep.addend && live) acc += ep.addend[o];
-    if (ep.Y) ep.Y[o] = acc;
-    if (ep.sum_out) {
-      float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
-      if (ep.div != 1.0f) sres = sres / ep.div;
-      if (ep.accumulate && live) sres = ep.sum_out[o] + sres;
-      ep.sum_out[o] = sres;
+    generic_epilogue(ep, tgt, f, acc);
+  }
+}
+
+// Any d: one wave per local row, its segments walked one after the other, combined in the published order.
+__global__ __launch_bounds__(BLOCK) void spmm_generic_local_kernel(const LocalRow* __restrict__ locals, int64_t n_local,
+                                                                   const int64_t* __restrict__ vptr,
+                                                                   const ColVal* __restrict__ cv,
+                                                                   const float* __restrict__ X, int64_t ldx,
+                                                                   float* __restrict__ partials, int64_t d, Epilogue ep,
+                                                                   const uint32_t* __restrict__ x_mask) {
+  const int64_t j = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  const int l = threadIdx.x % 64;
+  if (j >= n_local) return;
+  const LocalRow lr = locals[j];
+  for (int64_t f = l; f < d; f += 64) {
+    float way[FIX_WAYS] = {0.f, 0.f, 0.f, 0.f};
+    for (int sg = 0; sg < lr.n_seg; ++sg) {
+      float acc = 0.f;
+      for (int64_t k = vptr[lr.vrow + sg]; k < vptr[lr.vrow + sg + 1]; ++k)
+        if (!x_mask || mask_bit(x_mask, cv[k].col)) acc = __builtin_fmaf(cv[k].val, X[(int64_t)cv[k].col * ldx + f], acc);
+      way[sg % FIX_WAYS] = sg < FIX_WAYS ? acc : way[sg % FIX_WAYS] + acc;
     }
+    float row = way[0];
+    for (int q = 1; q < FIX_WAYS && q < lr.n_seg; ++q) row = row + way[q];
+    if (lr.tgt < 0)
+      partials[(int64_t)(~lr.tgt) * d + f] = row;
+    else
+      generic_epilogue(ep, lr.tgt, f, row);
   }
 }
 
@@ -642,16 +811,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
       for (int sgm = q + FIX_WAYS; sgm < lr.n_seg; sgm += FIX_WAYS) a += p[(int64_t)sgm * d];
       acc = q == 0 ? a : acc + a;
     }
-    const int64_t o = (int64_t)lr.row * ep.ldy + f;
-    const bool live = ep.mask == nullptr || mask_bit(ep.mask, lr.row);
-    if (ep.addend && live) acc += ep.addend[o];
-    if (ep.Y) ep.Y[o] = acc;
-    if (ep.sum_out) {
-      float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
-      if (ep.div != 1.0f) sres = sres / ep.div;
-      if (ep.accumulate && live) sres = ep.sum_out[o] + sres;
-      ep.sum_out[o] = sres;
-    }
+    generic_epilogue(ep, lr.row, f, acc);
   }
 }
 
@@ -670,35 +830,37 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
     // 36.9 MB panels -16 %); beyond it the two bands differ too much in miss cost (384 MB panel +9 %).
     const bool cache_resident = (int64_t)g->n_cols * d * 4 <= BAND_PANEL_BYTES;
     const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : g->d_tiles;
-#define IDG_TILE(U, DYN, MINW, NOISE)                                                                          \
+#define IDG_TILE(U, DYN, MINW, EPI)                                                                            \
   do {                                                                                                         \
     if (fused_fix)                                                                                             \
-      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, 1, NOISE, true>), grid, block, 0, st, tile_order,  \
-                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx);                          \
+      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, 1, EPI, true>  ), grid, block, 0, st, tile_order,  \
+                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);              \
     else                                                                                                       \
-      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, NOISE, false>), grid, block, 0, st,          \
-                         tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx);              \
+      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, EPI, false>  ), grid, block, 0, st,          \
+                         tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);  \
   } while (0)
     if (out_mask) {  // only flagged output rows (last forward layer of a training step)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask);
+                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
       else
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask);
+                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
     } else if (x_mask) {  // sparse-input form (first backward layer)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask);
+                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask, g->d_local);
       else
         hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, false>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask);
+                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask, g->d_local);
     } else if (ep.noise_eps != 0.f) {  // perturbed layers: own instantiation (Philox + row-norm shuffles)
-      IDG_TILE(8, true, 1, true);
+      IDG_TILE(8, true, 1, EPI_NOISE);
+    } else if (ep.adam_p) {  // last backward product of a training step: Adam applied to each finished gradient row
+      IDG_TILE(8, true, 1, EPI_ADAM);
     } else switch (g->variant) {
-      case 0: IDG_TILE(8, false, 1, false); break;
-      case 1: IDG_TILE(8, true, 1, false); break;
-      default: IDG_TILE(8, true, 8, false); break;
+      case 0: IDG_TILE(8, false, 1, EPI_PLAIN); break;
+      case 1: IDG_TILE(8, true, 1, EPI_PLAIN); break;
+      default: IDG_TILE(8, true, 8, EPI_PLAIN); break;
     }
 #undef IDG_TILE
   }
@@ -730,6 +892,7 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
       default: break;
     }
   }
+  if (ep.adam_p) return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: the fused Adam epilogue needs the tiled kernels");
   if (out_mask)
     return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: row-restricted output needs d in {32,64,128,256,512} and 16-byte aligned panels (d=%lld)",
                      (long long)d);
@@ -740,6 +903,11 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
     const unsigned nb = (unsigned)((g->n_vrows + (BLOCK / 64) - 1) / (BLOCK / 64));
     hipLaunchKernelGGL(spmm_generic_kernel, dim3(nb), dim3(BLOCK), 0, st, g->d_vptr, g->d_vtgt, g->n_vrows,
                        g->d_cv, X, ldx, partials, d, ep, x_mask);
+  }
+  if (g->n_local > 0) {
+    const unsigned nb = (unsigned)((g->n_local + (BLOCK / 64) - 1) / (BLOCK / 64));
+    hipLaunchKernelGGL(spmm_generic_local_kernel, dim3(nb), dim3(BLOCK), 0, st, g->d_local, g->n_local, g->d_vptr, g->d_cv,
+                       X, ldx, partials, d, ep, x_mask);
   }
   if (g->n_long > 0) {
     const unsigned nb = (unsigned)((g->n_long + (BLOCK / 64) - 1) / (BLOCK / 64));
@@ -830,11 +998,27 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   std::vector<int64_t> vptr;
   std::vector<int32_t> vtgt;
   std::vector<LongRow> longs;
+  std::vector<LocalRow> locals;  // in vrow order == tile order of creation
   std::vector<int32_t> slot_row, slot_long;
   vptr.reserve((size_t)n_rows + 1);
   vtgt.reserve((size_t)n_rows);
   vptr.push_back(0);
   int64_t slots = 0;
+  const int64_t C = std::min<int64_t>(CHUNK_NNZ, g->tile_cap);
+  // one row, or one chunk of a row: entries [s, e) -> target tgt (row id, or ~global partial slot)
+  auto emit_piece = [&](int64_t s, int64_t e, int32_t tgt, int64_t S) {
+    const int64_t nseg = (e - s + S - 1) / S;
+    if (nseg <= 1) {
+      vtgt.push_back(tgt);
+      vptr.push_back(e);
+      return;
+    }
+    locals.push_back(LocalRow{tgt, (int32_t)vtgt.size(), (int16_t)nseg, 0});
+    for (int64_t k = 0; k < nseg; ++k) {
+      vtgt.push_back(LOCAL_CODE);  // LDS slot assigned when the tile is packed
+      vptr.push_back(std::min(e, s + (k + 1) * S));
+    }
+  };
   for (int64_t r = 0; r < n_rows; ++r) {
     const int64_t s = indptr[r], e = indptr[r + 1], len = e - s;
     if (exact || len <= T) {
@@ -842,32 +1026,47 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
       vptr.push_back(e);
       continue;
     }
-    const int64_t S = seg_len_for(len);
-    const int64_t nseg = (len + S - 1) / S;
-    if (slots + nseg >= ((int64_t)1 << 31)) {
+    if (vtgt.size() + (size_t)(len / 64) + 8 >= (size_t)INT32_MAX) {
       delete g;
       return idg::fail(IDG_E_UNSUPPORTED, "idg_graph_create: too many row segments");
     }
-    longs.push_back(LongRow{slots, (int32_t)r, (int32_t)nseg});
+    ++g->n_split;
     g->h_long_rows.push_back(r);
+    if (len <= C) {  // all segments in one tile: combined in LDS
+      const int64_t S = std::max<int64_t>(seg_len_for(len), (len + LSLOTS - 1) / LSLOTS);
+      g->h_seg_len.push_back(S);
+      g->h_chunk_len.push_back(0);
+      emit_piece(s, e, (int32_t)r, S);
+      continue;
+    }
+    // chunks of C entries, each a local row that produces one global partial
+    const int64_t S = std::max<int64_t>(seg_len_for(C), (C + LSLOTS - 1) / LSLOTS);
+    const int64_t nch = (len + C - 1) / C;
+    if (slots + nch >= (int64_t)INT32_MAX - 2 * LSLOTS) {
+      delete g;
+      return idg::fail(IDG_E_UNSUPPORTED, "idg_graph_create: too many row chunks");
+    }
     g->h_seg_len.push_back(S);
-    for (int64_t k = 0; k < nseg; ++k) {
+    g->h_chunk_len.push_back(C);
+    longs.push_back(LongRow{slots, (int32_t)r, (int32_t)nch});
+    for (int64_t k = 0; k < nch; ++k) {
       slot_row.push_back((int32_t)r);
       slot_long.push_back((int32_t)longs.size() - 1);
-      vtgt.push_back((int32_t)~(int32_t)(slots + k));
-      vptr.push_back(std::min(e, s + (k + 1) * S));
+      emit_piece(s + k * C, std::min(e, s + (k + 1) * C), (int32_t)~(int32_t)(slots + k), S);
     }
-    slots += nseg;
+    slots += nch;
   }
   g->n_vrows = (int64_t)vtgt.size();
   g->n_long = (int64_t)longs.size();
   g->n_slots = slots;
+  g->n_local = (int64_t)locals.size();
 
   // ---- tiles
   std::vector<Tile> tiles;
   std::vector<int32_t> xl;
   {
     int64_t v = 0;
+    size_t li = 0;  // next local row (they are in vrow order)
     const int64_t nv = g->n_vrows;
     while (v < nv) {
       const int64_t len0 = vptr[(size_t)v + 1] - vptr[(size_t)v];
@@ -878,12 +1077,30 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
       }
       int64_t w = v;
       const int64_t nz0 = vptr[(size_t)v];
-      while (w < nv && w - v < TILE_VROWS && (w == v || vptr[(size_t)w + 1] - nz0 <= g->tile_cap)) ++w;
-      Tile t;
+      const size_t li0 = li;
+      int lsl = 0;
+      while (w < nv && w - v < TILE_VROWS) {
+        if (li < locals.size() && locals[li].vrow == w) {  // a local row goes into a tile whole
+          LocalRow& L = locals[li];
+          const bool fits = (w - v + L.n_seg <= TILE_VROWS) && (lsl + L.n_seg <= LSLOTS) &&
+                            (w == v || vptr[(size_t)(w + L.n_seg)] - nz0 <= g->tile_cap);
+          if (!fits) break;
+          L.lslot = (int16_t)lsl;
+          for (int q = 0; q < L.n_seg; ++q) vtgt[(size_t)(w + q)] = LOCAL_CODE + lsl + q;
+          lsl += L.n_seg;
+          w += L.n_seg;
+          ++li;
+        } else {
+          if (!(w == v || vptr[(size_t)w + 1] - nz0 <= g->tile_cap)) break;
+          ++w;
+        }
+      }
+      Tile t{};
       t.nnz_begin = nz0;
       t.vrow_begin = (int32_t)v;
       t.n_vrows = (int16_t)(w - v);
-      t.pad_ = 0;
+      t.n_local = (int16_t)(li - li0);
+      t.local_begin = (int32_t)li0;
       tiles.push_back(t);
       v = w;
     }
@@ -950,6 +1167,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK) rc = upload(&g->d_vtgt, vtgt);
   if (rc == IDG_OK) rc = upload(&g->d_tiles, tiles_plain);
   if (rc == IDG_OK && banded) rc = upload(&g->d_tiles_banded, tiles_banded);
+  if (rc == IDG_OK) rc = upload(&g->d_local, locals);
   if (rc == IDG_OK) rc = upload(&g->d_long, longs);
   if (rc == IDG_OK) rc = upload(&g->d_slot_row, slot_row);
   if (rc == IDG_OK) rc = upload(&g->d_slot_long, slot_long);
@@ -973,6 +1191,7 @@ int idg_graph_destroy(idg_graph* g) {
       (void)hipFree(g->d_vtgt);
       (void)hipFree(g->d_tiles);
       (void)hipFree(g->d_tiles_banded);
+      (void)hipFree(g->d_local);
       (void)hipFree(g->d_long);
       (void)hipFree(g->d_slot_row);
       (void)hipFree(g->d_slot_long);
@@ -990,18 +1209,19 @@ int idg_graph_info(const idg_graph* g, int64_t info[8]) {
   info[1] = g->n_cols;
   info[2] = g->nnz;
   info[3] = g->n_tiles + g->n_xl;
-  info[4] = g->n_long;
+  info[4] = g->n_split;
   info[5] = g->n_slots;
   info[6] = g->split_threshold;
   info[7] = g->flags;
   return IDG_OK;
 }
 
-int idg_graph_long_rows(const idg_graph* g, int64_t* long_rows, int64_t* seg_len) {
+int idg_graph_long_rows(const idg_graph* g, int64_t* long_rows, int64_t* seg_len, int64_t* chunk_len) {
   IDG_REQUIRE(g, "idg_graph_long_rows: NULL handle");
   for (size_t i = 0; i < g->h_long_rows.size(); ++i) {
     if (long_rows) long_rows[i] = g->h_long_rows[i];
     if (seg_len) seg_len[i] = g->h_seg_len[i];
+    if (chunk_len) chunk_len[i] = g->h_chunk_len[i];
   }
   return IDG_OK;
 }
@@ -1066,7 +1286,8 @@ size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {
 static int propagate_common(const idg_graph* g, const float* in, float* out, int K, int include0, int64_t d,
                             void* ws, hipStream_t st, bool backward, int accumulate,
                             const uint32_t* in_mask = nullptr, float noise_eps = 0.f, uint64_t noise_seed = 0,
-                            uint64_t noise_stream = 0, const uint32_t* out_rows = nullptr) {
+                            uint64_t noise_stream = 0, const uint32_t* out_rows = nullptr,
+                            const Epilogue* adam = nullptr) {
   IDG_REQUIRE(g && in && out && ws, "idg_propagate: NULL argument");
   IDG_REQUIRE(g->n_rows == g->n_cols, "idg_propagate: graph must be square");
   IDG_REQUIRE(K >= 1, "idg_propagate: K must be >= 1 (got %d)", K);
@@ -1113,6 +1334,11 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
         ep.sum_out = out;
         ep.div = cnt;
         ep.accumulate = accumulate;
+        if (adam) {
+          ep.adam_p = adam->adam_p, ep.adam_m = adam->adam_m, ep.adam_v = adam->adam_v;
+          ep.adam_w1 = adam->adam_w1, ep.adam_beta2 = adam->adam_beta2, ep.adam_w2 = adam->adam_w2;
+          ep.adam_step_size = adam->adam_step_size, ep.adam_bc2_sqrt = adam->adam_bc2_sqrt, ep.adam_eps = adam->adam_eps;
+        }
       }
     }
     int rc = spmm_dispatch(g, X, d, d, partials, ep, st, (backward && k == 1) ? in_mask : nullptr,
@@ -1141,6 +1367,35 @@ int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint
               "idg_propagate_mean_bwd_f32: graph not flagged IDG_GRAPH_SYMMETRIC (build the transposed handle and "
               "chain idg_spmm_f32 instead)");
   return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate, gout_mask);
+}
+
+int idg_propagate_mean_bwd_adam_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask, float* gE0, int K,
+                                    int include_layer0, int64_t d, int accumulate, float* param, float* exp_avg,
+                                    float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int64_t step,
+                                    void* ws, void* stream) {
+  IDG_REQUIRE(g, "idg_propagate_mean_bwd_adam_f32: NULL graph");
+  IDG_REQUIRE(g->flags & IDG_GRAPH_SYMMETRIC, "idg_propagate_mean_bwd_adam_f32: graph not flagged IDG_GRAPH_SYMMETRIC");
+  IDG_REQUIRE(param && exp_avg && exp_avg_sq && gE0, "idg_propagate_mean_bwd_adam_f32: NULL argument");
+  IDG_REQUIRE(step >= 1, "idg_propagate_mean_bwd_adam_f32: step is 1-based");
+  IDG_REQUIRE(((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)gE0) % 16 == 0,
+              "idg_propagate_mean_bwd_adam_f32: pointers must be 16-byte aligned");
+  // The update rides in the epilogue of the LAST product when that is a launch of the dense tiled kernel
+  // (K >= 2, tiled widths); otherwise the two steps simply run one after the other.  Same bits either way.
+  const bool tiled = (d == 32 || d == 64 || d == 128 || d == 256 || d == 512) && (uintptr_t)gout % 16 == 0;
+  if (K < 2 || !tiled) {
+    const int rc = idg_propagate_mean_bwd_f32(g, gout, gout_mask, gE0, K, include_layer0, d, accumulate, ws, stream);
+    if (rc != IDG_OK) return rc;
+    return idg_adam_step_f32(param, gE0, exp_avg, exp_avg_sq, g->n_rows * d, lr, beta1, beta2, eps, step, stream);
+  }
+  Epilogue adam{};
+  adam.adam_p = param, adam.adam_m = exp_avg, adam.adam_v = exp_avg_sq;
+  // scalars in double on the host, exactly as idg_adam_step_f32 (and torch/optim/adam.py) forms them
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  adam.adam_w1 = (float)(1.0 - beta1), adam.adam_beta2 = (float)beta2, adam.adam_w2 = (float)(1.0 - beta2);
+  adam.adam_step_size = (float)(lr / bc1), adam.adam_bc2_sqrt = (float)std::sqrt(bc2), adam.adam_eps = (float)eps;
+  return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate, gout_mask, 0.f, 0, 0,
+                          nullptr, &adam);
 }
 
 }  // extern "C"

@@ -42,6 +42,7 @@ class PropagationEngine:
         self._final_version = -1  # step_count the cached propagation belongs to
         self._side = None   # side stream for index-only work
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
+        self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
     # ---- views handed to nn.Embedding
@@ -111,7 +112,9 @@ class PropagationEngine:
 
     # ---- forward + backward: losses [bpr, reg_lambda*reg] and d(sum)/dE0 into self.grad
     @torch.no_grad()
-    def loss_and_grad(self, users, pos, neg, loss_out=None):
+    def loss_and_grad(self, users, pos, neg, loss_out=None, _adam_step=0):
+        """_adam_step > 0 (train_step): the Adam update of self.params rides in the epilogue of the last
+        backward product (idg_propagate_mean_bwd_adam_f32) instead of a separate pass over the gradient."""
         loss = self.loss if loss_out is None else loss_out
         main = torch.cuda.current_stream()
         if self.graph is None:
@@ -153,8 +156,13 @@ class PropagationEngine:
         # propagation reads flagged rows only: neither panel is ever zero-filled
         ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
                           self.grad, loss=loss, deterministic=2, touched=slot.bitmap, ws=slot.ws)
-        self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True,
-                                          mask=slot.bitmap)
+        if _adam_step > 0:
+            self.graph.propagate_mean_bwd_adam_raw(self.g_final, self.K, self.inc, self.grad, True, slot.bitmap, self.params,
+                                                   self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
+                                                   self.betas[1], self.eps)
+        else:
+            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True,
+                                              mask=slot.bitmap)
         slot.free = main.record_event()
         self._final_version = -1
         return loss
@@ -162,9 +170,12 @@ class PropagationEngine:
     # ---- one whole training step (loss_and_grad + dense Adam), for callers without a torch optimizer
     @torch.no_grad()
     def train_step(self, users, pos, neg, loss_out=None):
-        loss = self.loss_and_grad(users, pos, neg, loss_out)
         if self.exp_avg is None:
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        if self.graph is not None and self.deterministic and self.fuse_adam:
+            self.step_count += 1
+            return self.loss_and_grad(users, pos, neg, loss_out, _adam_step=self.step_count)
+        loss = self.loss_and_grad(users, pos, neg, loss_out)
         self.step_count += 1
         ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
                           self.betas[0], self.betas[1], self.eps)

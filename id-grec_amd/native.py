@@ -40,7 +40,7 @@ PROTOTYPES = {
                                    C.c_int64, C.POINTER(c_vp)]),
     "idg_graph_destroy": (C.c_int, [c_vp]),
     "idg_graph_info": (C.c_int, [c_vp, c_i64p]),
-    "idg_graph_long_rows": (C.c_int, [c_vp, c_i64p, c_i64p]),
+    "idg_graph_long_rows": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p]),
     "idg_spmm_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
     "idg_spmm_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, c_vp]),
     "idg_spmm_ex_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_float, C.c_int,
@@ -54,6 +54,9 @@ PROTOTYPES = {
                                                C.c_uint64, c_vp, c_vp]),
     "idg_propagate_mean_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int, c_vp,
                                              c_vp]),
+    "idg_propagate_mean_bwd_adam_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int, c_vp, c_vp,
+                                                  c_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
+                                                  c_vp, c_vp]),
     "idg_bpr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "idg_bpr_fused_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                     C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),

@@ -112,9 +112,10 @@ class Graph:
         n = self.info()["n_long_rows"]
         rows = np.empty(n, dtype=np.int64)
         seg = np.empty(n, dtype=np.int64)
-        check(lib.idg_graph_long_rows(self._h, native.np_ptr(rows, C.c_int64), native.np_ptr(seg, C.c_int64)),
-              "idg_graph_long_rows")
-        return rows, seg
+        chunk = np.empty(n, dtype=np.int64)
+        check(lib.idg_graph_long_rows(self._h, native.np_ptr(rows, C.c_int64), native.np_ptr(seg, C.c_int64),
+                                      native.np_ptr(chunk, C.c_int64)), "idg_graph_long_rows")
+        return rows, seg, chunk
 
     def _workspace(self, kind, d):
         key = (kind, int(d))
@@ -169,6 +170,23 @@ class Graph:
         check(lib.idg_propagate_mean_bwd_f32(self._h, _ptr(gout), _ptr(mask), _ptr(out), int(K), int(bool(include_layer0)), d,
                                              int(bool(accumulate)), _ptr(ws), _stream()),
               "idg_propagate_mean_bwd_f32")
+        return out
+
+    def propagate_mean_bwd_adam_raw(self, gout, K, include_layer0, out, accumulate, mask, param, exp_avg, exp_avg_sq, lr,
+                                    step, beta1=0.9, beta2=0.999, eps=1e-8):
+        """idg_propagate_mean_bwd_adam_f32: the backward above with the dense Adam step on `param` applied in the
+        epilogue of its last product (bit-identical to propagate_mean_bwd_raw + adam_step_raw)."""
+        _require_device(gout, out, mask, param, exp_avg, exp_avg_sq)
+        gout = _f32c(gout, "gout")
+        d = gout.shape[1]
+        for t in (out, param, exp_avg, exp_avg_sq):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != gout.shape:
+                raise TypeError("propagate_mean_bwd_adam_raw needs contiguous float32 panels shaped like gout")
+        ws = self._workspace("prop", d)
+        check(lib.idg_propagate_mean_bwd_adam_f32(self._h, _ptr(gout), _ptr(mask), _ptr(out), int(K), int(bool(include_layer0)),
+                                                  d, int(bool(accumulate)), _ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                                  float(lr), float(beta1), float(beta2), float(eps), int(step), _ptr(ws),
+                                                  _stream()), "idg_propagate_mean_bwd_adam_f32")
         return out
 
 

@@ -122,19 +122,24 @@ typedef struct idg_graph idg_graph;
 /* CSR arrays are HOST pointers; the handle uploads and owns device copies plus its
  * row-block tile schedule.  split_threshold: rows with more stored entries than this are
  * cut into segments summed in a fixed published order (0 = library default 128; ignored with
- * EXACT_ORDER). */
+ * EXACT_ORDER).  Rows of up to 512 entries are combined inside one workgroup (LDS); longer rows go
+ * through one global partial per 512-entry chunk (workspace = n_long_chunks x d floats). */
 int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                      const int32_t* indices, const float* values, uint32_t flags,
                      int64_t split_threshold, idg_graph** out);
 int idg_graph_destroy(idg_graph* g);
 /* info[0..7] = n_rows, n_cols, nnz, n_tiles, n_long_rows, n_long_chunks, split_threshold, flags */
 int idg_graph_info(const idg_graph* g, int64_t info[8]);
-/* The split schedule, so a checker can restate the exact summation order: row
- * long_rows[i] is cut into consecutive segments of seg_len[i] stored entries, each a
- * sequential fmaf chain from +0.  Segment partials p_0, p_1, ... are combined 4-way strided:
- * s_q = p_q + p_{q+4} + p_{q+8} + ... (left to right) for q = 0..3, row = ((s_0 + s_1) + s_2) + s_3
- * (absent s_q skipped).  Both arrays hold n_long_rows (info[4]) elements; either may be NULL. */
-int idg_graph_long_rows(const idg_graph* g, int64_t* long_rows, int64_t* seg_len);
+/* The split schedule, so a checker can restate the exact summation order.  Define
+ *   SEG(entries, S): cut the entry range into consecutive segments of S stored entries, each a
+ *   sequential fmaf chain from +0; combine the segment partials p_0, p_1, ... 4-way strided:
+ *   s_q = p_q + p_{q+4} + p_{q+8} + ... (left to right) for q = 0..3, result = ((s_0 + s_1) + s_2) + s_3
+ *   (absent s_q skipped).
+ * Row long_rows[i] with chunk_len[i] == 0 is SEG(row, seg_len[i]).  With chunk_len[i] = C > 0 the row is
+ * first cut into consecutive chunks of C entries, chunk sums c_k = SEG(chunk k, seg_len[i]), and the c_k are
+ * combined by the same 4-way strided rule.  Every other row is one sequential chain.
+ * The arrays hold n_long_rows (info[4]) elements; any may be NULL. */
+int idg_graph_long_rows(const idg_graph* g, int64_t* long_rows, int64_t* seg_len, int64_t* chunk_len);
 
 /* Y = A.X  (torch.sparse.mm(Graph, X): models/LightGCN.py:44, SimGCL.py:48, XSimGCL.py:51,
  * NGCF.py:85, SGL.py:48,50).  X [n_cols, d], Y [n_rows, d] row-major fp32 with leading
@@ -196,6 +201,17 @@ int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out
 int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask,
                                float* gE0, int K, int include_layer0, int64_t d, int accumulate,
                                void* ws, void* stream);
+/* The same backward followed by the dense Adam step on the [n, d] parameter panel E0 the gradient
+ * belongs to (loss.backward() + optimizer.step(), utility/utility_train/trainer.py:54-56): each
+ * finished gradient row is consumed by its Adam update in the epilogue of the last product instead
+ * of being re-read by a second kernel.  gE0 still receives the gradient.  Bit-identical to
+ * idg_propagate_mean_bwd_f32 + idg_adam_step_f32 (which is what runs when K < 2 or d is not a tiled
+ * width).  Hyper-parameters as idg_adam_step_f32. */
+int idg_propagate_mean_bwd_adam_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask,
+                                    float* gE0, int K, int include_layer0, int64_t d, int accumulate,
+                                    float* param, float* exp_avg, float* exp_avg_sq, double lr,
+                                    double beta1, double beta2, double eps, int64_t step, void* ws,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: fused gather + BPR + L2-reg loss and gradients

@@ -37,38 +37,67 @@ void orc_spmm_f32(int64_t n_rows, const int64_t* indptr, const int32_t* indices,
  * idg_graph_long_rows): the rows listed in long_rows (ascending) are cut into consecutive
  * segments of seg_len[i] entries, each a fmaf chain from +0; the segment partials are combined
  * 4-way strided: s_q = p_q + p_{q+4} + ... for q = 0..3, row = ((s_0 + s_1) + s_2) + s_3.
+ * With chunk_len[i] = C > 0 the row is first cut into chunks of C entries, the rule above gives each
+ * chunk's sum, and the chunk sums are combined by the same 4-way rule.
  * All other rows are the plain sequential chain.  This restates the summation ORDER only;
  * the operands are the reference's. */
+enum { ORC_WAYS = 4 };
+
+/* SEG(entries [s,e), S) of include/idgrec.h: segments of S entries, each a sequential fmaf chain
+ * from +0, combined 4-way strided.  part: d floats, way: 4*d floats of scratch; result in y. */
+static void orc_seg_sum(const int32_t* indices, const float* values, const float* X, int64_t d, int64_t s, int64_t e,
+                        int64_t S, float* part, float* way, float* y) {
+  int64_t nseg = 0;
+  for (int64_t b = s; b < e; b += S, ++nseg) {
+    const int64_t be = b + S < e ? b + S : e;
+    for (int64_t f = 0; f < d; ++f) part[f] = 0.0f;
+    for (int64_t k = b; k < be; ++k) {
+      const float v = values[k];
+      const float* x = X + (int64_t)indices[k] * d;
+      for (int64_t f = 0; f < d; ++f) part[f] = fmaf(v, x[f], part[f]);
+    }
+    float* w = way + (nseg % ORC_WAYS) * d;
+    if (nseg < ORC_WAYS)
+      for (int64_t f = 0; f < d; ++f) w[f] = part[f];
+    else
+      for (int64_t f = 0; f < d; ++f) w[f] = w[f] + part[f];
+  }
+  for (int64_t f = 0; f < d; ++f) y[f] = nseg > 0 ? way[f] : 0.0f;
+  for (int64_t q = 1; q < ORC_WAYS && q < nseg; ++q)
+    for (int64_t f = 0; f < d; ++f) y[f] = y[f] + way[q * d + f];
+}
+
 void orc_spmm_sched_f32(int64_t n_rows, const int64_t* indptr, const int32_t* indices, const float* values,
                         const float* X, int64_t d, const int64_t* long_rows, const int64_t* seg_len,
-                        int64_t n_long, float* Y) {
-  enum { WAYS = 4 };
+                        const int64_t* chunk_len, int64_t n_long, float* Y) {
   int64_t li = 0;
   float* part = (float*)malloc((size_t)d * sizeof(float));
-  float* way = (float*)malloc((size_t)d * WAYS * sizeof(float));
+  float* way = (float*)malloc((size_t)d * ORC_WAYS * sizeof(float));
+  float* csum = (float*)malloc((size_t)d * sizeof(float));
+  float* cway = (float*)malloc((size_t)d * ORC_WAYS * sizeof(float));
   for (int64_t r = 0; r < n_rows; ++r) {
     float* y = Y + r * d;
     const int64_t s = indptr[r], e = indptr[r + 1];
     if (li < n_long && long_rows[li] == r) {
-      const int64_t S = seg_len[li++];
-      int64_t nseg = 0;
-      for (int64_t b = s; b < e; b += S, ++nseg) {
-        const int64_t be = b + S < e ? b + S : e;
-        for (int64_t f = 0; f < d; ++f) part[f] = 0.0f;
-        for (int64_t k = b; k < be; ++k) {
-          const float v = values[k];
-          const float* x = X + (int64_t)indices[k] * d;
-          for (int64_t f = 0; f < d; ++f) part[f] = fmaf(v, x[f], part[f]);
-        }
-        float* w = way + (nseg % WAYS) * d;
-        if (nseg < WAYS)
-          for (int64_t f = 0; f < d; ++f) w[f] = part[f];
-        else
-          for (int64_t f = 0; f < d; ++f) w[f] = w[f] + part[f];
+      const int64_t S = seg_len[li], Cn = chunk_len ? chunk_len[li] : 0;
+      ++li;
+      if (Cn <= 0) {
+        orc_seg_sum(indices, values, X, d, s, e, S, part, way, y);
+        continue;
       }
-      for (int64_t f = 0; f < d; ++f) y[f] = nseg > 0 ? way[f] : 0.0f;
-      for (int64_t q = 1; q < WAYS && q < nseg; ++q)
-        for (int64_t f = 0; f < d; ++f) y[f] = y[f] + way[q * d + f];
+      /* chunk sums c_k = SEG(chunk k, S), then the same 4-way strided rule over the c_k */
+      int64_t nch = 0;
+      for (int64_t b = s; b < e; b += Cn, ++nch) {
+        orc_seg_sum(indices, values, X, d, b, b + Cn < e ? b + Cn : e, S, part, way, csum);
+        float* w = cway + (nch % ORC_WAYS) * d;
+        if (nch < ORC_WAYS)
+          for (int64_t f = 0; f < d; ++f) w[f] = csum[f];
+        else
+          for (int64_t f = 0; f < d; ++f) w[f] = w[f] + csum[f];
+      }
+      for (int64_t f = 0; f < d; ++f) y[f] = nch > 0 ? cway[f] : 0.0f;
+      for (int64_t q = 1; q < ORC_WAYS && q < nch; ++q)
+        for (int64_t f = 0; f < d; ++f) y[f] = y[f] + cway[q * d + f];
     } else {
       for (int64_t f = 0; f < d; ++f) y[f] = 0.0f;
       for (int64_t k = s; k < e; ++k) {
@@ -80,6 +109,8 @@ void orc_spmm_sched_f32(int64_t n_rows, const int64_t* indptr, const int32_t* in
   }
   free(part);
   free(way);
+  free(csum);
+  free(cway);
 }
 
 /* LightGCN.aggregate (models/LightGCN.py:36-52) with include_layer0 = 1;
@@ -89,7 +120,7 @@ void orc_spmm_sched_f32(int64_t n_rows, const int64_t* indptr, const int32_t* in
  * schedule.  tmp: 2*n*d floats. */
 void orc_propagate_mean_f32(int64_t n, const int64_t* indptr, const int32_t* indices, const float* values,
                             const float* E0, int64_t d, int K, int include_layer0, const int64_t* long_rows,
-                            const int64_t* seg_len, int64_t n_long, float* out, float* tmp) {
+                            const int64_t* seg_len, const int64_t* chunk_len, int64_t n_long, float* out, float* tmp) {
   const int64_t nd = n * d;
   float* P[2] = {tmp, tmp + nd};
   const float* X = E0;
@@ -101,7 +132,7 @@ void orc_propagate_mean_f32(int64_t n, const int64_t* indptr, const int32_t* ind
   for (int k = 1; k <= K; ++k) {
     float* Y = P[(k - 1) & 1];
     if (n_long > 0)
-      orc_spmm_sched_f32(n, indptr, indices, values, X, d, long_rows, seg_len, n_long, Y);
+      orc_spmm_sched_f32(n, indptr, indices, values, X, d, long_rows, seg_len, chunk_len, n_long, Y);
     else
       orc_spmm_f32(n, indptr, indices, values, X, d, Y);
     if (!have_sum) {

@@ -59,7 +59,7 @@ def _csr(indptr, indices, values):
 
 
 # ---------------------------------------------------------------------------- fp32 kernels
-def spmm(indptr, indices, values, X, long_rows=None, seg_len=None):
+def spmm(indptr, indices, values, X, long_rows=None, seg_len=None, chunk_len=None):
     indptr, indices, values = _csr(indptr, indices, values)
     X = np.ascontiguousarray(X, dtype=np.float32)
     n, d = indptr.shape[0] - 1, X.shape[1]
@@ -68,8 +68,9 @@ def spmm(indptr, indices, values, X, long_rows=None, seg_len=None):
     if long_rows is not None and len(long_rows):
         lr = np.ascontiguousarray(long_rows, dtype=np.int64)
         sl = np.ascontiguousarray(seg_len, dtype=np.int64)
+        cl = np.ascontiguousarray(np.zeros_like(lr) if chunk_len is None else chunk_len, dtype=np.int64)
         L.orc_spmm_sched_f32(C.c_int64(n), _p(indptr, C.c_int64), _p(indices, C.c_int32), _p(values, C.c_float),
-                             _p(X, C.c_float), C.c_int64(d), _p(lr, C.c_int64), _p(sl, C.c_int64),
+                             _p(X, C.c_float), C.c_int64(d), _p(lr, C.c_int64), _p(sl, C.c_int64), _p(cl, C.c_int64),
                              C.c_int64(len(lr)), _p(Y, C.c_float))
     else:
         L.orc_spmm_f32(C.c_int64(n), _p(indptr, C.c_int64), _p(indices, C.c_int32), _p(values, C.c_float),
@@ -77,7 +78,7 @@ def spmm(indptr, indices, values, X, long_rows=None, seg_len=None):
     return Y
 
 
-def propagate_mean(indptr, indices, values, E0, K, include_layer0=True, long_rows=None, seg_len=None):
+def propagate_mean(indptr, indices, values, E0, K, include_layer0=True, long_rows=None, seg_len=None, chunk_len=None):
     indptr, indices, values = _csr(indptr, indices, values)
     E0 = np.ascontiguousarray(E0, dtype=np.float32)
     n, d = E0.shape
@@ -86,10 +87,11 @@ def propagate_mean(indptr, indices, values, E0, K, include_layer0=True, long_row
     nl = 0 if long_rows is None else len(long_rows)
     lr = np.ascontiguousarray(long_rows if nl else [0], dtype=np.int64)
     sl = np.ascontiguousarray(seg_len if nl else [0], dtype=np.int64)
+    cl = np.ascontiguousarray(chunk_len if (nl and chunk_len is not None) else np.zeros_like(lr), dtype=np.int64)
     _load().orc_propagate_mean_f32(C.c_int64(n), _p(indptr, C.c_int64), _p(indices, C.c_int32),
                                    _p(values, C.c_float), _p(E0, C.c_float), C.c_int64(d), C.c_int(K),
                                    C.c_int(int(include_layer0)), _p(lr, C.c_int64), _p(sl, C.c_int64),
-                                   C.c_int64(nl), _p(out, C.c_float), _p(tmp, C.c_float))
+                                   _p(cl, C.c_int64), C.c_int64(nl), _p(out, C.c_float), _p(tmp, C.c_float))
     return out
 
 

@@ -1,0 +1,10 @@
+"""stdin: bench.py output; prints the few numbers compared during kernel tuning."""
+import json, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else ""
+for line in sys.stdin:
+    if not line.startswith("{"):
+        continue
+    d = json.loads(line)
+    r = d.get("roofline", {})
+    print("%-14s ms/step %.4f  triples/s %.0f  dense launch %.1f us  rows layer %.1f us  tiles %s" % (
+        tag, d["ms_per_step"], d["value"], r.get("us_per_launch", 0), r.get("row_restricted_last_layer_us", 0), r.get("tiles")))

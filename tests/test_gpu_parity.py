@@ -78,11 +78,11 @@ def test_spmm_split_rows_follow_published_schedule(ops, d, thr, fused, monkeypat
     indptr, indices, values = random_csr(900, 6000, 12, seed=5, hubs=[(0, 5000), (17, 2049), (899, 700), (450, 257)])
     X = np.random.default_rng(2).standard_normal((6000, d)).astype(np.float32)
     G = ops.Graph(indptr, indices, values, 900, 6000, symmetric=False, split_threshold=thr)
-    rows, seg = G.long_rows()
-    assert len(rows) >= 3 and G.info()["n_segments"] > len(rows)
+    rows, seg, chunk = G.long_rows()
+    assert len(rows) >= 3 and (chunk > 0).sum() >= 2 and (chunk == 0).sum() >= 1 and G.info()["n_segments"] > (chunk > 0).sum()
     Y = G.spmm_raw(dev(X)).cpu().numpy()
     # bit-exact against the oracle evaluated in the same published summation order ...
-    assert np.array_equal(Y, oracle.spmm(indptr, indices, values, X, rows, seg))
+    assert np.array_equal(Y, oracle.spmm(indptr, indices, values, X, rows, seg, chunk))
     # ... and within fp32 rounding of the reference's sequential order: |err| <= c.eps.sum|a.x|
     scale = oracle.spmm(indptr, indices, np.abs(values), np.abs(X))
     assert (np.abs(Y - oracle.spmm(indptr, indices, values, X)) <= 2e-6 * scale + 1e-30).all()
@@ -362,6 +362,44 @@ def test_six_training_steps_vs_reference(ops, model, golden_small):
         np.testing.assert_allclose(wi.detach().cpu().numpy(), g["traj_%s_item" % model][step], rtol=RTOL, atol=1e-7)
 
 
+@pytest.mark.parametrize("fix", ["0", "1"])
+@pytest.mark.parametrize("K,inc,d", [(3, True, 64), (2, False, 64), (1, True, 64), (3, True, 256), (2, True, 128)])
+def test_train_step_adam_in_epilogue_is_bit_identical(ops, K, inc, d, fix, monkeypatch):
+    """engine.train_step applies Adam in the epilogue of the last backward product (idg_propagate_mean_bwd_adam_f32);
+    parameters, moments and the exposed gradient equal the two-pass form bit for bit — also on rows that are
+    combined in LDS, rows whose chunks meet in global memory (either combine), and the K < 2 / odd-width fallbacks."""
+    monkeypatch.setenv("IDG_FUSED_FIX", fix)
+    from idgrec_amd.engine import PropagationEngine
+
+    import idgrec_amd.host as H
+
+    rng = np.random.default_rng(K * 100 + d)
+    U, I = 2500, 900
+    # two hub items (degree 2000 and 700: chunked rows), a heavy tail of local rows, many short rows
+    eu = np.concatenate([rng.integers(0, U, 30000), rng.choice(U, 2000, replace=False), rng.choice(U, 700, replace=False)])
+    ei = np.concatenate([(rng.zipf(1.3, 30000) % I), np.full(2000, 5), np.full(700, 77)])
+    eu, ei = np.unique(np.stack([eu, ei]), axis=1)
+    ip, ix, dv = H.build_norm_adj(U, I, eu.astype(np.int64), ei.astype(np.int64))
+    n = U + I
+    W0 = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+    pick = rng.permutation(len(eu))[: 4 * 200]
+    tri = np.stack([eu[pick], ei[pick], rng.integers(0, I, len(pick))], axis=1).astype(np.int64)
+    tu, tp, tn = (dev(np.ascontiguousarray(tri[:, c])) for c in range(3))
+    out = []
+    for fuse in (True, False):
+        G = ops.Graph(ip, ix, dv, n, n)
+        sched = G.long_rows()
+        assert (sched[2] > 0).sum() >= 2 and (sched[2] == 0).sum() >= 5
+        eng = PropagationEngine(G, U, I, d, K, include_layer0=inc, params=dev(W0.copy()))
+        eng.fuse_adam = fuse
+        losses = [eng.train_step(tu[i * 200:(i + 1) * 200], tp[i * 200:(i + 1) * 200], tn[i * 200:(i + 1) * 200]).clone()
+                  for i in range(4)]
+        out.append((eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.grad.clone(), torch.stack(losses)))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert not torch.equal(out[0][0].cpu(), torch.from_numpy(W0))
+
+
 # --------------------------------------------------------------------------- scoring/top-K
 @pytest.mark.parametrize("gname", ["tiny", "small"])
 def test_rating_matrix_vs_reference(ops, gname, golden_tiny, golden_small):
@@ -511,12 +549,12 @@ def _yelp_shape_full_size(ops):
     assert np.array_equal(Ge.spmm_raw(dev(X)).cpu().numpy(), ref)
     G = ops.Graph(ip, ix, dv, n, n)
     assert G.info()["n_long_rows"] > 0
-    rows, seg = G.long_rows()
+    sched = G.long_rows()
     Y = G.spmm_raw(dev(X))
-    assert np.array_equal(Y.cpu().numpy(), oracle.spmm(ip, ix, dv, X, rows, seg))
+    assert np.array_equal(Y.cpu().numpy(), oracle.spmm(ip, ix, dv, X, *sched))
     np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=RTOL, atol=1e-6)
     out = ops.propagate_mean(G, dev(X), 3, True).cpu().numpy()
-    assert np.array_equal(out, oracle.propagate_mean(ip, ix, dv, X, 3, True, rows, seg))
+    assert np.array_equal(out, oracle.propagate_mean(ip, ix, dv, X, 3, True, *sched))
     # symmetry of the operator in double precision
     Z = dev((rng.standard_normal((n, 64)) * 0.1).astype(np.float32))
     lhs = (Z.double() * Y.double()).sum().item()
