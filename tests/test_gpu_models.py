@@ -102,6 +102,42 @@ def test_fused_step_equals_autograd_step(mname, tmp_path, golden_small):
     np.testing.assert_allclose(grads[1][1], g[key + "_grad_item"], rtol=RTOL, atol=1e-8)
 
 
+@pytest.mark.parametrize("mname", ["lgcn", "mf"])
+def test_fused_train_step_equals_grad_then_optimizer_step(mname, tmp_path, golden_small):
+    """One chain (Adam in the last backward epilogue, moments in packed panels viewed by the optimizer state)
+    == fused gradients + optimizer.step(), bit for bit, including switching between the two mid-run."""
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.LightGCN import LightGCN
+    from models.MFBPR import MFBPR
+
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", learn_rate=0.001, **BASE)
+    tri = torch.from_numpy(g["sample1"][:5 * 256]).cuda()
+    bt = [tuple(tri[i * 256:(i + 1) * 256, c].contiguous() for c in range(3)) for i in range(5)]
+    res = []
+    for plan in ("TTTTT", "FFFFF", "FTTFT"):
+        tools.set_seed(2024)
+        model = (LightGCN if mname == "lgcn" else MFBPR)(cfg, data, torch.device("cuda")).to("cuda")
+        opt = ops.Adam(model.parameters(), lr=0.001)
+        loss = torch.zeros((5, 2), device="cuda")
+        for i, one_chain in enumerate(plan):
+            if one_chain == "T":
+                assert model.fused_train_step(*bt[i], loss[i], opt)
+            else:
+                model.fused_loss_and_grad(*bt[i], loss_out=loss[i])
+                opt.step()
+        st = opt.state[model.item_embedding.weight]
+        assert st["step"] == 5 and opt.state[model.user_embedding.weight]["step"] == 5
+        res.append((model._storage.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), loss.clone(),
+                    model.user_embedding.weight.grad.clone()))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+    # a foreign optimizer is left to the two-call form
+    assert not model.fused_train_step(*bt[0], loss[0], torch.optim.Adam(model.parameters(), lr=0.001))
+
+
 def test_packed_storage_survives_to_and_optimizer(tmp_path, golden_small):
     from idgrec_amd import ops
     from models.MFBPR import MFBPR

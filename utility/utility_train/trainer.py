@@ -7,8 +7,9 @@ the triples to the device, shuffle them with the same stream, walk the mini-batc
 ways to run a step:
   * generic: `model(batch) -> [losses]`, sum, autograd backward, optimizer step — works for
     any nn.Module built from the differentiable operators in idgrec_amd.ops;
-  * fused (models that set `supports_fused_step`): `model.fused_loss_and_grad(batch)` writes
-    the losses and parameter gradients with a fixed chain of HIP kernels, no autograd graph.
+  * fused (models that set `supports_fused_step`): `model.fused_train_step(batch, optimizer)` runs
+    forward, backward and the Adam update as one fixed chain of HIP kernels, no autograd graph
+    (`model.fused_loss_and_grad(batch)` + `optimizer.step()` when the optimizer is not ours).
 Either way the per-step `loss.item()` host round trip of the reference (trainer.py:52) is
 replaced by one device->host copy per epoch; the logged numbers are formed from the same
 fp32 per-step losses, accumulated in float64 in step order, as the reference's Python floats.
@@ -59,8 +60,11 @@ def universal_trainer(model, args, config, dataset, device, logger):
                     step_losses = torch.zeros((num_batch, 2), dtype=torch.float32, device=device)
                 if batch_i + 1 < len(batches):
                     model.prefetch_batch(*batches[batch_i + 1])  # index-only work of the next step, off the critical path
-                model.fused_loss_and_grad(b_users, b_pos, b_neg, loss_out=step_losses[batch_i])
-                Optim.step()
+                # one chain of kernels for forward + backward + Adam when the optimizer is ours ...
+                if not model.fused_train_step(b_users, b_pos, b_neg, step_losses[batch_i], Optim):
+                    # ... otherwise gradients from the fused path, update by whatever optimizer this is
+                    model.fused_loss_and_grad(b_users, b_pos, b_neg, loss_out=step_losses[batch_i])
+                    Optim.step()
                 continue
             loss_list = model(b_users, b_pos, b_neg)
             if step_losses is None:
