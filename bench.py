@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--split", type=int, default=0, help="row split threshold (0 = library default)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--separate-adam", action="store_true",
+                   help="Adam as its own kernel instead of the last backward epilogue (PMC calibration runs)")
     p.add_argument("--seed", type=int, default=2024)
     p.add_argument("--force-sharded", action="store_true",
                    help="run the user-row-sharded path even at world size 1 (exercises the RCCL code path)")
@@ -159,6 +161,7 @@ def main():
     W0 = S.xavier_uniform_panel(U, I, d, args.seed)
     eng = PropagationEngine(graph, U, I, d, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
                             deterministic=not args.atomic, params=W0.cuda())
+    eng.fuse_adam = not args.separate_adam
     tri = torch.from_numpy(wl["triples"]).cuda()
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
     losses = torch.zeros((args.steps + args.warmup, 2), dtype=torch.float32, device="cuda")

@@ -48,7 +48,8 @@ struct __attribute__((aligned(16))) Tile {
   int16_t n_vrows;  // 1..TILE_VROWS
   int16_t n_local;  // local rows (LocalRow entries) of this tile
   int32_t local_begin;
-  int32_t pad_[3];
+  int32_t row_first, row_last;  // the tile's vrows produce (pieces of) the consecutive rows row_first..row_last
+  int32_t pad_;
 };
 
 struct LocalRow {
@@ -612,6 +613,17 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   __shared__ int s_next;
 
   const Tile t = tiles[blockIdx.x];
+  {
+    // a tile covers consecutive rows: a few (uniform) bitmap words decide whether anything here is requested
+    uint32_t any = 0;
+    for (int w = t.row_first >> 5; w <= (t.row_last >> 5); ++w) {
+      uint32_t m = out_mask[w];
+      if (w == (t.row_first >> 5)) m &= ~0u << (t.row_first & 31);
+      if (w == (t.row_last >> 5)) m &= ~0u >> (31 - (t.row_last & 31));
+      any |= m;
+    }
+    if (any == 0) return;
+  }
   const int tid = threadIdx.x;
   const int nv = t.n_vrows;
   const int64_t nz0 = t.nnz_begin;
@@ -997,6 +1009,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   // ---- virtual rows
   std::vector<int64_t> vptr;
   std::vector<int32_t> vtgt;
+  std::vector<int32_t> vrow_row;  // the CSR row each vrow is (a piece of); non-decreasing
   std::vector<LongRow> longs;
   std::vector<LocalRow> locals;  // in vrow order == tile order of creation
   std::vector<int32_t> slot_row, slot_long;
@@ -1021,6 +1034,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   };
   for (int64_t r = 0; r < n_rows; ++r) {
     const int64_t s = indptr[r], e = indptr[r + 1], len = e - s;
+    vrow_row.resize(vtgt.size(), r > 0 ? (int32_t)(r - 1) : 0);  // vrows of the previous row
     if (exact || len <= T) {
       vtgt.push_back((int32_t)r);
       vptr.push_back(e);
@@ -1056,6 +1070,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
     }
     slots += nch;
   }
+  vrow_row.resize(vtgt.size(), (int32_t)std::max<int64_t>(n_rows - 1, 0));
   g->n_vrows = (int64_t)vtgt.size();
   g->n_long = (int64_t)longs.size();
   g->n_slots = slots;
@@ -1101,6 +1116,8 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
       t.n_vrows = (int16_t)(w - v);
       t.n_local = (int16_t)(li - li0);
       t.local_begin = (int32_t)li0;
+      t.row_first = vrow_row[(size_t)v];
+      t.row_last = vrow_row[(size_t)w - 1];
       tiles.push_back(t);
       v = w;
     }
