@@ -224,7 +224,7 @@ def main():
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         info = graph.info()
         out["roofline"] = {
-            "bound": "hbm", "kernel": "spmm_tile_kernel<%d,1> (+ split-row fix-up)" % (d // 4),
+            "bound": "hbm", "kernel": "spmm_tile_kernel<%d,1,8,dyn> (split rows combined in-kernel)" % (d // 4),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "us_per_launch": spmm_ms * 1e3, "launches_timed": len(dense),
             "row_restricted_last_layer_us": rows_ms * 1e3,
