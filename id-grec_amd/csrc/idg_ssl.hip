@@ -1,0 +1,360 @@
+// In-batch InfoNCE between two views, forward and backward in one chain of kernels.
+//
+// Reference: utility/utility_function/losses.py:24-35 (get_InfoNCE_loss) as called by
+// models/SimGCL.py:79-84, XSimGCL.py:80-86 and SGL.py:96-101:
+//     idx = unique(batch ids);  a = normalize(view1[idx]);  b = normalize(view2[idx])
+//     pos_i = exp(<a_i, b_i>/t);  ttl_i = sum_k exp(<a_i, b_k>/t);  loss = mean_i -log(pos_i/ttl_i + 1e-5)
+// once for the batch's users and once for its positive items.  On stock PyTorch that is ~100
+// small launches per step (unique's sorts, gathers, normalisations, two GEMMs, exp/sum/log and
+// the autograd mirror of all of it) — more time than the step's twelve SpMM launches.  Here:
+//   rows    bitmap of the batch's rows -> ascending compact id list (== torch.unique's order)
+//   norm    a, b rows normalised into compact panels (one wave per row)
+//   logits  P = exp(a.b^T / t), 64x64 LDS tiles, both row sets in one launch (blockIdx.z)
+//   stats   per row: ttl, loss term, the backward weight w_i = -r_i / (t m (r_i + eps))
+//   grads   dL/da = w_i (b_i - sum_k Q_ik b_k),  dL/db_k = w_k a_k - sum_i w_i Q_ik a_i,  Q = P/ttl
+//   final   back through normalize(): dx = (g - <g, y> y) / ||x||, stored to the views' gradient rows
+// Everything is deterministic (no float atomics); sizes that depend on the data (the number of
+// unique ids) stay on the device: launches are shaped by the batch size and read the counts.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "idg_common.h"
+
+extern "C" int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
+                                  int64_t num_users, uint32_t* bitmap, void* stream);
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVE = 64;
+constexpr int TS = 64;  // tile edge of the logits / gradient GEMMs
+constexpr int KC = 16;  // reduction chunk staged in LDS
+
+struct SslWs {
+  uint32_t* bitmap;  // [(n+31)/32]
+  int32_t* idx;      // [2B] ascending panel rows: the user set, then the item set
+  int32_t* counts;   // [2] sizes of the two sets (+2 pad)
+  float* An;         // [2 views][2B][d] normalised rows
+  float* den;        // [2 views][2B]   max(||x||, 1e-12)
+  float* P;          // [2 sets][B][B]
+  float* invttl;     // [2B]
+  float* w;          // [2B]
+  float* lossrow;    // [2B]
+  float* G;          // [2 views][2B][d]  dL/d(normalised row)
+  size_t bytes;
+};
+
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+SslWs ssl_layout(void* base, int64_t n, int64_t B, int64_t d) {
+  SslWs w{};
+  char* p = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* q = p ? p + off : nullptr;
+    off += up256(bytes);
+    return q;
+  };
+  w.bitmap = reinterpret_cast<uint32_t*>(take((size_t)((n + 31) / 32) * 4));
+  w.idx = reinterpret_cast<int32_t*>(take((size_t)2 * B * 4));
+  w.counts = reinterpret_cast<int32_t*>(take(16));
+  w.An = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
+  w.den = reinterpret_cast<float*>(take((size_t)2 * 2 * B * 4));
+  w.P = reinterpret_cast<float*>(take((size_t)2 * B * B * 4));
+  w.invttl = reinterpret_cast<float*>(take((size_t)2 * B * 4));
+  w.w = reinterpret_cast<float*>(take((size_t)2 * B * 4));
+  w.lossrow = reinterpret_cast<float*>(take((size_t)2 * B * 4));
+  w.G = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
+  w.bytes = off;
+  return w;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+
+// ---- bitmap -> ascending id list; ids < num_users form set 0, the rest set 1.  One 1024-thread block.
+__global__ __launch_bounds__(1024) void ssl_compact_kernel(const uint32_t* __restrict__ bitmap, int64_t n,
+                                                            int64_t num_users, int32_t* __restrict__ idx,
+                                                            int32_t* __restrict__ counts, int64_t cap) {
+  __shared__ int s_cnt[1024];
+  __shared__ int s_users[1024];
+  const int tid = threadIdx.x;
+  const int64_t words = (n + 31) / 32;
+  const int64_t per = (words + 1023) / 1024;
+  const int64_t w0 = (int64_t)tid * per, w1 = w0 + per < words ? w0 + per : words;
+  int c = 0, cu = 0;
+  for (int64_t w = w0; w < w1; ++w) {
+    const uint32_t m = bitmap[w];
+    c += __popc(m);
+    // bits of this word that are user rows
+    const int64_t lo = w * 32;
+    if (lo + 32 <= num_users) cu += __popc(m);
+    else if (lo < num_users) cu += __popc(m & ((1u << (num_users - lo)) - 1u));
+  }
+  s_cnt[tid] = c;
+  s_users[tid] = cu;
+  __syncthreads();
+  // inclusive scan (Hillis-Steele) over 1024 partial counts
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int a = tid >= off ? s_cnt[tid - off] : 0;
+    const int b = tid >= off ? s_users[tid - off] : 0;
+    __syncthreads();
+    s_cnt[tid] += a;
+    s_users[tid] += b;
+    __syncthreads();
+  }
+  int64_t at = s_cnt[tid] - c;
+  for (int64_t w = w0; w < w1; ++w) {
+    uint32_t m = bitmap[w];
+    while (m) {
+      const int b = __ffs(m) - 1;
+      m &= m - 1;
+      if (at < cap) idx[at] = (int32_t)(w * 32 + b);
+      ++at;
+    }
+  }
+  if (tid == 1023) {
+    counts[0] = s_users[1023];
+    counts[1] = s_cnt[1023] - s_users[1023];
+  }
+}
+
+// ---- normalise: one wave per (compact row, view)
+__global__ __launch_bounds__(BLOCK) void ssl_normalize_kernel(const float* __restrict__ view1,
+                                                              const float* __restrict__ view2, int64_t d,
+                                                              const int32_t* __restrict__ idx,
+                                                              const int32_t* __restrict__ counts, int64_t B,
+                                                              float* __restrict__ An, float* __restrict__ den) {
+  const int lane = threadIdx.x % WAVE;
+  const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int v = blockIdx.y;
+  if (r >= counts[0] + counts[1]) return;
+  const float* x = (v == 0 ? view1 : view2) + (int64_t)idx[r] * d;
+  float ss = 0.f;
+  for (int64_t f = lane; f < d; f += WAVE) ss += x[f] * x[f];
+  ss = wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);  // torch.nn.functional.normalize: x / max(||x||, eps)
+  float* y = An + ((int64_t)v * 2 * B + r) * d;
+  for (int64_t f = lane; f < d; f += WAVE) y[f] = x[f] / nrm;
+  if (lane == 0) den[(int64_t)v * 2 * B + r] = nrm;
+}
+
+// ---- P[set][i][k] = exp(<a_i, b_k> / t): 64 x 64 tile per block, 4 x 4 per thread
+__global__ __launch_bounds__(BLOCK) void ssl_logits_kernel(const float* __restrict__ An, int64_t d, int64_t B,
+                                                           const int32_t* __restrict__ counts, float inv_t,
+                                                           float* __restrict__ P) {
+  __shared__ float sa[KC][TS + 1];
+  __shared__ float sb[KC][TS + 1];
+  const int set = blockIdx.z;
+  const int m = counts[set];
+  const int i0 = blockIdx.y * TS, k0 = blockIdx.x * TS;
+  if (i0 >= m || k0 >= m) return;
+  const int64_t base = set == 0 ? 0 : counts[0];
+  const float* A = An + base * d;                       // view 1 rows of this set
+  const float* Bm = An + ((int64_t)2 * B + base) * d;   // view 2 rows of this set
+  const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
+  float acc[4][4] = {};
+  for (int64_t f0 = 0; f0 < d; f0 += KC) {
+    for (int e = tid; e < TS * KC; e += BLOCK) {
+      const int row = e / KC, f = e % KC;
+      sa[f][row] = (i0 + row < m && f0 + f < d) ? A[(int64_t)(i0 + row) * d + f0 + f] : 0.f;
+      sb[f][row] = (k0 + row < m && f0 + f < d) ? Bm[(int64_t)(k0 + row) * d + f0 + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < KC; ++f) {
+      float a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = sa[f][ty * 4 + q], b[q] = sb[f][tx * 4 + q];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_fmaf(a[p], b[q], acc[p][q]);
+    }
+    __syncthreads();
+  }
+  float* Ps = P + (int64_t)set * B * B;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + ty * 4 + p, k = k0 + tx * 4 + q;
+      if (i < m && k < m) Ps[(int64_t)i * B + k] = expf(acc[p][q] * inv_t);
+    }
+}
+
+// ---- per row: ttl, loss term, backward weight.  One wave per row.
+__global__ __launch_bounds__(BLOCK) void ssl_rowstat_kernel(const float* __restrict__ P, int64_t B,
+                                                            const int32_t* __restrict__ counts, float inv_t, float eps,
+                                                            float* __restrict__ invttl, float* __restrict__ w,
+                                                            float* __restrict__ lossrow) {
+  const int set = blockIdx.y;
+  const int m = counts[set];
+  const int lane = threadIdx.x % WAVE;
+  const int64_t i = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  if (i >= m) return;
+  const float* row = P + (int64_t)set * B * B + i * B;
+  float s = 0.f;
+  for (int k = lane; k < m; k += WAVE) s += row[k];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float r = row[i] / s;
+    const int64_t o = (set == 0 ? 0 : counts[0]) + i;
+    invttl[o] = 1.0f / s;
+    lossrow[o] = -logf(r + eps);
+    w[o] = -r * inv_t / ((float)m * (r + eps));
+  }
+}
+
+// ---- loss[set] = mean of the row terms (one block per set, fixed tree)
+__global__ __launch_bounds__(BLOCK) void ssl_loss_kernel(const float* __restrict__ lossrow,
+                                                         const int32_t* __restrict__ counts, float* __restrict__ loss) {
+  __shared__ float s[BLOCK];
+  const int set = blockIdx.x;
+  const int m = counts[set];
+  const float* x = lossrow + (set == 0 ? 0 : counts[0]);
+  float a = 0.f;
+  for (int i = threadIdx.x; i < m; i += BLOCK) a += x[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int off = BLOCK / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[set] = s[0] / (float)m;
+}
+
+// ---- gradients with respect to the normalised rows.  blockIdx.z = set * 2 + side
+//   side 0: Ga[i,:] = w_i (b_i - invttl_i sum_k P_ik b_k)          (tile: 64 rows i x 64 features)
+//   side 1: Gb[k,:] = w_k a_k - sum_i (w_i invttl_i) P_ik a_i      (tile: 64 rows k x 64 features)
+__global__ __launch_bounds__(BLOCK) void ssl_grad_kernel(const float* __restrict__ An, const float* __restrict__ P,
+                                                         int64_t d, int64_t B, const int32_t* __restrict__ counts,
+                                                         const float* __restrict__ invttl, const float* __restrict__ w,
+                                                         float* __restrict__ G) {
+  __shared__ float sp[KC][TS + 1];  // P chunk: [reduction index][output row]
+  __shared__ float sx[KC][TS + 1];  // the other view's rows: [reduction index][feature]
+  const int set = blockIdx.z >> 1, side = blockIdx.z & 1;
+  const int m = counts[set];
+  const int r0 = blockIdx.y * TS;
+  const int64_t f0 = (int64_t)blockIdx.x * TS;
+  if (r0 >= m) return;
+  const int64_t base = set == 0 ? 0 : counts[0];
+  const float* A = An + base * d;
+  const float* Bm = An + ((int64_t)2 * B + base) * d;
+  const float* X = side == 0 ? Bm : A;  // rows being mixed
+  const float* Ps = P + (int64_t)set * B * B;
+  const float* it = invttl + base;
+  const float* ww = w + base;
+  const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
+  float acc[4][4] = {};
+  for (int c0 = 0; c0 < m; c0 += KC) {
+    for (int e = tid; e < TS * KC; e += BLOCK) {
+      // P element (output row r0+row, reduction index c0+c): side 0 reads P[row][c], side 1 reads P[c][row] * w_c invttl_c
+      const int row = side == 0 ? e / KC : e % TS, c = side == 0 ? e % KC : e / TS;
+      float v = 0.f;
+      if (r0 + row < m && c0 + c < m)
+        v = side == 0 ? Ps[(int64_t)(r0 + row) * B + c0 + c] : Ps[(int64_t)(c0 + c) * B + r0 + row] * (ww[c0 + c] * it[c0 + c]);
+      sp[c][row] = v;
+    }
+    for (int e = tid; e < TS * KC; e += BLOCK) {
+      const int c = e / TS, f = e % TS;
+      sx[c][f] = (c0 + c < m && f0 + f < d) ? X[(int64_t)(c0 + c) * d + f0 + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      float p[4], x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[q] = sp[c][ty * 4 + q], x[q] = sx[c][tx * 4 + q];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][q] = __builtin_fmaf(p[a], x[q], acc[a][q]);
+    }
+    __syncthreads();
+  }
+  float* Gs = G + ((int64_t)side * 2 * B + base) * d;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + ty * 4 + a;
+      const int64_t f = f0 + tx * 4 + q;
+      if (r < m && f < d) {
+        const float self = (side == 0 ? Bm : A)[(int64_t)r * d + f];  // b_i for Ga, a_k for Gb
+        Gs[(int64_t)r * d + f] = side == 0 ? ww[r] * (self - it[r] * acc[a][q]) : ww[r] * self - acc[a][q];
+      }
+    }
+}
+
+// ---- back through normalize() and out to the views' gradient rows.  One wave per (compact row, view).
+__global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restrict__ An, const float* __restrict__ den,
+                                                          const float* __restrict__ G, int64_t d, int64_t B,
+                                                          const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ counts, float* __restrict__ g1,
+                                                          float* __restrict__ g2) {
+  const int lane = threadIdx.x % WAVE;
+  const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int v = blockIdx.y;
+  if (r >= counts[0] + counts[1]) return;
+  float* out = v == 0 ? g1 : g2;
+  if (!out) return;
+  const float* y = An + ((int64_t)v * 2 * B + r) * d;
+  const float* g = G + ((int64_t)v * 2 * B + r) * d;
+  const float nrm = den[(int64_t)v * 2 * B + r];
+  float dot = 0.f;
+  for (int64_t f = lane; f < d; f += WAVE) dot += g[f] * y[f];
+  dot = wave_sum(dot);
+  float* o = out + (int64_t)idx[r] * d;
+  // ||x|| <= eps: normalize() divided by the constant eps, so the Jacobian is 1/eps (no projection)
+  const bool clamped = nrm <= 1e-12f;
+  for (int64_t f = lane; f < d; f += WAVE) o[f] = clamped ? g[f] / nrm : (g[f] - dot * y[f]) / nrm;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d) {
+  if (n <= 0 || B <= 0 || d <= 0) return 0;
+  return ssl_layout(nullptr, n, B, d).bytes;
+}
+
+int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
+                         const int64_t* items, int64_t B, int64_t num_users, float temperature, float* loss, float* g1,
+                         float* g2, void* ws, void* stream) {
+  IDG_REQUIRE(view1 && view2 && users && items && loss && ws, "idg_infonce_pair_f32: NULL argument");
+  IDG_REQUIRE(n > 0 && d > 0 && B > 0 && num_users >= 0 && num_users <= n, "idg_infonce_pair_f32: bad sizes");
+  IDG_REQUIRE(B <= 46340, "idg_infonce_pair_f32: batch of %lld ids is too large for the in-batch logits matrix", (long long)B);
+  IDG_REQUIRE(temperature > 0.f, "idg_infonce_pair_f32: temperature must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const SslWs w = ssl_layout(ws, n, B, d);
+  IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)((n + 31) / 32) * 4, st));
+  // rows of the batch's users and (positive) items; the third id list is not used here: pass the items twice
+  int rc = idg_bpr_touch_rows(users, items, items, B, num_users, w.bitmap, stream);
+  if (rc != IDG_OK) return rc;
+  hipLaunchKernelGGL(ssl_compact_kernel, dim3(1), dim3(1024), 0, st, w.bitmap, n, num_users, w.idx, w.counts, 2 * B);
+  const unsigned row_blocks = (unsigned)((2 * B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  hipLaunchKernelGGL(ssl_normalize_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, view1, view2, d, w.idx, w.counts, B,
+                     w.An, w.den);
+  const unsigned tb = (unsigned)((B + TS - 1) / TS);
+  const float inv_t = 1.0f / temperature;
+  hipLaunchKernelGGL(ssl_logits_kernel, dim3(tb, tb, 2), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
+  hipLaunchKernelGGL(ssl_rowstat_kernel, dim3((unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE)), 2), dim3(BLOCK), 0, st,
+                     w.P, B, w.counts, inv_t, 10e-6f, w.invttl, w.w, w.lossrow);
+  hipLaunchKernelGGL(ssl_loss_kernel, dim3(2), dim3(BLOCK), 0, st, w.lossrow, w.counts, loss);
+  if (g1 || g2) {
+    hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS), tb, 4), dim3(BLOCK), 0, st, w.An, w.P, d, B,
+                       w.counts, w.invttl, w.w, w.G);
+    hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, d, B, w.idx, w.counts,
+                       g1, g2);
+  }
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+}  // extern "C"

@@ -451,6 +451,55 @@ def bpr_fwd_bwd_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lamb
     return loss
 
 
+# ----------------------------------------------------------------------------------- InfoNCE
+_ssl_ws = {}
+
+
+def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None, g2=None, loss=None):
+    """idg_infonce_pair_f32: loss[2] = InfoNCE over unique(users) rows and over num_users + unique(items) rows of
+    the two [n, d] view panels; g1 / g2 (optional, pre-zeroed) receive d(loss[0] + loss[1]) / d view rows."""
+    _require_device(view1, view2, users, items, g1, g2, loss)
+    view1, view2 = _f32c(view1, "view1"), _f32c(view2, "view2")
+    users, items = _i64c(users, "users"), _i64c(items, "items")
+    n, d = view1.shape
+    B = users.shape[0]
+    if view2.shape != view1.shape or items.shape[0] != B:
+        raise ValueError("infonce_pair_raw: view panels / id lists of different shapes")
+    key = (n, B, d, view1.device)
+    ws = _ssl_ws.get(key)
+    if ws is None:
+        ws = _ssl_ws[key] = torch.empty(int(lib.idg_infonce_workspace_bytes(n, B, d)), dtype=torch.uint8, device=view1.device)
+    if loss is None:
+        loss = torch.empty(2, dtype=torch.float32, device=view1.device)
+    check(lib.idg_infonce_pair_f32(_ptr(view1), _ptr(view2), n, d, _ptr(users), _ptr(items), B, int(num_users),
+                                   float(temperature), _ptr(loss), _ptr(g1), _ptr(g2), _ptr(ws), _stream()),
+          "idg_infonce_pair_f32")
+    return loss
+
+
+class _InfoNCEPair(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, view1, view2, users, items, num_users, temperature):
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g1 = torch.zeros_like(view1, memory_format=torch.contiguous_format) if need1 else None
+        g2 = torch.zeros_like(view2, memory_format=torch.contiguous_format) if need2 else None
+        loss = infonce_pair_raw(view1.detach(), view2.detach(), users, items, num_users, temperature, g1, g2)
+        ctx.saved = (g1, g2)
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g1, g2 = ctx.saved
+        return (None if g1 is None else g1.mul_(grad_out), None if g2 is None else g2.mul_(grad_out), None, None, None, None)
+
+
+def infonce_pair(view1, view2, users, items, num_users, temperature):
+    """get_InfoNCE_loss(view1[U-rows of unique(users)], view2[...]) + get_InfoNCE_loss(... unique(items) rows ...)
+    — the self-supervised term of SimGCL / XSimGCL / SGL (models/SimGCL.py:79-84) — as one differentiable
+    operator on the two [n, d] view panels (users first)."""
+    return _InfoNCEPair.apply(view1, view2, users, items, num_users, temperature)
+
+
 # ----------------------------------------------------------------------------------- Adam
 def adam_step_raw(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     _require_device(param, grad, exp_avg, exp_avg_sq)

@@ -263,6 +263,24 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
                          void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * DEVICE: in-batch InfoNCE between two views, forward + backward
+ * (utility/utility_function/losses.py:24-35 get_InfoNCE_loss; call sites models/SimGCL.py:79-84,
+ *  XSimGCL.py:80-86, SGL.py:96-101: once over unique(batch users), once over unique(batch positive
+ *  items), rows gathered from the two [n, d] view panels, users first):
+ *     a = normalize(view1[idx]), b = normalize(view2[idx])      (x / max(||x||, 1e-12))
+ *     loss = mean_i -log( exp(<a_i,b_i>/t) / sum_k exp(<a_i,b_k>/t) + 1e-5 )
+ * loss[0] = the user-set loss, loss[1] = the item-set loss (rows num_users + item id).
+ * g1 / g2 (nullable): d(loss[0] + loss[1]) / d view1 / d view2 — the rows of the two sets are
+ * STORED, every other row is left untouched (zero-fill the panels first if you need dense
+ * gradients).  The unique id lists never visit the host: launches are shaped by B.
+ * ---------------------------------------------------------------------------------- */
+size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d);
+int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d,
+                         const int64_t* users, const int64_t* items, int64_t B, int64_t num_users,
+                         float temperature, float* loss, float* g1, float* g2, void* ws,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------
  * DEVICE: dense Adam step  (torch.optim.Adam defaults, utility/utility_train/trainer.py:11,56:
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  step is 1-based.  The
  * hyper-parameters are doubles because torch forms lr/(1-beta1^t) and sqrt(1-beta2^t) in

@@ -400,6 +400,52 @@ def test_train_step_adam_in_epilogue_is_bit_identical(ops, K, inc, d, fix, monke
     assert not torch.equal(out[0][0].cpu(), torch.from_numpy(W0))
 
 
+# --------------------------------------------------------------------------- InfoNCE
+@pytest.mark.parametrize("d,B,tau", [(64, 300, 0.2), (100, 77, 0.15), (256, 1024, 0.2), (32, 2048, 0.5)])
+def test_infonce_pair_vs_reference_formula(ops, d, B, tau):
+    """Loss and both gradients of the fused operator against the reference's op sequence
+    (unique -> gather -> normalize -> matmul -> exp/sum/log, losses.py:24-35) under torch autograd."""
+    import utility.utility_function.losses as losses
+
+    rng = np.random.default_rng(d + B)
+    U, I = 700, 500
+    v1 = torch.tensor(rng.standard_normal((U + I, d)).astype(np.float32), device="cuda", requires_grad=True)
+    v2 = torch.tensor((rng.standard_normal((U + I, d)) * 0.5 + 0.3).astype(np.float32), device="cuda", requires_grad=True)
+    users = dev(rng.integers(0, U, B))
+    items = dev(rng.zipf(1.5, B) % I)
+    ui, ii = torch.unique(users), torch.unique(items)
+    ref_u = losses.get_InfoNCE_loss(v1[:U][ui], v2[:U][ui], tau)
+    ref_i = losses.get_InfoNCE_loss(v1[U:][ii], v2[U:][ii], tau)
+    (ref_u + ref_i).backward()
+    r1, r2 = v1.grad.clone(), v2.grad.clone()
+    v1.grad = v2.grad = None
+    two = ops.infonce_pair_raw(v1.detach(), v2.detach(), users, items, U, tau)
+    np.testing.assert_allclose(two.cpu().numpy(), [ref_u.item(), ref_i.item()], rtol=2e-5)
+    out = ops.infonce_pair(v1, v2, users, items, U, tau)
+    np.testing.assert_allclose(out.item(), (ref_u + ref_i).item(), rtol=2e-5)
+    (3.0 * out).backward()
+    for mine, ref in ((v1.grad, r1), (v2.grad, r2)):
+        scale = ref.abs().max().item()
+        np.testing.assert_allclose(mine.cpu().numpy() / 3.0, ref.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale)
+        assert (mine[ref == 0] == 0).all()  # rows outside the two sets carry no gradient
+    # run-to-run identical bits (no atomics anywhere)
+    again = ops.infonce_pair_raw(v1.detach(), v2.detach(), users, items, U, tau)
+    assert torch.equal(two, again)
+
+
+def test_infonce_reference_golden_and_zero_rows(ops, golden_misc):
+    g = golden_misc
+    a, b = g["infonce_a"], g["infonce_b"]
+    m, d = a.shape
+    pad = np.zeros((3, d), dtype=np.float32)
+    v1, v2 = dev(np.concatenate([a, pad])), dev(np.concatenate([b, pad]))
+    users = dev(np.arange(m))
+    items = dev(np.zeros(m, dtype=np.int64))  # one item row, all zeros: normalize() clamps, loss = -log(1 + 1e-5)
+    loss = ops.infonce_pair_raw(v1, v2, users, items, m, 0.2).cpu().numpy()
+    np.testing.assert_allclose(loss[0], g["infonce_02"], rtol=1e-5)
+    np.testing.assert_allclose(loss[1], -np.log(1.0 + 1e-5), rtol=1e-3, atol=1e-7)
+
+
 # --------------------------------------------------------------------------- scoring/top-K
 @pytest.mark.parametrize("gname", ["tiny", "small"])
 def test_rating_matrix_vs_reference(ops, gname, golden_tiny, golden_small):
