@@ -29,7 +29,8 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
 constexpr int TS = 64;  // tile edge of the logits / gradient GEMMs
-constexpr int KC = 16;  // reduction chunk staged in LDS
+constexpr int KC = 16;  // reduction chunk staged in LDS (logits)
+constexpr int GS = 8;   // split-K slices of the gradient products
 
 struct SslWs {
   uint32_t* bitmap;  // [(n+31)/32]
@@ -41,7 +42,7 @@ struct SslWs {
   float* invttl;     // [2B]
   float* w;          // [2B]
   float* lossrow;    // [2B]
-  float* G;          // [2 views][2B][d]  dL/d(normalised row)
+  float* G;          // [2 sides][GS slices][2B][d]  split-K partial sums of the two gradient products
   size_t bytes;
 };
 
@@ -65,7 +66,7 @@ SslWs ssl_layout(void* base, int64_t n, int64_t B, int64_t d) {
   w.invttl = reinterpret_cast<float*>(take((size_t)2 * B * 4));
   w.w = reinterpret_cast<float*>(take((size_t)2 * B * 4));
   w.lossrow = reinterpret_cast<float*>(take((size_t)2 * B * 4));
-  w.G = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
+  w.G = reinterpret_cast<float*>(take((size_t)2 * GS * 2 * B * d * 4));
   w.bytes = off;
   return w;
 }
@@ -228,19 +229,23 @@ __global__ __launch_bounds__(BLOCK) void ssl_loss_kernel(const float* __restrict
   if (threadIdx.x == 0) loss[set] = s[0] / (float)m;
 }
 
-// ---- gradients with respect to the normalised rows.  blockIdx.z = set * 2 + side
-//   side 0: Ga[i,:] = w_i (b_i - invttl_i sum_k P_ik b_k)          (tile: 64 rows i x 64 features)
-//   side 1: Gb[k,:] = w_k a_k - sum_i (w_i invttl_i) P_ik a_i      (tile: 64 rows k x 64 features)
+// ---- gradients with respect to the normalised rows: the two products  sum_k P_ik b_k  (side 0, rows i) and
+//   sum_i (w_i invttl_i) P_ik a_i  (side 1, rows k), [m x m] . [m x d] each.  With m ~ 10^3 and d = 64 these are
+//   small GEMMs with a long reduction: the reduction index is cut into GS slices (split-K) so that ~10^3
+//   workgroups run at once; every block owns a 64-row x 64-feature tile of one slice and writes its raw sums
+//   to Gp[side][slice][row][d].  ssl_final_kernel adds the slices in slice order (deterministic).
+//   grid: (feature tiles * GS, row tiles, set * 2 + side)
 __global__ __launch_bounds__(BLOCK) void ssl_grad_kernel(const float* __restrict__ An, const float* __restrict__ P,
                                                          int64_t d, int64_t B, const int32_t* __restrict__ counts,
                                                          const float* __restrict__ invttl, const float* __restrict__ w,
-                                                         float* __restrict__ G) {
-  __shared__ float sp[KC][TS + 1];  // P chunk: [reduction index][output row]
-  __shared__ float sx[KC][TS + 1];  // the other view's rows: [reduction index][feature]
+                                                         float* __restrict__ Gp) {
+  __shared__ float sp[TS][TS + 1];                            // P chunk: [reduction index][output row]
+  __shared__ __attribute__((aligned(16))) float sx[TS][TS];   // the other view's rows: [reduction index][feature]
   const int set = blockIdx.z >> 1, side = blockIdx.z & 1;
   const int m = counts[set];
+  const int slice = blockIdx.x % GS;
+  const int64_t f0 = (int64_t)(blockIdx.x / GS) * TS;
   const int r0 = blockIdx.y * TS;
-  const int64_t f0 = (int64_t)blockIdx.x * TS;
   if (r0 >= m) return;
   const int64_t base = set == 0 ? 0 : counts[0];
   const float* A = An + base * d;
@@ -249,51 +254,58 @@ __global__ __launch_bounds__(BLOCK) void ssl_grad_kernel(const float* __restrict
   const float* Ps = P + (int64_t)set * B * B;
   const float* it = invttl + base;
   const float* ww = w + base;
+  const int per = ((m + GS - 1) / GS + TS - 1) / TS * TS;  // reduction indices per slice
+  const int c_lo = slice * per, c_hi = c_lo + per < m ? c_lo + per : m;
   const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
   float acc[4][4] = {};
-  for (int c0 = 0; c0 < m; c0 += KC) {
-    for (int e = tid; e < TS * KC; e += BLOCK) {
-      // P element (output row r0+row, reduction index c0+c): side 0 reads P[row][c], side 1 reads P[c][row] * w_c invttl_c
-      const int row = side == 0 ? e / KC : e % TS, c = side == 0 ? e % KC : e / TS;
+  for (int c0 = c_lo; c0 < c_hi; c0 += TS) {
+    for (int e = tid; e < TS * TS; e += BLOCK) {
+      // P element (output row r0+row, reduction index c0+c): side 0 reads P[row][c] (contiguous in c),
+      // side 1 reads P[c][row] * w_c invttl_c (contiguous in row)
+      const int row = side == 0 ? e / TS : e % TS, c = side == 0 ? e % TS : e / TS;
       float v = 0.f;
-      if (r0 + row < m && c0 + c < m)
+      if (r0 + row < m && c0 + c < c_hi)
         v = side == 0 ? Ps[(int64_t)(r0 + row) * B + c0 + c] : Ps[(int64_t)(c0 + c) * B + r0 + row] * (ww[c0 + c] * it[c0 + c]);
       sp[c][row] = v;
     }
-    for (int e = tid; e < TS * KC; e += BLOCK) {
+    for (int e = tid; e < TS * TS; e += BLOCK) {
       const int c = e / TS, f = e % TS;
-      sx[c][f] = (c0 + c < m && f0 + f < d) ? X[(int64_t)(c0 + c) * d + f0 + f] : 0.f;
+      sx[c][f] = (c0 + c < c_hi && f0 + f < d) ? X[(int64_t)(c0 + c) * d + f0 + f] : 0.f;
     }
     __syncthreads();
+#pragma unroll 8
+    for (int c = 0; c < TS; ++c) {
+      float p[4];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      float p[4], x[4];
+      for (int q = 0; q < 4; ++q) p[q] = sp[c][ty * 4 + q];
+      const float4 x = *reinterpret_cast<const float4*>(&sx[c][tx * 4]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) p[q] = sp[c][ty * 4 + q], x[q] = sx[c][tx * 4 + q];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[a][q] = __builtin_fmaf(p[a], x[q], acc[a][q]);
+      for (int a = 0; a < 4; ++a) {
+        acc[a][0] = __builtin_fmaf(p[a], x.x, acc[a][0]);
+        acc[a][1] = __builtin_fmaf(p[a], x.y, acc[a][1]);
+        acc[a][2] = __builtin_fmaf(p[a], x.z, acc[a][2]);
+        acc[a][3] = __builtin_fmaf(p[a], x.w, acc[a][3]);
+      }
     }
     __syncthreads();
   }
-  float* Gs = G + ((int64_t)side * 2 * B + base) * d;
+  float* out = Gp + (((int64_t)side * GS + slice) * 2 * B + base) * d;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a) {
+    const int r = r0 + ty * 4 + a;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int r = r0 + ty * 4 + a;
       const int64_t f = f0 + tx * 4 + q;
-      if (r < m && f < d) {
-        const float self = (side == 0 ? Bm : A)[(int64_t)r * d + f];  // b_i for Ga, a_k for Gb
-        Gs[(int64_t)r * d + f] = side == 0 ? ww[r] * (self - it[r] * acc[a][q]) : ww[r] * self - acc[a][q];
-      }
+      if (r < m && f < d) out[(int64_t)r * d + f] = acc[a][q];
     }
+  }
 }
 
-// ---- back through normalize() and out to the views' gradient rows.  One wave per (compact row, view).
+// ---- slices -> dL/d(normalised row) -> back through normalize() -> the views' gradient rows.
+//   One wave per (compact row, view): view 1 rows take side 0 (Ga), view 2 rows side 1 (Gb).
 __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restrict__ An, const float* __restrict__ den,
-                                                          const float* __restrict__ G, int64_t d, int64_t B,
+                                                          const float* __restrict__ Gp, const float* __restrict__ invttl,
+                                                          const float* __restrict__ w, int64_t d, int64_t B,
                                                           const int32_t* __restrict__ idx,
                                                           const int32_t* __restrict__ counts, float* __restrict__ g1,
                                                           float* __restrict__ g2) {
@@ -303,16 +315,26 @@ __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restric
   if (r >= counts[0] + counts[1]) return;
   float* out = v == 0 ? g1 : g2;
   if (!out) return;
-  const float* y = An + ((int64_t)v * 2 * B + r) * d;
-  const float* g = G + ((int64_t)v * 2 * B + r) * d;
+  const float* y = An + ((int64_t)v * 2 * B + r) * d;            // this view's normalised row
+  const float* other = An + ((int64_t)(1 - v) * 2 * B + r) * d;  // b_i for view 1, a_k for view 2
   const float nrm = den[(int64_t)v * 2 * B + r];
-  float dot = 0.f;
-  for (int64_t f = lane; f < d; f += WAVE) dot += g[f] * y[f];
-  dot = wave_sum(dot);
+  const float wr = w[r], itr = invttl[r];
   float* o = out + (int64_t)idx[r] * d;
-  // ||x|| <= eps: normalize() divided by the constant eps, so the Jacobian is 1/eps (no projection)
-  const bool clamped = nrm <= 1e-12f;
-  for (int64_t f = lane; f < d; f += WAVE) o[f] = clamped ? g[f] / nrm : (g[f] - dot * y[f]) / nrm;
+  const bool clamped = nrm <= 1e-12f;  // normalize() divided by the constant eps: Jacobian 1/eps, no projection
+  // d is walked in rounds of 64 features; the projection needs <g, y> over the whole row first
+  float dot = 0.f;
+  for (int64_t f = lane; f < d; f += WAVE) {
+    float acc = 0.f;
+    for (int sl = 0; sl < GS; ++sl) acc += Gp[(((int64_t)v * GS + sl) * 2 * B + r) * d + f];
+    const float g = v == 0 ? wr * (other[f] - itr * acc) : wr * other[f] - acc;
+    dot += g * y[f];
+    o[f] = g;  // parked in the output row until the projection below
+  }
+  dot = wave_sum(dot);
+  for (int64_t f = lane; f < d; f += WAVE) {
+    const float g = o[f];
+    o[f] = clamped ? g / nrm : (g - dot * y[f]) / nrm;
+  }
 }
 
 }  // namespace
@@ -348,10 +370,10 @@ int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int6
                      w.P, B, w.counts, inv_t, 10e-6f, w.invttl, w.w, w.lossrow);
   hipLaunchKernelGGL(ssl_loss_kernel, dim3(2), dim3(BLOCK), 0, st, w.lossrow, w.counts, loss);
   if (g1 || g2) {
-    hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS), tb, 4), dim3(BLOCK), 0, st, w.An, w.P, d, B,
+    hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 4), dim3(BLOCK), 0, st, w.An, w.P, d, B,
                        w.counts, w.invttl, w.w, w.G);
-    hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, d, B, w.idx, w.counts,
-                       g1, g2);
+    hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w, d, B,
+                       w.idx, w.counts, g1, g2);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
