@@ -190,6 +190,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i, timed=True)
+    t_issue = time.perf_counter() - t0  # host time to issue the steps; < dt means the GPU, not the host, is the limit
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     events, eng.events = collected, None
@@ -206,6 +207,7 @@ def main():
                                % (args.workload, U, I, wl["E"], nnz, args.model, K, d, B),
                    "batch": B, "dim": d, "layers": K, "scatter": "atomic" if args.atomic else "deterministic"},
         "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[-1].sum().item())],
+        "host_issue_ms_per_step": t_issue / args.steps * 1e3,
     }
     if graph is not None:
         # Inside the timed region the forward propagation runs one C-ABI call per layer with a HIP event

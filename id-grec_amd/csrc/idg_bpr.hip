@@ -514,6 +514,12 @@ int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* 
   return IDG_OK;
 }
 
+int idg_bitmap_clear(uint32_t* bitmap, int64_t n_bits, void* stream) {
+  IDG_REQUIRE(bitmap && n_bits >= 0, "idg_bitmap_clear: bad argument");
+  IDG_HIP(hipMemsetAsync(bitmap, 0, (size_t)((n_bits + 31) / 32) * sizeof(uint32_t), (hipStream_t)stream));
+  return IDG_OK;
+}
+
 int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
                      int64_t n, void* ws, void* stream) {
   return bpr_sort_plan(users, pos, neg, B, num_users, n, ws, (hipStream_t)stream, "idg_bpr_plan_f32");

@@ -1263,8 +1263,9 @@ int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int6
 
 int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, const float* addend,
                     const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
-                    const uint32_t* out_rows, int64_t d, void* ws, void* stream) {
+                    const uint32_t* out_rows, const uint32_t* x_rows, int64_t d, void* ws, void* stream) {
   IDG_REQUIRE(g && X && (Y || sum_out), "idg_spmm_ex_f32: NULL argument");
+  IDG_REQUIRE(!(out_rows && x_rows), "idg_spmm_ex_f32: out_rows and x_rows cannot be combined");
   IDG_REQUIRE(d > 0 && ldx >= d && ldy >= d, "idg_spmm_ex_f32: bad d/ldx/ldy (%lld,%lld,%lld)", (long long)d,
               (long long)ldx, (long long)ldy);
   IDG_REQUIRE(div != 0.0f, "idg_spmm_ex_f32: div must be non-zero");
@@ -1276,7 +1277,7 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
   ep.ldy = ldy;
   ep.div = div;
   ep.accumulate = accumulate;
-  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, nullptr, out_rows);
+  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, x_rows, out_rows);
 }
 
 int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t d, float eps,

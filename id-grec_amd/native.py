@@ -44,7 +44,7 @@ PROTOTYPES = {
     "idg_spmm_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
     "idg_spmm_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, c_vp]),
     "idg_spmm_ex_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_float, C.c_int,
-                                  c_vp, C.c_int64, c_vp, c_vp]),
+                                  c_vp, c_vp, C.c_int64, c_vp, c_vp]),
     "idg_lincomb_f32": (C.c_int, [c_vp, c_vp, C.c_float, c_vp, C.c_float, C.c_int64, c_vp]),
     "idg_spmm_noise_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_uint64, C.c_uint64,
                                      c_vp, c_vp]),
@@ -64,6 +64,7 @@ PROTOTYPES = {
     "idg_bpr_fused_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                     C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "idg_bpr_touch_rows": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
+    "idg_bitmap_clear": (C.c_int, [c_vp, C.c_int64, c_vp]),
     "idg_bpr_plan_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_bpr_forward_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                       C.c_float, c_vp, c_vp, c_vp]),

@@ -18,8 +18,16 @@ from . import native
 from .native import check, lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (~8 us): with ~40 launches per sharded step that alone made the host
+    the bottleneck, so the raw accessor is used when this torch has it."""
+    if _raw_stream is not None:
+        return _raw_stream(torch._C._cuda_getDevice())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _require_device(*tensors):
@@ -43,7 +51,7 @@ def _i64c(t, name):
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None  # ctypes converts int / None for void* parameters
 
 
 class Graph:
@@ -190,16 +198,18 @@ class Graph:
         return out
 
 
-def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False, out_rows=None):
-    """idg_spmm_ex_f32: t = A.X (+ addend); Y = t; sum_out (+)= (sum_in + t) / div.  All [*, d] contiguous."""
-    _require_device(X, Y, addend, sum_in, sum_out, out_rows)
+def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False, out_rows=None,
+                x_rows=None):
+    """idg_spmm_ex_f32: t = A.X (+ addend); Y = t; sum_out (+)= (sum_in + t) / div.  All [*, d] contiguous.
+    out_rows / x_rows: optional int32 bitmaps of the output rows wanted / of the non-zero rows of X."""
+    _require_device(X, Y, addend, sum_in, sum_out, out_rows, x_rows)
     d = X.shape[1]
     for t in (X, Y, addend, sum_in, sum_out):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != d):
             raise TypeError("spmm_ex_raw needs contiguous float32 [*, %d] panels" % d)
     ws = graph._workspace("spmm", d)
     check(lib.idg_spmm_ex_f32(graph._h, _ptr(X), d, _ptr(Y), _ptr(addend), _ptr(sum_in), _ptr(sum_out), d, float(div),
-                              int(bool(accumulate)), _ptr(out_rows), d, _ptr(ws), _stream()), "idg_spmm_ex_f32")
+                              int(bool(accumulate)), _ptr(out_rows), _ptr(x_rows), d, _ptr(ws), _stream()), "idg_spmm_ex_f32")
 
 
 def lincomb_raw(out, x, a, y=None, b=0.0):
@@ -400,22 +410,26 @@ class _BprLossSame(torch.autograd.Function):
         return g[0], None, None, None, None, None, None
 
 
-def bpr_touch_rows_raw(users, pos, neg, num_users, bitmap):
-    """Set the bits of the panel rows this batch touches (idg_bpr_touch_rows); bitmap: zeroed int32 [ceil(n/32)]."""
+def bpr_touch_rows_raw(users, pos, neg, num_users, bitmap, stream=None, clear_bits=0):
+    """Set the bits of the panel rows this batch touches (idg_bpr_touch_rows); bitmap: int32 [ceil(n/32)], zeroed
+    by the caller or here when clear_bits = n.  stream: raw handle of the stream to launch on (default: current)."""
     _require_device(users, pos, neg, bitmap)
-    check(lib.idg_bpr_touch_rows(_ptr(users), _ptr(pos), _ptr(neg), users.shape[0], int(num_users), _ptr(bitmap),
-                                 _stream()), "idg_bpr_touch_rows")
+    st = _stream() if stream is None else stream
+    if clear_bits:
+        check(lib.idg_bitmap_clear(_ptr(bitmap), int(clear_bits), st), "idg_bitmap_clear")
+    check(lib.idg_bpr_touch_rows(_ptr(users), _ptr(pos), _ptr(neg), users.shape[0], int(num_users), _ptr(bitmap), st),
+          "idg_bpr_touch_rows")
 
 
-def bpr_plan_raw(users, pos, neg, num_users, n, d, ws=None):
+def bpr_plan_raw(users, pos, neg, num_users, n, d, ws=None, stream=None):
     """Sort this batch's (row, slot) pairs into the BPR workspace (idg_bpr_plan_f32) on the CURRENT
     stream.  Index-only work: run it on a side stream while the propagation is in flight, then call
     bpr_fused_raw(..., deterministic=2)."""
     _require_device(users, pos, neg)
     B = users.shape[0]
     ws = _bpr_ws(B, d, users.device) if ws is None else ws
-    check(lib.idg_bpr_plan_f32(_ptr(users), _ptr(pos), _ptr(neg), B, int(num_users), int(n), _ptr(ws), _stream()),
-          "idg_bpr_plan_f32")
+    check(lib.idg_bpr_plan_f32(_ptr(users), _ptr(pos), _ptr(neg), B, int(num_users), int(n), _ptr(ws),
+                               _stream() if stream is None else stream), "idg_bpr_plan_f32")
 
 
 def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, g_final, g_ego, loss=None,
@@ -436,17 +450,21 @@ def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda
 
 
 def bpr_fwd_bwd_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, upstream, g_final, g_ego, loss,
-                    deterministic=True):
+                    deterministic=True, ws=None):
     """Forward then backward with the two upstream gradient scalars read from the DEVICE tensor
-    `upstream` (the sharded path scales a rank's share of the global batch this way)."""
+    `upstream` (the sharded path scales a rank's share of the global batch this way).
+    deterministic=2 with `ws` from bpr_plan_raw: the sorted scatter plan is already in the workspace."""
     _require_device(final_panel, ego_panel, users, pos, neg, upstream, g_final, g_ego, loss)
     n, d = final_panel.shape
     B = users.shape[0]
-    ws = _bpr_ws(B, d, final_panel.device)
+    if ws is None:
+        if int(deterministic) == 2:
+            raise ValueError("deterministic=2 (planned scatter) needs the workspace bpr_plan_raw filled")
+        ws = _bpr_ws(B, d, final_panel.device)
     args = (_ptr(final_panel), _ptr(ego_panel), int(num_users), n, _ptr(users), _ptr(pos), _ptr(neg), B, d,
             float(reg_lambda))
     check(lib.idg_bpr_forward_f32(*args, _ptr(loss), _ptr(ws), _stream()), "idg_bpr_forward_f32")
-    check(lib.idg_bpr_backward_f32(*args, _ptr(upstream), _ptr(g_final), _ptr(g_ego), int(bool(deterministic)), None,
+    check(lib.idg_bpr_backward_f32(*args, _ptr(upstream), _ptr(g_final), _ptr(g_ego), int(deterministic), None,
                                    _ptr(ws), _stream()), "idg_bpr_backward_f32")
     return loss
 

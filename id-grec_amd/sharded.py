@@ -73,8 +73,14 @@ class ShardedEngine:
     first ([0, U_g)), then ALL items ([U_g, U_g + I))."""
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
-                 reg_lambda=1e-4, lr=1e-3):
+                 reg_lambda=1e-4, lr=1e-3, batch_sparsity=True):
+        """batch_sparsity: use what a prepared batch (kernels.prepare) knows — the user side of the last forward
+        layer is produced for the batch's users only, the first backward product gathers its live rows only, the
+        gradient scatter follows a plan sorted ahead of time.  Exact; FIN's user rows outside the batch are then
+        stale, which no consumer reads."""
         self.k, self.comm = kernels, comm
+        self.batch_sparsity = bool(batch_sparsity)
+        self._prepared = {}
         self.Ug, self.I, self.d, self.K = int(n_local_users), int(num_items), int(dim), int(n_layers)
         self.c0 = 1 if include_layer0 else 0
         self.cnt = float(self.K + self.c0)
@@ -98,7 +104,7 @@ class ShardedEngine:
         return a[self.Ug:]
 
     # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
-    def propagate(self):
+    def propagate(self, prep=None):
         """Layer k: P_I(k) = R^T X_U(k-1) (local partial) -> all-reduce -> X_I(k);  X_U(k) = R X_I(k-1).
         P_I(k+1) needs only X_U(k), not X_I(k): it is launched BEFORE waiting for all-reduce k, so the
         collectives queue back to back on the communicator while the SpMMs keep the GPU busy."""
@@ -129,7 +135,8 @@ class ShardedEngine:
             else:
                 sum_in = fin_u if (c0 or layer > 2) else xu_prev
             xu_new = None if last else self.XU[layer & 1]
-            k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0)
+            k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0,
+                   out_rows=prep.bitmap if (last and prep is not None) else None)  # BPR reads the batch's users only
             pending = (work, xi_new, layer, xi_prev)
             xu_prev, xi_prev = xu_new, xi_new
         finish(pending)
@@ -137,7 +144,7 @@ class ShardedEngine:
 
     # ---- backward of the above given GF = d loss / d FIN (item rows still per-rank partials),
     #      accumulated onto G (which already holds the regulariser gradient, item rows partial)
-    def propagate_backward(self):
+    def propagate_backward(self, prep=None):
         """Horner steps h <- A.h + g, k = K..2, then gE0 = (A.h + c0.g)/cnt.  In block form
         (A.h)_U = R_g h_I (local), (A.h)_I = all-reduce(R_g^T h_U).  As in the forward pass the item-side
         partial of a step needs only the LOCAL h_U, so it is launched before waiting for the previous
@@ -155,9 +162,11 @@ class ShardedEngine:
                 k.lincomb(buf, buf, 1.0, g_i, 1.0)            # (A h)_I + g_I
             return buf
 
+        live = prep.bitmap if prep is not None else None      # h_U = g_U has the batch's users as its only live rows
         for layer in range(K, 1, -1):
             t_i = self.XI[layer % 3]
-            k.spmm(self.G_iu, h_u, Y=t_i)                     # partial of (A h)_I: needs h_U only
+            k.spmm(self.G_iu, h_u, Y=t_i, x_rows=live)        # partial of (A h)_I: needs h_U only
+            live = None
             h_i = finish(pending)                             # previous all-reduce (+ g_I) -> h_I
             work = self.comm.all_reduce_async(t_i)
             t_u = self.XU[layer & 1]
@@ -166,7 +175,7 @@ class ShardedEngine:
             h_u = t_u
         # last Horner step, scaled by 1/cnt; regulariser gradients ride along
         t_i = self.XI[1]  # 3-buffer rotation: never the buffer of the all-reduce still in flight (layer 2 -> XI[2])
-        k.spmm(self.G_iu, h_u, Y=t_i)
+        k.spmm(self.G_iu, h_u, Y=t_i, x_rows=live)            # (live only when K == 1: h_U is still g_U)
         h_i = finish(pending)
         k.lincomb(t_i, t_i, 1.0 / cnt, self._i(self.G), 1.0)  # partial/cnt + this rank's item reg grads
         work = self.comm.all_reduce_async(t_i)
@@ -180,23 +189,48 @@ class ShardedEngine:
         global_batch: total triples over all ranks this step (the mean's divisor)."""
         k = self.k
         B = len(users_local)
-        self.propagate()
+        prep = None
+        if self.batch_sparsity and B > 0:
+            prep = self._prepared.pop(_batch_key(users_local, pos, neg), None)
+            if prep is None:
+                prep = k.prepare(users_local, pos, neg, self.Ug, self.Ug + self.I, self.d)  # None for kernels without one
+            if prep is not None:
+                k.wait_rows(prep)
+        self.propagate(prep)
         k.fill(self.G, 0.0)
         k.fill(self.GF, 0.0)
         ratio = float(B) / float(global_batch)
         if B > 0:
             k.fill(self.upstream, ratio)
             k.bpr(self.FIN, self.P, self.Ug, users_local, pos, neg, self.reg_lambda, self.upstream, self.GF, self.G,
-                  self.loss)
+                  self.loss, prep)
             k.lincomb(self.loss, self.loss, ratio, None, 0.0)         # local mean -> share of the global mean
         else:
             k.fill(self.loss, 0.0)
         loss_work = self.comm.all_reduce_async(self.loss)
-        self.propagate_backward()
+        self.propagate_backward(prep)
+        if prep is not None:
+            k.release(prep)
         self.comm.wait(loss_work)
         self.step_count += 1
         k.adam(self.P, self.G, self.M, self.V, self.lr, self.step_count)
         return self.loss
+
+
+    def prefetch(self, users_local, pos, neg):
+        """One-batch lookahead of the index-only work of the NEXT step (row bitmap + sorted scatter plan), on
+        the kernels' side stream while this step's products run."""
+        if self.batch_sparsity and len(users_local) > 0:
+            while len(self._prepared) >= 2:  # lookaheads nobody came for (a skipped batch)
+                self.k.release(self._prepared.pop(next(iter(self._prepared))))
+            prep = self.k.prepare(users_local, pos, neg, self.Ug, self.Ug + self.I, self.d)
+            if prep is not None:
+                self._prepared[_batch_key(users_local, pos, neg)] = prep
+
+
+def _batch_key(users, pos, neg):
+    ptr = (lambda t: t.data_ptr()) if hasattr(users, "data_ptr") else (lambda t: t.__array_interface__["data"][0])
+    return (ptr(users), ptr(pos), ptr(neg), len(users))
 
 
 # --------------------------------------------------------------------------- product bindings
@@ -211,6 +245,7 @@ class HipKernels:
         self.torch, self.ops = torch, ops
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.deterministic = deterministic
+        self._side, self._pool = None, []
 
     def zeros(self, shape):
         return self.torch.zeros(shape, dtype=self.torch.float32, device=self.device)
@@ -223,15 +258,64 @@ class HipKernels:
         return self.ops.Graph(indptr, indices, values, n_rows, n_cols, device=self.device, symmetric=False,
                               build_transpose=False)
 
-    def spmm(self, graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False):
-        self.ops.spmm_ex_raw(graph, X, Y, addend, sum_in, sum_out, div, accumulate)
+    def spmm(self, graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False, out_rows=None,
+             x_rows=None):
+        self.ops.spmm_ex_raw(graph, X, Y, addend, sum_in, sum_out, div, accumulate, out_rows=out_rows, x_rows=x_rows)
 
     def lincomb(self, out, x, a, y, b):
         self.ops.lincomb_raw(out, x, a, y, b)
 
-    def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss):
-        self.ops.bpr_fwd_bwd_raw(fin, ego, users, pos, neg, n_users, reg_lambda, upstream, g_final, g_ego, loss,
-                                 self.deterministic)
+    def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss, prep=None):
+        if prep is not None:  # the sorted (row, slot) plan is in the prepared workspace already
+            self.torch.cuda.current_stream().wait_event(prep.done)
+            self.ops.bpr_fwd_bwd_raw(fin, ego, users, pos, neg, n_users, reg_lambda, upstream, g_final, g_ego, loss,
+                                     deterministic=2, ws=prep.ws)
+        else:
+            self.ops.bpr_fwd_bwd_raw(fin, ego, users, pos, neg, n_users, reg_lambda, upstream, g_final, g_ego, loss,
+                                     self.deterministic)
+
+    class _Prepared:
+        __slots__ = ("bitmap", "ws", "rows_done", "done", "free", "B", "busy")
+
+    def prepare(self, users, pos, neg, n_users, n, d):
+        """Index-only work of a batch on a side stream: bitmap of the panel rows it touches, and the sorted
+        scatter plan.  Returns None when the scatter is not the deterministic one.  Host cost matters here (the
+        sharded step issues ~50 calls): raw stream handles and events allocated once, no stream context manager."""
+        if not self.deterministic:
+            return None
+        torch, ops = self.torch, self.ops
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._side_raw = self._side.cuda_stream
+            self._fork = torch.cuda.Event()
+        B = users.shape[0]
+        prep = next((p for p in self._pool if p.B == B and not p.busy), None)
+        if prep is None:
+            prep = self._Prepared()
+            prep.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=self.device)
+            prep.ws, prep.B = ops.bpr_workspace(B, d, self.device), B
+            prep.rows_done, prep.done, prep.free = torch.cuda.Event(), torch.cuda.Event(), None
+            self._pool.append(prep)
+        prep.busy = True
+        main = torch.cuda.current_stream()
+        self._fork.record(main)              # the id tensors may have just been produced on the main stream,
+        self._side.wait_event(self._fork)    # and the step that last used these buffers is ordered before it
+        ops.bpr_touch_rows_raw(users, pos, neg, n_users, prep.bitmap, stream=self._side_raw, clear_bits=n)
+        prep.rows_done.record(self._side)
+        ops.bpr_plan_raw(users, pos, neg, n_users, n, d, ws=prep.ws, stream=self._side_raw)
+        prep.done.record(self._side)
+        return prep
+
+    def release(self, prep):
+        prep.busy = False  # reuse is ordered by the fork event of the next prepare()
+
+    def wait_rows(self, prep):
+        """The bitmap is first read by a product on the main stream."""
+        self.torch.cuda.current_stream().wait_event(prep.rows_done)
+
+    def release(self, prep):
+        prep.free = self.torch.cuda.current_stream().record_event()
+        self._pool.append(prep)
 
     def adam(self, p, g, m, v, lr, step):
         self.ops.adam_step_raw(p, g, m, v, lr, step)
@@ -245,6 +329,15 @@ class TorchComm:
     def __init__(self, dist):
         self.dist = dist
         self.backend = dist.get_backend()
+        # The sharded step issues 8 collectives; dist.all_reduce() spends ~25 us of host time per call in argument
+        # checks before it reaches the process group.  Call the group object directly when this torch exposes it.
+        self._pg = self._opts = None
+        try:
+            self._pg = dist.distributed_c10d._get_default_group()
+            self._opts = dist.AllreduceOptions()
+            self._opts.reduceOp = dist.ReduceOp.SUM
+        except Exception:  # noqa: BLE001 - private API: fall back to the public wrapper
+            self._pg = None
 
     def all_reduce_async(self, t):
         import torch
@@ -256,6 +349,8 @@ class TorchComm:
             self.dist.all_reduce(host)
             t.copy_(host)
             return None
+        if self._pg is not None and t.is_cuda:
+            return self._pg.allreduce([t], self._opts)
         return self.dist.all_reduce(t, async_op=True)
 
     def wait(self, work):
@@ -315,7 +410,12 @@ def run_sharded_bench(args, rank, world, dist):
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
     gB = B * world
 
+    last = args.warmup + args.steps - 1
+
     def step(i):
+        if i < last:
+            n = slice((i + 1) * B, (i + 2) * B)
+            eng.prefetch(tu[n], tp[n], tn[n])  # index-only work of the next batch, off the critical path
         s = slice(i * B, (i + 1) * B)
         return eng.train_step(tu[s], tp[s], tn[s], gB)
 
@@ -326,6 +426,7 @@ def run_sharded_bench(args, rank, world, dist):
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    t_enqueue = time.perf_counter() - t0  # host time to issue the steps (== wall time when the host is the bottleneck)
     torch.cuda.synchronize()
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
@@ -345,6 +446,7 @@ def run_sharded_bench(args, rank, world, dist):
                                       2 * args.layers + 1, I, args.dim),
                        "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "user-row shard x%d" % world},
             "loss_last": [float(x) for x in eng.loss.cpu()],
+            "host_issue_ms_per_step": t_enqueue / args.steps * 1e3,
         }
         print(json.dumps(out))
     dist.destroy_process_group()

@@ -157,7 +157,8 @@ int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int6
  * bitmap of the output rows to produce; the others are left untouched. */
 int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, const float* addend,
                     const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
-                    const uint32_t* out_rows, int64_t d, void* ws, void* stream);
+                    const uint32_t* out_rows, const uint32_t* x_rows, int64_t d, void* ws,
+                    void* stream);
 
 /* One perturbed layer (models/XSimGCL.py:51-54): Y = A.X;  Y += sign(Y) * normalize(u, dim=-1) * eps,
  * u ~ U[0,1)^d from Philox4x32-10(seed; stream_id, row, feature block).  d in {32,...,512}. */
@@ -249,6 +250,8 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
  * panel rows a batch touches.  bitmap: ceil(n/32) words, zeroed by the caller.  Index-only work. */
 int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                        int64_t num_users, uint32_t* bitmap, void* stream);
+/* Clear a row bitmap of n_bits bits ((n_bits + 31) / 32 words) on `stream`. */
+int idg_bitmap_clear(uint32_t* bitmap, int64_t n_bits, void* stream);
 #define IDG_BPR_PLANNED 2
 int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      int64_t num_users, int64_t n, void* ws, void* stream);

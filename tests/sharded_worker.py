@@ -29,7 +29,12 @@ class OracleKernels:
     def make_graph(self, indptr, indices, values, n_rows, n_cols):
         return (np.asarray(indptr), np.asarray(indices), np.asarray(values), n_rows, n_cols)
 
-    def spmm(self, graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False):
+    def prepare(self, users, pos, neg, n_users, n, d):
+        return None  # no batch lookahead in the checker-backed stub: every product is the dense one
+
+    def spmm(self, graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False, out_rows=None,
+             x_rows=None):
+        assert out_rows is None and x_rows is None
         t = self.o.spmm(graph[0], graph[1], graph[2], X)
         if addend is not None:
             t = t + addend
@@ -47,7 +52,7 @@ class OracleKernels:
             r = r + np.float32(b) * y
         out[...] = r
 
-    def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss):
+    def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss, prep=None):
         l, gf, ge = self.o.bpr(fin, ego, n_users, users, pos, neg, reg_lambda)
         loss[...] = l
         g_final += upstream[0] * gf
@@ -73,13 +78,14 @@ def run(rank, world, port, mode, path, steps):
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     ui, iu = sh.shard_adjacency(ip, ix, dv, U, I, lo, hi)
     if mode == "cpu":
-        kern, to_dev, to_np = OracleKernels(), (lambda a: a), (lambda a: a)
+        kern, to_dev, to_np = OracleKernels(), (lambda a: np.ascontiguousarray(a)), (lambda a: a)
     else:
         torch.cuda.set_device(0)
         kern = sh.HipKernels()
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         to_np = lambda a: a.cpu().numpy()  # noqa: E731
-    eng = sh.ShardedEngine(kern, sh.TorchComm(dist), ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3)
+    eng = sh.ShardedEngine(kern, sh.TorchComm(dist), ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
+                           batch_sparsity=(mode != "gpu-dense"))
     if mode == "cpu":
         eng.P[: hi - lo] = W0[lo:hi]
         eng.P[hi - lo:] = W0[U:]
@@ -87,13 +93,21 @@ def run(rank, world, port, mode, path, steps):
         eng.P[: hi - lo].copy_(to_dev(W0[lo:hi]))
         eng.P[hi - lo:].copy_(to_dev(W0[U:]))
     losses = []
-    for s in range(steps):
+    def batch(s):
         b = tri[s * B:(s + 1) * B]
         mine = b[(b[:, 0] >= lo) & (b[:, 0] < hi)]
-        loss = eng.train_step(to_dev(mine[:, 0] - lo), to_dev(mine[:, 1]), to_dev(mine[:, 2]), B)
+        return to_dev(mine[:, 0] - lo), to_dev(mine[:, 1]), to_dev(mine[:, 2]), mine
+
+    nxt = batch(0)
+    for s in range(steps):
+        cur, nxt = nxt, (batch(s + 1) if s + 1 < steps else None)
+        if nxt is not None and s % 2 == 0:  # every other step through the lookahead, the rest prepared in-step
+            eng.prefetch(*nxt[:3])
+        loss = eng.train_step(cur[0], cur[1], cur[2], B)
         losses.append(to_np(loss).copy())
+    touched = np.unique(cur[3][:, 0] - lo)  # local user rows of the LAST batch: the only FIN user rows guaranteed fresh
     np.savez(path + ".out%d.npz" % rank, P=to_np(eng.P), FIN=to_np(eng.FIN), G=to_np(eng.G), losses=np.stack(losses),
-             lo=lo, hi=hi)
+             lo=lo, hi=hi, fin_rows=touched)
     dist.barrier()
     dist.destroy_process_group()
 

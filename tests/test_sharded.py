@@ -56,13 +56,14 @@ def _launch(mode, path, steps, world=2):
     return [dict(np.load(path + ".out%d.npz" % r)) for r in range(world)]
 
 
-def _check(p, outs, steps, rtol, atol):
+def _check(p, outs, steps, rtol, atol, sparse=False):
     W, fin, grad, losses = _single_device_reference(p, steps)
     U = p["U"]
     for o in outs:
         lo, hi = int(o["lo"]), int(o["hi"])
         np.testing.assert_allclose(o["losses"], losses, rtol=rtol)                  # identical on every rank
-        np.testing.assert_allclose(o["FIN"][: hi - lo], fin[lo:hi], rtol=rtol, atol=atol)
+        rows = o["fin_rows"] if sparse else np.arange(hi - lo)   # batch sparsity: only the batch's users are produced
+        np.testing.assert_allclose(o["FIN"][: hi - lo][rows], fin[lo:hi][rows], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["FIN"][hi - lo:], fin[U:], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["G"][: hi - lo], grad[lo:hi], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["G"][hi - lo:], grad[U:], rtol=rtol, atol=atol)
@@ -119,10 +120,13 @@ def test_two_ranks_gloo_cpu_match_single_device(K, include0, tmp_path, golden_sm
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,include0", [(3, True), (2, False)])
-def test_two_ranks_hip_kernels_match_single_device(K, include0, tmp_path, golden_small):
-    p = _problem(golden_small, K, include0, B=160, steps=3)
+@pytest.mark.parametrize("mode", ["gpu", "gpu-dense"])
+@pytest.mark.parametrize("K,include0", [(3, True), (2, False), (1, True)])
+def test_two_ranks_hip_kernels_match_single_device(K, include0, mode, tmp_path, golden_small):
+    """mode "gpu": prepared batches (row-restricted last forward user product, sparse first backward product,
+    planned scatter, every other step through the one-batch lookahead); "gpu-dense": every product dense."""
+    p = _problem(golden_small, K, include0, B=160, steps=4)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
-    outs = _launch("gpu", path, 3)
-    _check(p, outs, 3, rtol=1e-4, atol=2e-7)
+    outs = _launch(mode, path, 4)
+    _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=(mode == "gpu"))
