@@ -41,6 +41,7 @@ class PropagationEngine:
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
         self._side = None   # side stream for index-only work
+        self._id_storage = None  # storages of the id tensors last ordered against the main stream
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
@@ -78,19 +79,26 @@ class PropagationEngine:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+            self._side_raw = self._side.cuda_stream  # raw handle: the launches below name their stream explicitly
+            self._fork = torch.cuda.Event()
         B = users.shape[0]
         if slot.ws is None or slot.ws_B != B:
             slot.ws, slot.ws_B = ops.bpr_workspace(B, self.d, self.device), B
+            slot.rows_done, slot.plan_done = torch.cuda.Event(), torch.cuda.Event()
         if slot.free is not None:
             self._side.wait_event(slot.free)   # the step that last used this slot has consumed it
-        else:
-            self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            slot.bitmap.zero_()
-            ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap)
-            slot.rows_done = self._side.record_event()       # needed by the last forward layer
-            ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws)
-            slot.plan_done = self._side.record_event()       # needed by the gradient scatter
+        # The side stream must not read the ids before the main stream has produced them.  Batches are slices of
+        # one epoch-long tensor: ordering after the main stream once per storage is enough (doing it per batch would
+        # also queue this batch's index work behind the previous step's kernels: measured +6 us/step).
+        src = (users.untyped_storage().data_ptr(), pos.untyped_storage().data_ptr(), neg.untyped_storage().data_ptr())
+        if slot.free is None or src != self._id_storage:
+            self._id_storage = src
+            self._fork.record(main)
+            self._side.wait_event(self._fork)
+        ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap, stream=self._side_raw, clear_bits=self.n)
+        slot.rows_done.record(self._side)      # needed by the last forward layer
+        ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
+        slot.plan_done.record(self._side)      # needed by the gradient scatter
         slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
 
     def _take_slot(self):
