@@ -574,17 +574,24 @@ def test_topk_ties_saturated_sigmoid_and_masked_fill(ops):
 @pytest.mark.parametrize("fused", ["0", "1"])
 def test_yelp_shape_full_size(ops, fused, monkeypatch):
     monkeypatch.setenv("IDG_FUSED_FIX", fused)
-    _yelp_shape_full_size(ops)
+    _shape_full_size(ops, "yelp2018")
 
 
-def _yelp_shape_full_size(ops):
-    """LightGCN-3 d=64 on the yelp2018-shaped graph (BASELINE.json configs[1]): exact-order
-    result bit-identical to the oracle over the whole panel; split schedule within fp32
-    rounding; linearity and symmetry (<y, A x> == <A y, x>) as size-independent checks."""
+def test_amazon_book_shape_full_size(ops):
+    """BASELINE.json configs[2] / [3] (52,643 x 91,599, 2.38 M edges)."""
+    _shape_full_size(ops, "amazon-book")
+
+
+def _shape_full_size(ops, shape):
+    """LightGCN-3 d=64 on a BASELINE-shaped graph: exact-order result bit-identical to the oracle over
+    the whole panel; split schedule bit-identical to the oracle in the published order and within fp32
+    rounding of the sequential one; symmetry (<y, A x> == <A y, x>) as a size-independent check; one
+    whole training step (propagate, BPR, backward, Adam) against the oracle's."""
     import idgrec_amd.host as H
     import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
 
-    U, I, E = S.SHAPES["yelp2018"]
+    U, I, E = S.SHAPES[shape]
     users, items = S.generate(U, I, E, seed=0)
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
     n = U + I
@@ -606,6 +613,27 @@ def _yelp_shape_full_size(ops):
     lhs = (Z.double() * Y.double()).sum().item()
     rhs = (G.spmm_raw(Z).double() * dev(X).double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    # one training step at full size: sampled triples (native sampler), loss, gradient, Adam
+    pos_ptr = np.zeros(U + 1, dtype=np.int64)
+    pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    tri = H.Rng(2024).sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
+    assert len(tri) == len(users) and np.array_equal(tri[:, 0], users) and np.array_equal(tri[:, 1], items)
+    item_sets = items.astype(np.int64) + users.astype(np.int64) * I  # (user, item) pairs as keys
+    assert not np.isin(tri[:, 0] * I + tri[:, 2], item_sets).any()   # a negative is never a train positive
+    b = tri[np.random.default_rng(1).permutation(len(tri))[:1024]]
+    eng = PropagationEngine(G, U, I, 64, 3, include_layer0=True, params=dev(X.copy()))
+    loss = eng.train_step(dev(b[:, 0]), dev(b[:, 1]), dev(b[:, 2])).cpu().numpy()
+    fin = oracle.propagate_mean(ip, ix, dv, X, 3, True, *sched)
+    loss_o, gf, ge = oracle.bpr(fin, X, U, b[:, 0], b[:, 1], b[:, 2], 1e-4)
+    np.testing.assert_allclose(loss, loss_o, rtol=1e-5)
+    grad_o = oracle.propagate_mean_bwd(ip, ix, dv, gf, 3, True) + ge
+    gscale = np.abs(grad_o).max()
+    np.testing.assert_allclose(eng.grad.cpu().numpy(), grad_o, rtol=RTOL, atol=1e-5 * gscale)
+    W, m, v = X.copy(), np.zeros_like(X), np.zeros_like(X)
+    oracle.adam(W, np.ascontiguousarray(grad_o), m, v, 1e-3, 1)
+    # Adam's first step is lr * sign-like: compare where the gradient is not at rounding level
+    big = np.abs(grad_o) > 1e-3 * gscale
+    np.testing.assert_allclose(eng.params.cpu().numpy()[big], W[big], rtol=1e-4, atol=1e-7)
 
 
 # ------------------------------------------------------------------------- noise epilogue
