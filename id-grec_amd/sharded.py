@@ -90,10 +90,14 @@ class ShardedEngine:
         n = self.Ug + self.I
         z = kernels.zeros
         self.P, self.G, self.M, self.V = z((n, dim)), z((n, dim)), z((n, dim)), z((n, dim))
-        self.FIN, self.GF = z((n, dim)), z((n, dim))
+        self.FIN = z((n, dim))
+        # d loss / d FIN, plus ONE extra row: its first two floats are this rank's share of the two losses, so the
+        # loss rides in the first backward all-reduce (item rows of GF) instead of needing a collective of its own
+        self._gf = z((n + 1, dim))
+        self.GF = self._gf[:n]
         self.XU = [z((self.Ug, dim)), z((self.Ug, dim))]
         self.XI = [z((self.I, dim)), z((self.I, dim)), z((self.I, dim))]
-        self.loss = z((2,))
+        self.loss = self._gf[n, :2]
         self.upstream = z((2,))
         self.step_count = 0
 
@@ -151,7 +155,7 @@ class ShardedEngine:
         all-reduce; the user-side product is what waits for it."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
         g_u, g_i = self._u(self.GF), self._i(self.GF)
-        first = self.comm.all_reduce_async(g_i)               # completes the item-side gradient g_I
+        first = self.comm.all_reduce_async(self._gf[self.Ug:])  # completes the item-side gradient g_I (+ the loss row)
         h_u = g_u
         pending = ("g", first, g_i)                           # h_I of the coming step, not yet usable
 
@@ -198,20 +202,16 @@ class ShardedEngine:
                 k.wait_rows(prep)
         self.propagate(prep)
         k.fill(self.G, 0.0)
-        k.fill(self.GF, 0.0)
+        k.fill(self._gf, 0.0)
         ratio = float(B) / float(global_batch)
         if B > 0:
             k.fill(self.upstream, ratio)
             k.bpr(self.FIN, self.P, self.Ug, users_local, pos, neg, self.reg_lambda, self.upstream, self.GF, self.G,
                   self.loss, prep)
             k.lincomb(self.loss, self.loss, ratio, None, 0.0)         # local mean -> share of the global mean
-        else:
-            k.fill(self.loss, 0.0)
-        loss_work = self.comm.all_reduce_async(self.loss)
-        self.propagate_backward(prep)
+        self.propagate_backward(prep)                          # its first all-reduce also sums the loss shares
         if prep is not None:
             k.release(prep)
-        self.comm.wait(loss_work)
         self.step_count += 1
         k.adam(self.P, self.G, self.M, self.V, self.lr, self.step_count)
         return self.loss
