@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--separate-adam", action="store_true",
                    help="Adam as its own kernel instead of the last backward epilogue (PMC calibration runs)")
     p.add_argument("--seed", type=int, default=2024)
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="torch.distributed backend of the sharded path: nccl (= RCCL over xGMI) for real runs; gloo only "
+                        "to rehearse the multi-rank code path with several ranks sharing one GPU (host-staged collectives)")
     p.add_argument("--force-sharded", action="store_true",
                    help="run the user-row-sharded path even at world size 1 (exercises the RCCL code path)")
     return p.parse_args()
@@ -135,13 +138,13 @@ def main():
                      % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path to time.")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if args.backend == "nccl" else local % torch.cuda.device_count())
     dist = None
     if world > 1 or args.force_sharded:
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.backend)
 
     import idgrec_amd.ops as ops
     import idgrec_amd.synth as S

@@ -429,7 +429,8 @@ def run_sharded_bench(args, rank, world, dist):
     t_enqueue = time.perf_counter() - t0  # host time to issue the steps (== wall time when the host is the bottleneck)
     torch.cuda.synchronize()
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                      device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     if rank == 0:
@@ -441,9 +442,10 @@ def run_sharded_bench(args, rank, world, dist):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d x %s-shape user blocks: %d users x %d items, %d train edges, nnz(A)=%d; "
                                    "LightGCN K=%d d=%d, B=%d per GPU (global %d); user rows sharded, item table "
-                                   "replicated, %d all-reduces of [%d,%d] fp32 per step over RCCL"
+                                   "replicated, %d all-reduces of [%d,%d] fp32 per step over %s"
                                    % (world, args.workload, U, I, len(users), nnz, args.layers, args.dim, B, gB,
-                                      2 * args.layers + 1, I, args.dim),
+                                      2 * args.layers + 1, I, args.dim,
+                                      "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
                        "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "user-row shard x%d" % world},
             "loss_last": [float(x) for x in eng.loss.cpu()],
             "host_issue_ms_per_step": t_enqueue / args.steps * 1e3,
