@@ -40,15 +40,23 @@ def universal_trainer(model, args, config, dataset, device, logger):
 
     best_results = {'count': 0, 'epoch': 0, 'recall': [0. for _ in top_k], 'ndcg': [0. for _ in top_k], 'stop': 0}
 
-    for epoch in range(int(config['training_epochs'])):
+    def draw_epoch():
+        """sample -> device -> shuffle, in the reference's order on NumPy's global stream (trainer.py:26-34)."""
+        sample_data = dataset.sample_data_to_train_all()
+        triples = torch.from_numpy(sample_data).to(device)  # int64 ids: no float32 round trip (trainer.py:27-29)
+        u, p, n = tools.shuffle(triples[:, 0], triples[:, 1], triples[:, 2])
+        return u.contiguous(), p.contiguous(), n.contiguous()
+
+    n_epochs, interval = int(config['training_epochs']), int(config['interval'])
+    on_gpu = torch.device(device).type == "cuda"
+    lookahead = None  # the next epoch's triples, drawn while the device was still working through this one
+    for epoch in range(n_epochs):
         print('-' * 100)
         start_time = time()
         model.train()
 
-        sample_data = dataset.sample_data_to_train_all()
-        triples = torch.from_numpy(sample_data).to(device)  # int64 ids: no float32 round trip (trainer.py:27-29)
-        users, pos_items, neg_items = tools.shuffle(triples[:, 0], triples[:, 1], triples[:, 2])
-        users, pos_items, neg_items = users.contiguous(), pos_items.contiguous(), neg_items.contiguous()
+        users, pos_items, neg_items = lookahead if lookahead is not None else draw_epoch()
+        lookahead = None
         num_batch = len(users) // batch_size + 1  # the reference's divisor, also when batch_size | E
 
         step_losses = None
@@ -78,6 +86,15 @@ def universal_trainer(model, args, config, dataset, device, logger):
             total_loss.backward()
             Optim.step()
 
+        # The steps above were only ISSUED: the device is still working through them.  Draw the next epoch's
+        # negatives now (host work, ~35 ms at yelp2018 size) instead of after the copy below has waited for the
+        # device.  Same draws in the same order — nothing else touches NumPy's stream in between; skipped when
+        # this epoch's test could end the run (the reference would then never have drawn them).
+        will_test = epoch % interval == 0
+        may_stop = will_test and best_results['count'] + 1 >= int(config['early_stopping'])
+        if on_gpu and epoch + 1 < n_epochs and not may_stop:
+            lookahead = draw_epoch()
+
         # one host copy per epoch; float64 accumulation in step order == summing loss.item() per step
         per_step = step_losses.double().cpu().numpy() if step_losses is not None else []
         total_loss_list = [0.] * (per_step.shape[1] if len(per_step) else 0)
@@ -91,7 +108,7 @@ def universal_trainer(model, args, config, dataset, device, logger):
         print("Training time: %.3f | training loss: %s" % (end_time - start_time, loss_strs))
         logger.info("Epoch: %4d | Training time: %.3f | training loss: %s" % (epoch + 1, end_time - start_time, loss_strs))
 
-        if epoch % int(config['interval']) == 0:
+        if will_test:
             result, best_results = batch_test.general_test(dataset, model, device, config, epoch, best_results)
             logger.info("Epoch: %4d | Test recall: %s | Test NDCG: %s" % (epoch + 1, result['recall'], result['ndcg']))
             if best_results['stop'] > 0:
