@@ -66,15 +66,17 @@ def _evaluate(dataset, model, device, config, users):
     batches = []
     with torch.no_grad():
         fused = _topk_for_users(dataset, model, device, users, max(topK)) if hasattr(model, "topk_for_test") and len(users) else None
+        hits = _hit_matrix(dataset, users, fused.numpy()) if fused is not None else None
         lo = 0
         for batch_users in mini_batch(users, batch_size=test_batch):
             truth = [dataset.test_dict[u] for u in batch_users]
             if fused is not None:
                 top = fused[lo:lo + len(batch_users)]
+                label = hits[lo:lo + len(batch_users)]
                 lo += len(batch_users)
             else:
-                top = _topk_for_users(dataset, model, device, batch_users, max(topK))
-            batches.append((top, truth))
+                top, label = _topk_for_users(dataset, model, device, batch_users, max(topK)), None
+            batches.append((top, truth, label))
     assert num_batch == len(batches)  # as the reference: breaks when test_batch_size divides #users
     for part in batches:
         res = test_one_batch(part, topK)
@@ -90,10 +92,24 @@ def Test(dataset: Data, model, device, config):
     return _evaluate(dataset, model, device, config, list(dataset.test_dict.keys()))
 
 
+def _hit_matrix(dataset, users, recommended):
+    """metrics.get_label for every user at once: r[i, j] = 1.0 iff recommended[i, j] is one of users[i]'s held-out
+    items — one sorted-key membership test over (user * num_items + item) instead of a Python loop over users."""
+    keys = getattr(dataset, "_test_pair_keys", None)
+    if keys is None:
+        n_items = int(dataset.num_items)
+        keys = np.sort(np.concatenate([np.asarray(list(items), dtype=np.int64) + np.int64(u) * n_items
+                                       for u, items in dataset.test_dict.items()] or [np.empty(0, dtype=np.int64)]))
+        dataset._test_pair_keys = keys
+    query = np.asarray(users, dtype=np.int64)[:, None] * np.int64(dataset.num_items) + np.asarray(recommended, dtype=np.int64)
+    return np.isin(query, keys).astype("float")
+
+
 def test_one_batch(X, topK):
+    """X = (recommended ids [B, max k], held-out item lists[, precomputed hit matrix])."""
     recommended = X[0].numpy()
     truth = X[1]
-    r = metrics.get_label(truth, recommended)
+    r = X[2] if len(X) > 2 and X[2] is not None else metrics.get_label(truth, recommended)
     out = {'recall': [], 'precision': [], 'ndcg': []}
     for k in topK:
         out['recall'].append(metrics.recall_at_k(r, k, truth))
