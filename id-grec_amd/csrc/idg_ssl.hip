@@ -124,6 +124,19 @@ __global__ __launch_bounds__(1024) void ssl_compact_kernel(const uint32_t* __res
   }
 }
 
+// ---- no de-duplication (SGL.py:85-86 indexes the views with the raw batch ids): the two lists as they are
+__global__ __launch_bounds__(BLOCK) void ssl_copy_ids_kernel(const int64_t* __restrict__ users,
+                                                             const int64_t* __restrict__ items, int64_t B,
+                                                             int64_t num_users, int32_t* __restrict__ idx,
+                                                             int32_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < B) {
+    idx[i] = (int32_t)users[i];
+    idx[B + i] = (int32_t)(num_users + items[i]);
+  }
+  if (i == 0) counts[0] = counts[1] = (int32_t)B;
+}
+
 // ---- normalise: one wave per (compact row, view)
 __global__ __launch_bounds__(BLOCK) void ssl_normalize_kernel(const float* __restrict__ view1,
                                                               const float* __restrict__ view2, int64_t d,
@@ -303,37 +316,52 @@ __global__ __launch_bounds__(BLOCK) void ssl_grad_kernel(const float* __restrict
 
 // ---- slices -> dL/d(normalised row) -> back through normalize() -> the views' gradient rows.
 //   One wave per (compact row, view): view 1 rows take side 0 (Ga), view 2 rows side 1 (Gb).
+//   With duplicate ids in a set (dedup == 0) the occurrences of one id all feed the same panel row: the wave of
+//   the FIRST occurrence adds them up in list order (deterministic), the others leave.
 __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restrict__ An, const float* __restrict__ den,
                                                           const float* __restrict__ Gp, const float* __restrict__ invttl,
                                                           const float* __restrict__ w, int64_t d, int64_t B,
                                                           const int32_t* __restrict__ idx,
-                                                          const int32_t* __restrict__ counts, float* __restrict__ g1,
-                                                          float* __restrict__ g2) {
+                                                          const int32_t* __restrict__ counts, int dedup,
+                                                          float* __restrict__ g1, float* __restrict__ g2) {
   const int lane = threadIdx.x % WAVE;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int v = blockIdx.y;
-  if (r >= counts[0] + counts[1]) return;
+  const int cu = counts[0], total = cu + counts[1];
+  if (r >= total) return;
   float* out = v == 0 ? g1 : g2;
   if (!out) return;
-  const float* y = An + ((int64_t)v * 2 * B + r) * d;            // this view's normalised row
-  const float* other = An + ((int64_t)(1 - v) * 2 * B + r) * d;  // b_i for view 1, a_k for view 2
-  const float nrm = den[(int64_t)v * 2 * B + r];
-  const float wr = w[r], itr = invttl[r];
-  float* o = out + (int64_t)idx[r] * d;
-  const bool clamped = nrm <= 1e-12f;  // normalize() divided by the constant eps: Jacobian 1/eps, no projection
-  // d is walked in rounds of 64 features; the projection needs <g, y> over the whole row first
-  float dot = 0.f;
-  for (int64_t f = lane; f < d; f += WAVE) {
-    float acc = 0.f;
-    for (int sl = 0; sl < GS; ++sl) acc += Gp[(((int64_t)v * GS + sl) * 2 * B + r) * d + f];
-    const float g = v == 0 ? wr * (other[f] - itr * acc) : wr * other[f] - acc;
-    dot += g * y[f];
-    o[f] = g;  // parked in the output row until the projection below
-  }
-  dot = wave_sum(dot);
-  for (int64_t f = lane; f < d; f += WAVE) {
-    const float g = o[f];
-    o[f] = clamped ? g / nrm : (g - dot * y[f]) / nrm;
+  const int32_t id = idx[r];
+  float* o = out + (int64_t)id * d;
+  const int s_lo = r < cu ? 0 : cu, s_hi = r < cu ? cu : total;  // this row's set
+  bool first = true;
+  // occurrences of `id` in the set, ascending; a de-duplicated set has exactly one: r itself
+  for (int c0 = dedup ? (int)r : s_lo; c0 < (dedup ? (int)r + 1 : s_hi); c0 += WAVE) {
+    unsigned long long match = dedup ? 1ull : __ballot(c0 + lane < s_hi && idx[c0 + lane] == id);
+    while (match) {
+      const int64_t j = c0 + __builtin_ctzll(match);
+      match &= match - 1;
+      if (first && j != r) return;  // an earlier occurrence owns this panel row
+      const float* y = An + ((int64_t)v * 2 * B + j) * d;            // this view's normalised row
+      const float* other = An + ((int64_t)(1 - v) * 2 * B + j) * d;  // b_i for view 1, a_k for view 2
+      const float nrm = den[(int64_t)v * 2 * B + j];
+      const float wr = w[j], itr = invttl[j];
+      const bool clamped = nrm <= 1e-12f;  // normalize() divided by the constant eps: Jacobian 1/eps, no projection
+      auto grad = [&](int64_t f) {
+        float acc = 0.f;
+        for (int sl = 0; sl < GS; ++sl) acc += Gp[(((int64_t)v * GS + sl) * 2 * B + j) * d + f];
+        return v == 0 ? wr * (other[f] - itr * acc) : wr * other[f] - acc;
+      };
+      float dot = 0.f;  // the projection needs <g, y> over the whole row first
+      for (int64_t f = lane; f < d; f += WAVE) dot += grad(f) * y[f];
+      dot = wave_sum(dot);
+      for (int64_t f = lane; f < d; f += WAVE) {
+        const float g = grad(f);
+        const float val = clamped ? g / nrm : (g - dot * y[f]) / nrm;
+        o[f] = first ? val : o[f] + val;
+      }
+      first = false;
+    }
   }
 }
 
@@ -347,19 +375,24 @@ size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d) {
 }
 
 int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
-                         const int64_t* items, int64_t B, int64_t num_users, float temperature, float* loss, float* g1,
-                         float* g2, void* ws, void* stream) {
+                         const int64_t* items, int64_t B, int64_t num_users, int dedup, float temperature, float* loss,
+                         float* g1, float* g2, void* ws, void* stream) {
   IDG_REQUIRE(view1 && view2 && users && items && loss && ws, "idg_infonce_pair_f32: NULL argument");
   IDG_REQUIRE(n > 0 && d > 0 && B > 0 && num_users >= 0 && num_users <= n, "idg_infonce_pair_f32: bad sizes");
   IDG_REQUIRE(B <= 46340, "idg_infonce_pair_f32: batch of %lld ids is too large for the in-batch logits matrix", (long long)B);
   IDG_REQUIRE(temperature > 0.f, "idg_infonce_pair_f32: temperature must be positive");
   hipStream_t st = (hipStream_t)stream;
   const SslWs w = ssl_layout(ws, n, B, d);
-  IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)((n + 31) / 32) * 4, st));
-  // rows of the batch's users and (positive) items; the third id list is not used here: pass the items twice
-  int rc = idg_bpr_touch_rows(users, items, items, B, num_users, w.bitmap, stream);
-  if (rc != IDG_OK) return rc;
-  hipLaunchKernelGGL(ssl_compact_kernel, dim3(1), dim3(1024), 0, st, w.bitmap, n, num_users, w.idx, w.counts, 2 * B);
+  if (dedup) {
+    IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)((n + 31) / 32) * 4, st));
+    // rows of the batch's users and (positive) items; the third id list is not used here: pass the items twice
+    int rc = idg_bpr_touch_rows(users, items, items, B, num_users, w.bitmap, stream);
+    if (rc != IDG_OK) return rc;
+    hipLaunchKernelGGL(ssl_compact_kernel, dim3(1), dim3(1024), 0, st, w.bitmap, n, num_users, w.idx, w.counts, 2 * B);
+  } else {
+    hipLaunchKernelGGL(ssl_copy_ids_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, items, B,
+                       num_users, w.idx, w.counts);
+  }
   const unsigned row_blocks = (unsigned)((2 * B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
   hipLaunchKernelGGL(ssl_normalize_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, view1, view2, d, w.idx, w.counts, B,
                      w.An, w.den);
@@ -373,7 +406,7 @@ int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int6
     hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 4), dim3(BLOCK), 0, st, w.An, w.P, d, B,
                        w.counts, w.invttl, w.w, w.G);
     hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w, d, B,
-                       w.idx, w.counts, g1, g2);
+                       w.idx, w.counts, dedup ? 1 : 0, g1, g2);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;

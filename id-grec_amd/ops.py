@@ -473,7 +473,7 @@ def bpr_fwd_bwd_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lamb
 _ssl_ws = {}
 
 
-def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None, g2=None, loss=None):
+def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None, g2=None, loss=None, dedup=True):
     """idg_infonce_pair_f32: loss[2] = InfoNCE over unique(users) rows and over num_users + unique(items) rows of
     the two [n, d] view panels; g1 / g2 (optional, pre-zeroed) receive d(loss[0] + loss[1]) / d view rows."""
     _require_device(view1, view2, users, items, g1, g2, loss)
@@ -490,32 +490,33 @@ def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None
     if loss is None:
         loss = torch.empty(2, dtype=torch.float32, device=view1.device)
     check(lib.idg_infonce_pair_f32(_ptr(view1), _ptr(view2), n, d, _ptr(users), _ptr(items), B, int(num_users),
-                                   float(temperature), _ptr(loss), _ptr(g1), _ptr(g2), _ptr(ws), _stream()),
+                                   int(bool(dedup)), float(temperature), _ptr(loss), _ptr(g1), _ptr(g2), _ptr(ws), _stream()),
           "idg_infonce_pair_f32")
     return loss
 
 
 class _InfoNCEPair(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, view1, view2, users, items, num_users, temperature):
+    def forward(ctx, view1, view2, users, items, num_users, temperature, dedup):
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g1 = torch.zeros_like(view1, memory_format=torch.contiguous_format) if need1 else None
         g2 = torch.zeros_like(view2, memory_format=torch.contiguous_format) if need2 else None
-        loss = infonce_pair_raw(view1.detach(), view2.detach(), users, items, num_users, temperature, g1, g2)
+        loss = infonce_pair_raw(view1.detach(), view2.detach(), users, items, num_users, temperature, g1, g2, dedup=dedup)
         ctx.saved = (g1, g2)
         return loss.sum()
 
     @staticmethod
     def backward(ctx, grad_out):
         g1, g2 = ctx.saved
-        return (None if g1 is None else g1.mul_(grad_out), None if g2 is None else g2.mul_(grad_out), None, None, None, None)
+        return (None if g1 is None else g1.mul_(grad_out), None if g2 is None else g2.mul_(grad_out), None, None, None, None,
+                None)
 
 
-def infonce_pair(view1, view2, users, items, num_users, temperature):
+def infonce_pair(view1, view2, users, items, num_users, temperature, dedup=True):
     """get_InfoNCE_loss(view1[U-rows of unique(users)], view2[...]) + get_InfoNCE_loss(... unique(items) rows ...)
-    — the self-supervised term of SimGCL / XSimGCL / SGL (models/SimGCL.py:79-84) — as one differentiable
-    operator on the two [n, d] view panels (users first)."""
-    return _InfoNCEPair.apply(view1, view2, users, items, num_users, temperature)
+    — the self-supervised term of SimGCL / XSimGCL (models/SimGCL.py:79-84) — as one differentiable operator on
+    the two [n, d] view panels (users first).  dedup=False: the id lists as they are, duplicates included (SGL)."""
+    return _InfoNCEPair.apply(view1, view2, users, items, num_users, temperature, bool(dedup))
 
 
 # ----------------------------------------------------------------------------------- Adam

