@@ -594,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
 // of a training step feeds nothing but the layer mean at the <= 3B rows of the batch).  A tile
 // without a flagged row exits before staging its entries; otherwise the flagged vrows run the
 // ordinary walk, so the produced rows are bit-identical to the full product.
-template <int LPR, int NB, bool FUSED>
+template <int LPR, int NB, bool FUSED, int EPI = EPI_PLAIN>
 __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __restrict__ tiles,
                                                                const int64_t* __restrict__ vptr,
                                                                const int32_t* __restrict__ vtgt,
@@ -662,14 +662,14 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   int q = g;
   while (q < nlive) {
     const int v = s_live[q];
-    do_vrow<LPR, NB, 8, EPI_PLAIN, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
+    do_vrow<LPR, NB, 8, EPI, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
     q = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
   }
   if (t.n_local > 0) {
     __syncthreads();
-    combine_local<LPR, NB, EPI_PLAIN, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, out_mask, slot_row);
+    combine_local<LPR, NB, EPI, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, out_mask, slot_row);
   }
 }
 
@@ -851,7 +851,14 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, EPI, false>  ), grid, block, 0, st,          \
                          tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);  \
   } while (0)
-    if (out_mask) {  // only flagged output rows (last forward layer of a training step)
+    if (out_mask && ep.noise_eps != 0.f) {  // flagged rows of a perturbed layer (the noise of a row depends on that row only)
+      if (fused_fix)
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true, EPI_NOISE>), grid, block, 0, st, tile_order, g->d_vptr,
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
+      else
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false, EPI_NOISE>), grid, block, 0, st, tile_order, g->d_vptr,
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
+    } else if (out_mask) {  // only flagged output rows (last forward layer of a training step)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
                            g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
@@ -1373,9 +1380,11 @@ int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out, cons
                           out_rows);
 }
 
-int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out, int K, int include_layer0, int64_t d,
-                                 float eps, uint64_t seed, uint64_t stream_id, void* ws, void* stream) {
-  return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0, nullptr, eps, seed, stream_id);
+int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out, const uint32_t* out_rows, int K,
+                                 int include_layer0, int64_t d, float eps, uint64_t seed, uint64_t stream_id, void* ws,
+                                 void* stream) {
+  return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0, nullptr, eps, seed, stream_id,
+                          out_rows);
 }
 
 int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask, float* gE0, int K,

@@ -322,46 +322,52 @@ __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restric
                                                           const float* __restrict__ Gp, const float* __restrict__ invttl,
                                                           const float* __restrict__ w, int64_t d, int64_t B,
                                                           const int32_t* __restrict__ idx,
-                                                          const int32_t* __restrict__ counts, int dedup,
-                                                          float* __restrict__ g1, float* __restrict__ g2) {
+                                                          const int32_t* __restrict__ counts, int dedup, float scale,
+                                                          int accumulate, int both_views, float* g1, float* g2) {
   const int lane = threadIdx.x % WAVE;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
-  const int v = blockIdx.y;
   const int cu = counts[0], total = cu + counts[1];
   if (r >= total) return;
-  float* out = v == 0 ? g1 : g2;
-  if (!out) return;
   const int32_t id = idx[r];
-  float* o = out + (int64_t)id * d;
   const int s_lo = r < cu ? 0 : cu, s_hi = r < cu ? cu : total;  // this row's set
+  // g1 == g2 (both_views): one wave adds both views' gradients into the shared panel row, view 1 first
+  const int v_lo = both_views ? 0 : blockIdx.y, v_hi = both_views ? 2 : blockIdx.y + 1;
+  bool fresh = !accumulate;  // the first value written to a row that is not accumulated into replaces its content
   bool first = true;
-  // occurrences of `id` in the set, ascending; a de-duplicated set has exactly one: r itself
-  for (int c0 = dedup ? (int)r : s_lo; c0 < (dedup ? (int)r + 1 : s_hi); c0 += WAVE) {
-    unsigned long long match = dedup ? 1ull : __ballot(c0 + lane < s_hi && idx[c0 + lane] == id);
-    while (match) {
-      const int64_t j = c0 + __builtin_ctzll(match);
-      match &= match - 1;
-      if (first && j != r) return;  // an earlier occurrence owns this panel row
-      const float* y = An + ((int64_t)v * 2 * B + j) * d;            // this view's normalised row
-      const float* other = An + ((int64_t)(1 - v) * 2 * B + j) * d;  // b_i for view 1, a_k for view 2
-      const float nrm = den[(int64_t)v * 2 * B + j];
-      const float wr = w[j], itr = invttl[j];
-      const bool clamped = nrm <= 1e-12f;  // normalize() divided by the constant eps: Jacobian 1/eps, no projection
-      auto grad = [&](int64_t f) {
-        float acc = 0.f;
-        for (int sl = 0; sl < GS; ++sl) acc += Gp[(((int64_t)v * GS + sl) * 2 * B + j) * d + f];
-        return v == 0 ? wr * (other[f] - itr * acc) : wr * other[f] - acc;
-      };
-      float dot = 0.f;  // the projection needs <g, y> over the whole row first
-      for (int64_t f = lane; f < d; f += WAVE) dot += grad(f) * y[f];
-      dot = wave_sum(dot);
-      for (int64_t f = lane; f < d; f += WAVE) {
-        const float g = grad(f);
-        const float val = clamped ? g / nrm : (g - dot * y[f]) / nrm;
-        o[f] = first ? val : o[f] + val;
+  for (int v = v_lo; v < v_hi; ++v) {
+    float* out = v == 0 ? g1 : g2;
+    if (!out) continue;
+    float* o = out + (int64_t)id * d;
+    // occurrences of `id` in the set, ascending; a de-duplicated set has exactly one: r itself
+    for (int c0 = dedup ? (int)r : s_lo; c0 < (dedup ? (int)r + 1 : s_hi); c0 += WAVE) {
+      unsigned long long match = dedup ? 1ull : __ballot(c0 + lane < s_hi && idx[c0 + lane] == id);
+      while (match) {
+        const int64_t j = c0 + __builtin_ctzll(match);
+        match &= match - 1;
+        if (first && j != r) return;  // an earlier occurrence owns this panel row
+        first = false;
+        const float* y = An + ((int64_t)v * 2 * B + j) * d;            // this view's normalised row
+        const float* other = An + ((int64_t)(1 - v) * 2 * B + j) * d;  // b_i for view 1, a_k for view 2
+        const float nrm = den[(int64_t)v * 2 * B + j];
+        const float wr = w[j], itr = invttl[j];
+        const bool clamped = nrm <= 1e-12f;  // normalize() divided by the constant eps: Jacobian 1/eps, no projection
+        auto grad = [&](int64_t f) {
+          float acc = 0.f;
+          for (int sl = 0; sl < GS; ++sl) acc += Gp[(((int64_t)v * GS + sl) * 2 * B + j) * d + f];
+          return v == 0 ? wr * (other[f] - itr * acc) : wr * other[f] - acc;
+        };
+        float dot = 0.f;  // the projection needs <g, y> over the whole row first
+        for (int64_t f = lane; f < d; f += WAVE) dot += grad(f) * y[f];
+        dot = wave_sum(dot);
+        for (int64_t f = lane; f < d; f += WAVE) {
+          const float g = grad(f);
+          const float val = scale * (clamped ? g / nrm : (g - dot * y[f]) / nrm);
+          o[f] = fresh ? val : o[f] + val;
+        }
+        fresh = false;
       }
-      first = false;
     }
+    if (!both_views) fresh = !accumulate;
   }
 }
 
@@ -376,7 +382,7 @@ size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d) {
 
 int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
                          const int64_t* items, int64_t B, int64_t num_users, int dedup, float temperature, float* loss,
-                         float* g1, float* g2, void* ws, void* stream) {
+                         float* g1, float* g2, float grad_scale, int accumulate, void* ws, void* stream) {
   IDG_REQUIRE(view1 && view2 && users && items && loss && ws, "idg_infonce_pair_f32: NULL argument");
   IDG_REQUIRE(n > 0 && d > 0 && B > 0 && num_users >= 0 && num_users <= n, "idg_infonce_pair_f32: bad sizes");
   IDG_REQUIRE(B <= 46340, "idg_infonce_pair_f32: batch of %lld ids is too large for the in-batch logits matrix", (long long)B);
@@ -405,8 +411,9 @@ int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int6
   if (g1 || g2) {
     hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 4), dim3(BLOCK), 0, st, w.An, w.P, d, B,
                        w.counts, w.invttl, w.w, w.G);
-    hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w, d, B,
-                       w.idx, w.counts, dedup ? 1 : 0, g1, g2);
+    const int both = (g1 && g1 == g2) ? 1 : 0;  // one panel for both views: a single wave per row adds them in turn
+    hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, both ? 1 : 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w,
+                       d, B, w.idx, w.counts, dedup ? 1 : 0, grad_scale, accumulate ? 1 : 0, both, g1, g2);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;

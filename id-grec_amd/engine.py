@@ -37,13 +37,16 @@ class PropagationEngine:
         self._slots = [self._Slot(words, dev), self._Slot(words, dev)] if graph is not None else None
         self.touched = None
         self._parity = 0
-        self.loss = torch.zeros(2, **f32)
+        self._loss3 = torch.zeros(3, **f32)  # [bpr, reg_lambda * reg, ssl_lambda * InfoNCE]
+        self.loss = self._loss3[:2]
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
         self._side = None   # side stream for index-only work
         self._id_storage = None  # storages of the id tensors last ordered against the main stream
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
+        self.ssl = None        # (eps, temperature, ssl_lambda): SimGCL's perturbed views + InfoNCE inside the fused step
+        self._views = self._ssl_loss = None
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
     # ---- views handed to nn.Embedding
@@ -122,8 +125,11 @@ class PropagationEngine:
     @torch.no_grad()
     def loss_and_grad(self, users, pos, neg, loss_out=None, _adam_step=0):
         """_adam_step > 0 (train_step): the Adam update of self.params rides in the epilogue of the last
-        backward product (idg_propagate_mean_bwd_adam_f32) instead of a separate pass over the gradient."""
-        loss = self.loss if loss_out is None else loss_out
+        backward product (idg_propagate_mean_bwd_adam_f32) instead of a separate pass over the gradient.
+        With self.ssl set (SimGCL): two noise-perturbed encoder passes next to the clean one, InfoNCE between
+        them over the batch's unique users / positive items, its gradients added (times ssl_lambda) to the BPR
+        gradient before the ONE backward propagation all three passes share; loss gets a third entry."""
+        loss = (self.loss if self.ssl is None else self._loss3) if loss_out is None else loss_out
         main = torch.cuda.current_stream()
         if self.graph is None:
             self.grad.zero_()
@@ -159,11 +165,27 @@ class PropagationEngine:
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
         else:
             self._forward_layer_by_layer(slot.bitmap)
+        if self.ssl is not None:
+            # the views are read at rows of the batch only as well (unique users / positives: a subset of the bitmap)
+            eps, temperature, ssl_lambda = self.ssl
+            if self._views is None:
+                self._views = (torch.empty_like(self.params), torch.empty_like(self.params))
+                self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+            for view in self._views:  # same (seed, stream) sequence as ops.propagate_views draws
+                seed, stream_id = ops._next_noise_stream()
+                self.graph.propagate_mean_noise_raw(self.params, self.K, self.inc, eps, seed, stream_id, out=view,
+                                                    out_rows=slot.bitmap)
         main.wait_event(slot.plan_done)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled
         ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
-                          self.grad, loss=loss, deterministic=2, touched=slot.bitmap, ws=slot.ws)
+                          self.grad, loss=loss[:2], deterministic=2, touched=slot.bitmap, ws=slot.ws)
+        if self.ssl is not None:
+            # d(ssl_lambda * InfoNCE)/d view_1 + d(...)/d view_2 join the BPR gradient in g_final's (stored) rows
+            ops.infonce_pair_raw(self._views[0], self._views[1], users, pos, self.U, temperature, g1=self.g_final,
+                                 g2=self.g_final, loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True)
+            torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
+            loss[2:3].mul_(ssl_lambda)
         if _adam_step > 0:
             self.graph.propagate_mean_bwd_adam_raw(self.g_final, self.K, self.inc, self.grad, True, slot.bitmap, self.params,
                                                    self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],

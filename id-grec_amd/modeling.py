@@ -106,6 +106,8 @@ class PackedRecommender(nn.Module):
 
     #: models whose training loss is exactly [bpr, reg] over the mean-propagated panel set this
     supports_fused_step = False
+    #: entries of the loss vector a fused step writes ([bpr, reg] + the model's own terms)
+    n_fused_losses = 2
 
     def fused_loss_and_grad(self, users, pos, neg, loss_out=None):
         """Losses [bpr, reg_lambda*reg] (device tensor) and d(sum)/d(weights) written into the

@@ -50,7 +50,7 @@ PROTOTYPES = {
                                      c_vp, c_vp]),
     "idg_propagate_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
     "idg_propagate_mean_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, c_vp, c_vp]),
-    "idg_propagate_mean_noise_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_uint64,
+    "idg_propagate_mean_noise_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_uint64,
                                                C.c_uint64, c_vp, c_vp]),
     "idg_propagate_mean_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int, c_vp,
                                              c_vp]),
@@ -59,7 +59,7 @@ PROTOTYPES = {
                                                   c_vp, c_vp]),
     "idg_infonce_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "idg_infonce_pair_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int, C.c_float,
-                                       c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                       c_vp, c_vp, c_vp, C.c_float, C.c_int, c_vp, c_vp]),
     "idg_bpr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "idg_bpr_fused_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                     C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),

@@ -165,6 +165,18 @@ class Graph:
                                          d, _ptr(ws), _stream()), "idg_propagate_mean_f32")
         return out
 
+    def propagate_mean_noise_raw(self, E0, K, include_layer0, eps, seed, stream_id, out=None, out_rows=None):
+        """idg_propagate_mean_noise_f32 (SimGCL's perturbed encoder pass); out_rows as in propagate_mean_raw."""
+        _require_device(E0, out, out_rows)
+        E0 = _f32c(E0, "E0")
+        d = E0.shape[1]
+        out = torch.empty_like(E0) if out is None else out
+        ws = self._workspace("prop", d)
+        check(lib.idg_propagate_mean_noise_f32(self._h, _ptr(E0), _ptr(out), _ptr(out_rows), int(K), int(bool(include_layer0)),
+                                               d, float(eps), C.c_uint64(seed), C.c_uint64(stream_id), _ptr(ws), _stream()),
+              "idg_propagate_mean_noise_f32")
+        return out
+
     def propagate_mean_bwd_raw(self, gout, K, include_layer0=True, out=None, accumulate=False, mask=None):
         """mask: int32/uint32 bitmap tensor of gout's live rows (see idg_propagate_mean_bwd_f32), or None."""
         _require_device(gout, out, mask)
@@ -274,7 +286,7 @@ class _PropagateViews(torch.autograd.Function):
         for _ in range(n_views):
             out = torch.empty_like(E0)
             seed, stream_id = _next_noise_stream()
-            check(lib.idg_propagate_mean_noise_f32(graph._h, _ptr(E0), _ptr(out), int(K), int(bool(include_layer0)), d,
+            check(lib.idg_propagate_mean_noise_f32(graph._h, _ptr(E0), _ptr(out), None, int(K), int(bool(include_layer0)), d,
                                                    float(eps), C.c_uint64(seed), C.c_uint64(stream_id), _ptr(ws),
                                                    _stream()), "idg_propagate_mean_noise_f32")
             outs.append(out)
@@ -473,7 +485,8 @@ def bpr_fwd_bwd_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lamb
 _ssl_ws = {}
 
 
-def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None, g2=None, loss=None, dedup=True):
+def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None, g2=None, loss=None, dedup=True,
+                     grad_scale=1.0, accumulate=False):
     """idg_infonce_pair_f32: loss[2] = InfoNCE over unique(users) rows and over num_users + unique(items) rows of
     the two [n, d] view panels; g1 / g2 (optional, pre-zeroed) receive d(loss[0] + loss[1]) / d view rows."""
     _require_device(view1, view2, users, items, g1, g2, loss)
@@ -490,7 +503,8 @@ def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None
     if loss is None:
         loss = torch.empty(2, dtype=torch.float32, device=view1.device)
     check(lib.idg_infonce_pair_f32(_ptr(view1), _ptr(view2), n, d, _ptr(users), _ptr(items), B, int(num_users),
-                                   int(bool(dedup)), float(temperature), _ptr(loss), _ptr(g1), _ptr(g2), _ptr(ws), _stream()),
+                                   int(bool(dedup)), float(temperature), _ptr(loss), _ptr(g1), _ptr(g2), float(grad_scale),
+                                   int(bool(accumulate)), _ptr(ws), _stream()),
           "idg_infonce_pair_f32")
     return loss
 

@@ -184,11 +184,12 @@ int idg_propagate_mean_f32(const idg_graph* g, const float* E0, float* out,
  * with u ~ U[0,1)^d, before it enters the running sum and feeds the next layer.  u comes from
  * Philox4x32-10 keyed by (seed, stream_id, layer, row, feature block): reproducible for a given
  * (seed, stream_id), independent of the tile schedule; like the reference's device generator it
- * matches a CPU run statistically, not bit for bit.  d in {32, 64, 128, 256, 512}.
+ * matches a CPU run statistically, not bit for bit.  d in {32, 64, 128, 256, 512}.  out_rows as in
+ * idg_propagate_mean_f32 (a row's noise depends on that row only: the produced rows are the same).
  * The gradient w.r.t. E0 is idg_propagate_mean_bwd_f32's (sign() has zero gradient, u is constant). */
-int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out, int K,
-                                 int include_layer0, int64_t d, float eps, uint64_t seed,
-                                 uint64_t stream_id, void* ws, void* stream);
+int idg_propagate_mean_noise_f32(const idg_graph* g, const float* E0, float* out,
+                                 const uint32_t* out_rows, int K, int include_layer0, int64_t d,
+                                 float eps, uint64_t seed, uint64_t stream_id, void* ws, void* stream);
 
 /* Backward of the above for a SYMMETRIC graph: gE0 = (1/cnt)(c0.g + A(g + A(g + ... A g))),
  * the Horner form of autograd's chain through K torch.sparse.mm nodes and the mean.
@@ -275,7 +276,10 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
  * loss[0] = the user-set loss, loss[1] = the item-set loss (rows num_users + item id).
  * g1 / g2 (nullable): d(loss[0] + loss[1]) / d view1 / d view2 — the rows of the two sets are
  * STORED, every other row is left untouched (zero-fill the panels first if you need dense
- * gradients).  The unique id lists never visit the host: launches are shaped by B.
+ * gradients), multiplied by grad_scale; with accumulate != 0 they are ADDED to what the rows hold.
+ * g1 == g2 is allowed (both views' gradients meet in one panel — a fused training step sums them
+ * with the BPR gradient before ONE backward propagation).  The unique id lists never visit the
+ * host: launches are shaped by B.
  * dedup = 0 keeps the id lists as they are, duplicates included (models/SGL.py:85-86 indexes its views with
  * the raw batch ids): every occurrence is a row of the in-batch matrix and the gradients of the occurrences
  * of one id are added, in list order, into its panel row.
@@ -283,8 +287,8 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
 size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d);
 int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d,
                          const int64_t* users, const int64_t* items, int64_t B, int64_t num_users,
-                         int dedup, float temperature, float* loss, float* g1, float* g2, void* ws,
-                         void* stream);
+                         int dedup, float temperature, float* loss, float* g1, float* g2,
+                         float grad_scale, int accumulate, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: dense Adam step  (torch.optim.Adam defaults, utility/utility_train/trainer.py:11,56:

@@ -17,6 +17,11 @@ from idgrec_amd.modeling import PackedRecommender
 
 class SimGCL(PackedRecommender):
     include_layer0 = False  # "Initial embedding is not included" (models/SimGCL.py:44-45)
+    # the trainer's fused step: clean + two perturbed passes, BPR, InfoNCE and the one shared backward propagation
+    # with Adam in its epilogue as a fixed chain of kernels (PropagationEngine with .ssl set); forward() below is
+    # the same computation under autograd
+    supports_fused_step = True
+    n_fused_losses = 3
 
     def __init__(self, config, dataset, device):
         super(SimGCL, self).__init__(config, dataset, device)
@@ -25,6 +30,11 @@ class SimGCL(PackedRecommender):
         self.epsilon = float(config['epsilon'])
         self.temperature = float(config['temperature'])
         self.attach_graph(data_graph.sparse_adjacency_matrix(dataset))
+
+    def engine(self):
+        eng = super().engine()
+        eng.ssl = (self.epsilon, self.temperature, self.ssl_lambda)
+        return eng
 
     def aggregate(self, perturbed=False):
         ego = self.ego_panel()

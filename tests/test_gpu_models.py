@@ -270,6 +270,43 @@ def test_simgcl_runs_and_clean_view_matches_reference(tmp_path, golden_small):
     assert float(sum(ll)) < first  # five steps on one batch reduce its loss
 
 
+def test_simgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
+    """The trainer's fused SimGCL step (row-restricted clean + perturbed passes, BPR, fused InfoNCE whose gradients
+    join the BPR gradient before ONE shared backward propagation with Adam in its epilogue) against forward()
+    under autograd + optimizer.step(), same noise streams: losses, gradients and weights over 3 steps."""
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.SimGCL import SimGCL
+
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", learn_rate=0.001, ssl_lambda=0.5, temperature=0.2, epsilon=0.05, **BASE)
+    tri = torch.from_numpy(g["sample1"][:3 * 256]).cuda()
+    bt = [tuple(tri[i * 256:(i + 1) * 256, c].contiguous() for c in range(3)) for i in range(3)]
+    res = []
+    for fused in (True, False):
+        tools.set_seed(2024)
+        ops.reset_noise_stream()
+        model = SimGCL(cfg, data, torch.device("cuda")).to("cuda")
+        opt = ops.Adam(model.parameters(), lr=0.001)
+        loss = torch.zeros((3, 3), device="cuda")
+        for i in range(3):
+            if fused:
+                assert model.fused_train_step(*bt[i], loss[i], opt)
+            else:
+                ll = model(*bt[i])
+                loss[i] = torch.stack([x.detach() for x in ll])
+                opt.zero_grad()
+                sum(ll).backward()
+                opt.step()
+        res.append((loss.cpu().numpy(), model.user_embedding.weight.grad.cpu().numpy(), model._storage.cpu().numpy(),
+                    opt.state[model.item_embedding.weight]["exp_avg_sq"].cpu().numpy()))
+    (l_f, g_f, w_f, v_f), (l_a, g_a, w_a, v_a) = res
+    np.testing.assert_allclose(l_f, l_a, rtol=2e-5)
+    np.testing.assert_allclose(g_f, g_a, rtol=1e-3, atol=1e-5 * np.abs(g_a).max())
+    np.testing.assert_allclose(w_f, w_a, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(v_f, v_a, rtol=2e-3, atol=1e-6 * np.abs(v_a).max())
+
+
 # ----------------------------------------------------------------- next models (SURVEY §8f)
 @pytest.fixture(scope="module")
 def golden_next():

@@ -65,7 +65,8 @@ def universal_trainer(model, args, config, dataset, device, logger):
                                                        total=int(num_batch)):
             if fused:
                 if step_losses is None:
-                    step_losses = torch.zeros((num_batch, 2), dtype=torch.float32, device=device)
+                    step_losses = torch.zeros((num_batch, int(getattr(model, "n_fused_losses", 2))), dtype=torch.float32,
+                                              device=device)
                 if batch_i + 1 < len(batches):
                     model.prefetch_batch(*batches[batch_i + 1])  # index-only work of the next step, off the critical path
                 # one chain of kernels for forward + backward + Adam when the optimizer is ours ...
