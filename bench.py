@@ -36,7 +36,8 @@ def parse():
     p.add_argument("--dim", type=int, default=64)
     p.add_argument("--layers", type=int, default=3)
     p.add_argument("--batch", type=int, default=1024)
-    p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MFBPR"])
+    p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MFBPR", "SimGCL"],
+                   help="SimGCL (BASELINE configs[3]): hyper-parameters from configure/SimGCL.txt, no CPU baseline leg")
     p.add_argument("--atomic", action="store_true", help="float-atomic scatter instead of the deterministic one")
     p.add_argument("--split", type=int, default=0, help="row split threshold (0 = library default)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -159,15 +160,20 @@ def main():
     U, I, d, K, B = wl["U"], wl["I"], args.dim, args.layers, args.batch
     n, nnz = U + I, len(wl["indices"])
     graph = None
-    if args.model == "LightGCN":
+    if args.model in ("LightGCN", "SimGCL"):
         graph = ops.Graph(wl["indptr"], wl["indices"], wl["values"], n, n, split_threshold=args.split)
     W0 = S.xavier_uniform_panel(U, I, d, args.seed)
-    eng = PropagationEngine(graph, U, I, d, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
+    eng = PropagationEngine(graph, U, I, d, K, include_layer0=(args.model != "SimGCL"), reg_lambda=1e-4, lr=1e-3,
                             deterministic=not args.atomic, params=W0.cuda())
+    if args.model == "SimGCL":
+        import utility.utility_function.tools as tools
+
+        c = tools.read_configuration(os.path.join(ROOT, "configure", "SimGCL.txt"), "SimGCL")
+        eng.ssl = (float(c["epsilon"]), float(c["temperature"]), float(c["ssl_lambda"]))
     eng.fuse_adam = not args.separate_adam
     tri = torch.from_numpy(wl["triples"]).cuda()
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
-    losses = torch.zeros((args.steps + args.warmup, 2), dtype=torch.float32, device="cuda")
+    losses = torch.zeros((args.steps + args.warmup, 3 if args.model == "SimGCL" else 2), dtype=torch.float32, device="cuda")
 
     def batch(i):
         s = slice(i * B, (i + 1) * B)
@@ -206,8 +212,10 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s-shape graph: %d users x %d items, %d train edges, nnz(A)=%d; %s K=%d d=%d B=%d; "
-                               "step = propagate + fused BPR + backward propagate + dense Adam"
-                               % (args.workload, U, I, wl["E"], nnz, args.model, K, d, B),
+                               "step = %s"
+                               % (args.workload, U, I, wl["E"], nnz, args.model, K, d, B,
+                                  "clean + 2 perturbed propagations + fused BPR + InfoNCE + one shared backward propagation + dense Adam"
+                                  if args.model == "SimGCL" else "propagate + fused BPR + backward propagate + dense Adam"),
                    "batch": B, "dim": d, "layers": K, "scatter": "atomic" if args.atomic else "deterministic"},
         "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[-1].sum().item())],
         "host_issue_ms_per_step": t_issue / args.steps * 1e3,
@@ -238,7 +246,7 @@ def main():
             "cache_resident": bool(4 * n * d < INFINITY_CACHE_BYTES),
             "tiles": info["n_tiles"], "split_rows": info["n_long_rows"],
         }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.model != "SimGCL":
         out["cpu_baseline"] = cpu_baseline(args, wl, W0.numpy())
     print(json.dumps(out))
 
