@@ -57,6 +57,9 @@ PROTOTYPES = {
     "idg_propagate_mean_bwd_adam_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_int, c_vp, c_vp,
                                                   c_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                                   c_vp, c_vp]),
+    "idg_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "idg_linear_wgrad_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_int, c_vp,
+                                       c_vp]),
     "idg_infonce_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "idg_infonce_pair_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int, C.c_float,
                                        c_vp, c_vp, c_vp, C.c_float, C.c_int, c_vp, c_vp]),

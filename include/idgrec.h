@@ -267,6 +267,17 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
                          void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * DEVICE: weight gradient of a thin dense layer  (autograd of torch.matmul(side, W) in NGCF's
+ * per-layer transforms, models/NGCF.py:91-99):  w_grad[d1, d2] (+)= X^T . G,  X [n, d1] (leading
+ * dimension ldx), G [n, d2] (ldg), row-major fp32.  All reduction (K = n), no output to speak of:
+ * rows are cut into slices summed in slice order (deterministic).  ws: *_workspace_bytes.
+ * ---------------------------------------------------------------------------------- */
+size_t idg_linear_wgrad_workspace_bytes(int64_t n, int64_t d1, int64_t d2);
+int idg_linear_wgrad_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n,
+                         int64_t d1, int64_t d2, float* w_grad, int accumulate, void* ws,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------
  * DEVICE: in-batch InfoNCE between two views, forward + backward
  * (utility/utility_function/losses.py:24-35 get_InfoNCE_loss; call sites models/SimGCL.py:79-84,
  *  XSimGCL.py:80-86, SGL.py:96-101: once over unique(batch users), once over unique(batch positive

@@ -37,8 +37,10 @@ class NGCF(PackedRecommender):
         for layer in range(self.n_layers):
             side = ops.spmm(self.Graph, ego)
             w = self.weight_dict
-            summed = torch.matmul(side, w['W_gcn_%d' % layer]) + w['b_gcn_%d' % layer]
-            bi = torch.matmul(torch.mul(ego, side), w['W_bi_%d' % layer]) + w['b_bi_%d' % layer]
+            # [n, d] x [d, d]: forward / input gradient are small GEMMs, the weight gradient (all reduction over the
+            # n rows) is the library's slice-summed kernel
+            summed = ops.tall_linear(side, w['W_gcn_%d' % layer]) + w['b_gcn_%d' % layer]
+            bi = ops.tall_linear(torch.mul(ego, side), w['W_bi_%d' % layer]) + w['b_bi_%d' % layer]
             ego = nn.functional.leaky_relu(summed + bi, negative_slope=0.2)
             # the reference instantiates nn.Dropout inside aggregate() (models/NGCF.py:104): a fresh module is
             # always in training mode, so message dropout is applied during evaluation as well — kept as is

@@ -400,6 +400,29 @@ def test_train_step_adam_in_epilogue_is_bit_identical(ops, K, inc, d, fix, monke
     assert not torch.equal(out[0][0].cpu(), torch.from_numpy(W0))
 
 
+# --------------------------------------------------------------------------- thin dense layer
+@pytest.mark.parametrize("n,d1,d2", [(69716, 64, 64), (1000, 64, 32), (257, 100, 70), (5, 3, 130)])
+def test_linear_wgrad_vs_float64(ops, n, d1, d2):
+    rng = np.random.default_rng(n + d1)
+    X = rng.standard_normal((n, d1)).astype(np.float32)
+    G = (rng.standard_normal((n, d2)) * 0.01).astype(np.float32)
+    ref = X.astype(np.float64).T @ G.astype(np.float64)
+    out = ops.linear_wgrad_raw(dev(X), dev(G))
+    scale = np.abs(X.astype(np.float64)).T @ np.abs(G.astype(np.float64))  # |err| <= c eps sum |x g|
+    assert (np.abs(out.cpu().numpy() - ref) <= 2e-6 * scale + 1e-30).all()
+    assert torch.equal(out, ops.linear_wgrad_raw(dev(X), dev(G)))  # slice order is fixed: same bits
+    acc = ops.linear_wgrad_raw(dev(X), dev(G), out=out.clone(), accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 2 * out.cpu().numpy(), rtol=1e-6)
+    # autograd wrapper against torch.matmul
+    Xt, W = dev(X).requires_grad_(), dev(rng.standard_normal((d1, d2)).astype(np.float32)).requires_grad_()
+    Y = ops.tall_linear(Xt, W)
+    Y.backward(dev(G))
+    X2, W2 = dev(X).requires_grad_(), W.detach().clone().requires_grad_()
+    torch.matmul(X2, W2).backward(dev(G))
+    np.testing.assert_allclose(W.grad.cpu().numpy(), W2.grad.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale.max())
+    assert torch.allclose(Xt.grad, X2.grad, rtol=1e-5, atol=1e-7)
+
+
 # --------------------------------------------------------------------------- InfoNCE
 @pytest.mark.parametrize("d,B,tau", [(64, 300, 0.2), (100, 77, 0.15), (256, 1024, 0.2), (32, 2048, 0.5)])
 def test_infonce_pair_vs_reference_formula(ops, d, B, tau):
