@@ -97,7 +97,13 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
+ABI_VERSION = 110  # include/idgrec.h IDG_VERSION the prototype table above was written against
+
 lib = C.CDLL(LIB_PATH)
+lib.idg_version.restype = C.c_int
+if lib.idg_version() != ABI_VERSION:
+    raise ImportError("%s reports ABI version %d, this binding expects %d: the library is stale — rebuild it with "
+                      "`python id-grec_amd/build.py`." % (LIB_PATH, lib.idg_version(), ABI_VERSION))
 for _name, (_res, _args) in PROTOTYPES.items():
     _fn = getattr(lib, _name)
     _fn.restype = _res

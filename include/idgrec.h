@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 100 /* 0.1.0 */
+#define IDG_VERSION 110 /* 0.1.10: in-kernel split-row combine, fused Adam / InfoNCE / top-K entry points */
 
 /* error classes */
 #define IDG_OK 0
