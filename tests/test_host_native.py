@@ -17,7 +17,8 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(native.lib, name), "libidgrec.so does not export %s" % name
     assert declared == set(native.PROTOTYPES), declared ^ set(native.PROTOTYPES)
-    assert native.lib.idg_version() == 110
+    version = int(re.search(r"#define IDG_VERSION (\d+)", hdr).group(1))
+    assert native.lib.idg_version() == native.ABI_VERSION == version  # header, binding and built library agree
 
 
 def test_errors_are_reported_not_thrown():
