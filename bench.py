@@ -48,6 +48,10 @@ def parse():
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend of the sharded path: nccl (= RCCL over xGMI) for real runs; gloo only "
                         "to rehearse the multi-rank code path with several ranks sharing one GPU (host-staged collectives)")
+    p.add_argument("--parallel", default="auto", choices=["auto", "dp", "shard"],
+                   help="multi-GPU form: dp = replicas + one gradient all-reduce per step (small graphs), shard = user-row "
+                        "shards + per-layer all-reduces of the item panel (graphs whose propagation is the cost); auto "
+                        "picks dp while the [n, d] panel fits the 256 MiB Infinity Cache")
     p.add_argument("--force-sharded", action="store_true",
                    help="run the user-row-sharded path even at world size 1 (exercises the RCCL code path)")
     return p.parse_args()
@@ -156,6 +160,12 @@ def main():
     from idgrec_amd.engine import PropagationEngine
 
     if world > 1 or args.force_sharded:
+        U_, I_, _ = S.SHAPES[args.workload]
+        small = 4 * (U_ + I_) * args.dim <= INFINITY_CACHE_BYTES
+        if not args.force_sharded and (args.parallel == "dp" or (args.parallel == "auto" and small)):
+            from idgrec_amd.replicated import run_replicated_bench
+
+            return run_replicated_bench(args, rank, world, dist)
         from idgrec_amd.sharded import run_sharded_bench
 
         return run_sharded_bench(args, rank, world, dist)

@@ -331,15 +331,20 @@ class TorchComm:
         self.backend = dist.get_backend()
         # The sharded step issues 8 collectives; dist.all_reduce() spends ~25 us of host time per call in argument
         # checks before it reaches the process group.  Call the group object directly when this torch exposes it.
-        self._pg = self._opts = None
+        self._pg = self._opts = self._opts_avg = None
+        self.averages = self.backend == "nccl"  # RCCL divides inside the collective (ReduceOp.AVG); gloo cannot
         try:
             self._pg = dist.distributed_c10d._get_default_group()
             self._opts = dist.AllreduceOptions()
             self._opts.reduceOp = dist.ReduceOp.SUM
+            self._opts_avg = dist.AllreduceOptions()
+            self._opts_avg.reduceOp = dist.ReduceOp.AVG
         except Exception:  # noqa: BLE001 - private API: fall back to the public wrapper
             self._pg = None
 
-    def all_reduce_async(self, t):
+    def all_reduce_async(self, t, average=False):
+        """Sum over ranks; average=True asks for the mean and gets it only when self.averages (otherwise the sum —
+        the caller scales)."""
         import torch
 
         if isinstance(t, np.ndarray):
@@ -349,9 +354,10 @@ class TorchComm:
             self.dist.all_reduce(host)
             t.copy_(host)
             return None
+        avg = average and self.averages
         if self._pg is not None and t.is_cuda:
-            return self._pg.allreduce([t], self._opts)
-        return self.dist.all_reduce(t, async_op=True)
+            return self._pg.allreduce([t], self._opts_avg if avg else self._opts)
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.AVG if avg else self.dist.ReduceOp.SUM, async_op=True)
 
     def wait(self, work):
         if work is not None:
@@ -361,7 +367,9 @@ class TorchComm:
 class NoComm:
     """world_size 1."""
 
-    def all_reduce_async(self, t):
+    averages = True
+
+    def all_reduce_async(self, t, average=False):
         return None
 
     def wait(self, work):

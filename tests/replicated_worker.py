@@ -1,0 +1,78 @@
+"""Worker for the world_size-2 tests of id-grec_amd/replicated.py (launched by tests/test_replicated.py).
+mode "cpu": a checker-backed engine (arithmetic by oracle/, TEST ONLY) over gloo; mode "gpu": the HIP
+engine, both ranks on cuda:0, gloo staging through the host."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleReplica:
+    """`engine` interface of ReplicatedStep on numpy + oracle/ (tests only)."""
+
+    def __init__(self, adj, W0, U, K, include0):
+        from oracle import oracle
+
+        self.o, self.adj, self.U, self.K, self.inc = oracle, adj, U, K, include0
+        n, d = W0.shape
+        self.params = W0.copy()
+        self.grad_and_loss = np.zeros((n + 1, d), dtype=np.float32)
+        self.grad = self.grad_and_loss[:n]
+        self.loss_row = self.grad_and_loss[n, :2]
+        self.m, self.v, self.step = np.zeros_like(W0), np.zeros_like(W0), 0
+
+    def loss_and_grad(self, users, pos, neg):
+        fin = self.o.propagate_mean(*self.adj, self.params, self.K, self.inc)
+        loss, gf, ge = self.o.bpr(fin, self.params, self.U, users, pos, neg, 1e-4)
+        self.grad[...] = self.o.propagate_mean_bwd(*self.adj, gf, self.K, self.inc) + ge
+        self.loss_row[...] = loss
+
+    def scale_grad_and_loss(self, a):
+        self.grad_and_loss *= np.float32(a)
+
+    def adam_step(self):
+        self.step += 1
+        self.o.adam(self.params, np.ascontiguousarray(self.grad), self.m, self.v, 1e-3, self.step)
+
+
+def run(rank, world, port, mode, path, steps):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import idgrec_amd.replicated as rp
+    import idgrec_amd.sharded as sh
+
+    z = np.load(path)
+    ip, ix, dv, W0, tri = z["indptr"], z["indices"], z["values"], z["W0"], z["triples"]
+    U, I, K, B = int(z["U"]), int(z["I"]), int(z["K"]), int(z["B"])  # B: per-rank batch; global batch = world * B
+    if mode == "cpu":
+        eng, to_dev, to_np = OracleReplica((ip, ix, dv), W0, U, K, bool(z["include0"])), (lambda a: np.ascontiguousarray(a)), (lambda a: a)
+    else:
+        import idgrec_amd.ops as ops
+
+        torch.cuda.set_device(0)
+        n = U + I
+        g = ops.Graph(ip, ix, dv, n, n)
+        eng = rp.HipReplica(g, U, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
+                            params=torch.from_numpy(W0.copy()).cuda())
+        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        to_np = lambda a: a.cpu().numpy()  # noqa: E731
+    step = rp.ReplicatedStep(eng, sh.TorchComm(dist), world)
+    losses = []
+    for s in range(steps):
+        b = tri[s * world * B:(s + 1) * world * B][rank * B:(rank + 1) * B]
+        loss = step.train_step(to_dev(b[:, 0]), to_dev(b[:, 1]), to_dev(b[:, 2]))
+        losses.append(to_np(loss).copy())
+    np.savez(path + ".out%d.npz" % rank, P=to_np(eng.params), G=to_np(eng.grad), losses=np.stack(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6]))
