@@ -1287,8 +1287,8 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
   return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, x_rows, out_rows);
 }
 
-int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t d, float eps,
-                       uint64_t seed, uint64_t stream_id, void* ws, void* stream) {
+int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, const uint32_t* out_rows,
+                       int64_t d, float eps, uint64_t seed, uint64_t stream_id, void* ws, void* stream) {
   IDG_REQUIRE(g && X && Y, "idg_spmm_noise_f32: NULL argument");
   IDG_REQUIRE(d > 0 && ldx >= d && ldy >= d, "idg_spmm_noise_f32: bad d/ldx/ldy");
   Epilogue ep{};
@@ -1298,7 +1298,7 @@ int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y
   ep.noise_eps = eps;
   ep.noise_seed = seed;
   ep.noise_stream = stream_id;
-  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream);
+  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, nullptr, out_rows);
 }
 
 size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {

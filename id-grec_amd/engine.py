@@ -46,6 +46,7 @@ class PropagationEngine:
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
         self.ssl = None        # (eps, temperature, ssl_lambda): SimGCL's perturbed views + InfoNCE inside the fused step
+        self.xssl = None       # the same triple for XSimGCL (one perturbed pass, cl_layer = 1)
         self._views = self._ssl_loss = None
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
@@ -129,7 +130,7 @@ class PropagationEngine:
         With self.ssl set (SimGCL): two noise-perturbed encoder passes next to the clean one, InfoNCE between
         them over the batch's unique users / positive items, its gradients added (times ssl_lambda) to the BPR
         gradient before the ONE backward propagation all three passes share; loss gets a third entry."""
-        loss = (self.loss if self.ssl is None else self._loss3) if loss_out is None else loss_out
+        loss = (self.loss if (self.ssl is None and self.xssl is None) else self._loss3) if loss_out is None else loss_out
         main = torch.cuda.current_stream()
         if self.graph is None:
             self.grad.zero_()
@@ -161,7 +162,19 @@ class PropagationEngine:
         self.touched = slot.bitmap
         # the BPR kernel reads the layer mean at the batch rows only: the last layer is restricted to them
         main.wait_event(slot.rows_done)
-        if self.events is None:
+        if self.xssl is not None:
+            # XSimGCL (models/XSimGCL.py:40-60): ONE perturbed pass; BPR reads its layer mean, InfoNCE contrasts the
+            # first layer's output with that mean.  Both are wanted at rows of the batch only.
+            eps, temperature, ssl_lambda = self.xssl
+            if self._views is None:
+                self._views = (torch.empty_like(self.params), torch.empty_like(self.params))  # (layer-1 view, its gradient)
+                self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+            stream = ops._next_noise_stream()
+            self.graph.propagate_mean_noise_raw(self.params, self.K, self.inc, eps, stream[0], stream[1], out=self.final,
+                                                out_rows=slot.bitmap)
+            seed1, sid1 = ops.layer_noise_stream(stream, 1)  # layer 1 again, on its own, for the rows of the batch
+            ops.spmm_noise_raw(self.graph, self.params, eps, seed1, sid1, out=self._views[0], out_rows=slot.bitmap)
+        elif self.events is None:
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
         else:
             self._forward_layer_by_layer(slot.bitmap)
@@ -186,6 +199,25 @@ class PropagationEngine:
                                  g2=self.g_final, loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True)
             torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
             loss[2:3].mul_(ssl_lambda)
+        if self.xssl is not None:
+            # InfoNCE(layer-1 view, layer mean): the mean's share joins the BPR gradient in g_final's stored rows; the
+            # view's share (added into its own, cleared, panel) reaches E0 through one more product, A . g_view, below
+            g_view = self._views[1]
+            g_view.zero_()
+            ops.infonce_pair_raw(self._views[0], self.final, users, pos, self.U, temperature, g1=g_view, g2=self.g_final,
+                                 loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True)
+            torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
+            loss[2:3].mul_(ssl_lambda)
+            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True, mask=slot.bitmap)
+            # grad += A . g_view (d view / d E0 = A for the first layer): live rows of g_view are the batch's unique users
+            # and positives, a subset of the bitmap (its other rows read zeros)
+            ops.spmm_ex_raw(self.graph, g_view, sum_in=self.grad, sum_out=self.grad, x_rows=slot.bitmap)
+            if _adam_step > 0:
+                ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
+                                  self.betas[1], self.eps)
+            slot.free = main.record_event()
+            self._final_version = -1
+            return loss
         if _adam_step > 0:
             self.graph.propagate_mean_bwd_adam_raw(self.g_final, self.K, self.inc, self.grad, True, slot.bitmap, self.params,
                                                    self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],

@@ -248,26 +248,40 @@ class _SpMMNoise(torch.autograd.Function):
     """Y = A.X, Y += sign(Y) * normalize(U[0,1)) * eps.  d Y / d X = A (sign has zero gradient)."""
 
     @staticmethod
-    def forward(ctx, X, graph, eps):
+    def forward(ctx, X, graph, eps, stream):
         _require_device(X)
         X = _f32c(X, "X")
         ctx.graph = graph
-        d = X.shape[1]
-        Y = torch.empty((graph.n_rows, d), dtype=torch.float32, device=X.device)
-        seed, stream_id = _next_noise_stream()
-        ws = graph._workspace("spmm", d)
-        check(lib.idg_spmm_noise_f32(graph._h, _ptr(X), d, _ptr(Y), d, d, float(eps), C.c_uint64(seed),
-                                     C.c_uint64(stream_id), _ptr(ws), _stream()), "idg_spmm_noise_f32")
-        return Y
+        seed, stream_id = _next_noise_stream() if stream is None else stream
+        return spmm_noise_raw(graph, X, eps, seed, stream_id)
 
     @staticmethod
     def backward(ctx, gY):
-        return ctx.graph.T.spmm_raw(gY), None, None
+        return ctx.graph.T.spmm_raw(gY), None, None, None
 
 
-def spmm_perturbed(graph, X, eps):
-    """One SimGCL/XSimGCL layer: torch.sparse.mm followed by the in-place noise (models/XSimGCL.py:51-54)."""
-    return _SpMMNoise.apply(X, graph, float(eps))
+def spmm_noise_raw(graph, X, eps, seed, stream_id, out=None, out_rows=None):
+    """idg_spmm_noise_f32: one perturbed layer; out_rows: bitmap of the rows to produce."""
+    _require_device(X, out, out_rows)
+    d = X.shape[1]
+    Y = torch.empty((graph.n_rows, d), dtype=torch.float32, device=X.device) if out is None else out
+    ws = graph._workspace("spmm", d)
+    check(lib.idg_spmm_noise_f32(graph._h, _ptr(X), d, _ptr(Y), d, _ptr(out_rows), d, float(eps), C.c_uint64(seed),
+                                 C.c_uint64(stream_id), _ptr(ws), _stream()), "idg_spmm_noise_f32")
+    return Y
+
+
+def spmm_perturbed(graph, X, eps, stream=None):
+    """One SimGCL/XSimGCL layer: torch.sparse.mm followed by the in-place noise (models/XSimGCL.py:51-54).
+    stream: (seed, stream id) of the noise; default: the next one of the device seed's sequence."""
+    return _SpMMNoise.apply(X, graph, float(eps), stream)
+
+
+def layer_noise_stream(pass_stream, layer):
+    """Noise stream of layer `layer` (1-based) of a perturbed K-layer pass drawn as ONE (seed, stream id) —
+    what idg_propagate_mean_noise_f32 uses internally, so a layer can be re-produced on its own."""
+    seed, sid = pass_stream
+    return seed, sid * 64 + int(layer)
 
 
 class _PropagateViews(torch.autograd.Function):

@@ -161,10 +161,12 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
                     void* stream);
 
 /* One perturbed layer (models/XSimGCL.py:51-54): Y = A.X;  Y += sign(Y) * normalize(u, dim=-1) * eps,
- * u ~ U[0,1)^d from Philox4x32-10(seed; stream_id, row, feature block).  d in {32,...,512}. */
+ * u ~ U[0,1)^d from Philox4x32-10(seed; stream_id, row, feature block).  d in {32,...,512}.
+ * out_rows (nullable): bitmap of the rows to produce.  Layer k of idg_propagate_mean_noise_f32(seed, s)
+ * draws from stream s * 64 + k: the same layer can be re-produced on its own. */
 int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
-                       int64_t d, float eps, uint64_t seed, uint64_t stream_id, void* ws,
-                       void* stream);
+                       const uint32_t* out_rows, int64_t d, float eps, uint64_t seed,
+                       uint64_t stream_id, void* ws, void* stream);
 
 /* LightGCN.aggregate (models/LightGCN.py:36-52) / SimGCL.aggregate(perturbed=False)
  * (models/SimGCL.py:39-60): out = mean over layers of E_k, E_{k+1} = A.E_k, k < K,

@@ -22,6 +22,16 @@ class XSimGCL(PackedRecommender):
         self.temperature = float(config['temperature'])
         self.cl_layer = int(config['cl_layer'])
         self.attach_graph(data_graph.sparse_adjacency_matrix(dataset))
+        # the trainer's fused step (PropagationEngine with .xssl set: perturbed pass restricted to the batch's rows in
+        # its last layer, BPR, fused InfoNCE, backward + one extra sparse product for the view's gradient) covers the
+        # shipped configuration, cl_layer = 1; forward() below is the same computation under autograd for any cl_layer
+        self.supports_fused_step = self.cl_layer == 1
+        self.n_fused_losses = 3
+
+    def engine(self):
+        eng = super().engine()
+        eng.xssl = (self.epsilon, self.temperature, self.ssl_lambda)
+        return eng
 
     def aggregate(self, perturbed=False):
         U, I = self.dataset.num_users, self.dataset.num_items
@@ -29,8 +39,10 @@ class XSimGCL(PackedRecommender):
         if not perturbed:
             return torch.split(ops.propagate_mean(self.Graph, ego, self.n_layers, include_layer0=False), [U, I])
         x, total, view = ego, None, ego
+        pass_stream = ops._next_noise_stream()  # one noise stream per pass; layer k draws from its k-th sub-stream
         for layer in range(self.n_layers):
-            x = ops.spmm_perturbed(self.Graph, x, self.epsilon)  # SpMM + fused noise epilogue
+            # SpMM + fused noise epilogue
+            x = ops.spmm_perturbed(self.Graph, x, self.epsilon, stream=ops.layer_noise_stream(pass_stream, layer + 1))
             total = x if total is None else total + x
             if layer == self.cl_layer - 1:
                 view = x

@@ -270,6 +270,42 @@ def test_simgcl_runs_and_clean_view_matches_reference(tmp_path, golden_small):
     assert float(sum(ll)) < first  # five steps on one batch reduce its loss
 
 
+def test_xsimgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
+    """XSimGCL's fused trainer step (cl_layer = 1) against forward() under autograd + optimizer.step(), same noise
+    streams: three loss terms, gradients and weights over 3 steps."""
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.XSimGCL import XSimGCL
+
+    g = golden_small
+    data, cfg = _dataset(tmp_path, g, "small", learn_rate=0.001, ssl_lambda=0.2, temperature=0.15, epsilon=0.2, cl_layer=1,
+                         **BASE)
+    tri = torch.from_numpy(g["sample1"][:3 * 256]).cuda()
+    bt = [tuple(tri[i * 256:(i + 1) * 256, c].contiguous() for c in range(3)) for i in range(3)]
+    res = []
+    for fused in (True, False):
+        tools.set_seed(2024)
+        ops.reset_noise_stream()
+        model = XSimGCL(cfg, data, torch.device("cuda")).to("cuda")
+        assert model.supports_fused_step
+        opt = ops.Adam(model.parameters(), lr=0.001)
+        loss = torch.zeros((3, 3), device="cuda")
+        for i in range(3):
+            if fused:
+                assert model.fused_train_step(*bt[i], loss[i], opt)
+            else:
+                ll = model(*bt[i])
+                loss[i] = torch.stack([x.detach() for x in ll])
+                opt.zero_grad()
+                sum(ll).backward()
+                opt.step()
+        res.append((loss.cpu().numpy(), model.user_embedding.weight.grad.cpu().numpy(), model._storage.cpu().numpy()))
+    (l_f, g_f, w_f), (l_a, g_a, w_a) = res
+    np.testing.assert_allclose(l_f, l_a, rtol=2e-5)
+    np.testing.assert_allclose(g_f, g_a, rtol=1e-3, atol=1e-5 * np.abs(g_a).max())
+    np.testing.assert_allclose(w_f, w_a, rtol=1e-4, atol=1e-6)
+
+
 def test_simgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
     """The trainer's fused SimGCL step (row-restricted clean + perturbed passes, BPR, fused InfoNCE whose gradients
     join the BPR gradient before ONE shared backward propagation with Adam in its epilogue) against forward()
