@@ -179,6 +179,47 @@ int idg_sample_epoch(idg_rng* rng, const int64_t* train_user, const int64_t* tra
   return IDG_OK;
 }
 
+// Python's random.sample(range(n), k) (Lib/random.py, CPython 3.10+) on the same MT19937 stream the `random`
+// module owns (tools.create_adj_mat, utility/utility_function/tools.py:80, draws SGL's kept edges with it):
+//   _randbelow(m): b = m.bit_length(); r = getrandbits(b) until r < m;  getrandbits(b <= 32) = genrand_uint32() >> (32 - b)
+//   use_pool (n <= setsize, decided by the caller with random.py's own expression): partial Fisher-Yates over a pool;
+//   otherwise: draw until unseen, membership kept in a bitmap.
+int idg_py_random_sample(idg_rng* rng, int64_t n, int64_t k, int use_pool, int64_t* out) {
+  IDG_REQUIRE(rng && (out || k == 0), "idg_py_random_sample: NULL argument");
+  IDG_REQUIRE(n >= 0 && k >= 0 && k <= n, "idg_py_random_sample: need 0 <= k <= n (n=%lld k=%lld)", (long long)n, (long long)k);
+  IDG_REQUIRE(n < ((int64_t)1 << 32), "idg_py_random_sample: populations of 2^32 or more are not supported");
+  auto bit_length = [](uint64_t m) {
+    int b = 0;
+    while (m) ++b, m >>= 1;
+    return b;
+  };
+  auto randbelow = [&](uint64_t m) -> uint64_t {  // m >= 1
+    const int b = bit_length(m);
+    uint64_t r;
+    do r = (uint64_t)(rng->next32() >> (32 - b));
+    while (r >= m);
+    return r;
+  };
+  if (use_pool) {
+    std::vector<int64_t> pool((size_t)n);
+    for (int64_t i = 0; i < n; ++i) pool[(size_t)i] = i;
+    for (int64_t i = 0; i < k; ++i) {
+      const uint64_t j = randbelow((uint64_t)(n - i));
+      out[i] = pool[(size_t)j];
+      pool[(size_t)j] = pool[(size_t)(n - i - 1)];
+    }
+  } else {
+    std::vector<uint64_t> seen((size_t)((n + 63) / 64), 0);
+    for (int64_t i = 0; i < k; ++i) {
+      uint64_t j = randbelow((uint64_t)n);
+      while (seen[(size_t)(j >> 6)] >> (j & 63) & 1) j = randbelow((uint64_t)n);
+      seen[(size_t)(j >> 6)] |= (uint64_t)1 << (j & 63);
+      out[i] = (int64_t)j;
+    }
+  }
+  return IDG_OK;
+}
+
 int idg_shuffle_perm(idg_rng* rng, int64_t n, int64_t* out_perm) {
   IDG_REQUIRE(rng && (out_perm || n == 0), "idg_shuffle_perm: NULL argument");
   IDG_REQUIRE(n >= 0, "idg_shuffle_perm: negative length");

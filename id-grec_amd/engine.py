@@ -47,6 +47,7 @@ class PropagationEngine:
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
         self.ssl = None        # (eps, temperature, ssl_lambda): SimGCL's perturbed views + InfoNCE inside the fused step
         self.xssl = None       # the same triple for XSimGCL (one perturbed pass, cl_layer = 1)
+        self.sgl = None        # (temperature, ssl_lambda, sub_graph_1, sub_graph_2): SGL's two edge-dropped views
         self._views = self._ssl_loss = None
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
@@ -130,7 +131,8 @@ class PropagationEngine:
         With self.ssl set (SimGCL): two noise-perturbed encoder passes next to the clean one, InfoNCE between
         them over the batch's unique users / positive items, its gradients added (times ssl_lambda) to the BPR
         gradient before the ONE backward propagation all three passes share; loss gets a third entry."""
-        loss = (self.loss if (self.ssl is None and self.xssl is None) else self._loss3) if loss_out is None else loss_out
+        three = self.ssl is not None or self.xssl is not None or self.sgl is not None
+        loss = (self._loss3 if three else self.loss) if loss_out is None else loss_out
         main = torch.cuda.current_stream()
         if self.graph is None:
             self.grad.zero_()
@@ -178,6 +180,15 @@ class PropagationEngine:
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
         else:
             self._forward_layer_by_layer(slot.bitmap)
+        if self.sgl is not None:
+            # SGL (models/SGL.py:75-101): the same encoder on two edge-dropped sub-graphs of this epoch; their layer
+            # means are contrasted at the batch's users / positives (raw ids, duplicates count)
+            temperature, ssl_lambda, sub_1, sub_2 = self.sgl
+            if self._views is None:
+                self._views = tuple(torch.empty_like(self.params) for _ in range(4))  # two views, their gradients
+                self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+            sub_1.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[0], out_rows=slot.bitmap)
+            sub_2.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[1], out_rows=slot.bitmap)
         if self.ssl is not None:
             # the views are read at rows of the batch only as well (unique users / positives: a subset of the bitmap)
             eps, temperature, ssl_lambda = self.ssl
@@ -199,6 +210,24 @@ class PropagationEngine:
                                  g2=self.g_final, loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True)
             torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
             loss[2:3].mul_(ssl_lambda)
+        if self.sgl is not None:
+            g_1, g_2 = self._views[2], self._views[3]
+            g_1.zero_()
+            g_2.zero_()
+            ops.infonce_pair_raw(self._views[0], self._views[1], users, pos, self.U, temperature, g1=g_1, g2=g_2,
+                                 loss=self._ssl_loss, dedup=False, grad_scale=ssl_lambda, accumulate=True)
+            torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
+            loss[2:3].mul_(ssl_lambda)
+            # three encoders, three backward propagations (each sub-graph is its own symmetric operator), one gradient
+            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True, mask=slot.bitmap)
+            sub_1.propagate_mean_bwd_raw(g_1, self.K, self.inc, out=self.grad, accumulate=True)
+            sub_2.propagate_mean_bwd_raw(g_2, self.K, self.inc, out=self.grad, accumulate=True)
+            if _adam_step > 0:
+                ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
+                                  self.betas[1], self.eps)
+            slot.free = main.record_event()
+            self._final_version = -1
+            return loss
         if self.xssl is not None:
             # InfoNCE(layer-1 view, layer mean): the mean's share joins the BPR gradient in g_final's stored rows; the
             # view's share (added into its own, cleared, panel) reaches E0 through one more product, A . g_view, below

@@ -94,6 +94,30 @@ class GlobalStream:
         return False
 
 
+def py_random_sample(n, k):
+    """random.sample(range(n), k) — same values, same final state of Python's `random` module — computed natively
+    (the module's MT19937 state is loaded into an idg_rng, advanced there and written back).  int64 array [k]."""
+    import random
+    from math import ceil, log
+
+    n, k = int(n), int(k)
+    if not 0 <= k <= n:
+        raise ValueError("Sample larger than population or is negative")
+    setsize = 21
+    if k > 5:
+        setsize += 4 ** ceil(log(k * 3, 4))  # random.py's own expression decides the branch
+    version, internal, gauss = random.getstate()
+    if version != 3 or len(internal) != 625:
+        raise RuntimeError("unexpected random.getstate() layout")
+    rng = Rng(0)
+    rng.set_state(np.asarray(internal[:624], dtype=np.uint32), int(internal[624]))
+    out = np.empty(k, dtype=np.int64)
+    check(lib.idg_py_random_sample(rng._h, n, k, int(n <= setsize), np_ptr(out, C.c_int64)), "idg_py_random_sample")
+    key, pos = rng.get_state()
+    random.setstate((version, tuple(int(x) for x in key) + (pos,), gauss))
+    return out
+
+
 def parse_ratings(path, counts=False):
     """Native Data.read_ratings (data_loader.py:48-70).
     Returns (users[E], items[E], line_users[L], max_user, max_item); with counts=True also

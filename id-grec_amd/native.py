@@ -31,6 +31,7 @@ PROTOTYPES = {
     "idg_sample_epoch": (C.c_int, [c_vp, c_i64p, c_i64p, C.c_int64, c_i64p, c_i32p, C.c_int64, C.c_int64,
                                    c_i64p, c_i64p]),
     "idg_shuffle_perm": (C.c_int, [c_vp, C.c_int64, c_i64p]),
+    "idg_py_random_sample": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int, c_i64p]),
     "idg_ratings_open": (C.c_int, [C.c_char_p, C.POINTER(c_vp), c_i64p, c_i64p, c_i64p, c_i64p]),
     "idg_ratings_read": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p, c_i64p]),
     "idg_ratings_destroy": (C.c_int, [c_vp]),

@@ -77,6 +77,13 @@ int idg_sample_epoch(idg_rng* rng, const int64_t* train_user, const int64_t* tra
 /* np.random.shuffle(np.arange(n)) (utility/utility_function/tools.py:41-42) */
 int idg_shuffle_perm(idg_rng* rng, int64_t n, int64_t* out_perm);
 
+/* random.sample(range(n), k) of Python's `random` module (CPython >= 3.10) on its own MT19937 stream — the
+ * draw of SGL's kept edges (utility/utility_function/tools.py:80, never seeded by the reference).  Load the
+ * module's state with idg_rng_set_state (random.getstate()[1]: 624 words + index), write it back afterwards.
+ * use_pool: the branch random.py takes (n <= 21 + 4 ** ceil(log(3k, 4)) for k > 5), decided by the caller
+ * with that very expression.  n < 2^32. */
+int idg_py_random_sample(idg_rng* rng, int64_t n, int64_t k, int use_pool, int64_t* out);
+
 /* ------------------------------------------------------------------------------------
  * HOST: rating-file parser and adjacency builder
  * ---------------------------------------------------------------------------------- */

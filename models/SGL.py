@@ -52,6 +52,16 @@ class SGL(PackedRecommender):
         return [bpr_loss, reg_loss, self.ssl_lambda * ssl]
 
 
+    supports_fused_step = True  # through fused_sgl_step (the sub-graphs change every epoch)
+    n_fused_losses = 3
+
+    def fused_sgl_step(self, user, positive, negative, sub_graph_1, sub_graph_2, loss_out, optimizer):
+        """forward() + backward() + optimizer.step() for single-graph views as one chain of kernels."""
+        eng = self.engine()
+        eng.sgl = (self.temperature, self.ssl_lambda, sub_graph_1, sub_graph_2)
+        return self.fused_train_step(user, positive, negative, loss_out, optimizer)
+
+
 class Trainer():
     def __init__(self, args, config, dataset, device, logger):
         self.model = SGL(config, dataset, device)
@@ -93,7 +103,17 @@ class Trainer():
             users, pos_items, neg_items = tools.shuffle(triples[:, 0], triples[:, 1], triples[:, 2])
             num_batch = len(users) // batch_size + 1
             step_losses = torch.zeros((num_batch, 3), dtype=torch.float32, device=device)
-            for batch_i, (b_u, b_p, b_n) in enumerate(tools.mini_batch(users, pos_items, neg_items, batch_size=batch_size)):
+            # one sub-graph per view ('ed' / 'nd'): the step runs as a fixed chain of kernels (PropagationEngine.sgl);
+            # per-layer graph lists ('rw') go through forward() under autograd
+            fused = not isinstance(sub_graph_1, list) and torch.device(device).type == "cuda"
+            users, pos_items, neg_items = users.contiguous(), pos_items.contiguous(), neg_items.contiguous()
+            batches = list(tools.mini_batch(users, pos_items, neg_items, batch_size=batch_size))
+            for batch_i, (b_u, b_p, b_n) in enumerate(batches):
+                if fused:
+                    if batch_i + 1 < len(batches):
+                        model.prefetch_batch(*batches[batch_i + 1])
+                    if model.fused_sgl_step(b_u, b_p, b_n, sub_graph_1, sub_graph_2, step_losses[batch_i], Optim):
+                        continue
                 loss_list = model(b_u, b_p, b_n, sub_graph_1, sub_graph_2)
                 step_losses[batch_i] = torch.stack([l.detach() for l in loss_list])
                 Optim.zero_grad()

@@ -431,6 +431,45 @@ def test_sgl_three_views_vs_reference(tmp_path, golden_small, golden_next):
     assert torch.allclose(u1, u2, rtol=1e-6, atol=1e-8) and torch.allclose(i1, i2, rtol=1e-6, atol=1e-8)
 
 
+def test_sgl_fused_step_equals_autograd_step(tmp_path, golden_small, golden_next):
+    """SGL's fused trainer step (three row-restricted encoder passes, BPR, InfoNCE over the raw batch ids, three
+    backward propagations into one gradient, Adam) against forward() under autograd + optimizer.step()."""
+    import scipy.sparse as sp
+
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.SGL import SGL
+
+    g, nx = golden_small, golden_next
+    cfg = _cfg("SGL")
+    data = _data_with(tmp_path, g, cfg)
+    n = data.num_users + data.num_items
+    tri = torch.from_numpy(g["sample1"][:3 * 256]).cuda()
+    bt = [tuple(tri[i * 256:(i + 1) * 256, c].contiguous() for c in range(3)) for i in range(3)]
+    res = []
+    for fused in (True, False):
+        tools.set_seed(2024)
+        m = SGL(cfg, data, torch.device("cuda")).to("cuda")
+        subs = [tools.convert_sp_mat_to_graph(sp.csr_matrix((nx[k + "_data"], nx[k + "_indices"], nx[k + "_indptr"]), shape=(n, n)),
+                                              torch.device("cuda")) for k in ("sgl_sub1", "sgl_sub2")]
+        opt = ops.Adam(m.parameters(), lr=0.001)
+        loss = torch.zeros((3, 3), device="cuda")
+        for i in range(3):
+            if fused:
+                assert m.fused_sgl_step(*bt[i], subs[0], subs[1], loss[i], opt)
+            else:
+                ll = m(*bt[i], subs[0], subs[1])
+                loss[i] = torch.stack([x.detach() for x in ll])
+                opt.zero_grad()
+                sum(ll).backward()
+                opt.step()
+        res.append((loss.cpu().numpy(), m.user_embedding.weight.grad.cpu().numpy(), m._storage.cpu().numpy()))
+    (l_f, g_f, w_f), (l_a, g_a, w_a) = res
+    np.testing.assert_allclose(l_f, l_a, rtol=2e-5)
+    np.testing.assert_allclose(g_f, g_a, rtol=1e-3, atol=3e-4 * np.abs(g_a).max())
+    np.testing.assert_allclose(w_f, w_a, rtol=1e-4, atol=1e-6)
+
+
 def test_sgl_trainer_loop_runs(tmp_path, golden_small):
     import utility.utility_function.tools as tools
     from models.SGL import Trainer

@@ -136,3 +136,21 @@ def test_adjacency_isolated_nodes_and_empty():
     assert np.isfinite(dv).all()
     ip, ix, dv = H.build_norm_adj(2, 2, np.array([], dtype=np.int64), np.array([], dtype=np.int64))
     assert ip.tolist() == [0, 0, 0, 0, 0] and len(ix) == 0
+
+
+@pytest.mark.parametrize("n,k", [(10, 3), (10, 10), (100, 90), (1000, 5), (1000, 6), (5000, 40), (100000, 90000),
+                                 (100000, 10), (1, 1), (0, 0), (77, 21), (1 << 20, 3)])
+def test_py_random_sample_is_pythons_random_sample(n, k):
+    """tools.create_adj_mat keeps int((1 - ssl_rate) * E) edges chosen by random.sample (tools.py:80): the native
+    restatement returns the same list and leaves Python's `random` module in the same state (both branches of
+    random.py: pool and rejection-by-set)."""
+    import random
+
+    for seed in (1, 2024):
+        random.seed(seed)
+        want, nxt = random.sample(range(n), k), random.random()
+        random.seed(seed)
+        got = H.py_random_sample(n, k)
+        assert got.tolist() == want and random.random() == nxt
+    with pytest.raises(ValueError):
+        H.py_random_sample(3, 4)

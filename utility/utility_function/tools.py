@@ -92,8 +92,6 @@ def create_adj_mat(inter_graph, aug_type, ssl_rate):
     python's `random.sample` (never seeded by the reference), rebuild the symmetric bipartite
     adjacency on the kept edges and normalise it — natively, through idg_build_norm_adj.
     Returns a scipy CSR float32 matrix like the reference."""
-    import random
-
     import scipy.sparse as sp
 
     num_users, num_items = inter_graph.get_shape()
@@ -103,9 +101,10 @@ def create_adj_mat(inter_graph, aug_type, ssl_rate):
     if aug_type not in ('ed', 'rw'):
         raise ValueError("unknown aug_type %r" % (aug_type,))
     edge_number = inter_graph.count_nonzero()
-    keep_index = random.sample(range(edge_number), k=int((1 - ssl_rate) * edge_number))
-    keep_users = np.array(user_index)[keep_index]
-    keep_items = np.array(item_index)[keep_index]
+    # random.sample(range(edge_number), k) — the same draws from Python's `random` stream, taken natively
+    keep_index = _host.py_random_sample(edge_number, int((1 - ssl_rate) * edge_number))
+    keep_users = np.asarray(user_index)[keep_index]
+    keep_items = np.asarray(item_index)[keep_index]
     indptr, indices, values = _host.build_norm_adj(num_users, num_items, keep_users, keep_items)
     n = num_users + num_items
     return sp.csr_matrix((values, indices, indptr), shape=(n, n))
