@@ -537,3 +537,44 @@ def test_training_is_bit_reproducible_run_to_run(tmp_path, golden_small):
         outs.append((lines, model.user_embedding.weight.detach().clone(), model.item_embedding.weight.detach().clone()))
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("model_name", ["LightGCN", "MFBPR", "SimGCL"])
+def test_main_py_entry_point_end_to_end(model_name, tmp_path, golden_small):
+    """`python main.py --model=<M>` exactly as a user of the reference would run it: working directory with
+    ./configure/<M>.txt, ./dataset/<name>/{train,test}.txt and ./log/; two epochs; the log file is written in the
+    reference's layout and the losses are finite and decreasing."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / "run"
+    work.mkdir()
+    for name in ("main.py", "Parser.py", "idgrec_amd.py", "models", "utility", "id-grec_amd"):
+        os.symlink(os.path.join(root, name), work / name)
+    (work / "configure").mkdir()
+    cfg = open(os.path.join(root, "configure", model_name + ".txt")).read().splitlines()
+    over = {"training_epochs": "2", "interval": "1", "dataset": "small", "batch_size": "256", "test_batch_size": "64",
+            "top_K": "[5, 10]"}
+    lines = []
+    for ln in cfg:
+        key = ln.split("=")[0].strip()
+        lines.append("%s = %s" % (key, over[key]) if key in over else ln)
+    (work / "configure" / (model_name + ".txt")).write_text("\n".join(lines) + "\n")
+    d = work / "dataset" / "small"
+    d.mkdir(parents=True)
+    (d / "train.txt").write_bytes(golden_small["train_txt"].tobytes())
+    (d / "test.txt").write_bytes(golden_small["test_txt"].tobytes())
+    (work / "log").mkdir()
+    out = subprocess.run([sys.executable, "main.py", "--model=" + model_name], cwd=str(work), capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, PYTHONPATH=""))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Model training process completed." in out.stdout
+    log = (work / "log" / model_name / "small.log").read_text().splitlines()
+    assert any("Run with %s on small" % model_name in ln for ln in log)
+    losses = [float(ln.split("training loss: ")[1].split(" = ")[0]) for ln in log if "training loss: " in ln]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0]
+    assert sum("Test recall" in ln for ln in log) == 2
+    shutil.rmtree(work / "log")
