@@ -74,7 +74,7 @@ def main():
     try:
         trainer_cls = importlib.import_module('models.' + model_name).Trainer
     except ModuleNotFoundError as err:
-        raise SystemExit("models/%s.py is not part of this build (%s). Implemented: MFBPR, LightGCN, SimGCL, XSimGCL, SGL, NGCF."
+        raise SystemExit("models/%s.py is not part of this build (%s). Implemented: MFBPR, LightGCN, SimGCL, XSimGCL, SGL, NGCF, EGCF."
                          % (model_name, err))
     config = tools.read_configuration('./configure/' + model_name + ".txt", model_name)
     logger = open_logger(model_name, config['dataset'])

@@ -578,3 +578,57 @@ def test_main_py_entry_point_end_to_end(model_name, tmp_path, golden_small):
     assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0]
     assert sum("Test recall" in ln for ln in log) == 2
     shutil.rmtree(work / "log")
+
+
+@pytest.mark.parametrize("mode", ["parallel", "alternating"])
+def test_egcf_vs_reference(mode, tmp_path):
+    """EGCF (rectangular R / R^T operator pair) against the reference's encoder outputs, three loss
+    terms, item gradient and rating rows (tests/golden/egcf_small.npz, oracle/gen_golden_egcf.py), both modes."""
+    import os
+
+    import utility.utility_function.tools as tools
+    from models.EGCF import EGCF
+
+    eg = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "egcf_small.npz")))
+    cfg = dict(zip(eg["config_keys"].tolist(), eg["config_values"].tolist()))
+    cfg["mode"] = mode
+    data = _data_with(tmp_path, eg, cfg)  # the fixture carries its own dataset files
+    tools.set_seed(2024)
+    m = EGCF(cfg, data, torch.device("cuda")).to("cuda")
+    assert np.array_equal(m.item_embedding.weight.detach().cpu().numpy(), eg[mode + "_init_item"])
+    with torch.no_grad():
+        u, i = m.aggregate()
+    np.testing.assert_allclose(u.cpu().numpy(), eg[mode + "_user"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(i.cpu().numpy(), eg[mode + "_item"], rtol=1e-5, atol=1e-7)
+    b = torch.from_numpy(eg["batch"]).cuda()
+    ll = m(b[:, 0], b[:, 1], b[:, 2])
+    np.testing.assert_allclose([x.item() for x in ll], eg[mode + "_loss"], rtol=RTOL)
+    sum(ll).backward()
+    ref = eg[mode + "_grad_item"]
+    np.testing.assert_allclose(m.item_embedding.weight.grad.cpu().numpy(), ref, rtol=1e-3, atol=3e-4 * np.abs(ref).max())
+    m.eval()
+    users = torch.from_numpy(eg["rating_users"]).cuda()
+    np.testing.assert_allclose(m.get_rating_for_test(users).cpu().numpy(), eg[mode + "_rating"], rtol=1e-5, atol=1e-6)
+    top = m.topk_for_test(users, 10).cpu().numpy()
+    dense = m.get_rating_for_test(users).cpu().numpy()
+    for r, uid in enumerate(eg["rating_users"]):
+        dense[r, data.all_positive[int(uid)]] = -1
+    ok, msg = __import__("oracle.oracle", fromlist=["x"]).topk_is_valid(dense, top, 10, tol=2e-6)
+    assert ok, msg
+
+
+def test_egcf_trainer_loop_runs(tmp_path, golden_small):
+    import utility.utility_function.tools as tools
+    from models.EGCF import Trainer
+
+    cfg = _cfg("EGCF", training_epochs=2, batch_size=256, test_batch_size=64, top_K="[5, 10]")
+    data = _data_with(tmp_path, golden_small, cfg)
+    stream = io.StringIO()
+    logger = logging.getLogger("egcf_loop")
+    logger.setLevel(logging.INFO)
+    logger.handlers = [logging.StreamHandler(stream)]
+    tools.set_seed(2024)
+    Trainer(None, cfg, data, torch.device("cuda"), logger).train()
+    lines = stream.getvalue().splitlines()
+    losses_ = [float(ln.split("training loss: ")[1].split(" = ")[0]) for ln in lines if "training loss: " in ln]
+    assert len(losses_) == 2 and losses_[1] < losses_[0]
