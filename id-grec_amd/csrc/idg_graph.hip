@@ -9,7 +9,7 @@
 //     partials live in LDS and the workgroup combines them itself ("local" rows).  A longer
 //     row is first cut into chunks of CHUNK_NNZ entries; each chunk is such a local row whose
 //     sum goes to a global partial slot, and the chunk sums are combined in the same 4-way
-//     order by the fix-up kernel (or by the last workgroup to arrive, IDG_FUSED_FIX).
+//     order by the last workgroup to arrive (IDG_FUSED_FIX=0: by a separate fix-up kernel).
 //   * consecutive vrows are packed into tiles of <= tile_cap entries and <= TILE_VROWS
 //     vrows.  One 256-thread workgroup per tile stages the tile's (column,value) pairs and
 //     vrow pointers in LDS with coalesced loads, then LPR = d/4 lanes walk one vrow each:

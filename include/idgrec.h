@@ -130,7 +130,9 @@ typedef struct idg_graph idg_graph;
  * row-block tile schedule.  split_threshold: rows with more stored entries than this are
  * cut into segments summed in a fixed published order (0 = library default 128; ignored with
  * EXACT_ORDER).  Rows of up to 512 entries are combined inside one workgroup (LDS); longer rows go
- * through one global partial per 512-entry chunk (workspace = n_long_chunks x d floats). */
+ * through one global partial per 512-entry chunk (workspace = n_long_chunks x d floats).  A handle
+ * owns the arrival counters of its chunked rows: launches that use one handle must be ordered (one
+ * stream, or events between streams); different handles are independent. */
 int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                      const int32_t* indices, const float* values, uint32_t flags,
                      int64_t split_threshold, idg_graph** out);
