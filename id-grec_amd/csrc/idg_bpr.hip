@@ -237,8 +237,20 @@ static void launch_lds_sort(const int32_t* keys, const int32_t* slots, int n3, i
 }
 
 // One wave per sorted position that starts a run of equal rows.
+template <int NT>
+__device__ __forceinline__ void bpr_reduce_block(const float* __restrict__ loss_i, const float* __restrict__ sq, int64_t B,
+                                                 float reg_lambda, float* __restrict__ loss, float (*s)[1024]);
+
+// loss_out != NULL: one extra trailing workgroup reduces the per-triple loss terms while the others scatter (the
+// loss is on nobody's critical path; as its own launch it cost 6 us between the forward and the backward)
 __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int32_t* __restrict__ skeys,
-                                                            const int32_t* __restrict__ sslots) {
+                                                            const int32_t* __restrict__ sslots, float reg_lambda,
+                                                            float* __restrict__ loss_out) {
+  if (loss_out && blockIdx.x == gridDim.x - 1) {
+    __shared__ float s_red[4][1024];
+    bpr_reduce_block<BLOCK>(a.loss_i, a.sq, a.B, reg_lambda, loss_out, s_red);
+    return;
+  }
   const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int lane = threadIdx.x % WAVE;
   const int64_t n3 = 3 * a.B;
@@ -291,23 +303,26 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
 }
 
 // loss[0] = mean(loss_i); loss[1] = reg_lambda * sum_blocks 0.5 * (sqrt(sum sq))^2 / B
-__global__ __launch_bounds__(1024) void bpr_reduce_kernel(const float* __restrict__ loss_i,
-                                                          const float* __restrict__ sq, int64_t B, float reg_lambda,
-                                                          float* __restrict__ loss) {
-  __shared__ float s[4][1024];
+// One workgroup of NT threads plays the 1024 "virtual threads" of a fixed reduction tree, so that the result does not
+// depend on NT (the fused step runs this inside the scatter launch with 256 threads, the stand-alone kernel with 1024).
+template <int NT>
+__device__ __forceinline__ void bpr_reduce_block(const float* __restrict__ loss_i, const float* __restrict__ sq, int64_t B,
+                                                 float reg_lambda, float* __restrict__ loss, float (*s)[1024]) {
   const int tid = threadIdx.x;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t i = tid; i < B; i += 1024) {
-    acc[0] += loss_i[i];
-    acc[1] += sq[i];
-    acc[2] += sq[B + i];
-    acc[3] += sq[2 * B + i];
+  for (int vt = tid; vt < 1024; vt += NT) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = vt; i < B; i += 1024) {
+      acc[0] += loss_i[i];
+      acc[1] += sq[i];
+      acc[2] += sq[B + i];
+      acc[3] += sq[2 * B + i];
+    }
+    for (int q = 0; q < 4; ++q) s[q][vt] = acc[q];
   }
-  for (int q = 0; q < 4; ++q) s[q][tid] = acc[q];
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
-    if (tid < o)
-      for (int q = 0; q < 4; ++q) s[q][tid] += s[q][tid + o];
+    for (int vt = tid; vt < o; vt += NT)
+      for (int q = 0; q < 4; ++q) s[q][vt] += s[q][vt + o];
     __syncthreads();
   }
   if (tid == 0) {
@@ -320,6 +335,13 @@ __global__ __launch_bounds__(1024) void bpr_reduce_kernel(const float* __restric
     }
     loss[1] = reg_lambda * reg;
   }
+}
+
+__global__ __launch_bounds__(1024) void bpr_reduce_kernel(const float* __restrict__ loss_i,
+                                                          const float* __restrict__ sq, int64_t B, float reg_lambda,
+                                                          float* __restrict__ loss) {
+  __shared__ float s[4][1024];
+  bpr_reduce_block<1024>(loss_i, sq, B, reg_lambda, loss, s);
 }
 
 __global__ __launch_bounds__(BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -448,9 +470,9 @@ static int bpr_args(BprArgs& a, const BprWs& w, const float* final_panel, const 
   return IDG_OK;
 }
 
-int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
-                        const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
-                        float reg_lambda, float* loss, void* ws, void* stream) {
+static int bpr_forward_impl(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                            const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                            float reg_lambda, float* loss, void* ws, void* stream, bool reduce_now) {
   IDG_REQUIRE(loss, "idg_bpr_forward_f32: loss is NULL");
   hipStream_t st = (hipStream_t)stream;
   const BprWs w = bpr_layout(B > 0 ? B : 1, cub_temp_bound(3 * B));
@@ -460,9 +482,15 @@ int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_
   if (rc != IDG_OK) return rc;
   const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
   hipLaunchKernelGGL(bpr_triple_kernel, dim3(nb), dim3(BLOCK), 0, st, a);
-  hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, a.loss_i, a.sq, B, reg_lambda, loss);
+  if (reduce_now) hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, a.loss_i, a.sq, B, reg_lambda, loss);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
+}
+
+int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                        const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                        float reg_lambda, float* loss, void* ws, void* stream) {
+  return bpr_forward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, loss, ws, stream, true);
 }
 
 static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
@@ -525,10 +553,12 @@ int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* ne
   return bpr_sort_plan(users, pos, neg, B, num_users, n, ws, (hipStream_t)stream, "idg_bpr_plan_f32");
 }
 
-int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
-                         const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
-                         float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
-                         uint32_t* touched, void* ws, void* stream) {
+// loss_out != NULL (deterministic scatter only): the scatter launch also reduces the loss terms the forward left
+// in the workspace (the forward was then run without its own reduction)
+static int bpr_backward_impl(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                             float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
+                             uint32_t* touched, void* ws, void* stream, float* loss_out) {
   hipStream_t st = (hipStream_t)stream;
   IDG_REQUIRE(!touched || (deterministic && g_final != g_ego),
               "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter and g_final distinct from g_ego");
@@ -555,20 +585,31 @@ int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64
     const int32_t* skeys = reinterpret_cast<const int32_t*>(base + w.skeys);
     const int32_t* sslots = reinterpret_cast<const int32_t*>(base + w.sslots);
     const unsigned nb3 = (unsigned)((n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
-    hipLaunchKernelGGL(bpr_scatter_kernel, dim3(nb3), dim3(BLOCK), 0, st, a, skeys, sslots);
+    hipLaunchKernelGGL(bpr_scatter_kernel, dim3(nb3 + (loss_out ? 1u : 0u)), dim3(BLOCK), 0, st, a, skeys, sslots, reg_lambda,
+                       loss_out);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
+}
+
+int idg_bpr_backward_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
+                         const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
+                         float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
+                         uint32_t* touched, void* ws, void* stream) {
+  return bpr_backward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, upstream, g_final, g_ego,
+                           deterministic, touched, ws, stream, nullptr);
 }
 
 int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
                       const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
                       float reg_lambda, float* loss, float* g_final, float* g_ego, int deterministic,
                       uint32_t* touched, void* ws, void* stream) {
-  int rc = idg_bpr_forward_f32(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, loss, ws, stream);
+  // with a deterministic scatter the loss reduction rides in the scatter launch (same reduction tree, same bits)
+  const bool ride = deterministic != 0 && (g_final || g_ego);
+  int rc = bpr_forward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, loss, ws, stream, !ride);
   if (rc != IDG_OK) return rc;
-  return idg_bpr_backward_f32(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr,
-                              g_final, g_ego, deterministic, touched, ws, stream);
+  return bpr_backward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr, g_final, g_ego,
+                           deterministic, touched, ws, stream, ride ? loss : nullptr);
 }
 
 int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b, int64_t count, void* stream) {
