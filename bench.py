@@ -182,6 +182,8 @@ def main():
     if args.model == "SimGCL":
         import utility.utility_function.tools as tools
 
+        torch.cuda.manual_seed(args.seed)  # the noise streams follow the device seed: same seed, same run
+
         c = tools.read_configuration(os.path.join(ROOT, "configure", "SimGCL.txt"), "SimGCL")
         eng.ssl = (float(c["epsilon"]), float(c["temperature"]), float(c["ssl_lambda"]))
     eng.fuse_adam = not args.separate_adam
