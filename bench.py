@@ -256,6 +256,10 @@ def main():
             "bound": "hbm", "kernel": "spmm_tile_kernel<%d,1,8,dyn> (split rows combined in-kernel)" % (d // 4),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "us_per_launch": spmm_ms * 1e3, "launches_timed": len(dense),
+            # PMC-measured fabric-side bytes per launch over the launch time measured here: what the memory side of
+            # the L2s actually moved (Infinity-Cache hits included), as a rate and as a fraction of the HBM peak
+            "traffic_gbs": (traffic / (spmm_ms * 1e-3) / 1e9) if traffic else None,
+            "frac_traffic": (traffic / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "row_restricted_last_layer_us": rows_ms * 1e3,
             "bytes_gather": gather, "bytes_min": minimum,
             "frac_bytes_min": minimum / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
