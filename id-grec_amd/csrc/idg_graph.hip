@@ -780,6 +780,26 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
   }
 }
 
+// The perturbation on its own: Y[r] = X[r] + sign(X[r]) * normalize(u_r) * eps for every row (or the rows of a bitmap) —
+// the same arithmetic as the EPI_NOISE epilogue, so a layer whose product is shared between several perturbed passes
+// (SimGCL: A.E0 feeds the clean pass and both views) is perturbed once per view without being multiplied again.
+template <int LPR, int NB>
+__global__ __launch_bounds__(BLOCK) void perturb_rows_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t n,
+                                                             int64_t ld, Epilogue ep, const uint32_t* __restrict__ rows) {
+  constexpr int GROUPS = BLOCK / LPR;
+  const int64_t r = (int64_t)blockIdx.x * GROUPS + threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  if (r >= n) return;                        // whole lane groups leave together
+  if (rows && !mask_bit(rows, r)) return;
+  const float scale = noise_row_scale<LPR, NB>(ep, r, l);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int64_t o = r * ld + (b * LPR + l) * 4;
+    const float4 t = *reinterpret_cast<const float4*>(X + o);
+    *reinterpret_cast<float4*>(Y + o) = perturb(ep, r, b * LPR + l, scale, t);
+  }
+}
+
 // Any d: one wave per local row, its segments walked one after the other, combined in the published order.
 __global__ __launch_bounds__(BLOCK) void spmm_generic_local_kernel(const LocalRow* __restrict__ locals, int64_t n_local,
                                                                    const int64_t* __restrict__ vptr,
@@ -1299,6 +1319,32 @@ int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y
   ep.noise_seed = seed;
   ep.noise_stream = stream_id;
   return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, nullptr, out_rows);
+}
+
+int idg_perturb_f32(const float* X, float* Y, int64_t n, int64_t d, const uint32_t* rows, float eps, uint64_t seed,
+                    uint64_t stream_id, void* stream) {
+  IDG_REQUIRE(X && Y && n >= 0, "idg_perturb_f32: NULL argument");
+  IDG_REQUIRE(((uintptr_t)X | (uintptr_t)Y) % 16 == 0, "idg_perturb_f32: panels must be 16-byte aligned");
+  if (n == 0) return IDG_OK;
+  Epilogue ep{};
+  ep.noise_eps = eps;
+  ep.noise_seed = seed;
+  ep.noise_stream = stream_id;
+  hipStream_t st = (hipStream_t)stream;
+#define IDG_PERTURB(LPR, NB)                                                                                      \
+  hipLaunchKernelGGL((perturb_rows_kernel<LPR, NB>), dim3((unsigned)((n + BLOCK / LPR - 1) / (BLOCK / LPR))),     \
+                     dim3(BLOCK), 0, st, X, Y, n, d, ep, rows)
+  switch (d) {
+    case 32: IDG_PERTURB(8, 1); break;
+    case 64: IDG_PERTURB(16, 1); break;
+    case 128: IDG_PERTURB(32, 1); break;
+    case 256: IDG_PERTURB(64, 1); break;
+    case 512: IDG_PERTURB(64, 2); break;
+    default: return idg::fail(IDG_E_UNSUPPORTED, "idg_perturb_f32: d must be one of 32, 64, 128, 256, 512 (got %lld)", (long long)d);
+  }
+#undef IDG_PERTURB
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
 }
 
 size_t idg_propagate_workspace_bytes(const idg_graph* g, int64_t d) {

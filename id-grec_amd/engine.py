@@ -164,7 +164,18 @@ class PropagationEngine:
         self.touched = slot.bitmap
         # the BPR kernel reads the layer mean at the batch rows only: the last layer is restricted to them
         main.wait_event(slot.rows_done)
-        if self.xssl is not None:
+        if self.ssl is not None:
+            # SimGCL (models/SimGCL.py:62-66): the clean pass and two perturbed ones, read at rows of the batch only
+            # (unique users / positives are a subset of the bitmap); the first product is shared between the passes
+            eps, temperature, ssl_lambda = self.ssl
+            if self._views is None:
+                self._views = tuple(torch.empty_like(self.params) for _ in range(4))  # two views + two scratch panels
+                self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+            streams = [ops._next_noise_stream(), ops._next_noise_stream()]  # the sequence ops.propagate_views draws
+            ops.propagate_views_raw(self.graph, self.params, self.K, self.inc, eps, streams,
+                                    [self.final, self._views[0], self._views[1]], out_rows=slot.bitmap,
+                                    scratch=self._views[2:])
+        elif self.xssl is not None:
             # XSimGCL (models/XSimGCL.py:40-60): ONE perturbed pass; BPR reads its layer mean, InfoNCE contrasts the
             # first layer's output with that mean.  Both are wanted at rows of the batch only.
             eps, temperature, ssl_lambda = self.xssl
@@ -189,16 +200,6 @@ class PropagationEngine:
                 self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
             sub_1.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[0], out_rows=slot.bitmap)
             sub_2.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[1], out_rows=slot.bitmap)
-        if self.ssl is not None:
-            # the views are read at rows of the batch only as well (unique users / positives: a subset of the bitmap)
-            eps, temperature, ssl_lambda = self.ssl
-            if self._views is None:
-                self._views = (torch.empty_like(self.params), torch.empty_like(self.params))
-                self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
-            for view in self._views:  # same (seed, stream) sequence as ops.propagate_views draws
-                seed, stream_id = ops._next_noise_stream()
-                self.graph.propagate_mean_noise_raw(self.params, self.K, self.inc, eps, seed, stream_id, out=view,
-                                                    out_rows=slot.bitmap)
         main.wait_event(slot.plan_done)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled

@@ -284,6 +284,38 @@ def layer_noise_stream(pass_stream, layer):
     return seed, sid * 64 + int(layer)
 
 
+def perturb_raw(X, eps, seed, stream_id, out=None, rows=None):
+    """idg_perturb_f32: out = X + sign(X) * normalize(u) * eps row by row (the epilogue's perturbation on its own)."""
+    _require_device(X, out, rows)
+    X = _f32c(X, "X")
+    out = torch.empty_like(X) if out is None else out
+    check(lib.idg_perturb_f32(_ptr(X), _ptr(out), X.shape[0], X.shape[1], _ptr(rows), float(eps), C.c_uint64(seed),
+                              C.c_uint64(stream_id), _stream()), "idg_perturb_f32")
+    return out
+
+
+def propagate_views_raw(graph, E0, K, include_layer0, eps, streams, outs, out_rows=None, scratch=None):
+    """outs[0] = the clean layer mean of E0, outs[1 + i] = the perturbed one drawn from streams[i] = (seed, stream id)
+    (SimGCL's encoder passes, models/SimGCL.py:63-65).  Without layer 0 in the mean and K >= 2 the first product,
+    A.E0, is the same in every pass: it is computed ONCE, each view perturbs its own copy (sub-stream 0 of its
+    stream) and all passes continue from layer 2 — mean(X1..XK) = propagate_mean(X1, K - 1, include_layer0=True).
+    scratch: two [n, d] panels (allocated when None).  out_rows as in propagate_mean_raw."""
+    d = E0.shape[1]
+    shared = (not include_layer0) and K >= 2 and d in (32, 64, 128, 256, 512)
+    if not shared:
+        graph.propagate_mean_raw(E0, K, include_layer0, out=outs[0], out_rows=out_rows)
+        for out, (seed, sid) in zip(outs[1:], streams):
+            graph.propagate_mean_noise_raw(E0, K, include_layer0, eps, seed, sid, out=out, out_rows=out_rows)
+        return outs
+    T, X1 = scratch if scratch is not None else (torch.empty_like(E0), torch.empty_like(E0))
+    graph.spmm_raw(E0, out=T)
+    graph.propagate_mean_raw(T, K - 1, True, out=outs[0], out_rows=out_rows)
+    for out, (seed, sid) in zip(outs[1:], streams):
+        perturb_raw(T, eps, seed, sid * 64, out=X1)  # layer 1 of this view; layers 2..K draw sub-streams 1..K-1
+        graph.propagate_mean_noise_raw(X1, K - 1, True, eps, seed, sid, out=out, out_rows=out_rows)
+    return outs
+
+
 class _PropagateViews(torch.autograd.Function):
     """(clean, view_1, ..., view_n): the unperturbed layer mean and n independently perturbed ones.
     Every output has the same Jacobian w.r.t. E0 — (1/cnt) sum_k A^k — so backward adds the incoming
@@ -294,16 +326,9 @@ class _PropagateViews(torch.autograd.Function):
         _require_device(E0)
         E0 = _f32c(E0, "E0")
         ctx.graph, ctx.K, ctx.inc = graph, K, include_layer0
-        d = E0.shape[1]
-        outs = [graph.propagate_mean_raw(E0, K, include_layer0)]
-        ws = graph._workspace("prop", d)
-        for _ in range(n_views):
-            out = torch.empty_like(E0)
-            seed, stream_id = _next_noise_stream()
-            check(lib.idg_propagate_mean_noise_f32(graph._h, _ptr(E0), _ptr(out), None, int(K), int(bool(include_layer0)), d,
-                                                   float(eps), C.c_uint64(seed), C.c_uint64(stream_id), _ptr(ws),
-                                                   _stream()), "idg_propagate_mean_noise_f32")
-            outs.append(out)
+        outs = [torch.empty_like(E0) for _ in range(n_views + 1)]
+        streams = [_next_noise_stream() for _ in range(n_views)]
+        propagate_views_raw(graph, E0, K, include_layer0, eps, streams, outs)
         return tuple(outs)
 
     @staticmethod

@@ -176,6 +176,11 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
 int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy,
                        const uint32_t* out_rows, int64_t d, float eps, uint64_t seed,
                        uint64_t stream_id, void* ws, void* stream);
+/* The perturbation alone, Y[r] = X[r] + sign(X[r]) * normalize(u_r) * eps with the same generator and arithmetic
+ * as the epilogue form, for all n rows or the rows of a bitmap (nullable).  Lets passes that share a product
+ * (SimGCL: A.E0 feeds the clean pass and both perturbed views) perturb it without multiplying again. */
+int idg_perturb_f32(const float* X, float* Y, int64_t n, int64_t d, const uint32_t* rows, float eps,
+                    uint64_t seed, uint64_t stream_id, void* stream);
 
 /* LightGCN.aggregate (models/LightGCN.py:36-52) / SimGCL.aggregate(perturbed=False)
  * (models/SimGCL.py:39-60): out = mean over layers of E_k, E_{k+1} = A.E_k, k < K,
