@@ -632,3 +632,27 @@ def test_egcf_trainer_loop_runs(tmp_path, golden_small):
     lines = stream.getvalue().splitlines()
     losses_ = [float(ln.split("training loss: ")[1].split(" = ")[0]) for ln in lines if "training loss: " in ln]
     assert len(losses_) == 2 and losses_[1] < losses_[0]
+
+
+def test_sparsity_test_evaluation_path(tmp_path, golden_small, capsys):
+    """sparsity_test = 1 (batch_test.py:110-170): the four interaction-count buckets are evaluated through the fused
+    top-K path and printed in the reference's format; the first bucket is what general_test returns."""
+    import utility.utility_function.tools as tools
+    import utility.utility_train.batch_test as batch_test
+    from models.LightGCN import LightGCN
+
+    data, cfg = _dataset(tmp_path, golden_small, "small", learn_rate=0.001, **BASE)
+    cfg["sparsity_test"] = "1"
+    import utility.utility_data.data_loader as data_loader
+
+    data = data_loader.Data(str(tmp_path / "small"), cfg)  # the split is built when the flag is set at load time
+    tools.set_seed(2024)
+    model = LightGCN(cfg, data, torch.device("cuda")).to("cuda")
+    best = {'count': 0, 'epoch': 0, 'recall': [0., 0.], 'ndcg': [0., 0.], 'stop': 0}
+    result, best = batch_test.general_test(data, model, torch.device("cuda"), cfg, 0, best)
+    out = capsys.readouterr().out
+    assert all(("level_%d: recall:" % lv) in out for lv in (1, 2, 3, 4))
+    whole = batch_test.sparsity_test(data, model, torch.device("cuda"), cfg)
+    assert len(whole) >= 4 and np.allclose(result["recall"], whole[0]["recall"])
+    # every test user falls in exactly one bucket
+    assert sorted(u for bucket in data.split_test_dict for u in bucket) == sorted(data.test_dict.keys())
