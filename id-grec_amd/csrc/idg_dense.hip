@@ -112,3 +112,112 @@ int idg_linear_wgrad_f32(const float* X, int64_t ldx, const float* G, int64_t ld
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// NGCF's per-layer tail (models/NGCF.py:95-108), everything after the two thin GEMMs, as one pass over the rows:
+//     t = (S1 + b1) + (S2 + b2);  a = leaky_relu(t, 0.2);  e = dropout(a, p) (ALWAYS on: the reference builds
+//     nn.Dropout inside aggregate(), so it is in training mode during evaluation too);  nrm = normalize(e, dim=1)
+// and its backward.  The dropout mask is regenerated from (seed, stream, row, feature) in the backward pass; the sign of
+// t is recovered from e (where the mask kept the element; where it did not, the gradient is zero anyway), so the only
+// tensor kept for backward is e itself.  One wave per row, any width.
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t stream, int64_t row, int64_t f) {
+  // counter-based: one 64-bit mix (splitmix64 finaliser) of the element's coordinates; 24 bits feed the keep test
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (stream + 1) + (uint64_t)row * 0xBF58476D1CE4E5B9ull + (uint64_t)f * 0x94D049BB133111EBull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 40);  // 24 bits
+}
+__device__ __forceinline__ float keep_scale(float p, uint64_t seed, uint64_t stream, int64_t row, int64_t f) {
+  if (p <= 0.f) return 1.0f;
+  const float u = mix32(seed, stream, row, f) * (1.0f / 16777216.0f);  // [0, 1)
+  return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(BLOCK) void ngcf_tail_fwd_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                              const float* __restrict__ b1, const float* __restrict__ b2,
+                                                              int64_t n, int64_t d, float slope, float p, uint64_t seed,
+                                                              uint64_t stream, float* __restrict__ E,
+                                                              float* __restrict__ N) {
+  const int lane = threadIdx.x % 64;
+  const int64_t r = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  if (r >= n) return;
+  float ss = 0.f;
+  for (int64_t f = lane; f < d; f += 64) {
+    const float t = (S1[r * d + f] + b1[f]) + (S2[r * d + f] + b2[f]);
+    const float a = t > 0.f ? t : t * slope;
+    const float e = a * keep_scale(p, seed, stream, r, f);
+    E[r * d + f] = e;
+    ss += e * e;
+  }
+  ss = wsum(ss);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);
+  for (int64_t f = lane; f < d; f += 64) N[r * d + f] = E[r * d + f] / den;
+}
+
+// gT = d loss / d t given gE (through the layer's output as next ego) and gN (through its normalised copy)
+__global__ __launch_bounds__(BLOCK) void ngcf_tail_bwd_kernel(const float* __restrict__ E, const float* __restrict__ gE,
+                                                              const float* __restrict__ gN, int64_t n, int64_t d,
+                                                              float slope, float p, uint64_t seed, uint64_t stream,
+                                                              float* __restrict__ gT) {
+  const int lane = threadIdx.x % 64;
+  const int64_t r = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  if (r >= n) return;
+  float ss = 0.f, dot = 0.f;
+  for (int64_t f = lane; f < d; f += 64) {
+    const float e = E[r * d + f];
+    ss += e * e;
+    if (gN) dot += gN[r * d + f] * e;
+  }
+  ss = wsum(ss);
+  dot = wsum(dot);
+  const float nrm = sqrtf(ss);
+  const float den = fmaxf(nrm, 1e-12f);
+  for (int64_t f = lane; f < d; f += 64) {
+    const float e = E[r * d + f];
+    float g = gE ? gE[r * d + f] : 0.f;
+    if (gN) {
+      // y = e / max(||e||, eps): dy/de = (I - y y^T) / ||e|| above the clamp, I / eps below it
+      const float gn = gN[r * d + f];
+      g += nrm > 1e-12f ? (gn - dot * e / (den * den)) / den : gn / den;
+    }
+    const float k = keep_scale(p, seed, stream, r, f);
+    // t > 0  <=>  e > 0 wherever the element was kept (k > 0); dropped elements carry no gradient
+    gT[r * d + f] = g * k * (e > 0.f ? 1.0f : (e < 0.f ? slope : (k > 0.f ? slope : 0.f)));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int idg_ngcf_tail_f32(const float* S1, const float* S2, const float* b1, const float* b2, int64_t n, int64_t d,
+                      float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* E, float* N, void* stream) {
+  IDG_REQUIRE(S1 && S2 && b1 && b2 && E && N, "idg_ngcf_tail_f32: NULL argument");
+  IDG_REQUIRE(n >= 0 && d > 0 && p >= 0.f && p < 1.f, "idg_ngcf_tail_f32: bad sizes / drop probability");
+  if (n == 0) return IDG_OK;
+  hipLaunchKernelGGL(ngcf_tail_fwd_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, S1, S2, b1, b2, n, d, negative_slope, p, seed, stream_id, E, N);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_ngcf_tail_bwd_f32(const float* E, const float* gE, const float* gN, int64_t n, int64_t d, float negative_slope,
+                          float p, uint64_t seed, uint64_t stream_id, float* gT, void* stream) {
+  IDG_REQUIRE(E && gT && (gE || gN), "idg_ngcf_tail_bwd_f32: NULL argument");
+  IDG_REQUIRE(n >= 0 && d > 0 && p >= 0.f && p < 1.f, "idg_ngcf_tail_bwd_f32: bad sizes / drop probability");
+  if (n == 0) return IDG_OK;
+  hipLaunchKernelGGL(ngcf_tail_bwd_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, E, gE, gN, n, d, negative_slope, p, seed, stream_id, gT);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+}  // extern "C"

@@ -62,6 +62,10 @@ PROTOTYPES = {
     "idg_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "idg_linear_wgrad_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_int, c_vp,
                                        c_vp]),
+    "idg_ngcf_tail_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
+                                    c_vp, c_vp, c_vp]),
+    "idg_ngcf_tail_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
+                                        c_vp, c_vp]),
     "idg_infonce_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "idg_infonce_pair_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int, C.c_float,
                                        c_vp, c_vp, c_vp, C.c_float, C.c_int, c_vp, c_vp]),

@@ -567,6 +567,44 @@ def tall_linear(X, W):
     return _TallLinear.apply(X, W)
 
 
+class _NgcfTail(torch.autograd.Function):
+    """(E, N) = NGCF's layer tail of (S1, S2, b1, b2): leaky_relu((S1 + b1) + (S2 + b2)) -> dropout -> (itself,
+    its row-normalised copy) in one kernel; backward in one kernel + the bias column sums."""
+
+    @staticmethod
+    def forward(ctx, S1, S2, b1, b2, slope, p, stream):
+        _require_device(S1, S2, b1, b2)
+        S1, S2 = _f32c(S1, "S1"), _f32c(S2, "S2")
+        n, d = S1.shape
+        E, N = torch.empty_like(S1), torch.empty_like(S1)
+        seed, sid = stream
+        check(lib.idg_ngcf_tail_f32(_ptr(S1), _ptr(S2), _ptr(_f32c(b1.reshape(-1), "b1")), _ptr(_f32c(b2.reshape(-1), "b2")), n, d,
+                                    float(slope), float(p), C.c_uint64(seed), C.c_uint64(sid), _ptr(E), _ptr(N), _stream()),
+              "idg_ngcf_tail_f32")
+        ctx.save_for_backward(E)
+        ctx.args = (float(slope), float(p), seed, sid, b1.shape, b2.shape)
+        return E, N
+
+    @staticmethod
+    def backward(ctx, gE, gN):
+        (E,) = ctx.saved_tensors
+        slope, p, seed, sid, shape1, shape2 = ctx.args
+        n, d = E.shape
+        gE = None if gE is None else _f32c(gE, "gE")
+        gN = None if gN is None else _f32c(gN, "gN")
+        gT = torch.empty_like(E)
+        check(lib.idg_ngcf_tail_bwd_f32(_ptr(E), _ptr(gE), _ptr(gN), n, d, slope, p, C.c_uint64(seed), C.c_uint64(sid),
+                                        _ptr(gT), _stream()), "idg_ngcf_tail_bwd_f32")
+        gb = gT.sum(dim=0)
+        return gT, gT, gb.reshape(shape1), gb.reshape(shape2), None, None, None
+
+
+def ngcf_layer_tail(S1, S2, b1, b2, negative_slope=0.2, p=0.0, stream=None):
+    """(next ego, its L2-normalised copy) of one NGCF layer from the two transformed panels (models/NGCF.py:95-108).
+    stream: (seed, stream id) of the dropout mask; default: the next one of the device seed's sequence."""
+    return _NgcfTail.apply(S1, S2, b1, b2, negative_slope, p, _next_noise_stream() if stream is None else stream)
+
+
 # ----------------------------------------------------------------------------------- InfoNCE
 _ssl_ws = {}
 

@@ -293,6 +293,20 @@ int idg_linear_wgrad_f32(const float* X, int64_t ldx, const float* G, int64_t ld
                          int64_t d1, int64_t d2, float* w_grad, int accumulate, void* ws,
                          void* stream);
 
+/* NGCF's per-layer tail after the two thin GEMMs (models/NGCF.py:95-108), one pass over the rows:
+ *   t = (S1 + b1) + (S2 + b2);  a = leaky_relu(t, negative_slope);  E = dropout(a, p);  N = normalize(E, dim=1)
+ * (S1 = side.W_gcn, S2 = (ego * side).W_bi, all [n, d] row-major; b1, b2 [d]).  The dropout mask is a counter-based
+ * function of (seed, stream_id, row, feature) — always applied, as in the reference, where nn.Dropout is built
+ * inside aggregate() — and regenerated by the backward call, which needs only E:
+ *   gT = d loss / d t  given  gE (gradient through E as the next layer's input, nullable) and gN (through N, nullable);
+ * then gS1 = gS2 = gT, g b1 = g b2 = column sums of gT. */
+int idg_ngcf_tail_f32(const float* S1, const float* S2, const float* b1, const float* b2, int64_t n,
+                      int64_t d, float negative_slope, float p, uint64_t seed, uint64_t stream_id,
+                      float* E, float* N, void* stream);
+int idg_ngcf_tail_bwd_f32(const float* E, const float* gE, const float* gN, int64_t n, int64_t d,
+                          float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* gT,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------
  * DEVICE: in-batch InfoNCE between two views, forward + backward
  * (utility/utility_function/losses.py:24-35 get_InfoNCE_loss; call sites models/SimGCL.py:79-84,

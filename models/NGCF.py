@@ -39,13 +39,14 @@ class NGCF(PackedRecommender):
             w = self.weight_dict
             # [n, d] x [d, d]: forward / input gradient are small GEMMs, the weight gradient (all reduction over the
             # n rows) is the library's slice-summed kernel
-            summed = ops.tall_linear(side, w['W_gcn_%d' % layer]) + w['b_gcn_%d' % layer]
-            bi = ops.tall_linear(torch.mul(ego, side), w['W_bi_%d' % layer]) + w['b_bi_%d' % layer]
-            ego = nn.functional.leaky_relu(summed + bi, negative_slope=0.2)
-            # the reference instantiates nn.Dropout inside aggregate() (models/NGCF.py:104): a fresh module is
-            # always in training mode, so message dropout is applied during evaluation as well — kept as is
-            ego = nn.functional.dropout(ego, p=self.mess_dropout[layer], training=True)
-            layers.append(nn.functional.normalize(ego, p=2, dim=1))
+            s1 = ops.tall_linear(side, w['W_gcn_%d' % layer])
+            s2 = ops.tall_linear(torch.mul(ego, side), w['W_bi_%d' % layer])
+            # bias adds, LeakyReLU(0.2), message dropout and the L2-normalised copy in one kernel.  The reference
+            # instantiates nn.Dropout inside aggregate() (models/NGCF.py:104): a fresh module is always in training
+            # mode, so message dropout is applied during evaluation as well — kept as is
+            ego, normed = ops.ngcf_layer_tail(s1, s2, w['b_gcn_%d' % layer], w['b_bi_%d' % layer], 0.2,
+                                              self.mess_dropout[layer])
+            layers.append(normed)
         final = torch.cat(layers, dim=1)
         return torch.split(final, [self.dataset.num_users, self.dataset.num_items])
 

@@ -423,6 +423,39 @@ def test_linear_wgrad_vs_float64(ops, n, d1, d2):
     assert torch.allclose(Xt.grad, X2.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_ngcf_layer_tail_vs_torch_ops(ops, p):
+    """leaky_relu((S1 + b1) + (S2 + b2)) -> dropout -> (E, normalize(E)) and its backward against the stock op chain
+    (models/NGCF.py:95-108), using the kernel's own dropout mask for the torch side."""
+    rng = np.random.default_rng(int(p * 10))
+    n, d = 3000, 64
+    S1 = dev(rng.standard_normal((n, d)).astype(np.float32)).requires_grad_()
+    S2 = dev(rng.standard_normal((n, d)).astype(np.float32)).requires_grad_()
+    b1 = dev((rng.standard_normal((1, d)) * 0.1).astype(np.float32)).requires_grad_()
+    b2 = dev((rng.standard_normal((1, d)) * 0.1).astype(np.float32)).requires_grad_()
+    E, N = ops.ngcf_layer_tail(S1, S2, b1, b2, 0.2, p, stream=(1234, 7))
+    a = torch.nn.functional.leaky_relu((S1 + b1) + (S2 + b2), negative_slope=0.2)
+    mask = torch.where(E.detach() != 0, torch.full_like(E, 1.0 / (1.0 - p)), torch.zeros_like(E)) if p > 0 else torch.ones_like(E)
+    if p > 0:
+        drop = float((E == 0).float().mean())
+        assert abs(drop - p) < 0.01                                     # Bernoulli(1 - p) keep mask, scaled 1 / (1 - p)
+        E2, _ = ops.ngcf_layer_tail(S1, S2, b1, b2, 0.2, p, stream=(1234, 7))
+        assert torch.equal(E, E2)                                       # a function of (seed, stream, row, feature)
+        E3, _ = ops.ngcf_layer_tail(S1, S2, b1, b2, 0.2, p, stream=(1234, 8))
+        assert not torch.equal(E, E3)
+    Er = a * mask
+    Nr = torch.nn.functional.normalize(Er, p=2, dim=1)
+    assert torch.allclose(E, Er, rtol=1e-6, atol=1e-7) and torch.allclose(N, Nr, rtol=1e-5, atol=1e-7)
+    wE, wN = dev(rng.standard_normal((n, d)).astype(np.float32)), dev(rng.standard_normal((n, d)).astype(np.float32))
+    ((E * wE).sum() + (N * wN).sum()).backward()
+    mine = [t.grad.clone() for t in (S1, S2, b1, b2)]
+    for t in (S1, S2, b1, b2):
+        t.grad = None
+    ((Er * wE).sum() + (Nr * wN).sum()).backward()
+    for m, t in zip(mine, (S1, S2, b1, b2)):
+        assert torch.allclose(m, t.grad, rtol=2e-4, atol=2e-5 * float(t.grad.abs().max()))
+
+
 # --------------------------------------------------------------------------- InfoNCE
 @pytest.mark.parametrize("d,B,tau", [(64, 300, 0.2), (100, 77, 0.15), (256, 1024, 0.2), (32, 2048, 0.5)])
 def test_infonce_pair_vs_reference_formula(ops, d, B, tau):
