@@ -14,11 +14,11 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int T = 64;    // output tile edge
-constexpr int RC = 16;   // rows staged per round
+constexpr int RC = 32;   // rows staged per round
 constexpr int MAX_SLICES = 1024;
 
 inline int64_t n_slices(int64_t n) {
-  int64_t s = (n + 127) / 128;  // >= 128 rows per slice
+  int64_t s = (n + 63) / 64;  // >= 64 rows per slice: ~10^3 workgroups at 10^5 rows
   return s < 1 ? 1 : (s > MAX_SLICES ? MAX_SLICES : s);
 }
 
@@ -34,12 +34,27 @@ __global__ __launch_bounds__(BLOCK) void wgrad_partial_kernel(const float* __res
   const int64_t i0 = (int64_t)blockIdx.z * T, j0 = (int64_t)blockIdx.y * T;
   const int tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
   float acc[4][4] = {};
+  const bool vec = (ldx % 4 == 0) && (ldg % 4 == 0) && (((uintptr_t)X | (uintptr_t)G) % 16 == 0);
   for (int64_t r0 = r_lo; r0 < r_hi; r0 += RC) {
-    for (int e = tid; e < RC * T; e += BLOCK) {
-      const int rr = e / T, c = e % T;
-      const bool row_ok = r0 + rr < r_hi;
-      sx[rr][c] = (row_ok && i0 + c < d1) ? X[(r0 + rr) * ldx + i0 + c] : 0.f;
-      sg[rr][c] = (row_ok && j0 + c < d2) ? G[(r0 + rr) * ldg + j0 + c] : 0.f;
+    if (vec && i0 + T <= d1 && j0 + T <= d2) {
+      // 16-byte loads: RC rows x 16 float4 per operand, two per thread
+      for (int e = tid; e < RC * (T / 4); e += BLOCK) {
+        const int rr = e / (T / 4), c4 = (e % (T / 4)) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), g = x;
+        if (r0 + rr < r_hi) {
+          x = *reinterpret_cast<const float4*>(X + (r0 + rr) * ldx + i0 + c4);
+          g = *reinterpret_cast<const float4*>(G + (r0 + rr) * ldg + j0 + c4);
+        }
+        sx[rr][c4] = x.x, sx[rr][c4 + 1] = x.y, sx[rr][c4 + 2] = x.z, sx[rr][c4 + 3] = x.w;
+        sg[rr][c4] = g.x, sg[rr][c4 + 1] = g.y, sg[rr][c4 + 2] = g.z, sg[rr][c4 + 3] = g.w;
+      }
+    } else {
+      for (int e = tid; e < RC * T; e += BLOCK) {
+        const int rr = e / T, c = e % T;
+        const bool row_ok = r0 + rr < r_hi;
+        sx[rr][c] = (row_ok && i0 + c < d1) ? X[(r0 + rr) * ldx + i0 + c] : 0.f;
+        sg[rr][c] = (row_ok && j0 + c < d2) ? G[(r0 + rr) * ldg + j0 + c] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll

@@ -53,7 +53,12 @@ class NGCF(PackedRecommender):
     def forward(self, user, positive, negative):
         all_user, all_item = self.aggregate()
         bpr_loss = losses.get_bpr_loss(all_user[user.long()], all_item[positive.long()], all_item[negative.long()])
-        reg_loss = losses.get_reg_loss(self.item_embedding(positive), self.item_embedding(negative))
+        # get_reg_loss(item_embedding(positive), item_embedding(negative)) (models/NGCF.py:125; losses.py:16-21):
+        # sum_b 1/2 ||W[pos_b]||^2 + 1/2 ||W[neg_b]||^2 over the batch = sum_i count_i * 1/2 ||W_i||^2, which autograd
+        # differentiates as one dense product instead of two sort-based embedding backward passes
+        W = self.item_embedding.weight
+        count = torch.bincount(torch.cat([positive.long(), negative.long()]), minlength=W.shape[0]).to(W.dtype)
+        reg_loss = 0.5 * (count * (W * W).sum(dim=1)).sum() / float(len(user))
         return [bpr_loss, self.reg_lambda * reg_loss]
 
     def _eval_panels(self):
