@@ -39,7 +39,10 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(ROOT, "include", "idgrec.h"), os.path.join(CSRC, "idg_common.h")]
-    common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+    # -ffp-contract=off: the kernels spell out every fused multiply-add they want (fmaf); left to itself the compiler
+    # contracts a*b+c differently in different instantiations of the same source, and paths that must agree bit for
+    # bit (single- vs multi-panel kernels, epilogue vs stand-alone perturbation) then differ in the last place
+    common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off",
               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     jobs = []
     objs = []

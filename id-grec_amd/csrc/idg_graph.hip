@@ -190,10 +190,12 @@ __device__ __forceinline__ float sgn(float x) { return (float)(x > 0.f) - (float
 
 __device__ __forceinline__ float4 perturb(const Epilogue& ep, int64_t r, int fblock, float scale, float4 t) {
   const float4 u = noise4(ep, r, fblock);
-  t.x += sgn(t.x) * u.x * scale;
-  t.y += sgn(t.y) * u.y * scale;
-  t.z += sgn(t.z) * u.z * scale;
-  t.w += sgn(t.w) * u.w * scale;
+  // explicit fused multiply-adds: every instantiation that perturbs (epilogues, the stand-alone kernel, the multi-panel
+  // kernel) then rounds the same way, whatever the compiler would have contracted on its own
+  t.x = __builtin_fmaf(sgn(t.x) * u.x, scale, t.x);
+  t.y = __builtin_fmaf(sgn(t.y) * u.y, scale, t.y);
+  t.z = __builtin_fmaf(sgn(t.z) * u.z, scale, t.z);
+  t.w = __builtin_fmaf(sgn(t.w) * u.w, scale, t.w);
   return t;
 }
 
@@ -673,6 +675,116 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   }
 }
 
+// The row-restricted product for several panels at once (SimGCL's last forward layer: the clean pass and its
+// perturbed views all want the same rows of A.X for their own X).  The restricted kernel is bound by what surrounds
+// the walks — tile / pointer / bitmap loads, compaction, staging, barriers — and all of that is shared here: only the
+// walks (and the epilogues) run once per panel.  Panel 0 has epilogue EPI0, the others perturb (EPI_NOISE).
+// Chunked rows use the last-arriver combine with one partial region and one ticket array per panel.
+constexpr int MAX_PANELS = 3;
+struct MultiPanel {
+  const float* X[MAX_PANELS];
+  float* partials[MAX_PANELS];
+  int* cnt[MAX_PANELS];
+  Epilogue ep[MAX_PANELS];
+};
+
+template <int LPR, int NB, int NP, int EPI0>
+__global__ __launch_bounds__(BLOCK) void spmm_tile_rows_multi_kernel(const Tile* __restrict__ tiles,
+                                                                     const int64_t* __restrict__ vptr,
+                                                                     const int32_t* __restrict__ vtgt,
+                                                                     const int32_t* __restrict__ slot_row,
+                                                                     const ColVal* __restrict__ cv, MultiPanel mp,
+                                                                     int64_t ldx, int64_t d, FixCtx fx,
+                                                                     const uint32_t* __restrict__ out_mask,
+                                                                     const LocalRow* __restrict__ locals) {
+  constexpr int SLAB = LSLOTS * NB * LPR;
+  __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ float4 s_part[NP * SLAB];
+  __shared__ int s_ptr[TILE_VROWS + 1];
+  __shared__ int s_tgt[TILE_VROWS];
+  __shared__ int s_live[TILE_VROWS];
+  __shared__ int s_nlive;
+  __shared__ int s_next;
+
+  const Tile t = tiles[blockIdx.x];
+  {
+    uint32_t any = 0;
+    for (int w = t.row_first >> 5; w <= (t.row_last >> 5); ++w) {
+      uint32_t m = out_mask[w];
+      if (w == (t.row_first >> 5)) m &= ~0u << (t.row_first & 31);
+      if (w == (t.row_last >> 5)) m &= ~0u >> (31 - (t.row_last & 31));
+      any |= m;
+    }
+    if (any == 0) return;
+  }
+  const int tid = threadIdx.x;
+  const int nv = t.n_vrows;
+  const int64_t nz0 = t.nnz_begin;
+  constexpr int GROUPS = BLOCK / LPR;
+  if (tid == 0) {
+    s_nlive = 0;
+    s_next = GROUPS;
+  }
+  __syncthreads();
+  for (int i = tid; i <= nv; i += BLOCK) s_ptr[i] = (int)(vptr[t.vrow_begin + i] - nz0);
+  for (int i = tid; i < nv; i += BLOCK) {
+    const int tg = vtgt[t.vrow_begin + i];
+    s_tgt[i] = tg;
+    if (is_local(tg)) continue;
+    const int row = tg >= 0 ? tg : slot_row[~tg];
+    if (mask_bit(out_mask, row)) s_live[atomicAdd(&s_nlive, 1)] = i;
+  }
+  for (int j = tid; j < t.n_local; j += BLOCK) {
+    const LocalRow lr = locals[t.local_begin + j];
+    if (!mask_bit(out_mask, lr.tgt >= 0 ? lr.tgt : slot_row[~lr.tgt])) continue;
+    const int at = atomicAdd(&s_nlive, (int)lr.n_seg);
+    for (int q = 0; q < lr.n_seg; ++q) s_live[at + q] = lr.vrow - t.vrow_begin + q;
+  }
+  __syncthreads();
+  const int nlive = s_nlive;
+  if (nlive == 0) return;
+  const int cnt = s_ptr[nv];
+  {
+    const ColVal* src = cv + nz0;
+    for (int i = tid; i < cnt; i += BLOCK) s_cv[i] = src[i];
+  }
+  __syncthreads();
+
+  const int g = tid / LPR;
+  const int l = tid % LPR;
+  int q = g;
+  while (q < nlive) {
+    const int v = s_live[q];
+    const int vs = s_ptr[v], ve = s_ptr[v + 1], tg = s_tgt[v];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      FixCtx f = fx;
+      f.cnt = mp.cnt[p];
+      if (p == 0)
+        do_vrow<LPR, NB, 8, EPI0, true>(s_cv, vs, ve, tg, l, mp.X[p], ldx, mp.partials[p], d, mp.ep[p], f, s_part + p * SLAB);
+      else
+        do_vrow<LPR, NB, 8, EPI_NOISE, true>(s_cv, vs, ve, tg, l, mp.X[p], ldx, mp.partials[p], d, mp.ep[p], f,
+                                             s_part + p * SLAB);
+    }
+    int nxt = 0;
+    if (l == 0) nxt = atomicAdd(&s_next, 1);
+    q = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
+  }
+  if (t.n_local > 0) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      FixCtx f = fx;
+      f.cnt = mp.cnt[p];
+      if (p == 0)
+        combine_local<LPR, NB, EPI0, true>(t, locals, s_part + p * SLAB, g, l, mp.partials[p], d, mp.ep[p], f, out_mask, slot_row);
+      else
+        combine_local<LPR, NB, EPI_NOISE, true>(t, locals, s_part + p * SLAB, g, l, mp.partials[p], d, mp.ep[p], f, out_mask,
+                                                slot_row);
+    }
+  }
+}
+
 // EXACT_ORDER rows longer than a tile: one lane group streams the row from global memory.
 template <int LPR, int NB>
 __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__ xl,
@@ -957,6 +1069,25 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
   return IDG_OK;
 }
 
+template <int LPR, int NB>
+static int launch_rows_multi(const idg_graph* g, int np, const MultiPanel& mp, int64_t ldx, int64_t d,
+                             const uint32_t* out_rows, bool first_is_noise, hipStream_t st) {
+  FixCtx fx{g->d_long, g->d_slot_long, g->d_long_cnt, (uint32_t)(g->n_slots * d * (int64_t)sizeof(float))};
+  const bool cache_resident = (int64_t)g->n_cols * d * 4 <= BAND_PANEL_BYTES;
+  const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : g->d_tiles;
+  const dim3 grid((unsigned)g->n_tiles), block(BLOCK);
+#define IDG_MULTI(NP, E0)                                                                                              \
+  hipLaunchKernelGGL((spmm_tile_rows_multi_kernel<LPR, NB, NP, E0>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt, \
+                     g->d_slot_row, g->d_cv, mp, ldx, d, fx, out_rows, g->d_local)
+  if (np == 3 && !first_is_noise) IDG_MULTI(3, EPI_PLAIN);
+  else if (np == 2 && !first_is_noise) IDG_MULTI(2, EPI_PLAIN);
+  else if (np == 2 && first_is_noise) IDG_MULTI(2, EPI_NOISE);
+  else return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate_views: unsupported panel combination");
+#undef IDG_MULTI
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
 int64_t seg_len_for(int64_t len) {
   // ~sqrt(len) balances the parallel segment pass against the sequential fix-up pass.
   int64_t s = (int64_t)std::ceil(std::sqrt((double)len));
@@ -1215,7 +1346,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK) rc = upload(&g->d_long, longs);
   if (rc == IDG_OK) rc = upload(&g->d_slot_row, slot_row);
   if (rc == IDG_OK) rc = upload(&g->d_slot_long, slot_long);
-  if (rc == IDG_OK) rc = upload(&g->d_long_cnt, std::vector<int>(longs.size(), 0));
+  if (rc == IDG_OK) rc = upload(&g->d_long_cnt, std::vector<int>(longs.size() * MAX_PANELS, 0));  // one set per panel
   if (rc == IDG_OK) rc = upload(&g->d_xl, xl);
   if (rc != IDG_OK) {
     idg_graph_destroy(g);
@@ -1416,6 +1547,97 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
                            (!backward && last) ? out_rows : nullptr);
     if (rc != IDG_OK) return rc;
     X = P[(k - 1) & 1];
+  }
+  return IDG_OK;
+}
+
+// ---- clean pass + perturbed views with a shared first product and ONE multi-panel launch for the last layer ----
+size_t idg_propagate_views_workspace_bytes(const idg_graph* g, int64_t d, int n_views) {
+  if (!g || d <= 0 || n_views < 0 || n_views + 1 > MAX_PANELS) return 0;
+  const size_t panel = ((size_t)std::max(g->n_rows, g->n_cols) * (size_t)d * sizeof(float) + 255) / 256 * 256;
+  const size_t part = (idg_spmm_workspace_bytes(g, d) + 255) / 256 * 256;
+  return (size_t)(n_views + 1) * (2 * panel + part);
+}
+
+int idg_propagate_views_f32(const idg_graph* g, const float* E0, int K, int64_t d, float eps, int n_views,
+                            const uint64_t* seeds, const uint64_t* stream_ids, float* out_clean, float* const* out_views,
+                            const uint32_t* out_rows, void* ws, void* stream) {
+  IDG_REQUIRE(g && E0 && out_clean && ws, "idg_propagate_views_f32: NULL argument");
+  IDG_REQUIRE(g->n_rows == g->n_cols, "idg_propagate_views_f32: graph must be square");
+  IDG_REQUIRE(K >= 2, "idg_propagate_views_f32: needs K >= 2 (the first product is what the passes share)");
+  IDG_REQUIRE(n_views >= 1 && n_views + 1 <= MAX_PANELS && seeds && stream_ids && out_views,
+              "idg_propagate_views_f32: 1..%d views", MAX_PANELS - 1);
+  IDG_REQUIRE(d == 32 || d == 64 || d == 128 || d == 256 || d == 512, "idg_propagate_views_f32: d must be a tiled width");
+  hipStream_t st = (hipStream_t)stream;
+  const int np = n_views + 1;
+  const int64_t n = g->n_rows;
+  const size_t panel = ((size_t)n * (size_t)d * sizeof(float) + 255) / 256 * 256;
+  const size_t part = (idg_spmm_workspace_bytes(g, d) + 255) / 256 * 256;
+  char* base = reinterpret_cast<char*>(ws);
+  float* P[MAX_PANELS][2];
+  float* partials[MAX_PANELS];
+  float* outs[MAX_PANELS];
+  for (int p = 0; p < np; ++p) {
+    P[p][0] = reinterpret_cast<float*>(base + (size_t)p * (2 * panel + part));
+    P[p][1] = reinterpret_cast<float*>(base + (size_t)p * (2 * panel + part) + panel);
+    partials[p] = reinterpret_cast<float*>(base + (size_t)p * (2 * panel + part) + 2 * panel);
+    outs[p] = p == 0 ? out_clean : out_views[p - 1];
+    IDG_REQUIRE(outs[p] && (uintptr_t)outs[p] % 16 == 0, "idg_propagate_views_f32: output %d is NULL or unaligned", p);
+  }
+  IDG_REQUIRE((uintptr_t)E0 % 16 == 0, "idg_propagate_views_f32: E0 must be 16-byte aligned");
+  // layer 1, shared: T = A.E0
+  {
+    Epilogue ep{};
+    ep.ldy = d;
+    ep.div = 1.0f;
+    ep.Y = P[0][0];
+    int rc = spmm_dispatch(g, E0, d, d, partials[0], ep, st);
+    if (rc != IDG_OK) return rc;
+  }
+  for (int p = 1; p < np; ++p) {  // each view perturbs its own copy (sub-stream 0 of its stream)
+    int rc = idg_perturb_f32(P[0][0], P[p][0], n, d, nullptr, eps, seeds[p - 1], stream_ids[p - 1] * 64, stream);
+    if (rc != IDG_OK) return rc;
+  }
+  // layers 2..K: mean(X1..XK) = propagate_mean(X1, K - 1, include_layer0 = 1), per pass
+  const bool multi_ok = out_rows && g->n_tiles > 0 && g->n_xl == 0 && !g->no_fused_fix &&
+                        (g->n_slots * d * (int64_t)sizeof(float)) < ((int64_t)1 << 31);
+  for (int k = 2; k <= K; ++k) {
+    const bool last = (k == K);
+    MultiPanel mp{};
+    for (int p = 0; p < np; ++p) {
+      Epilogue ep{};
+      ep.ldy = d;
+      ep.div = last ? (float)K : 1.0f;
+      const float* Xp = P[p][(k - 2) & 1];
+      if (!last) ep.Y = P[p][(k - 1) & 1];
+      ep.sum_in = (k == 2) ? P[p][0] : outs[p];
+      ep.sum_out = outs[p];
+      if (p > 0) {
+        ep.noise_eps = eps;
+        ep.noise_seed = seeds[p - 1];
+        ep.noise_stream = stream_ids[p - 1] * 64 + (uint64_t)(k - 1);
+      }
+      mp.X[p] = Xp;
+      mp.partials[p] = partials[p];
+      mp.cnt[p] = g->d_long_cnt + (int64_t)p * g->n_long;
+      mp.ep[p] = ep;
+    }
+    if (last && multi_ok) {
+      int rc;
+      switch (d) {
+        case 32: rc = launch_rows_multi<8, 1>(g, np, mp, d, d, out_rows, false, st); break;
+        case 64: rc = launch_rows_multi<16, 1>(g, np, mp, d, d, out_rows, false, st); break;
+        case 128: rc = launch_rows_multi<32, 1>(g, np, mp, d, d, out_rows, false, st); break;
+        case 256: rc = launch_rows_multi<64, 1>(g, np, mp, d, d, out_rows, false, st); break;
+        default: rc = launch_rows_multi<64, 2>(g, np, mp, d, d, out_rows, false, st); break;
+      }
+      if (rc != IDG_OK) return rc;
+    } else {
+      for (int p = 0; p < np; ++p) {
+        int rc = spmm_dispatch(g, mp.X[p], d, d, partials[p], mp.ep[p], st, nullptr, last ? out_rows : nullptr);
+        if (rc != IDG_OK) return rc;
+      }
+    }
   }
   return IDG_OK;
 }

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "idg_spmm_noise_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64,
                                      c_vp, c_vp]),
     "idg_perturb_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, C.c_float, C.c_uint64, C.c_uint64, c_vp]),
+    "idg_propagate_views_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64, C.c_int]),
+    "idg_propagate_views_f32": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int64, C.c_float, C.c_int, C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64), c_vp, C.POINTER(C.c_void_p), c_vp, c_vp, c_vp]),
     "idg_propagate_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
     "idg_propagate_mean_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, c_vp, c_vp]),
     "idg_propagate_mean_noise_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_uint64,

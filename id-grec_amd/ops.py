@@ -294,6 +294,9 @@ def perturb_raw(X, eps, seed, stream_id, out=None, rows=None):
     return out
 
 
+_compose_views = [False]  # tests: True = assemble the passes from the single-purpose entry points instead
+
+
 def propagate_views_raw(graph, E0, K, include_layer0, eps, streams, outs, out_rows=None, scratch=None):
     """outs[0] = the clean layer mean of E0, outs[1 + i] = the perturbed one drawn from streams[i] = (seed, stream id)
     (SimGCL's encoder passes, models/SimGCL.py:63-65).  Without layer 0 in the mean and K >= 2 the first product,
@@ -306,6 +309,23 @@ def propagate_views_raw(graph, E0, K, include_layer0, eps, streams, outs, out_ro
         graph.propagate_mean_raw(E0, K, include_layer0, out=outs[0], out_rows=out_rows)
         for out, (seed, sid) in zip(outs[1:], streams):
             graph.propagate_mean_noise_raw(E0, K, include_layer0, eps, seed, sid, out=out, out_rows=out_rows)
+        return outs
+    if len(streams) <= 2 and not _compose_views[0]:
+        # one C call: shared first product, per-view perturbation, and (with out_rows) ONE multi-panel launch for the
+        # last layer of all passes — same values as the composition below
+        n_views = len(streams)
+        key = ("views", d, n_views)
+        ws = graph._ws.get(key)
+        if ws is None:
+            ws = graph._ws[key] = torch.empty(int(lib.idg_propagate_views_workspace_bytes(graph._h, d, n_views)),
+                                              dtype=torch.uint8, device=E0.device)
+        seeds = (C.c_uint64 * n_views)(*[int(sd) for sd, _ in streams])
+        sids = (C.c_uint64 * n_views)(*[int(si) for _, si in streams])
+        views = (C.c_void_p * n_views)(*[o.data_ptr() for o in outs[1:]])
+        _require_device(E0, out_rows, *outs)
+        check(lib.idg_propagate_views_f32(graph._h, _ptr(_f32c(E0, "E0")), int(K), d, float(eps), n_views, seeds, sids,
+                                          _ptr(outs[0]), views, _ptr(out_rows), _ptr(ws), _stream()),
+              "idg_propagate_views_f32")
         return outs
     T, X1 = scratch if scratch is not None else (torch.empty_like(E0), torch.empty_like(E0))
     graph.spmm_raw(E0, out=T)

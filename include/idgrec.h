@@ -182,6 +182,18 @@ int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y
 int idg_perturb_f32(const float* X, float* Y, int64_t n, int64_t d, const uint32_t* rows, float eps,
                     uint64_t seed, uint64_t stream_id, void* stream);
 
+/* SimGCL's encoder passes of one step (models/SimGCL.py:63-65) — the clean layer mean and n_views (1..2)
+ * perturbed ones, layer 0 not in the mean — as one call: the first product A.E0 is computed once, each view
+ * perturbs its own copy (sub-stream 0 of (seeds[i], stream_ids[i])) and continues with sub-streams 1..K-1 exactly as
+ * idg_propagate_mean_noise_f32(X1, K - 1, include_layer0 = 1) would; with out_rows the last layer of ALL passes is ONE
+ * launch of a multi-panel row-restricted kernel.  Same values as composing idg_spmm_f32, idg_perturb_f32,
+ * idg_propagate_mean_f32 and idg_propagate_mean_noise_f32 by hand.  K >= 2, tiled d.
+ * out_views: HOST array of n_views device pointers.  ws: idg_propagate_views_workspace_bytes. */
+size_t idg_propagate_views_workspace_bytes(const idg_graph* g, int64_t d, int n_views);
+int idg_propagate_views_f32(const idg_graph* g, const float* E0, int K, int64_t d, float eps, int n_views,
+                            const uint64_t* seeds, const uint64_t* stream_ids, float* out_clean,
+                            float* const* out_views, const uint32_t* out_rows, void* ws, void* stream);
+
 /* LightGCN.aggregate (models/LightGCN.py:36-52) / SimGCL.aggregate(perturbed=False)
  * (models/SimGCL.py:39-60): out = mean over layers of E_k, E_{k+1} = A.E_k, k < K,
  * E_0 included iff include_layer0.  Running sum left-to-right then a true division by the

@@ -456,6 +456,43 @@ def test_ngcf_layer_tail_vs_torch_ops(ops, p):
         assert torch.allclose(m, t.grad, rtol=2e-4, atol=2e-5 * float(t.grad.abs().max()))
 
 
+@pytest.mark.parametrize("d,K,n_views", [(64, 3, 2), (64, 2, 1), (256, 3, 2), (32, 4, 2)])
+def test_propagate_views_one_call_equals_composition(ops, d, K, n_views, monkeypatch):
+    """idg_propagate_views_f32 (shared first product, ONE multi-panel restricted launch for the last layer of all
+    passes, per-panel last-arriver tickets for chunked rows) against the same passes assembled from idg_spmm_f32 /
+    idg_perturb_f32 / idg_propagate_mean[_noise]_f32: identical bits, with and without a row bitmap."""
+    import idgrec_amd.host as H
+
+    rng = np.random.default_rng(d + K)
+    U, I = 2500, 900
+    eu = np.concatenate([rng.integers(0, U, 30000), rng.choice(U, 2000, replace=False), rng.choice(U, 700, replace=False)])
+    ei = np.concatenate([(rng.zipf(1.3, 30000) % I), np.full(2000, 5), np.full(700, 77)])
+    eu, ei = np.unique(np.stack([eu, ei]), axis=1)
+    ip, ix, dv = H.build_norm_adj(U, I, eu.astype(np.int64), ei.astype(np.int64))
+    n = U + I
+    G = ops.Graph(ip, ix, dv, n, n)
+    assert (G.long_rows()[2] > 0).sum() >= 2
+    E0 = dev((rng.standard_normal((n, d)) * 0.1).astype(np.float32))
+    rows = rng.choice(n, 400, replace=False)
+    rows = np.concatenate([rows, [U + 5, U + 77]])  # the chunked hub rows are requested too
+    bitmap = np.zeros((n + 31) // 32, dtype=np.uint32)
+    np.bitwise_or.at(bitmap, rows >> 5, (1 << (rows & 31)).astype(np.uint32))
+    bm = dev(bitmap.view(np.int32))
+    streams = [(1234, 5), (1234, 6)][:n_views]
+    for out_rows in (None, bm):
+        res = []
+        for composed in (False, True):
+            monkeypatch.setattr(ops, "_compose_views", [composed])
+            outs = [torch.full((n, d), float("nan"), device="cuda") for _ in range(n_views + 1)]
+            ops.propagate_views_raw(G, E0, K, False, 0.1, streams, outs, out_rows=out_rows)
+            res.append(outs)
+        sel = torch.from_numpy(rows).cuda() if out_rows is not None else slice(None)
+        for a, b in zip(*res):
+            assert torch.equal(a[sel], b[sel]) and not torch.isnan(a[sel]).any()
+        if n_views == 2:
+            assert not torch.equal(res[0][1][sel], res[0][2][sel])  # the two views differ
+
+
 # --------------------------------------------------------------------------- InfoNCE
 @pytest.mark.parametrize("d,B,tau", [(64, 300, 0.2), (100, 77, 0.15), (256, 1024, 0.2), (32, 2048, 0.5)])
 def test_infonce_pair_vs_reference_formula(ops, d, B, tau):
