@@ -71,7 +71,7 @@ def test_spmm_all_widths_exact_order(ops, d):
 
 
 @pytest.mark.parametrize("fused", ["0", "1"])
-@pytest.mark.parametrize("d,thr", [(64, 0), (64, 64), (256, 100), (48, 64)])
+@pytest.mark.parametrize("d,thr", [(64, 0), (64, 64), (256, 100), (48, 64), (32, 0), (128, 200), (512, 0)])
 def test_spmm_split_rows_follow_published_schedule(ops, d, thr, fused, monkeypatch):
     monkeypatch.setenv("IDG_FUSED_FIX", fused)  # separate fix-up launch (default) / in-kernel last-arriver combine
     # hub rows far above the split threshold, incl. one longer than a whole tile (2048)
