@@ -390,7 +390,10 @@ def run_sharded_bench(args, rank, world, dist):
     from . import synth as S
 
     U1, I, E1 = S.SHAPES[args.workload]
-    U, E = U1 * world, E1 * world
+    # weak scaling in the graph: one named-shape user block per rank — unless that would exceed any sensible host
+    # budget (BASELINE config 5 is ONE 10M-user graph cut across the ranks, not eight of them)
+    blocks = world if U1 * world <= 20_000_000 else 1
+    U, E = U1 * blocks, E1 * blocks
     users, items = S.generate(U, I, E, seed=0)           # every rank derives the same global graph
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
     deg_u = np.bincount(users, minlength=U)
@@ -448,10 +451,10 @@ def run_sharded_bench(args, rank, world, dist):
             "value": gB * args.steps / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d x %s-shape user blocks: %d users x %d items, %d train edges, nnz(A)=%d; "
+            "config": {"workload": "%d x %s-shape user blocks (graph cut across the ranks by user rows): %d users x %d items, %d train edges, nnz(A)=%d; "
                                    "LightGCN K=%d d=%d, B=%d per GPU (global %d); user rows sharded, item table "
                                    "replicated, %d all-reduces of [%d,%d] fp32 per step over %s"
-                                   % (world, args.workload, U, I, len(users), nnz, args.layers, args.dim, B, gB,
+                                   % (blocks, args.workload, U, I, len(users), nnz, args.layers, args.dim, B, gB,
                                       2 * args.layers + 1, I, args.dim,
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
                        "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "user-row shard x%d" % world},
