@@ -119,6 +119,9 @@ struct idg_graph {
   LocalRow* d_local = nullptr; // local rows, grouped by tile
   Tile* d_tiles = nullptr;         // heaviest-first order
   Tile* d_tiles_banded = nullptr;  // XCD column-band placement (used when the gathered panel is cache resident)
+  Tile* d_tiles_seq = nullptr;     // the bands one after the other (used when it is not): at any moment the chip gathers
+                                   // from one band's share of the panel — for the bipartite adjacency, first all user
+                                   // rows (item panel), then all item rows (user panel)
   LongRow* d_long = nullptr;
   int32_t* d_slot_row = nullptr;   // partial slot -> the row it belongs to
   int32_t* d_slot_long = nullptr;  // partial slot -> index into d_long
@@ -973,7 +976,7 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
     // Band placement pays while the gathered panel lives in L2 / Infinity Cache (measured: 17.8 and
     // 36.9 MB panels -16 %); beyond it the two bands differ too much in miss cost (384 MB panel +9 %).
     const bool cache_resident = (int64_t)g->n_cols * d * 4 <= BAND_PANEL_BYTES;
-    const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : g->d_tiles;
+    const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : (g->d_tiles_seq ? g->d_tiles_seq : g->d_tiles);
 #define IDG_TILE(U, DYN, MINW, EPI)                                                                            \
   do {                                                                                                         \
     if (fused_fix)                                                                                             \
@@ -1074,7 +1077,7 @@ static int launch_rows_multi(const idg_graph* g, int np, const MultiPanel& mp, i
                              const uint32_t* out_rows, bool first_is_noise, hipStream_t st) {
   FixCtx fx{g->d_long, g->d_slot_long, g->d_long_cnt, (uint32_t)(g->n_slots * d * (int64_t)sizeof(float))};
   const bool cache_resident = (int64_t)g->n_cols * d * 4 <= BAND_PANEL_BYTES;
-  const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : g->d_tiles;
+  const Tile* tile_order = (g->d_tiles_banded && cache_resident) ? g->d_tiles_banded : (g->d_tiles_seq ? g->d_tiles_seq : g->d_tiles);
   const dim3 grid((unsigned)g->n_tiles), block(BLOCK);
 #define IDG_MULTI(NP, E0)                                                                                              \
   hipLaunchKernelGGL((spmm_tile_rows_multi_kernel<LPR, NB, NP, E0>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt, \
@@ -1292,6 +1295,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   int bands = 8;
   if (const char* v = std::getenv("IDG_XCD_BANDS")) bands = std::atoi(v);
   const std::vector<Tile> tiles_plain = tiles;
+  std::vector<Tile> tiles_seq;
   bool banded = false;
   if ((bands == 2 || bands == 4 || bands == 8) && tiles.size() >= 64) {
     banded = true;
@@ -1312,6 +1316,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
     }
     std::vector<std::vector<Tile>> by_band((size_t)bands);
     for (size_t t = 0; t < nt; ++t) by_band[(size_t)band[t]].push_back(tiles[t]);  // keeps heaviest-first inside a band
+    for (const auto& bt : by_band) tiles_seq.insert(tiles_seq.end(), bt.begin(), bt.end());
     std::vector<size_t> cur((size_t)bands, 0);
     std::vector<Tile> placed;
     placed.reserve(nt);
@@ -1342,6 +1347,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK) rc = upload(&g->d_vtgt, vtgt);
   if (rc == IDG_OK) rc = upload(&g->d_tiles, tiles_plain);
   if (rc == IDG_OK && banded) rc = upload(&g->d_tiles_banded, tiles_banded);
+  if (rc == IDG_OK && banded && !std::getenv("IDG_NO_SEQ_BANDS")) rc = upload(&g->d_tiles_seq, tiles_seq);
   if (rc == IDG_OK) rc = upload(&g->d_local, locals);
   if (rc == IDG_OK) rc = upload(&g->d_long, longs);
   if (rc == IDG_OK) rc = upload(&g->d_slot_row, slot_row);
@@ -1366,6 +1372,7 @@ int idg_graph_destroy(idg_graph* g) {
       (void)hipFree(g->d_vtgt);
       (void)hipFree(g->d_tiles);
       (void)hipFree(g->d_tiles_banded);
+      (void)hipFree(g->d_tiles_seq);
       (void)hipFree(g->d_local);
       (void)hipFree(g->d_long);
       (void)hipFree(g->d_slot_row);
