@@ -49,11 +49,19 @@ def parse():
                    help="torch.distributed backend of the sharded path: nccl (= RCCL over xGMI) for real runs; gloo only "
                         "to rehearse the multi-rank code path with several ranks sharing one GPU (host-staged collectives)")
     p.add_argument("--parallel", default="auto", choices=["auto", "dp", "shard"],
-                   help="multi-GPU form: dp = replicas + one gradient all-reduce per step (small graphs), shard = user-row "
+                   help="multi-GPU form: dp = replicas + one gradient exchange per step (small graphs), shard = user-row "
                         "shards + per-layer all-reduces of the item panel (graphs whose propagation is the cost); auto "
                         "picks dp while the [n, d] panel fits the 256 MiB Infinity Cache")
+    p.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
+                   help="collectives through libidgrec's RCCL communicator (native: on the step's own stream, or — from "
+                        "64 MB — on a second stream the next product overlaps) or through torch.distributed (torch); auto = "
+                        "native when every rank can set it up and passes its self-test, torch otherwise")
+    p.add_argument("--dp-exchange", default="rows", choices=["rows", "grad"],
+                   help="what dp replicas exchange: rows = all-gather of the batches' gradient rows before the backward "
+                        "propagation (default), grad = all-reduce of the dense [n, d] gradient after it")
     p.add_argument("--force-sharded", action="store_true",
-                   help="run the user-row-sharded path even at world size 1 (exercises the RCCL code path)")
+                   help="run a multi-GPU path even at world size 1 (exercises the RCCL code path): the user-row-sharded one, "
+                        "or the replicas with --parallel dp")
     return p.parse_args()
 
 
@@ -145,6 +153,13 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
+    if (world > 1 or args.force_sharded) and "GPU_MAX_HW_QUEUES" not in os.environ:
+        # Multi-GPU forms run several streams per process (step, batch preparation, communicators).  HIP spreads them
+        # over GPU_MAX_HW_QUEUES (default 4) hardware queues in order of first use, and waits between streams on
+        # DIFFERENT queues cost the host tens of microseconds each: measured on the sharded step at world size 1,
+        # 0.53 ms with 2-3 queues, 0.59-0.70 ms (depending on which stream met which queue) with 4, 0.90 ms with 8.
+        # Must be set before the HIP runtime initialises (the first torch.cuda call below).
+        os.environ["GPU_MAX_HW_QUEUES"] = "3"
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path to time.")
     torch.cuda.set_device(local if args.backend == "nccl" else local % torch.cuda.device_count())
@@ -162,7 +177,7 @@ def main():
     if world > 1 or args.force_sharded:
         U_, I_, _ = S.SHAPES[args.workload]
         small = 4 * (U_ + I_) * args.dim <= INFINITY_CACHE_BYTES
-        if not args.force_sharded and (args.parallel == "dp" or (args.parallel == "auto" and small)):
+        if args.parallel == "dp" or (args.parallel == "auto" and small and not args.force_sharded):
             from idgrec_amd.replicated import run_replicated_bench
 
             return run_replicated_bench(args, rank, world, dist)

@@ -398,6 +398,119 @@ __global__ __launch_bounds__(BLOCK) void lincomb_kernel(float* __restrict__ out,
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += BLOCK) out[i] = y ? __builtin_fmaf(b, y[i], a * x[i]) : a * x[i];
 }
 
+// ---- gradient rows as a message (data-parallel replicas, id-grec_amd/replicated.py).  Backward propagation is linear, so
+// replicas exchange the batch's few thousand gradient rows BEFORE it instead of all-reducing the dense [n, d] result
+// after it.  Message of one rank, in 4-byte words: [0] bpr loss, [1] reg loss, ... | keys[3B] (the batch's rows,
+// ascending, one per (triple, role) slot: the sorted scatter plan) | rows[3B, d] (g_final row of keys[j], present at the
+// first slot of each run of equal keys).
+constexpr int64_t MSG_HEADER = 64;
+constexpr int MSG_MAX_WORLD = 64;
+
+struct MsgLayout {
+  int64_t keys, rows, total;
+};
+
+inline MsgLayout msg_layout(int64_t B, int64_t d) {
+  MsgLayout m;
+  m.keys = MSG_HEADER;
+  m.rows = (m.keys + 3 * B + 63) / 64 * 64;
+  m.total = m.rows + 3 * B * d;
+  return m;
+}
+
+__global__ __launch_bounds__(BLOCK) void bpr_pack_rows_kernel(const int32_t* __restrict__ skeys, int64_t n3, int64_t d,
+                                                              const float* __restrict__ g_final,
+                                                              const float* __restrict__ loss, float* __restrict__ header,
+                                                              int32_t* __restrict__ keys, float* __restrict__ rows) {
+  if (blockIdx.x == 0 && threadIdx.x < MSG_HEADER) header[threadIdx.x] = threadIdx.x < 2 ? loss[threadIdx.x] : 0.f;
+  const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int lane = threadIdx.x % WAVE;
+  if (j >= n3) return;
+  const int32_t row = skeys[j];
+  if (lane == 0) keys[j] = row;
+  if (j > 0 && skeys[j - 1] == row) return;
+  for (int64_t f = lane; f < d; f += WAVE) rows[j * d + f] = g_final[(int64_t)row * d + f];
+}
+
+// First position of `row` in the ascending keys[0..n), or -1: a 64-ary search, the wave samples 64 positions per round
+// (3B = 3072 keys: two dependent loads).  Every lane of the wave must call it with the same arguments.
+__device__ __forceinline__ int64_t wave_find_first(const int32_t* __restrict__ keys, int64_t n, int32_t row, int lane) {
+  int64_t lo = 0, len = n;
+  while (len > WAVE) {
+    const int64_t stride = (len + WAVE - 1) / WAVE;
+    const int64_t p = lo + lane * stride;
+    const bool less = p < lo + len && keys[p] < row;
+    const int c = __popcll(__ballot(less));  // the samples below `row` are a prefix: keys ascend
+    if (c == 0) {
+      len = 1;  // keys[lo] >= row: the lower bound is lo itself
+    } else {
+      const int64_t nlo = lo + (int64_t)(c - 1) * stride + 1;  // lower bound in (sample c-1, sample c]
+      const int64_t end = lo + (int64_t)c * stride + 1 < lo + len ? lo + (int64_t)c * stride + 1 : lo + len;
+      lo = nlo;
+      len = end - nlo;
+    }
+  }
+  const bool eq = lane < len && keys[lo + lane] == row;
+  const unsigned long long m = __ballot(eq);
+  return m ? lo + (int64_t)__builtin_ctzll(m) : -1;
+}
+
+// One wave per (rank, slot).  The wave of the LOWEST rank that names a row owns it: it adds the ranks' rows in rank
+// order — every replica performs the same additions in the same order and ends with the same bits — and stores the
+// result (the panels are never zero-filled; `touched` flags the stored rows).
+__global__ __launch_bounds__(BLOCK) void bpr_unpack_rows_kernel(const float* __restrict__ messages, int world, MsgLayout m,
+                                                                int64_t n3, int64_t d, float scale, float reg_scale,
+                                                                const float* __restrict__ ego, float* __restrict__ g_final,
+                                                                float* __restrict__ g_ego, uint32_t* __restrict__ touched,
+                                                                float* __restrict__ loss, unsigned blocks_per_rank) {
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    float s = messages[threadIdx.x] * scale;
+    for (int r = 1; r < world; ++r) s += messages[(int64_t)r * m.total + threadIdx.x] * scale;
+    loss[threadIdx.x] = s;
+  }
+  const int r = (int)(blockIdx.x / blocks_per_rank);
+  const int64_t j = (int64_t)(blockIdx.x % blocks_per_rank) * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int lane = threadIdx.x % WAVE;
+  if (j >= n3) return;
+  const float* msg = messages + (int64_t)r * m.total;
+  const int32_t* keys = reinterpret_cast<const int32_t*>(msg + m.keys);
+  const int32_t row = keys[j];
+  if (j > 0 && keys[j - 1] == row) return;
+  for (int q = 0; q < r; ++q)
+    if (wave_find_first(reinterpret_cast<const int32_t*>(messages + (int64_t)q * m.total + m.keys), n3, row, lane) >= 0) return;
+  int64_t cnt = 1;
+  while (j + cnt < n3 && keys[j + cnt] == row) ++cnt;
+  int64_t mine = -1;  // lane q: where rank q (> r) keeps this row
+  for (int q = r + 1; q < world; ++q) {
+    const int32_t* kq = reinterpret_cast<const int32_t*>(messages + (int64_t)q * m.total + m.keys);
+    const int64_t p = wave_find_first(kq, n3, row, lane);
+    if (p >= 0) {
+      int64_t e = p + 1;
+      while (e < n3 && kq[e] == row) ++e;
+      cnt += e - p;
+    }
+    if (lane == q) mine = p;
+  }
+  if (lane == 0) atomicOr(touched + (row >> 5), 1u << (row & 31));
+  for (int64_t f0 = 0; f0 < d; f0 += WAVE) {
+    const int64_t f = f0 + lane;
+    const bool live = f < d;
+    float acc = live ? msg[m.rows + j * d + f] * scale : 0.f;
+    for (int q = r + 1; q < world; ++q) {
+      const int64_t p = __shfl(mine, q, WAVE);
+      if (p >= 0 && live) acc += messages[(int64_t)q * m.total + m.rows + p * d + f] * scale;
+    }
+    if (live) {
+      const int64_t o = (int64_t)row * d + f;
+      const float r1 = reg_scale * ego[o];
+      float reg = r1;
+      for (int64_t t = 1; t < cnt; ++t) reg += r1;
+      g_final[o] = acc;
+      g_ego[o] = reg;
+    }
+  }
+}
+
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct BprWs {
@@ -610,6 +723,45 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
   if (rc != IDG_OK) return rc;
   return bpr_backward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr, g_final, g_ego,
                            deterministic, touched, ws, stream, ride ? loss : nullptr);
+}
+
+size_t idg_bpr_rows_message_floats(int64_t B, int64_t d) {
+  if (B <= 0 || d <= 0) return 0;
+  return (size_t)msg_layout(B, d).total;
+}
+
+int idg_bpr_pack_rows_f32(const void* ws, int64_t B, int64_t d, const float* g_final, const float* loss, float* message,
+                          void* stream) {
+  IDG_REQUIRE(ws && g_final && loss && message, "idg_bpr_pack_rows_f32: NULL argument");
+  IDG_REQUIRE(B > 0 && d > 0 && 3 * B < ((int64_t)1 << 31), "idg_bpr_pack_rows_f32: bad sizes");
+  const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
+  const MsgLayout m = msg_layout(B, d);
+  const int32_t* skeys = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ws) + w.skeys);
+  const int64_t n3 = 3 * B;
+  const unsigned nb = (unsigned)((n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  hipLaunchKernelGGL(bpr_pack_rows_kernel, dim3(nb), dim3(BLOCK), 0, (hipStream_t)stream, skeys, n3, d, g_final, loss, message,
+                     reinterpret_cast<int32_t*>(message + m.keys), message + m.rows);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t d, int64_t n, const float* ego_panel,
+                            float reg_lambda, float* g_final, float* g_ego, uint32_t* touched, float* loss, void* stream) {
+  IDG_REQUIRE(messages && ego_panel && g_final && g_ego && touched && loss, "idg_bpr_unpack_rows_f32: NULL argument");
+  IDG_REQUIRE(world > 0 && world <= MSG_MAX_WORLD, "idg_bpr_unpack_rows_f32: world size %d outside [1, %d]", world, MSG_MAX_WORLD);
+  IDG_REQUIRE(B > 0 && d > 0 && n > 0 && g_final != g_ego, "idg_bpr_unpack_rows_f32: bad sizes / aliased panels");
+  hipStream_t st = (hipStream_t)stream;
+  const MsgLayout m = msg_layout(B, d);
+  const int64_t n3 = 3 * B;
+  const int64_t nb = (n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE);
+  IDG_REQUIRE(nb * world < ((int64_t)1 << 31), "idg_bpr_unpack_rows_f32: batch x world too large for one launch");
+  const float scale = 1.0f / (float)world;
+  const float reg_scale = (reg_lambda / (float)B) * scale;
+  IDG_HIP(hipMemsetAsync(touched, 0, (size_t)((n + 31) / 32) * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(bpr_unpack_rows_kernel, dim3((unsigned)(nb * world)), dim3(BLOCK), 0, st, messages, world, m, n3, d, scale,
+                     reg_scale, ego_panel, g_final, g_ego, touched, loss, (unsigned)nb);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
 }
 
 int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b, int64_t count, void* stream) {

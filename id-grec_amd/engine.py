@@ -41,7 +41,10 @@ class PropagationEngine:
         self.loss = self._loss3[:2]
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
-        self._side = None   # side stream for index-only work
+        # side stream for index-only work, claimed at construction (ops.side_stream: hardware-queue placement)
+        self._side = ops.side_stream(dev) if (graph is not None and self.deterministic) else None
+        self._side_raw = self._side.cuda_stream if self._side is not None else None  # launches name their stream explicitly
+        self._fork = torch.cuda.Event() if self._side is not None else None
         self._id_storage = None  # storages of the id tensors last ordered against the main stream
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
@@ -49,6 +52,8 @@ class PropagationEngine:
         self.xssl = None       # the same triple for XSimGCL (one perturbed pass, cl_layer = 1)
         self.sgl = None        # (temperature, ssl_lambda, sub_graph_1, sub_graph_2): SGL's two edge-dropped views
         self._views = self._ssl_loss = None
+        self.exchange = None   # replicas (replicated.py): hook(slot, loss) -> bitmap, swaps this batch's gradient rows for
+        #                        the average over all ranks' batches before the (linear) backward propagation
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
     # ---- views handed to nn.Embedding
@@ -82,10 +87,6 @@ class PropagationEngine:
 
     def _prepare(self, slot, users, pos, neg):
         main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._side_raw = self._side.cuda_stream  # raw handle: the launches below name their stream explicitly
-            self._fork = torch.cuda.Event()
         B = users.shape[0]
         if slot.ws is None or slot.ws_B != B:
             slot.ws, slot.ws_B = ops.bpr_workspace(B, self.d, self.device), B
@@ -200,6 +201,7 @@ class PropagationEngine:
                 self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
             sub_1.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[0], out_rows=slot.bitmap)
             sub_2.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[1], out_rows=slot.bitmap)
+        assert self.exchange is None or not three, "gradient-row exchange: LightGCN-family steps only"
         main.wait_event(slot.plan_done)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled
@@ -248,13 +250,15 @@ class PropagationEngine:
             slot.free = main.record_event()
             self._final_version = -1
             return loss
+        mask = slot.bitmap
+        if self.exchange is not None:
+            mask = self.touched = self.exchange(slot, loss)
         if _adam_step > 0:
-            self.graph.propagate_mean_bwd_adam_raw(self.g_final, self.K, self.inc, self.grad, True, slot.bitmap, self.params,
+            self.graph.propagate_mean_bwd_adam_raw(self.g_final, self.K, self.inc, self.grad, True, mask, self.params,
                                                    self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
                                                    self.betas[1], self.eps)
         else:
-            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True,
-                                              mask=slot.bitmap)
+            self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True, mask=mask)
         slot.free = main.record_event()
         self._final_version = -1
         return loss

@@ -77,6 +77,17 @@ PROTOTYPES = {
                                     C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "idg_bpr_touch_rows": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_bitmap_clear": (C.c_int, [c_vp, C.c_int64, c_vp]),
+    "idg_comm_load": (C.c_int, [C.c_char_p]),
+    "idg_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "idg_comm_unique_id": (C.c_int, [c_vp]),
+    "idg_comm_create": (C.c_int, [C.c_int, C.c_int, c_vp, C.c_int, C.POINTER(c_vp)]),
+    "idg_comm_destroy": (C.c_int, [c_vp]),
+    "idg_allreduce_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, c_vp]),
+    "idg_allgather_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
+    "idg_bpr_rows_message_floats": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "idg_bpr_pack_rows_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, c_vp]),
+    "idg_bpr_unpack_rows_f32": (C.c_int, [c_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_float, c_vp, c_vp,
+                                          c_vp, c_vp, c_vp]),
     "idg_bpr_plan_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_bpr_forward_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                       C.c_float, c_vp, c_vp, c_vp]),
@@ -106,7 +117,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 110  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 111  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

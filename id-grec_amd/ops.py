@@ -406,6 +406,20 @@ def propagate_mean(graph, E0, K, include_layer0=True):
 _bpr_ws_cache = {}
 
 
+def side_stream(device):
+    """A second stream for index-only work, bound to a hardware queue NOW.  HIP multiplexes a process's streams over a
+    few hardware queues, binding each at its first use; a side stream first used after other streams have taken theirs
+    (a communicator's) can land on the MAIN stream's queue, and its kernels then serialise with the step's (measured:
+    +30 us per step).  Engines therefore create theirs at construction — before any communicator exists — and touch it
+    once.  (A high-priority stream would have a queue class of its own, but waits between the two classes cost far
+    more than they save: measured 0.33 -> 0.91 ms per step.)"""
+    s = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(s):
+        torch.zeros(1, dtype=torch.int32, device=device)
+    s.synchronize()
+    return s
+
+
 def bpr_workspace(B, d, device):
     """A private BPR scratch buffer (callers that pipeline batches keep one per in-flight batch)."""
     return torch.empty(int(lib.idg_bpr_workspace_bytes(int(B), int(d))), dtype=torch.uint8, device=device)
@@ -518,6 +532,29 @@ def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda
                                 _ptr(neg), B, d, float(reg_lambda), _ptr(loss), _ptr(g_final), _ptr(g_ego),
                                 int(deterministic), _ptr(touched), _ptr(ws), _stream()), "idg_bpr_fused_f32")
     return loss
+
+
+def bpr_rows_message_floats(B, d):
+    """Length (fp32 words) of one rank's gradient-row message (idg_bpr_rows_message_floats)."""
+    return int(lib.idg_bpr_rows_message_floats(int(B), int(d)))
+
+
+def bpr_pack_rows_raw(ws, B, g_final, loss, message):
+    """After bpr_fused_raw(..., deterministic=2, touched=...): this batch's stored g_final rows, their ids and
+    multiplicities and loss[2] -> `message` (idg_bpr_pack_rows_f32)."""
+    _require_device(ws, g_final, loss, message)
+    check(lib.idg_bpr_pack_rows_f32(_ptr(ws), int(B), g_final.shape[1], _ptr(g_final), _ptr(loss), _ptr(message), _stream()),
+          "idg_bpr_pack_rows_f32")
+
+
+def bpr_unpack_rows_raw(messages, world, B, ego_panel, reg_lambda, g_final, g_ego, touched, loss):
+    """Merge `world` all-gathered messages in rank order into g_final / g_ego (averaged over ranks), the union
+    bitmap `touched` (cleared first) and loss[2] (idg_bpr_unpack_rows_f32)."""
+    _require_device(messages, ego_panel, g_final, g_ego, touched, loss)
+    n, d = ego_panel.shape
+    check(lib.idg_bpr_unpack_rows_f32(_ptr(messages), int(world), int(B), d, n, _ptr(ego_panel), float(reg_lambda),
+                                      _ptr(g_final), _ptr(g_ego), _ptr(touched), _ptr(loss), _stream()),
+          "idg_bpr_unpack_rows_f32")
 
 
 def bpr_fwd_bwd_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda, upstream, g_final, g_ego, loss,

@@ -1,19 +1,27 @@
 """Data-parallel replicas of the fused training step: every rank holds the whole graph and both
-embedding tables, a global batch of world x B triples is cut into per-rank slices, the per-rank
-gradients [n, d] are averaged by ONE all-reduce per step (RCCL over xGMI), and every rank applies
+embedding tables, a global batch of world x B triples is cut into per-rank slices, and every rank applies
 the same Adam update — synchronous data-parallel SGD with the reference's loss at batch size
 world x B (loss = mean over the global batch, trainer.py:42-56).
+
+What the ranks exchange (one collective per step either way):
+  * RowExchangeStep (default): backward propagation is LINEAR in the batch's gradient rows, so the ranks all-gather
+    those rows (<= 3B rows of d floats per rank: 0.8 MB at B = 1024, d = 64) BEFORE it, merge them in rank order and
+    every replica back-propagates the averaged rows — with the Adam update in the last product's epilogue, exactly as
+    on one GPU.  Exchanged bytes do not grow with the graph.
+  * ReplicatedStep: every rank back-propagates its own rows and the dense [n, d] gradients are averaged by an
+    all-reduce (17.8 MB at yelp2018 size) AFTER it; Adam is a separate pass.  Kept as the plain form (and for
+    engines whose backward is not exposed as rows).
 
 When to use which multi-GPU form (bench.py --parallel auto decides by the panel size):
   * replicas (this file): the graph is small enough that one GPU propagates it in tens of
     microseconds (BASELINE configs 1-4: panels of 18-37 MB).  Sharding such a graph by user rows
-    needs 2K+1 all-reduces of the item panel per step, each longer than the product it follows;
-    replicating it needs one all-reduce of the gradient.
+    needs 2K+1 all-reduces of the item panel per step, each longer than the product it follows.
   * user-row shards (sharded.py): the propagation itself is the cost (config 5: 70 ms per product
     on one GPU) and divides across ranks.
 
 The engine is anything with `loss_and_grad(users, pos, neg) -> loss[2]`, `.grad` [n, d] and
-`adam_step()`: the HIP engine in the product, a checker-backed stub in the CPU (gloo) tests.
+`adam_step()` (ReplicatedStep) or `train_step_rows(users, pos, neg, gather) -> loss[2]` (RowExchangeStep): the HIP
+engine in the product, a checker-backed stub in the CPU (gloo) tests.
 """
 import numpy as np
 
@@ -35,12 +43,27 @@ class ReplicatedStep:
         return eng.loss_row
 
 
+class RowExchangeStep:
+    def __init__(self, engine, comm, world):
+        self.eng, self.comm, self.world = engine, comm, int(world)
+
+    def _gather(self, message, out):
+        """out[r * L:(r + 1) * L] = rank r's message."""
+        self.comm.wait(self.comm.all_gather_async(out, message))
+
+    def train_step(self, users, pos, neg):
+        """users/pos/neg: THIS rank's slice of the global batch (the same B on every rank).  Returns the global
+        [bpr, reg] losses."""
+        return self.eng.train_step_rows(users, pos, neg, self._gather)
+
+
 class HipReplica:
-    """PropagationEngine with its gradient panel extended by one row that carries the two losses, so that
-    one all-reduce moves both."""
+    """PropagationEngine as one replica.  For ReplicatedStep its gradient panel is extended by one row that carries
+    the two losses, so that one all-reduce moves both; for RowExchangeStep (world given) the engine's exchange hook
+    packs / all-gathers / merges the batch's gradient rows between the BPR kernel and the backward propagation."""
 
     def __init__(self, graph, num_users, num_items, dim, n_layers, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
-                 params=None):
+                 params=None, world=1):
         import torch
 
         from . import ops
@@ -54,11 +77,33 @@ class HipReplica:
         self.grad = self.eng.grad = self.grad_and_loss[:n]  # the engine writes its gradient straight into the buffer
         self.loss_row = self.grad_and_loss[n, :2]
         self.params = self.eng.params
+        self.world = int(world)
+        self._msg = self._msgs = self._gather = None
+        self._union = torch.zeros((n + 31) // 32, dtype=torch.int32, device=self.eng.device)
 
+    # ---- RowExchangeStep
+    def train_step_rows(self, users, pos, neg, gather):
+        self._gather = gather
+        self.eng.exchange = self._exchange
+        return self.eng.train_step(users, pos, neg, loss_out=self.loss_row)
+
+    def _exchange(self, slot, loss):
+        e, B = self.eng, slot.ws_B
+        words = self.ops.bpr_rows_message_floats(B, e.d)
+        if self._msg is None or self._msg.numel() != words:
+            self._msg = self.torch.zeros(words, dtype=self.torch.float32, device=e.device)
+            self._msgs = self.torch.zeros(words * self.world, dtype=self.torch.float32, device=e.device)
+        self.ops.bpr_pack_rows_raw(slot.ws, B, e.g_final, loss, self._msg)
+        self._gather(self._msg, self._msgs)
+        self.ops.bpr_unpack_rows_raw(self._msgs, self.world, B, e.params, e.reg_lambda, e.g_final, e.grad, self._union, loss)
+        return self._union
+
+    # ---- ReplicatedStep
     def prefetch(self, users, pos, neg):
         self.eng.prefetch(users, pos, neg)
 
     def loss_and_grad(self, users, pos, neg):
+        self.eng.exchange = None
         return self.eng.loss_and_grad(users, pos, neg, loss_out=self.loss_row)
 
     def scale_grad_and_loss(self, a):
@@ -83,7 +128,7 @@ def run_replicated_bench(args, rank, world, dist):
     from . import host as H
     from . import ops
     from . import synth as S
-    from .sharded import TorchComm
+    from .sharded import make_comm
 
     U, I, E = S.SHAPES[args.workload]
     users, items = S.generate(U, I, E, seed=0)               # every rank derives the same graph and the same epoch
@@ -91,8 +136,10 @@ def run_replicated_bench(args, rank, world, dist):
     n, nnz = U + I, len(ix)
     graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
     W0 = S.xavier_uniform_panel(U, I, args.dim, args.seed)
-    rep = HipReplica(graph, U, I, args.dim, args.layers, True, 1e-4, 1e-3, params=W0.cuda())
-    step_ = ReplicatedStep(rep, TorchComm(dist), world)
+    rep = HipReplica(graph, U, I, args.dim, args.layers, True, 1e-4, 1e-3, params=W0.cuda(), world=world)
+    rows = getattr(args, "dp_exchange", "rows") == "rows"
+    comm, comm_name = make_comm(dist, getattr(args, "comm", "auto"))
+    step_ = (RowExchangeStep if rows else ReplicatedStep)(rep, comm, world)
     pos_ptr = np.zeros(U + 1, dtype=np.int64)
     pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
     rng = H.Rng(args.seed)
@@ -141,11 +188,16 @@ def run_replicated_bench(args, rank, world, dist):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s-shape graph replicated on %d GPUs: %d users x %d items, %d train edges, nnz(A)=%d; "
                                    "LightGCN K=%d d=%d, B=%d per GPU (global batch %d, slices of one shuffled epoch); step = "
-                                   "propagate + fused BPR + backward propagate on every replica, ONE all-reduce of the "
-                                   "[%d,%d] fp32 gradient over %s, identical dense Adam on every replica"
-                                   % (args.workload, world, U, I, len(users), nnz, args.layers, args.dim, B, gB, n, args.dim,
+                                   "propagate + fused BPR on every replica, %s over %s, backward propagate + identical "
+                                   "dense Adam on every replica"
+                                   % (args.workload, world, U, I, len(users), nnz, args.layers, args.dim, B, gB,
+                                      ("ONE all-gather of the batches' gradient rows (%d fp32 words per rank) BEFORE the "
+                                       "backward propagation" % ops.bpr_rows_message_floats(B, args.dim)) if rows else
+                                      ("ONE all-reduce of the [%d,%d] fp32 gradient AFTER the backward propagation" % (n, args.dim)),
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
-                       "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "dp%d" % world},
+                       "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "dp%d" % world,
+                       "exchange": "gradient rows (all-gather)" if rows else "dense gradient (all-reduce)",
+                       "comm": comm_name},
             "loss_last": [float(x) for x in rep.loss_row.cpu()],
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "replicas_bit_identical": bool(lo.item() == hi.item()),

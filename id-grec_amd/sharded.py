@@ -21,6 +21,8 @@ epilogue, fused BPR, Adam, linear combination, allocation) and `comm` (all-reduc
 world_size-2 gloo tests in tests/ can drive it on CPU with a checker-backed stub while the
 product binds it to the HIP kernels (`HipKernels`) and torch.distributed/RCCL (`TorchComm`).
 """
+import os
+
 import numpy as np
 
 
@@ -245,7 +247,11 @@ class HipKernels:
         self.torch, self.ops = torch, ops
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.deterministic = deterministic
-        self._side, self._pool = None, []
+        self._pool = []
+        # side stream of the batch preparation, claimed at construction (ops.side_stream: hardware-queue placement)
+        self._side = ops.side_stream(self.device) if deterministic else None
+        self._side_raw = self._side.cuda_stream if deterministic else None
+        self._fork = torch.cuda.Event() if deterministic else None
 
     def zeros(self, shape):
         return self.torch.zeros(shape, dtype=self.torch.float32, device=self.device)
@@ -284,10 +290,6 @@ class HipKernels:
         if not self.deterministic:
             return None
         torch, ops = self.torch, self.ops
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._side_raw = self._side.cuda_stream
-            self._fork = torch.cuda.Event()
         B = users.shape[0]
         prep = next((p for p in self._pool if p.B == B and not p.busy), None)
         if prep is None:
@@ -359,9 +361,174 @@ class TorchComm:
             return self._pg.allreduce([t], self._opts_avg if avg else self._opts)
         return self.dist.all_reduce(t, op=self.dist.ReduceOp.AVG if avg else self.dist.ReduceOp.SUM, async_op=True)
 
+    def all_gather_async(self, out, t):
+        """out (world x len(t) elements, rank-major) <- every rank's t."""
+        import torch
+
+        if isinstance(t, np.ndarray):
+            t, out = torch.from_numpy(t), torch.from_numpy(out)  # share memory
+        if self.backend == "gloo" and t.is_cuda:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, t.cpu())
+            out.copy_(host)
+            return None
+        return self.dist.all_gather_into_tensor(out, t, async_op=True)
+
     def wait(self, work):
         if work is not None:
             work.wait()
+
+
+class NativeComm:
+    """`comm` on libidgrec's own RCCL communicator (idg_comm_*, include/idgrec.h): collectives are enqueued on the
+    CURRENT HIP stream, in order with the kernels around them — no second stream, no event pair and no work object
+    per call (torch.distributed's process group costs ~20 us of host time and two cross-stream waits per
+    collective, which is most of a step on the small graphs).  torch.distributed is used once, to hand rank 0's
+    unique id to the other ranks."""
+
+    averages = True
+
+    def __init__(self, dist, device_index, overlap_bytes=64 << 20):
+        """overlap_bytes: collectives of at least this many bytes run on a stream of their own, ordered after the
+        current stream by an event, so that the caller's next kernels overlap them until wait(); smaller ones stay on
+        the current stream (the two cross-stream waits cost ~40 us of host time per collective — measured on the
+        9.7 MB item panel of the yelp2018 shape: 0.69 ms per sharded step with them, 0.53 without)."""
+        import ctypes as C
+
+        import torch
+
+        from . import native
+
+        self.torch, self.lib, self.check = torch, native.lib, native.check
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the copy this process already runs
+        self.check(self.lib.idg_comm_load(path.encode() if os.path.exists(path) else None), "idg_comm_load")
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            self.check(self.lib.idg_comm_unique_id(uid.data_ptr()), "idg_comm_unique_id")
+        if self.world > 1:
+            # through the rendezvous store, not a collective: this communicator must be the FIRST RCCL communicator the
+            # process creates (measured: created after torch's, every collective on it costs ~30 us more)
+            store = dist.distributed_c10d._get_default_store()
+            if self.rank == 0:
+                store.set("idg_comm_unique_id", bytes(uid.numpy().tobytes()))
+            uid = torch.frombuffer(bytearray(store.get("idg_comm_unique_id")), dtype=torch.uint8).clone()
+        handle = C.c_void_p()
+        self.check(self.lib.idg_comm_create(self.rank, self.world, uid.data_ptr(), int(device_index), C.byref(handle)),
+                   "idg_comm_create")
+        self.handle = handle
+        self.overlap_bytes = int(overlap_bytes)
+        self._own = self._own_raw = None   # the collectives' own stream, made on first use
+        self._ring, self._next = [], 0     # (issued, done) event pairs, reused round-robin (<= 2 collectives are in flight)
+
+    def _fork(self):
+        """Order the communicator's stream after the current one; returns (raw stream handle, event to record when done)."""
+        torch = self.torch
+        if self._own is None:
+            self._own = torch.cuda.Stream()
+            self._own_raw = self._own.cuda_stream
+            self._ring = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(8)]
+        issued, done = self._ring[self._next]
+        self._next = (self._next + 1) % len(self._ring)
+        issued.record()
+        self._own.wait_event(issued)
+        return self._own_raw, done
+
+    @staticmethod
+    def _stream():
+        from .ops import _stream
+
+        return _stream()
+
+    def _f32(self, t):
+        assert t.is_cuda and t.dtype == self.torch.float32 and t.is_contiguous(), "NativeComm moves contiguous fp32 device tensors"
+        return t.data_ptr()
+
+    def all_reduce_async(self, t, average=False):
+        if t.numel() * 4 >= self.overlap_bytes:
+            stream, done = self._fork()
+            self.check(self.lib.idg_allreduce_f32(self.handle, self._f32(t), t.numel(), int(bool(average)), stream),
+                       "idg_allreduce_f32")
+            done.record(self._own)
+            return done
+        self.check(self.lib.idg_allreduce_f32(self.handle, self._f32(t), t.numel(), int(bool(average)), self._stream()),
+                   "idg_allreduce_f32")
+        return None
+
+    def all_gather_async(self, out, t):
+        assert out.numel() == t.numel() * self.world
+        if out.numel() * 4 >= self.overlap_bytes:
+            stream, done = self._fork()
+            self.check(self.lib.idg_allgather_f32(self.handle, self._f32(t), self._f32(out), t.numel(), stream),
+                       "idg_allgather_f32")
+            done.record(self._own)
+            return done
+        self.check(self.lib.idg_allgather_f32(self.handle, self._f32(t), self._f32(out), t.numel(), self._stream()),
+                   "idg_allgather_f32")
+        return None
+
+    def wait(self, work):
+        if work is not None:
+            self.torch.cuda.current_stream().wait_event(work)
+
+    def self_test(self):
+        """One all-reduce and one all-gather with known answers; True when both are right on this rank."""
+        torch = self.torch
+        a = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device="cuda")
+        g = torch.zeros(1024 * self.world, dtype=torch.float32, device="cuda")
+        self.all_gather_async(g, a)
+        self.all_reduce_async(a)
+        big = torch.full((self.overlap_bytes // 4 + 1024,), float(self.rank + 1), dtype=torch.float32, device="cuda")
+        work = self.all_reduce_async(big, average=True)   # the second-stream form
+        self.wait(work)
+        big += 1.0                                        # ordered after the collective by wait()
+        torch.cuda.synchronize()
+        want = torch.arange(1, self.world + 1, dtype=torch.float32, device="cuda").repeat_interleave(1024)
+        return (bool((a == self.world * (self.world + 1) / 2).all().item()) and bool(torch.equal(g, want))
+                and bool((big == (self.world + 1) / 2 + 1.0).all().item()))
+
+    def close(self):
+        if self.handle is not None:
+            self.torch.cuda.synchronize()
+            self.lib.idg_comm_destroy(self.handle)
+            self.handle = None
+
+
+def make_comm(dist, kind="auto"):
+    """kind: "torch" (torch.distributed process group), "native" (libidgrec's RCCL communicator; fails loudly if it
+    cannot be set up) or "auto": native when the backend is nccl and EVERY rank both set it up and passed its
+    self-test, torch.distributed otherwise (both are RCCL over xGMI; the choice is recorded in the bench line)."""
+    import torch
+
+    if kind == "torch" or (kind == "auto" and dist.get_backend() != "nccl"):
+        return TorchComm(dist), "torch.distributed"
+    if kind == "native":
+        comm = NativeComm(dist, torch.cuda.current_device())
+        assert comm.self_test(), "libidgrec RCCL communicator: self-test failed"
+        return comm, "libidgrec RCCL communicator"
+    # auto: agree rank by rank before the collective idg_comm_create (a rank that cannot load the library must not
+    # leave the others waiting inside ncclCommInitRank)
+    from . import native
+
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    loaded = native.lib.idg_comm_load(path.encode() if os.path.exists(path) else None) == 0
+    rank, world = dist.get_rank(), dist.get_world_size()
+    store = dist.distributed_c10d._get_default_store()  # no collective yet: see NativeComm.__init__
+    store.set("idg_comm_loaded_%d" % rank, b"1" if loaded else b"0")
+    if not all(bytes(store.get("idg_comm_loaded_%d" % r)) == b"1" for r in range(world)):
+        return TorchComm(dist), "torch.distributed (libidgrec could not load librccl)"
+    why = ""
+    try:
+        comm = NativeComm(dist, torch.cuda.current_device())
+        good = comm.self_test()
+    except Exception as exc:  # noqa: BLE001 - any failure selects the other RCCL path, and is reported
+        comm, good = None, False
+        why = str(exc)[:120]
+    ok = torch.tensor([1 if good else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return comm, "libidgrec RCCL communicator"
+    return TorchComm(dist), "torch.distributed (libidgrec communicator unavailable%s)" % ((": " + why) if comm is None else "")
 
 
 class NoComm:
@@ -370,6 +537,10 @@ class NoComm:
     averages = True
 
     def all_reduce_async(self, t, average=False):
+        return None
+
+    def all_gather_async(self, out, t):
+        out[...] = t
         return None
 
     def wait(self, work):
@@ -401,7 +572,8 @@ def run_sharded_bench(args, rank, world, dist):
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     ui, iu = shard_adjacency(ip, ix, dv, U, I, lo, hi)
     kern = HipKernels(deterministic=not args.atomic)
-    eng = ShardedEngine(kern, TorchComm(dist), ui, iu, hi - lo, I, args.dim, args.layers, True, 1e-4, 1e-3)
+    comm, comm_name = make_comm(dist, getattr(args, "comm", "auto"))
+    eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, args.dim, args.layers, True, 1e-4, 1e-3)
     W0 = S.xavier_uniform_panel(U, I, args.dim, args.seed)  # same initialisation as the single-GPU run
     eng.P[: hi - lo].copy_(W0[lo:hi])
     eng.P[hi - lo:].copy_(W0[U:])
@@ -457,7 +629,8 @@ def run_sharded_bench(args, rank, world, dist):
                                    % (blocks, args.workload, U, I, len(users), nnz, args.layers, args.dim, B, gB,
                                       2 * args.layers + 1, I, args.dim,
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
-                       "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "user-row shard x%d" % world},
+                       "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "user-row shard x%d" % world,
+                       "comm": comm_name},
             "loss_last": [float(x) for x in eng.loss.cpu()],
             "host_issue_ms_per_step": t_enqueue / args.steps * 1e3,
         }

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 110 /* 0.1.10: in-kernel split-row combine, fused Adam / InfoNCE / top-K entry points */
+#define IDG_VERSION 111 /* 0.1.11: + gradient-row messages for data-parallel replicas, RCCL communicator */
 
 /* error classes */
 #define IDG_OK 0
@@ -281,6 +281,23 @@ int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* 
                        int64_t num_users, uint32_t* bitmap, void* stream);
 /* Clear a row bitmap of n_bits bits ((n_bits + 31) / 32 words) on `stream`. */
 int idg_bitmap_clear(uint32_t* bitmap, int64_t n_bits, void* stream);
+
+/* Gradient rows as a message, for data-parallel replicas (the reference trains on one device,
+ * utility/utility_train/trainer.py:42-56 — the replicas reproduce its loss at batch size world x B).
+ * After idg_bpr_fused_f32 / idg_bpr_backward_f32 with a touched-row bitmap and the sorted plan in ws, g_final holds
+ * one stored row per distinct row of the batch.  idg_bpr_pack_rows_f32 copies them, the sorted row keys of the plan
+ * and the two losses into `message` (idg_bpr_rows_message_floats(B, d) floats).  Replicas all-gather their messages;
+ * idg_bpr_unpack_rows_f32 then clears `touched` (n bits) and merges `world` (<= 64) consecutive messages in ONE launch:
+ * the lowest rank naming a row owns it and adds the ranks' rows IN RANK ORDER — g_final rows averaged over ranks,
+ * g_ego = the regulariser's gradient (reg_lambda / (world B)) x multiplicity x ego row, loss[2] = mean of the ranks'
+ * losses — so that every replica obtains the same bits; at world 1 the panels equal what the scatter left.  The
+ * backward propagation then runs on the union bitmap `touched`. */
+size_t idg_bpr_rows_message_floats(int64_t B, int64_t d);
+int idg_bpr_pack_rows_f32(const void* ws, int64_t B, int64_t d, const float* g_final, const float* loss,
+                          float* message, void* stream);
+int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t d, int64_t n,
+                            const float* ego_panel, float reg_lambda, float* g_final, float* g_ego,
+                            uint32_t* touched, float* loss, void* stream);
 #define IDG_BPR_PLANNED 2
 int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      int64_t num_users, int64_t n, void* ws, void* stream);
@@ -385,6 +402,28 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
                        int64_t Bt, int64_t I, int64_t d, const int64_t* excl_indptr,
                        const int32_t* excl_items, int k, int apply_sigmoid, int64_t* out_idx,
                        float* out_val, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * MULTI-GPU: RCCL collectives on the caller's stream (the reference is single-device,
+ * utility/utility_train/trainer.py:8-74 — these serve the replicas / user-row shards around its step).
+ * One communicator per process (one process per GPU).  Collectives are enqueued on `stream` in order with the
+ * kernels around them.  The RCCL library is opened at run time, not linked: idg_comm_load(path) — NULL or "" for
+ * the loader's default "librccl.so"; pass the copy the process already uses (PyTorch ships one).  Without it
+ * every entry point below fails with IDG_E_UNSUPPORTED.
+ * Bootstrap: rank 0 calls idg_comm_unique_id and hands the IDG_COMM_ID_BYTES bytes to every rank by any
+ * out-of-band means; then EVERY rank calls idg_comm_create (collective: returns when all ranks have joined).
+ * ---------------------------------------------------------------------------------- */
+#define IDG_COMM_ID_BYTES 128
+typedef struct idg_comm idg_comm;
+int idg_comm_load(const char* librccl_path);
+int idg_comm_rccl_version(int* version);
+int idg_comm_unique_id(void* out_id /* IDG_COMM_ID_BYTES */);
+int idg_comm_create(int rank, int world, const void* unique_id, int device, idg_comm** out);
+int idg_comm_destroy(idg_comm* comm);
+/* buf[0..count) <- sum over ranks (average != 0: mean over ranks), in place. */
+int idg_allreduce_f32(idg_comm* comm, float* buf, int64_t count, int average, void* stream);
+/* out[r * count .. (r + 1) * count) <- rank r's in[0..count). */
+int idg_allgather_f32(idg_comm* comm, const float* in, float* out, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -246,6 +246,64 @@ def test_bpr_touched_bitmap_and_stored_rows(ops, golden_small):
     assert torch.isnan(gf1[~fl]).all() and torch.isnan(ge1[~fl]).all()
 
 
+@pytest.mark.parametrize("world,B,d,U,I", [(1, 128, 64, 300, 200), (2, 16, 64, 40, 30), (5, 200, 64, 300, 200), (8, 1024, 64, 3000, 2000),
+                                           (3, 4000, 100, 5000, 3000), (4, 21, 7, 9, 5)])
+def test_gradient_row_messages_merge_in_rank_order(ops, world, B, d, U, I):
+    """idg_bpr_pack_rows_f32 / idg_bpr_unpack_rows_f32 (replicas exchange gradient rows before the backward propagation):
+    `world` batches scattered on one device, packed, concatenated as an all-gather would, merged — against the same
+    additions in rank order in numpy float32, BIT for bit; untouched rows of the panels are never written."""
+    rng = np.random.default_rng(world * 1000 + B)
+    n = U + I
+    fin = dev(rng.standard_normal((n, d)).astype(np.float32))
+    ego = dev(rng.standard_normal((n, d)).astype(np.float32))
+    words = ops.bpr_rows_message_floats(B, d)
+    msgs = torch.zeros(world * words, dtype=torch.float32, device="cuda")
+    want_f, want_e = np.zeros((n, d), np.float32), np.zeros((n, d), np.float32)
+    seen, count = np.zeros(n, bool), np.zeros(n, np.int64)
+    scale = np.float32(1.0 / world)
+    losses = []
+    gf, ge = torch.full((n, d), float("nan"), device="cuda"), torch.full((n, d), float("nan"), device="cuda")
+    for r in range(world):
+        u = dev(rng.integers(0, U, B))
+        p = dev(rng.integers(0, I, B))
+        ng = dev(rng.integers(0, I, B))
+        touched = torch.zeros((n + 31) // 32, dtype=torch.int32, device="cuda")
+        ws = ops.bpr_workspace(B, d, "cuda")
+        ops.bpr_plan_raw(u, p, ng, U, n, d, ws=ws)
+        loss = ops.bpr_fused_raw(fin, ego, u, p, ng, U, 1e-4, gf, ge, deterministic=2, touched=touched, ws=ws)
+        ops.bpr_pack_rows_raw(ws, B, gf, loss, msgs[r * words:(r + 1) * words])
+        losses.append(loss.cpu().numpy().copy())
+        rows, cnt = np.unique(np.concatenate([u.cpu().numpy(), U + p.cpu().numpy(), U + ng.cpu().numpy()]), return_counts=True)
+        contrib = gf.cpu().numpy()[rows] * scale
+        first = ~seen[rows]
+        want_f[rows[first]] = contrib[first]
+        want_f[rows[~first]] += contrib[~first]
+        seen[rows] = True
+        count[rows] += cnt
+    reg_scale = np.float32(np.float32(np.float32(1e-4) / np.float32(B)) * scale)
+    r1 = reg_scale * ego.cpu().numpy()
+    live = np.nonzero(seen)[0]
+    for row in live:
+        acc = r1[row].copy()
+        for _ in range(count[row] - 1):
+            acc += r1[row]
+        want_e[row] = acc
+    want_l = losses[0] * scale
+    for l in losses[1:]:
+        want_l = want_l + l * scale
+    out_f, out_e = torch.full((n, d), float("nan"), device="cuda"), torch.full((n, d), float("nan"), device="cuda")
+    union = torch.full(((n + 31) // 32,), -1, dtype=torch.int32, device="cuda")  # unpack clears it itself
+    out_l = torch.zeros(2, device="cuda")
+    ops.bpr_unpack_rows_raw(msgs, world, B, ego, 1e-4, out_f, out_e, union, out_l)
+    bits = union.cpu().numpy().view(np.uint32)
+    flagged = ((bits[np.arange(n) >> 5] >> (np.arange(n) & 31).astype(np.uint32)) & 1).astype(bool)
+    assert np.array_equal(flagged, seen)
+    of, oe = out_f.cpu().numpy(), out_e.cpu().numpy()
+    assert np.array_equal(of[seen], want_f[seen]) and np.array_equal(oe[seen], want_e[seen])
+    assert np.isnan(of[~seen]).all() and np.isnan(oe[~seen]).all()
+    assert np.array_equal(out_l.cpu().numpy(), want_l.astype(np.float32))
+
+
 # ------------------------------------------------------------------------------------- BPR
 @pytest.mark.parametrize("gname", ["tiny", "small"])
 @pytest.mark.parametrize("deterministic", [True, False])

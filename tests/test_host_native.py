@@ -154,3 +154,17 @@ def test_py_random_sample_is_pythons_random_sample(n, k):
         assert got.tolist() == want and random.random() == nxt
     with pytest.raises(ValueError):
         H.py_random_sample(3, 4)
+
+
+
+def test_comm_entry_points_fail_loudly_without_rccl_or_communicator():
+    """The RCCL communicator is opened at run time: a wrong path and a missing communicator are errors with a
+    message, never a crash or a silent no-op."""
+    from idgrec_amd import native
+
+    rc = native.lib.idg_comm_load(b"/nonexistent/librccl.so")
+    assert rc == -6 and b"dlopen" in native.lib.idg_last_error()
+    rc = native.lib.idg_allreduce_f32(None, None, 4, 0, None)
+    assert rc == -1 and b"communicator" in native.lib.idg_last_error()
+    rc = native.lib.idg_allgather_f32(None, None, None, 4, None)
+    assert rc == -1 and b"communicator" in native.lib.idg_last_error()

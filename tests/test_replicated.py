@@ -45,11 +45,11 @@ def _single_device_reference(p, steps, world=2):
     return W, grad, np.stack(losses)
 
 
-def _launch(mode, path, steps, world=2):
+def _launch(mode, path, steps, world=2, exchange="grad"):
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "replicated_worker.py"), str(r), str(world),
-                               str(port), mode, path, str(steps)], env=env, stdout=subprocess.PIPE,
+                               str(port), mode, path, str(steps), exchange], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
@@ -67,18 +67,112 @@ def _check(p, outs, steps):
     assert np.array_equal(outs[0]["P"], outs[1]["P"])  # replicas stay bit-identical
 
 
+@pytest.mark.parametrize("exchange", ["grad", "rows"])
 @pytest.mark.parametrize("K,include0", [(3, True), (2, False)])
-def test_two_replicas_gloo_cpu_match_single_device(K, include0, tmp_path, golden_small):
+def test_two_replicas_gloo_cpu_match_single_device(K, include0, exchange, tmp_path, golden_small):
     p = _problem(golden_small, K, include0, B=96, steps=3)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
-    _check(p, _launch("cpu", path, 3), 3)
+    _check(p, _launch("cpu", path, 3, exchange=exchange), 3)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["grad", "rows"])
 @pytest.mark.parametrize("K,include0", [(3, True), (2, False)])
-def test_two_replicas_hip_engine_match_single_device(K, include0, tmp_path, golden_small):
+def test_two_replicas_hip_engine_match_single_device(K, include0, exchange, tmp_path, golden_small):
     p = _problem(golden_small, K, include0, B=96, steps=4)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
-    _check(p, _launch("gpu", path, 4), 4)
+    _check(p, _launch("gpu", path, 4, exchange=exchange), 4)
+
+
+@pytest.mark.gpu
+def test_row_exchange_world_1_is_the_plain_fused_step(golden_small):
+    """One rank: packing the gradient rows into a message and merging that one message back must not change a bit
+    of the fused step (same stored rows, same regulariser arithmetic, Adam in the same epilogue)."""
+    import torch
+
+    import idgrec_amd.ops as ops
+    import idgrec_amd.replicated as rp
+    from idgrec_amd.engine import PropagationEngine
+    from idgrec_amd.sharded import NoComm
+
+    p = _problem(golden_small, 3, True, B=128, steps=3, world=1)
+    n = p["U"] + p["I"]
+    g = ops.Graph(p["indptr"], p["indices"], p["values"], n, n)
+    plain = PropagationEngine(g, p["U"], p["I"], 64, 3, params=torch.from_numpy(p["W0"].copy()).cuda())
+    rep = rp.HipReplica(g, p["U"], p["I"], 64, 3, params=torch.from_numpy(p["W0"].copy()).cuda(), world=1)
+    step = rp.RowExchangeStep(rep, NoComm(), 1)
+    for s in range(3):
+        b = torch.from_numpy(p["triples"][s * 128:(s + 1) * 128]).cuda()
+        u, i, j = b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous()
+        l0 = plain.train_step(u, i, j).clone()
+        l1 = step.train_step(u, i, j).clone()
+        assert torch.equal(l0, l1)
+        assert torch.equal(plain.grad, rep.grad)
+        assert torch.equal(plain.params, rep.params)
+
+
+
+class _World1:
+    """torch.distributed's face for a single rank (NativeComm asks it for rank / world only)."""
+
+    @staticmethod
+    def get_rank():
+        return 0
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def get_backend():
+        return "nccl"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["rows", "grad"])
+def test_native_rccl_communicator_world_1(form, golden_small):
+    """libidgrec's own RCCL communicator (idg_comm_*): set-up, self-test, and a replica step through it — collectives
+    on the step's stream — against the plain fused step (bit-equal at world size 1)."""
+    import torch
+
+    import idgrec_amd.ops as ops
+    import idgrec_amd.replicated as rp
+    from idgrec_amd.engine import PropagationEngine
+    from idgrec_amd.sharded import NativeComm
+
+    torch.cuda.set_device(0)
+    comm = NativeComm(_World1, 0)
+    try:
+        assert comm.self_test()
+        x = torch.arange(4096, dtype=torch.float32, device="cuda")
+        y = x.clone()
+        comm.all_reduce_async(y, average=True)
+        out = torch.zeros_like(x)
+        comm.all_gather_async(out, x)
+        torch.cuda.synchronize()
+        assert torch.equal(x, y) and torch.equal(x, out)
+        big = torch.arange(17 << 20, dtype=torch.float32, device="cuda")  # 68 MB: the second-stream form
+        ref = big.clone()
+        work = comm.all_reduce_async(big)
+        assert work is not None
+        comm.wait(work)
+        torch.cuda.synchronize()
+        assert torch.equal(big, ref)
+        p = _problem(golden_small, 3, True, B=128, steps=3, world=1)
+        n = p["U"] + p["I"]
+        g = ops.Graph(p["indptr"], p["indices"], p["values"], n, n)
+        plain = PropagationEngine(g, p["U"], p["I"], 64, 3, params=torch.from_numpy(p["W0"].copy()).cuda())
+        plain.fuse_adam = form == "rows"
+        rep = rp.HipReplica(g, p["U"], p["I"], 64, 3, params=torch.from_numpy(p["W0"].copy()).cuda(), world=1)
+        step = (rp.RowExchangeStep if form == "rows" else rp.ReplicatedStep)(rep, comm, 1)
+        for s in range(3):
+            b = torch.from_numpy(p["triples"][s * 128:(s + 1) * 128]).cuda()
+            u, i, j = b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous()
+            l0 = plain.train_step(u, i, j).clone()
+            l1 = step.train_step(u, i, j).clone()
+            assert torch.equal(l0, l1)
+            assert torch.equal(plain.params, rep.params)
+    finally:
+        comm.close()
