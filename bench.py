@@ -25,6 +25,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INFINITY_CACHE_BYTES = 256 << 20
+REPLICA_BUDGET_BYTES = 200 << 30  # of the 288 GB of HBM3E: graphs whose training state fits are replicated, not sharded
 
 
 def parse():
@@ -50,8 +51,10 @@ def parse():
                         "to rehearse the multi-rank code path with several ranks sharing one GPU (host-staged collectives)")
     p.add_argument("--parallel", default="auto", choices=["auto", "dp", "shard"],
                    help="multi-GPU form: dp = replicas + one gradient exchange per step (small graphs), shard = user-row "
-                        "shards + per-layer all-reduces of the item panel (graphs whose propagation is the cost); auto "
-                        "picks dp while the [n, d] panel fits the 256 MiB Infinity Cache")
+                        "shards + per-layer all-reduces of the item panel; auto picks dp while the whole training state "
+                        "(~9 [n, d] panels + the graph) fits one GPU's HBM (all five BASELINE configs do: config 5 needs "
+                        "~140 of 288 GB) — replicas exchange a few MB of gradient rows per step whatever the graph's size, "
+                        "shards all-reduce the [I, d] item panel 2K+1 times")
     p.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                    help="collectives through libidgrec's RCCL communicator (native: on the step's own stream, or — from "
                         "64 MB — on a second stream the next product overlaps) or through torch.distributed (torch); auto = "
@@ -80,26 +83,8 @@ def build_workload(args, rank, world):
     t0 = time.time()
     users, items = S.generate(U, I, E, seed=0)
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
-    pos_ptr = np.zeros(U + 1, dtype=np.int64)
-    pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
-    rng = H.Rng(args.seed)
     need = (args.steps + args.warmup) * args.batch
-    items32 = items.astype(np.int32)
-    if len(users) > 8 * need:
-        # a handful of steps on a huge graph: draw negatives for a uniform subset of the edges only (same
-        # triple distribution as slicing a shuffled epoch) instead of sampling all E edges
-        pick = np.sort(np.random.default_rng(args.seed).choice(len(users), size=2 * need, replace=False))
-        su, si = users[pick], items[pick]
-    else:
-        su, si = users, items
-    t_s = time.perf_counter()
-    tri = rng.sample_epoch(su, si, pos_ptr, items32, I)
-    perm = rng.shuffle_perm(len(tri))
-    sampler_rate = len(tri) / (time.perf_counter() - t_s)  # native sampler + shuffle permutation, one host core
-    tri = tri[perm]
-    while len(tri) < need:  # more steps than one epoch holds: draw further epochs
-        t2 = rng.sample_epoch(su, si, pos_ptr, items32, I)
-        tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
+    tri, sampler_rate, pos_ptr, items32 = S.draw_triples(args.seed, users, items, U, I, need)  # native sampler, one host core
     return dict(U=U, I=I, E=len(users), indptr=ip, indices=ix, values=dv, triples=tri, prep_s=time.time() - t0,
                 sampler_rate=sampler_rate, pos_ptr=pos_ptr, items32=items32)
 
@@ -176,7 +161,10 @@ def main():
 
     if world > 1 or args.force_sharded:
         U_, I_, _ = S.SHAPES[args.workload]
-        small = 4 * (U_ + I_) * args.dim <= INFINITY_CACHE_BYTES
+        # replicas need the whole training state on every GPU: 9 [n, d] fp32 panels (parameters, two Adam moments,
+        # gradient, layer mean and its gradient, two layer buffers, messages/partials) + ~16 B per stored entry
+        resident = 9 * 4 * (U_ + I_) * args.dim + 16 * 2 * S.SHAPES[args.workload][2]
+        small = resident <= REPLICA_BUDGET_BYTES
         if args.parallel == "dp" or (args.parallel == "auto" and small and not args.force_sharded):
             from idgrec_amd.replicated import run_replicated_bench
 

@@ -133,22 +133,17 @@ def run_replicated_bench(args, rank, world, dist):
     U, I, E = S.SHAPES[args.workload]
     users, items = S.generate(U, I, E, seed=0)               # every rank derives the same graph and the same epoch
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
-    n, nnz = U + I, len(ix)
+    n, nnz, n_edges = U + I, len(ix), len(users)
     graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
     W0 = S.xavier_uniform_panel(U, I, args.dim, args.seed)
     rep = HipReplica(graph, U, I, args.dim, args.layers, True, 1e-4, 1e-3, params=W0.cuda(), world=world)
     rows = getattr(args, "dp_exchange", "rows") == "rows"
     comm, comm_name = make_comm(dist, getattr(args, "comm", "auto"))
     step_ = (RowExchangeStep if rows else ReplicatedStep)(rep, comm, world)
-    pos_ptr = np.zeros(U + 1, dtype=np.int64)
-    pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
-    rng = H.Rng(args.seed)
     B, gB = args.batch, args.batch * world
     need = (args.steps + args.warmup) * gB
-    tri = np.empty((0, 3), dtype=np.int64)
-    while len(tri) < need:
-        t2 = rng.sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
-        tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
+    tri = S.draw_triples(args.seed, users, items, U, I, need)[0]  # the same global sequence on every rank
+    del users, items, ip, ix, dv
     # global step i = triples [i*gB, (i+1)*gB); this rank's slice of it
     mine = tri[:need].reshape(args.steps + args.warmup, world, B, 3)[:, rank]
     mine = torch.from_numpy(np.ascontiguousarray(mine)).cuda()
@@ -190,7 +185,7 @@ def run_replicated_bench(args, rank, world, dist):
                                    "LightGCN K=%d d=%d, B=%d per GPU (global batch %d, slices of one shuffled epoch); step = "
                                    "propagate + fused BPR on every replica, %s over %s, backward propagate + identical "
                                    "dense Adam on every replica"
-                                   % (args.workload, world, U, I, len(users), nnz, args.layers, args.dim, B, gB,
+                                   % (args.workload, world, U, I, n_edges, nnz, args.layers, args.dim, B, gB,
                                       ("ONE all-gather of the batches' gradient rows (%d fp32 words per rank) BEFORE the "
                                        "backward propagation" % ops.bpr_rows_message_floats(B, args.dim)) if rows else
                                       ("ONE all-reduce of the [%d,%d] fp32 gradient AFTER the backward propagation" % (n, args.dim)),
@@ -203,4 +198,6 @@ def run_replicated_bench(args, rank, world, dist):
             "replicas_bit_identical": bool(lo.item() == hi.item()),
         }
         print(json.dumps(out))
+    if hasattr(comm, "close"):
+        comm.close()
     dist.destroy_process_group()

@@ -106,3 +106,33 @@ def xavier_uniform_panel(num_users, num_items, d, seed):
         bound = (6.0 / ((hi - lo) + d)) ** 0.5
         out[lo:hi] = (torch.rand(hi - lo, d, generator=g) * 2 - 1) * bound
     return out
+
+
+def draw_triples(seed, users, items, num_users, num_items, need):
+    """`need` (or more) BPR triples for a bench run, drawn with the native sampler exactly as the reference's epoch
+    loop draws them (sample every edge, shuffle; further epochs when one does not suffice).  On a graph with far more
+    edges than the run consumes, negatives are drawn for a uniform subset of the edges only — the same triple
+    distribution as slicing a shuffled epoch.  Deterministic in `seed`: every rank of a multi-GPU run calls this and
+    slices the same global sequence.  Returns (triples [>= need, 3] int64, sampler rate in triples/s)."""
+    import time
+
+    from . import host as H
+
+    pos_ptr = np.zeros(num_users + 1, dtype=np.int64)
+    pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=num_users))
+    items32 = items.astype(np.int32)
+    rng = H.Rng(seed)
+    if len(users) > 8 * need:
+        pick = np.sort(np.random.default_rng(seed).choice(len(users), size=2 * need, replace=False))
+        su, si = users[pick], items[pick]
+    else:
+        su, si = users, items
+    t_s = time.perf_counter()
+    tri = rng.sample_epoch(su, si, pos_ptr, items32, num_items)
+    perm = rng.shuffle_perm(len(tri))
+    rate = len(tri) / (time.perf_counter() - t_s)
+    tri = tri[perm]
+    while len(tri) < need:
+        t2 = rng.sample_epoch(su, si, pos_ptr, items32, num_items)
+        tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
+    return tri, rate, pos_ptr, items32

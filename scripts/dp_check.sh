@@ -1,8 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/dp
-for nt in 0 1 2 4 3 7; do
-IDG_NT=$nt python bench.py --no-cpu-baseline --steps 300 --warmup 30 > gpurun_out/dp/nt_$nt.json 2> gpurun_out/dp/nt_$nt.err
-done
-for nt in 0 1 3; do
-IDG_NT=$nt python bench.py --no-cpu-baseline --workload synth-1M --steps 40 --warmup 5 > gpurun_out/dp/nt1m_$nt.json 2> gpurun_out/dp/nt1m_$nt.err
-done
+python bench.py --no-cpu-baseline --steps 300 --warmup 30 > gpurun_out/dp/plain.json 2> gpurun_out/dp/plain.err
+bash scripts/dp1.sh --steps 300 --warmup 30 > gpurun_out/dp/dp_yelp.json 2> gpurun_out/dp/dp_yelp.err
+bash scripts/dp1.sh --workload synth-10M --dim 256 --steps 12 --warmup 4 > gpurun_out/dp/dp_c5.json 2> gpurun_out/dp/dp_c5.err
+tail -c 500 gpurun_out/dp/dp_c5.json; tail -n 5 gpurun_out/dp/dp_c5.err
