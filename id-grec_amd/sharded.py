@@ -513,7 +513,10 @@ def make_comm(dist, kind="auto"):
     path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     loaded = native.lib.idg_comm_load(path.encode() if os.path.exists(path) else None) == 0
     rank, world = dist.get_rank(), dist.get_world_size()
-    store = dist.distributed_c10d._get_default_store()  # no collective yet: see NativeComm.__init__
+    try:
+        store = dist.distributed_c10d._get_default_store()  # no collective yet: see NativeComm.__init__
+    except Exception:  # noqa: BLE001 - private torch API: without it there is no collective-free way to agree
+        return TorchComm(dist), "torch.distributed (rendezvous store not reachable)"
     store.set("idg_comm_loaded_%d" % rank, b"1" if loaded else b"0")
     if not all(bytes(store.get("idg_comm_loaded_%d" % r)) == b"1" for r in range(world)):
         return TorchComm(dist), "torch.distributed (libidgrec could not load librccl)"
