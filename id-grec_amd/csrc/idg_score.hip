@@ -232,6 +232,13 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
     }
     my_ex_cur = lo;
   }
+  int32_t win[FT_UPW / 2];  // per PAIR of users of this wave: their next 32 train items each (see the masking step)
+#pragma unroll
+  for (int p = 0; p < FT_UPW / 2; ++p) {
+    const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h);
+    const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
+    win[p] = (excl_indptr && cur + i < end) ? excl_items[cur + i] : 0x7fffffff;
+  }
   unsigned long long best[FT_UPW], tau[FT_UPW];  // per user of this wave: list (lane = rank) and its k-th key
 #pragma unroll
   for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull, tau[uu] = 0ull;
@@ -244,15 +251,15 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
       f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
-      // 16 features of each operand at a time (same product order as score_dense_kernel: MFMA q of a 64-deep
-      // chunk pairs feature kc+q with feature kc+32+q) keeps the operand registers at 48
+      // 8 features of each operand at a time (same product order as score_dense_kernel: MFMA q of a 64-deep chunk
+      // pairs feature kc+q with feature kc+32+q) keeps the operand registers at 24
 #pragma unroll 1
-      for (int64_t kq = 0; kq < (d + 63) / 64 * 64; kq += 32) {
-        const int64_t k0 = (kq / 64) * 64 + 32 * h + (kq % 64) / 2;  // kq%64 in {0, 32} -> offset {0, 16}
-        float a0[16], a1[16], bb[16];
-        if (d4 && k0 + 16 <= d) {
+      for (int64_t kq = 0; kq < (d + 63) / 64 * 64; kq += 16) {
+        const int64_t k0 = (kq / 64) * 64 + 32 * h + (kq % 64) / 2;  // kq%64 in {0,16,32,48} -> offset {0,8,16,24}
+        float a0[8], a1[8], bb[8];
+        if (d4 && k0 + 8 <= d) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < 2; ++q) {
             const float4 x = *reinterpret_cast<const float4*>(urow0 + k0 + 4 * q);
             const float4 y = *reinterpret_cast<const float4*>(urow1 + k0 + 4 * q);
             const float4 z = *reinterpret_cast<const float4*>(vrow + k0 + 4 * q);
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
+          for (int q = 0; q < 8; ++q) {
             const bool in = k0 + q < d;
             a0[q] = in ? urow0[k0 + q] : 0.f;
             a1[q] = in ? urow1[k0 + q] : 0.f;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
           }
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < 8; ++q) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bb[q], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bb[q], acc1, 0, 0, 0);
         }
@@ -289,31 +296,29 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
     const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
     if (excl_indptr) {
       const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
-      // all 16 users' next <= 64 train items are fetched with independent coalesced loads first ...
-      int32_t nxt[FT_UPW];
+      // win[p]: lanes 0-31 hold the next 32 train items of user 2p, lanes 32-63 those of user 2p+1 (entry = cursor +
+      // (lane & 31)), loaded once and kept across slabs: the lists are ascending, so the entries inside this slab are
+      // those in [slab, slab_end); a half is re-read only when its 32 entries have all been passed (users average ~40
+      // train items over the whole catalogue)
 #pragma unroll
-      for (int uu = 0; uu < FT_UPW; ++uu) {
-        const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, uu);
-        const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, uu);
-        nxt[uu] = cur + lane < end ? excl_items[cur + lane] : 0x7fffffff;
-      }
-      // ... then the ones inside this slab overwrite their scores and move the cursor
-#pragma unroll
-      for (int uu = 0; uu < FT_UPW; ++uu) {
-        bool in = nxt[uu] < (int32_t)slab_end;
-        if (in) s_score[(FT_UPW * wave + uu) * FT_LD + (nxt[uu] - (int32_t)slab)] = masked;
-        int n_in = __popcll(__ballot(in));
-        int64_t adv = n_in;
-        while (n_in == WAVE) {  // more than 64 train items inside one 128-item slab: keep going (rare)
-          const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, uu) + adv;
-          const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, uu);
-          const int32_t v = cur + lane < end ? excl_items[cur + lane] : 0x7fffffff;
-          in = v < (int32_t)slab_end;
-          if (in) s_score[(FT_UPW * wave + uu) * FT_LD + (v - (int32_t)slab)] = masked;
-          n_in = __popcll(__ballot(in));
-          adv += n_in;
+      for (int p = 0; p < FT_UPW / 2; ++p) {
+        unsigned long long below = __ballot(win[p] < (int32_t)slab_end);
+        if (below == 0ull) continue;  // nothing of these two users up to the end of the slab
+        const int row = FT_UPW * wave + 2 * p + h;
+        if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
+        while ((uint32_t)below == 0xffffffffu || (uint32_t)(below >> 32) == 0xffffffffu) {  // a half used up (rare)
+          const bool reload = h == 0 ? (uint32_t)below == 0xffffffffu : (uint32_t)(below >> 32) == 0xffffffffu;
+          const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h) + (reload ? 32 : 0);
+          const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
+          if (reload) {
+            win[p] = cur + i < end ? excl_items[cur + i] : 0x7fffffff;
+            if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
+          }
+          const unsigned long long moved = __ballot(reload);
+          if (lane == 2 * p && (uint32_t)moved) my_ex_cur += 32;
+          if (lane == 2 * p + 1 && (uint32_t)(moved >> 32)) my_ex_cur += 32;
+          below = __ballot(win[p] < (int32_t)slab_end);
         }
-        if (lane == uu) my_ex_cur += adv;
       }
       __builtin_amdgcn_wave_barrier();
     }
