@@ -165,6 +165,7 @@ constexpr int FT_USERS = 64;
 constexpr int FT_SLAB = 128;
 constexpr int FT_LD = FT_SLAB + 4;
 constexpr int FT_UPW = FT_USERS / (BLOCK / WAVE);  // users per wave
+constexpr int TOPK_WGS = 1024;                      // workgroups wanted per launch (3 fit a CU; measured best of 512..1536)
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
@@ -413,7 +414,9 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 // roughly three workgroups per CU (what its register budget allows); scratch = one best-64 list per (user, chunk).
 static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
-  int64_t nc = (768 + user_tiles - 1) / user_tiles;
+  int64_t nc = (TOPK_WGS + user_tiles - 1) / user_tiles;
+  if (const char* v = std::getenv("IDG_TOPK_WGS"))
+    if (*v) nc = (std::atoll(v) + user_tiles - 1) / user_tiles;  // testing knob
   const int64_t max_nc = (I + 1023) / 1024;
   if (const char* v = std::getenv("IDG_TOPK_CHUNKS"))
     if (*v) nc = std::atoll(v);  // testing knob
