@@ -131,6 +131,17 @@ def cpu_baseline(args, wl, W0):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON.  Libraries print there too (RCCL announces its version on fd 1 when a
+    # communicator comes up): hand fd 1 to stderr for the run and keep the real stdout for the result alone.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
+    args.emit = emit
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -303,7 +314,7 @@ def main():
                        "what": "propagate + score + train-positive mask + top-20 for all %d users x %d items" % (U, I)}
     if not args.no_cpu_baseline and args.model != "SimGCL":
         out["cpu_baseline"] = cpu_baseline(args, wl, W0.numpy())
-    print(json.dumps(out))
+    args.emit(out)
 
 
 if __name__ == "__main__":

@@ -197,7 +197,7 @@ def run_replicated_bench(args, rank, world, dist):
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "replicas_bit_identical": bool(lo.item() == hi.item()),
         }
-        print(json.dumps(out))
+        getattr(args, "emit", lambda o: print(json.dumps(o)))(out)
     if hasattr(comm, "close"):
         comm.close()
     dist.destroy_process_group()

@@ -637,5 +637,5 @@ def run_sharded_bench(args, rank, world, dist):
             "loss_last": [float(x) for x in eng.loss.cpu()],
             "host_issue_ms_per_step": t_enqueue / args.steps * 1e3,
         }
-        print(json.dumps(out))
+        getattr(args, "emit", lambda o: print(json.dumps(o)))(out)
     dist.destroy_process_group()
