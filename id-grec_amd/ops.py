@@ -540,8 +540,8 @@ def bpr_rows_message_floats(B, d):
 
 
 def bpr_pack_rows_raw(ws, B, g_final, loss, message):
-    """After bpr_fused_raw(..., deterministic=2, touched=...): this batch's stored g_final rows, their ids and
-    multiplicities and loss[2] -> `message` (idg_bpr_pack_rows_f32)."""
+    """After bpr_fused_raw(..., deterministic=2, touched=...): this batch's stored g_final rows, the plan's sorted row
+    keys (ids and multiplicities) and loss[2] -> `message` (idg_bpr_pack_rows_f32)."""
     _require_device(ws, g_final, loss, message)
     check(lib.idg_bpr_pack_rows_f32(_ptr(ws), int(B), g_final.shape[1], _ptr(g_final), _ptr(loss), _ptr(message), _stream()),
           "idg_bpr_pack_rows_f32")
