@@ -99,7 +99,9 @@ def run(rank, world, port, mode, path, steps, exchange="grad"):
                             params=torch.from_numpy(W0.copy()).cuda(), world=world)
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         to_np = lambda a: a.cpu().numpy()  # noqa: E731
-    step = (rp.RowExchangeStep if exchange == "rows" else rp.ReplicatedStep)(eng, sh.TorchComm(dist), world)
+    comm, comm_name = sh.make_comm(dist, "auto")  # gloo: the torch.distributed form (host-staged for device tensors)
+    assert isinstance(comm, sh.TorchComm) and comm_name == "torch.distributed"
+    step = (rp.RowExchangeStep if exchange == "rows" else rp.ReplicatedStep)(eng, comm, world)
     losses = []
     for s in range(steps):
         b = tri[s * world * B:(s + 1) * world * B][rank * B:(rank + 1) * B]

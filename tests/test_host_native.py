@@ -168,3 +168,23 @@ def test_comm_entry_points_fail_loudly_without_rccl_or_communicator():
     assert rc == -1 and b"communicator" in native.lib.idg_last_error()
     rc = native.lib.idg_allgather_f32(None, None, None, 4, None)
     assert rc == -1 and b"communicator" in native.lib.idg_last_error()
+
+
+
+def test_bench_triples_are_deterministic_and_cover_both_sampling_paths():
+    """synth.draw_triples: every rank of a multi-GPU bench derives the same global sequence from the seed; a run that
+    consumes far fewer triples than the graph has edges samples negatives for a uniform subset of the edges only."""
+    import idgrec_amd.synth as S
+
+    U, I, E = 300, 200, 6000
+    users, items = S.generate(U, I, E, seed=0)
+    a = S.draw_triples(7, users, items, U, I, 2 * len(users))       # more than one epoch: whole-epoch path, twice
+    b = S.draw_triples(7, users, items, U, I, 2 * len(users))
+    assert np.array_equal(a[0], b[0]) and len(a[0]) >= 2 * len(users)
+    c = S.draw_triples(7, users, items, U, I, 64)                    # 8 * need < E: subset path
+    d = S.draw_triples(7, users, items, U, I, 64)
+    assert np.array_equal(c[0], d[0]) and 64 <= len(c[0]) == 128
+    pos = {(int(u), int(i)) for u, i in zip(users, items)}
+    for t in (a[0], c[0]):
+        assert all((int(u), int(p)) in pos for u, p, _ in t[:500])          # positives are train edges
+        assert all((int(u), int(n)) not in pos for u, _, n in t[:500])      # negatives are not
