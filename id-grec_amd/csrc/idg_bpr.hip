@@ -421,8 +421,12 @@ inline MsgLayout msg_layout(int64_t B, int64_t d) {
 __global__ __launch_bounds__(BLOCK) void bpr_pack_rows_kernel(const int32_t* __restrict__ skeys, int64_t n3, int64_t d,
                                                               const float* __restrict__ g_final,
                                                               const float* __restrict__ loss, float* __restrict__ header,
-                                                              int32_t* __restrict__ keys, float* __restrict__ rows) {
+                                                              int32_t* __restrict__ keys, float* __restrict__ rows,
+                                                              uint32_t* __restrict__ clear, int64_t clear_words) {
   if (blockIdx.x == 0 && threadIdx.x < MSG_HEADER) header[threadIdx.x] = threadIdx.x < 2 ? loss[threadIdx.x] : 0.f;
+  // the bitmap the merge will fill (idg_bpr_unpack_rows_f32) is cleared here, on the way: a memset between the
+  // all-gather and the merge would sit on the step's critical path (two fill launches, ~10 us)
+  for (int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x; w < clear_words; w += (int64_t)gridDim.x * BLOCK) clear[w] = 0u;
   const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int lane = threadIdx.x % WAVE;
   if (j >= n3) return;
@@ -731,8 +735,9 @@ size_t idg_bpr_rows_message_floats(int64_t B, int64_t d) {
 }
 
 int idg_bpr_pack_rows_f32(const void* ws, int64_t B, int64_t d, const float* g_final, const float* loss, float* message,
-                          void* stream) {
+                          uint32_t* clear_bitmap, int64_t clear_bits, void* stream) {
   IDG_REQUIRE(ws && g_final && loss && message, "idg_bpr_pack_rows_f32: NULL argument");
+  IDG_REQUIRE(clear_bits >= 0 && (clear_bitmap || clear_bits == 0), "idg_bpr_pack_rows_f32: bad bitmap to clear");
   IDG_REQUIRE(B > 0 && d > 0 && 3 * B < ((int64_t)1 << 31), "idg_bpr_pack_rows_f32: bad sizes");
   const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
   const MsgLayout m = msg_layout(B, d);
@@ -740,13 +745,14 @@ int idg_bpr_pack_rows_f32(const void* ws, int64_t B, int64_t d, const float* g_f
   const int64_t n3 = 3 * B;
   const unsigned nb = (unsigned)((n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
   hipLaunchKernelGGL(bpr_pack_rows_kernel, dim3(nb), dim3(BLOCK), 0, (hipStream_t)stream, skeys, n3, d, g_final, loss, message,
-                     reinterpret_cast<int32_t*>(message + m.keys), message + m.rows);
+                     reinterpret_cast<int32_t*>(message + m.keys), message + m.rows, clear_bitmap, (clear_bits + 31) / 32);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }
 
 int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t d, int64_t n, const float* ego_panel,
-                            float reg_lambda, float* g_final, float* g_ego, uint32_t* touched, float* loss, void* stream) {
+                            float reg_lambda, float* g_final, float* g_ego, uint32_t* touched, int touched_is_clear,
+                            float* loss, void* stream) {
   IDG_REQUIRE(messages && ego_panel && g_final && g_ego && touched && loss, "idg_bpr_unpack_rows_f32: NULL argument");
   IDG_REQUIRE(world > 0 && world <= MSG_MAX_WORLD, "idg_bpr_unpack_rows_f32: world size %d outside [1, %d]", world, MSG_MAX_WORLD);
   IDG_REQUIRE(B > 0 && d > 0 && n > 0 && g_final != g_ego, "idg_bpr_unpack_rows_f32: bad sizes / aliased panels");
@@ -757,7 +763,7 @@ int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t
   IDG_REQUIRE(nb * world < ((int64_t)1 << 31), "idg_bpr_unpack_rows_f32: batch x world too large for one launch");
   const float scale = 1.0f / (float)world;
   const float reg_scale = (reg_lambda / (float)B) * scale;
-  IDG_HIP(hipMemsetAsync(touched, 0, (size_t)((n + 31) / 32) * sizeof(uint32_t), st));
+  if (!touched_is_clear) IDG_HIP(hipMemsetAsync(touched, 0, (size_t)((n + 31) / 32) * sizeof(uint32_t), st));
   hipLaunchKernelGGL(bpr_unpack_rows_kernel, dim3((unsigned)(nb * world)), dim3(BLOCK), 0, st, messages, world, m, n3, d, scale,
                      reg_scale, ego_panel, g_final, g_ego, touched, loss, (unsigned)nb);
   IDG_HIP(hipGetLastError());

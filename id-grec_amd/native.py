@@ -85,9 +85,9 @@ PROTOTYPES = {
     "idg_allreduce_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, c_vp]),
     "idg_allgather_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "idg_bpr_rows_message_floats": (C.c_size_t, [C.c_int64, C.c_int64]),
-    "idg_bpr_pack_rows_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, c_vp]),
+    "idg_bpr_pack_rows_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "idg_bpr_unpack_rows_f32": (C.c_int, [c_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_float, c_vp, c_vp,
-                                          c_vp, c_vp, c_vp]),
+                                          c_vp, C.c_int, c_vp, c_vp]),
     "idg_bpr_plan_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_bpr_forward_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                       C.c_float, c_vp, c_vp, c_vp]),
@@ -117,7 +117,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 111  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 112  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -539,21 +539,23 @@ def bpr_rows_message_floats(B, d):
     return int(lib.idg_bpr_rows_message_floats(int(B), int(d)))
 
 
-def bpr_pack_rows_raw(ws, B, g_final, loss, message):
+def bpr_pack_rows_raw(ws, B, g_final, loss, message, clear=None, clear_bits=0):
     """After bpr_fused_raw(..., deterministic=2, touched=...): this batch's stored g_final rows, the plan's sorted row
-    keys (ids and multiplicities) and loss[2] -> `message` (idg_bpr_pack_rows_f32)."""
+    keys (ids and multiplicities) and loss[2] -> `message` (idg_bpr_pack_rows_f32).  clear / clear_bits: a bitmap to zero
+    in the same launch (the union bitmap of the coming merge)."""
     _require_device(ws, g_final, loss, message)
-    check(lib.idg_bpr_pack_rows_f32(_ptr(ws), int(B), g_final.shape[1], _ptr(g_final), _ptr(loss), _ptr(message), _stream()),
-          "idg_bpr_pack_rows_f32")
+    check(lib.idg_bpr_pack_rows_f32(_ptr(ws), int(B), g_final.shape[1], _ptr(g_final), _ptr(loss), _ptr(message),
+                                    _ptr(clear), int(clear_bits), _stream()), "idg_bpr_pack_rows_f32")
 
 
-def bpr_unpack_rows_raw(messages, world, B, ego_panel, reg_lambda, g_final, g_ego, touched, loss):
+def bpr_unpack_rows_raw(messages, world, B, ego_panel, reg_lambda, g_final, g_ego, touched, loss, touched_is_clear=False):
     """Merge `world` all-gathered messages in rank order into g_final / g_ego (averaged over ranks), the union
     bitmap `touched` (cleared first) and loss[2] (idg_bpr_unpack_rows_f32)."""
     _require_device(messages, ego_panel, g_final, g_ego, touched, loss)
     n, d = ego_panel.shape
     check(lib.idg_bpr_unpack_rows_f32(_ptr(messages), int(world), int(B), d, n, _ptr(ego_panel), float(reg_lambda),
-                                      _ptr(g_final), _ptr(g_ego), _ptr(touched), _ptr(loss), _stream()),
+                                      _ptr(g_final), _ptr(g_ego), _ptr(touched), int(bool(touched_is_clear)), _ptr(loss),
+                                      _stream()),
           "idg_bpr_unpack_rows_f32")
 
 

@@ -93,9 +93,10 @@ class HipReplica:
         if self._msg is None or self._msg.numel() != words:
             self._msg = self.torch.zeros(words, dtype=self.torch.float32, device=e.device)
             self._msgs = self.torch.zeros(words * self.world, dtype=self.torch.float32, device=e.device)
-        self.ops.bpr_pack_rows_raw(slot.ws, B, e.g_final, loss, self._msg)
+        self.ops.bpr_pack_rows_raw(slot.ws, B, e.g_final, loss, self._msg, clear=self._union, clear_bits=e.n)
         self._gather(self._msg, self._msgs)
-        self.ops.bpr_unpack_rows_raw(self._msgs, self.world, B, e.params, e.reg_lambda, e.g_final, e.grad, self._union, loss)
+        self.ops.bpr_unpack_rows_raw(self._msgs, self.world, B, e.params, e.reg_lambda, e.g_final, e.grad, self._union, loss,
+                                     touched_is_clear=True)
         return self._union
 
     # ---- ReplicatedStep

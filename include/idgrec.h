@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 111 /* 0.1.11: + gradient-row messages for data-parallel replicas, RCCL communicator */
+#define IDG_VERSION 112 /* 0.1.11: + gradient-row messages for data-parallel replicas, RCCL communicator */
 
 /* error classes */
 #define IDG_OK 0
@@ -287,17 +287,19 @@ int idg_bitmap_clear(uint32_t* bitmap, int64_t n_bits, void* stream);
  * After idg_bpr_fused_f32 / idg_bpr_backward_f32 with a touched-row bitmap and the sorted plan in ws, g_final holds
  * one stored row per distinct row of the batch.  idg_bpr_pack_rows_f32 copies them, the sorted row keys of the plan
  * and the two losses into `message` (idg_bpr_rows_message_floats(B, d) floats).  Replicas all-gather their messages;
- * idg_bpr_unpack_rows_f32 then clears `touched` (n bits) and merges `world` (<= 64) consecutive messages in ONE launch:
+ * idg_bpr_unpack_rows_f32 then clears `touched` (n bits; unless told it is clear) and merges `world` (<= 64) consecutive messages in ONE launch:
  * the lowest rank naming a row owns it and adds the ranks' rows IN RANK ORDER — g_final rows averaged over ranks,
  * g_ego = the regulariser's gradient (reg_lambda / (world B)) x multiplicity x ego row, loss[2] = mean of the ranks'
  * losses — so that every replica obtains the same bits; at world 1 the panels equal what the scatter left.  The
  * backward propagation then runs on the union bitmap `touched`. */
 size_t idg_bpr_rows_message_floats(int64_t B, int64_t d);
+/* clear_bitmap (nullable) / clear_bits: a bitmap the pack launch zeroes on the way — hand it the `touched` of the
+ * coming merge and pass touched_is_clear = 1 there, and no memset sits between the all-gather and the merge. */
 int idg_bpr_pack_rows_f32(const void* ws, int64_t B, int64_t d, const float* g_final, const float* loss,
-                          float* message, void* stream);
+                          float* message, uint32_t* clear_bitmap, int64_t clear_bits, void* stream);
 int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t d, int64_t n,
                             const float* ego_panel, float reg_lambda, float* g_final, float* g_ego,
-                            uint32_t* touched, float* loss, void* stream);
+                            uint32_t* touched, int touched_is_clear, float* loss, void* stream);
 #define IDG_BPR_PLANNED 2
 int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      int64_t num_users, int64_t n, void* ws, void* stream);

@@ -248,7 +248,8 @@ def test_bpr_touched_bitmap_and_stored_rows(ops, golden_small):
 
 @pytest.mark.parametrize("world,B,d,U,I", [(1, 128, 64, 300, 200), (2, 16, 64, 40, 30), (5, 200, 64, 300, 200), (8, 1024, 64, 3000, 2000),
                                            (3, 4000, 100, 5000, 3000), (4, 21, 7, 9, 5)])
-def test_gradient_row_messages_merge_in_rank_order(ops, world, B, d, U, I):
+@pytest.mark.parametrize("fold_clear", [False, True])
+def test_gradient_row_messages_merge_in_rank_order(ops, world, B, d, U, I, fold_clear):
     """idg_bpr_pack_rows_f32 / idg_bpr_unpack_rows_f32 (replicas exchange gradient rows before the backward propagation):
     `world` batches scattered on one device, packed, concatenated as an all-gather would, merged — against the same
     additions in rank order in numpy float32, BIT for bit; untouched rows of the panels are never written."""
@@ -263,6 +264,7 @@ def test_gradient_row_messages_merge_in_rank_order(ops, world, B, d, U, I):
     scale = np.float32(1.0 / world)
     losses = []
     gf, ge = torch.full((n, d), float("nan"), device="cuda"), torch.full((n, d), float("nan"), device="cuda")
+    union = torch.full(((n + 31) // 32,), -1, dtype=torch.int32, device="cuda")  # somebody must clear it: pack or unpack
     for r in range(world):
         u = dev(rng.integers(0, U, B))
         p = dev(rng.integers(0, I, B))
@@ -271,7 +273,10 @@ def test_gradient_row_messages_merge_in_rank_order(ops, world, B, d, U, I):
         ws = ops.bpr_workspace(B, d, "cuda")
         ops.bpr_plan_raw(u, p, ng, U, n, d, ws=ws)
         loss = ops.bpr_fused_raw(fin, ego, u, p, ng, U, 1e-4, gf, ge, deterministic=2, touched=touched, ws=ws)
-        ops.bpr_pack_rows_raw(ws, B, gf, loss, msgs[r * words:(r + 1) * words])
+        # fold_clear: the last pack launch also zeroes the merge's bitmap (no memset between all-gather and merge)
+        last = fold_clear and r == world - 1
+        ops.bpr_pack_rows_raw(ws, B, gf, loss, msgs[r * words:(r + 1) * words], clear=union if last else None,
+                              clear_bits=n if last else 0)
         losses.append(loss.cpu().numpy().copy())
         rows, cnt = np.unique(np.concatenate([u.cpu().numpy(), U + p.cpu().numpy(), U + ng.cpu().numpy()]), return_counts=True)
         contrib = gf.cpu().numpy()[rows] * scale
@@ -292,9 +297,8 @@ def test_gradient_row_messages_merge_in_rank_order(ops, world, B, d, U, I):
     for l in losses[1:]:
         want_l = want_l + l * scale
     out_f, out_e = torch.full((n, d), float("nan"), device="cuda"), torch.full((n, d), float("nan"), device="cuda")
-    union = torch.full(((n + 31) // 32,), -1, dtype=torch.int32, device="cuda")  # unpack clears it itself
     out_l = torch.zeros(2, device="cuda")
-    ops.bpr_unpack_rows_raw(msgs, world, B, ego, 1e-4, out_f, out_e, union, out_l)
+    ops.bpr_unpack_rows_raw(msgs, world, B, ego, 1e-4, out_f, out_e, union, out_l, touched_is_clear=fold_clear)
     bits = union.cpu().numpy().view(np.uint32)
     flagged = ((bits[np.arange(n) >> 5] >> (np.arange(n) & 31).astype(np.uint32)) & 1).astype(bool)
     assert np.array_equal(flagged, seen)
