@@ -34,9 +34,10 @@ class PropagationEngine:
         self.final = torch.empty((self.n, self.d), **f32) if graph is not None else None
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
         words = (self.n + 31) // 32
-        self._slots = [self._Slot(words, dev), self._Slot(words, dev)] if graph is not None else None
+        # two slots: the batch being processed and the one prepared ahead (measured: 3 or 4 change nothing)
+        self._slots = [self._Slot(words, dev) for _ in range(2)] if graph is not None else None
         self.touched = None
-        self._parity = 0
+        self._stamp = 0
         self._loss3 = torch.zeros(3, **f32)  # [bpr, reg_lambda * reg, ssl_lambda * InfoNCE]
         self.loss = self._loss3[:2]
         self.step_count = 0
@@ -44,7 +45,7 @@ class PropagationEngine:
         # side stream for index-only work, claimed at construction (ops.side_stream: hardware-queue placement)
         self._side = ops.side_stream(dev) if (graph is not None and self.deterministic) else None
         self._side_raw = self._side.cuda_stream if self._side is not None else None  # launches name their stream explicitly
-        self._fork = torch.cuda.Event() if self._side is not None else None
+        self._fork = ops.LocalEvent() if self._side is not None else None  # device-local events (ops.LocalEvent) throughout
         self._id_storage = None  # storages of the id tensors last ordered against the main stream
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
@@ -83,38 +84,40 @@ class PropagationEngine:
             self.ws = None
             self.key = None
             self.rows_done = self.plan_done = None
-            self.free = None  # recorded on the main stream when the step that used this slot is done
+            self.free = None  # = free_ev once recorded on the main stream: the step that used this slot is done
+            self.free_ev = None
+            self.stamp = 0    # order of last hand-out (the ring recycles the oldest)
 
     def _prepare(self, slot, users, pos, neg):
         main = torch.cuda.current_stream()
         B = users.shape[0]
         if slot.ws is None or slot.ws_B != B:
             slot.ws, slot.ws_B = ops.bpr_workspace(B, self.d, self.device), B
-            slot.rows_done, slot.plan_done = torch.cuda.Event(), torch.cuda.Event()
+            slot.rows_done, slot.plan_done, slot.free_ev = ops.LocalEvent(), ops.LocalEvent(), ops.LocalEvent()
         if slot.free is not None:
-            self._side.wait_event(slot.free)   # the step that last used this slot has consumed it
+            slot.free.wait(self._side_raw)     # the step that last used this slot has consumed it
         # The side stream must not read the ids before the main stream has produced them.  Batches are slices of
         # one epoch-long tensor: ordering after the main stream once per storage is enough (doing it per batch would
         # also queue this batch's index work behind the previous step's kernels: measured +6 us/step).
         src = (users.untyped_storage().data_ptr(), pos.untyped_storage().data_ptr(), neg.untyped_storage().data_ptr())
         if slot.free is None or src != self._id_storage:
             self._id_storage = src
-            self._fork.record(main)
-            self._side.wait_event(self._fork)
+            self._fork.record(main.cuda_stream)
+            self._fork.wait(self._side_raw)
         ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap, stream=self._side_raw, clear_bits=self.n)
-        slot.rows_done.record(self._side)      # needed by the last forward layer
+        slot.rows_done.record(self._side_raw)  # needed by the last forward layer
         ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
-        slot.plan_done.record(self._side)      # needed by the gradient scatter
+        slot.plan_done.record(self._side_raw)  # needed by the gradient scatter
         slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
 
     def _take_slot(self):
-        """Next slot of the two-entry ring (the other one may hold the batch about to be processed)."""
-        for i, slot in enumerate(self._slots):  # a slot whose batch has been consumed (or never filled)
-            if slot.key is None:
-                self._parity = i ^ 1
-                return slot
-        slot = self._slots[self._parity]          # both hold unconsumed prefetches: recycle the older one
-        self._parity ^= 1
+        """Next slot of the ring: one whose batch has been consumed the longest ago (or never filled); when every slot
+        holds an unconsumed prefetch, the oldest of those is recycled."""
+        free = [sl for sl in self._slots if sl.key is None]
+        pool = free if free else self._slots
+        slot = min(pool, key=lambda sl: sl.stamp)
+        self._stamp += 1
+        slot.stamp = self._stamp
         return slot
 
     def prefetch(self, users, pos, neg):
@@ -164,7 +167,9 @@ class PropagationEngine:
         slot.key = None
         self.touched = slot.bitmap
         # the BPR kernel reads the layer mean at the batch rows only: the last layer is restricted to them
-        main.wait_event(slot.rows_done)
+        # a batch prepared one step ahead finished long ago: ask the event first and spare the stream a wait packet
+        if not slot.rows_done.query():
+            slot.rows_done.wait(main.cuda_stream)
         if self.ssl is not None:
             # SimGCL (models/SimGCL.py:62-66): the clean pass and two perturbed ones, read at rows of the batch only
             # (unique users / positives are a subset of the bitmap); the first product is shared between the passes
@@ -202,7 +207,8 @@ class PropagationEngine:
             sub_1.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[0], out_rows=slot.bitmap)
             sub_2.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[1], out_rows=slot.bitmap)
         assert self.exchange is None or not three, "gradient-row exchange: LightGCN-family steps only"
-        main.wait_event(slot.plan_done)
+        if not slot.plan_done.query():
+            slot.plan_done.wait(main.cuda_stream)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled
         ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
@@ -228,7 +234,8 @@ class PropagationEngine:
             if _adam_step > 0:
                 ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
                                   self.betas[1], self.eps)
-            slot.free = main.record_event()
+            slot.free = slot.free_ev
+            slot.free.record(main.cuda_stream)
             self._final_version = -1
             return loss
         if self.xssl is not None:
@@ -247,7 +254,8 @@ class PropagationEngine:
             if _adam_step > 0:
                 ops.adam_step_raw(self.params, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
                                   self.betas[1], self.eps)
-            slot.free = main.record_event()
+            slot.free = slot.free_ev
+            slot.free.record(main.cuda_stream)
             self._final_version = -1
             return loss
         mask = slot.bitmap
@@ -259,7 +267,8 @@ class PropagationEngine:
                                                    self.betas[1], self.eps)
         else:
             self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True, mask=mask)
-        slot.free = main.record_event()
+        slot.free = slot.free_ev
+        slot.free.record(main.cuda_stream)
         self._final_version = -1
         return loss
 

@@ -77,6 +77,11 @@ PROTOTYPES = {
                                     C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "idg_bpr_touch_rows": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_bitmap_clear": (C.c_int, [c_vp, C.c_int64, c_vp]),
+    "idg_event_create": (C.c_int, [C.POINTER(c_vp)]),
+    "idg_event_destroy": (C.c_int, [c_vp]),
+    "idg_event_record": (C.c_int, [c_vp, c_vp]),
+    "idg_stream_wait_event": (C.c_int, [c_vp, c_vp]),
+    "idg_event_query": (C.c_int, [c_vp, C.POINTER(C.c_int)]),
     "idg_comm_load": (C.c_int, [C.c_char_p]),
     "idg_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
     "idg_comm_unique_id": (C.c_int, [c_vp]),
@@ -117,7 +122,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 112  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 113  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -406,6 +406,39 @@ def propagate_mean(graph, E0, K, include_layer0=True):
 _bpr_ws_cache = {}
 
 
+class LocalEvent:
+    """A device-local event (idg_event_*): orders two streams of one device without the system-scope fence of a default
+    HIP / torch event (see include/idgrec.h).  record / wait take raw stream handles (torch.cuda.Stream.cuda_stream)."""
+
+    __slots__ = ("_h", "_done")
+
+    def __init__(self):
+        import ctypes as C
+
+        h = C.c_void_p()
+        check(lib.idg_event_create(C.byref(h)), "idg_event_create")
+        self._h, self._done = h, C.c_int(0)
+
+    def record(self, stream):
+        check(lib.idg_event_record(self._h, stream), "idg_event_record")
+
+    def wait(self, stream):
+        """Make `stream` wait for the recorded work."""
+        check(lib.idg_stream_wait_event(stream, self._h), "idg_stream_wait_event")
+
+    def query(self):
+        import ctypes as C
+
+        check(lib.idg_event_query(self._h, C.byref(self._done)), "idg_event_query")
+        return bool(self._done.value)
+
+    def __del__(self):
+        try:
+            lib.idg_event_destroy(self._h)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def side_stream(device):
     """A second stream for index-only work, bound to a hardware queue NOW.  HIP multiplexes a process's streams over a
     few hardware queues, binding each at its first use; a side stream first used after other streams have taken theirs

@@ -251,7 +251,7 @@ class HipKernels:
         # side stream of the batch preparation, claimed at construction (ops.side_stream: hardware-queue placement)
         self._side = ops.side_stream(self.device) if deterministic else None
         self._side_raw = self._side.cuda_stream if deterministic else None
-        self._fork = torch.cuda.Event() if deterministic else None
+        self._fork = ops.LocalEvent() if deterministic else None
 
     def zeros(self, shape):
         return self.torch.zeros(shape, dtype=self.torch.float32, device=self.device)
@@ -273,7 +273,8 @@ class HipKernels:
 
     def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss, prep=None):
         if prep is not None:  # the sorted (row, slot) plan is in the prepared workspace already
-            self.torch.cuda.current_stream().wait_event(prep.done)
+            if not prep.done.query():
+                prep.done.wait(self.torch.cuda.current_stream().cuda_stream)
             self.ops.bpr_fwd_bwd_raw(fin, ego, users, pos, neg, n_users, reg_lambda, upstream, g_final, g_ego, loss,
                                      deterministic=2, ws=prep.ws)
         else:
@@ -296,28 +297,25 @@ class HipKernels:
             prep = self._Prepared()
             prep.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=self.device)
             prep.ws, prep.B = ops.bpr_workspace(B, d, self.device), B
-            prep.rows_done, prep.done, prep.free = torch.cuda.Event(), torch.cuda.Event(), None
+            prep.rows_done, prep.done, prep.free = ops.LocalEvent(), ops.LocalEvent(), None  # device-local events
             self._pool.append(prep)
         prep.busy = True
         main = torch.cuda.current_stream()
-        self._fork.record(main)              # the id tensors may have just been produced on the main stream,
-        self._side.wait_event(self._fork)    # and the step that last used these buffers is ordered before it
+        self._fork.record(main.cuda_stream)  # the id tensors may have just been produced on the main stream,
+        self._fork.wait(self._side_raw)      # and the step that last used these buffers is ordered before it
         ops.bpr_touch_rows_raw(users, pos, neg, n_users, prep.bitmap, stream=self._side_raw, clear_bits=n)
-        prep.rows_done.record(self._side)
+        prep.rows_done.record(self._side_raw)
         ops.bpr_plan_raw(users, pos, neg, n_users, n, d, ws=prep.ws, stream=self._side_raw)
-        prep.done.record(self._side)
+        prep.done.record(self._side_raw)
         return prep
-
-    def release(self, prep):
-        prep.busy = False  # reuse is ordered by the fork event of the next prepare()
 
     def wait_rows(self, prep):
         """The bitmap is first read by a product on the main stream."""
-        self.torch.cuda.current_stream().wait_event(prep.rows_done)
+        if not prep.rows_done.query():
+            prep.rows_done.wait(self.torch.cuda.current_stream().cuda_stream)
 
     def release(self, prep):
-        prep.free = self.torch.cuda.current_stream().record_event()
-        self._pool.append(prep)
+        prep.busy = False  # its buffers go back to the pool; reuse is ordered by the fork event of the next prepare()
 
     def adam(self, p, g, m, v, lr, step):
         self.ops.adam_step_raw(p, g, m, v, lr, step)

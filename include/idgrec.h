@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 112 /* 0.1.11: + gradient-row messages for data-parallel replicas, RCCL communicator */
+#define IDG_VERSION 113 /* 0.1.11: + gradient-row messages for data-parallel replicas, RCCL communicator */
 
 /* error classes */
 #define IDG_OK 0
@@ -404,6 +404,18 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
                        int64_t Bt, int64_t I, int64_t d, const int64_t* excl_indptr,
                        const int32_t* excl_items, int k, int apply_sigmoid, int64_t* out_idx,
                        float* out_val, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DEVICE-LOCAL EVENTS: ordering between the caller's streams on ONE device (the step's stream and the stream that
+ * prepares the next batch's index-only work).  Created without timing and WITHOUT the system-scope fence a default
+ * HIP event performs when recorded (cache write-back/invalidate for the host's and other devices' benefit: ~7 us on
+ * the recording stream); kernel boundaries already order memory at device scope.  Not for host-visible data.
+ * ---------------------------------------------------------------------------------- */
+int idg_event_create(void** out_event);
+int idg_event_destroy(void* event);
+int idg_event_record(void* event, void* stream);
+int idg_stream_wait_event(void* stream, void* event);
+int idg_event_query(void* event, int* done);
 
 /* ------------------------------------------------------------------------------------
  * MULTI-GPU: RCCL collectives on the caller's stream (the reference is single-device,
