@@ -1,22 +1,15 @@
 """User-row sharding (id-grec_amd/sharded.py): partitioner, shard extraction, and the
 distributed step against the single-device result — world_size 2 over gloo."""
 import os
-import socket
-import subprocess
 import sys
 
 import numpy as np
 import pytest
 
 from oracle import oracle
+from tests.ranks import run_ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def _problem(g, K, include0, B, steps, seed=0):
@@ -45,14 +38,7 @@ def _single_device_reference(p, steps):
 
 
 def _launch(mode, path, steps, world=2):
-    port = _free_port()
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(r), str(world),
-                               str(port), mode, path, str(steps)], env=env, stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-3000:]
+    run_ranks("sharded_worker.py", world, [mode, path, steps])
     return [dict(np.load(path + ".out%d.npz" % r)) for r in range(world)]
 
 
