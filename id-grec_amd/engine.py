@@ -167,9 +167,7 @@ class PropagationEngine:
         slot.key = None
         self.touched = slot.bitmap
         # the BPR kernel reads the layer mean at the batch rows only: the last layer is restricted to them
-        # a batch prepared one step ahead finished long ago: ask the event first and spare the stream a wait packet
-        if not slot.rows_done.query():
-            slot.rows_done.wait(main.cuda_stream)
+        slot.rows_done.wait(main.cuda_stream)
         if self.ssl is not None:
             # SimGCL (models/SimGCL.py:62-66): the clean pass and two perturbed ones, read at rows of the batch only
             # (unique users / positives are a subset of the bitmap); the first product is shared between the passes
@@ -207,8 +205,7 @@ class PropagationEngine:
             sub_1.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[0], out_rows=slot.bitmap)
             sub_2.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[1], out_rows=slot.bitmap)
         assert self.exchange is None or not three, "gradient-row exchange: LightGCN-family steps only"
-        if not slot.plan_done.query():
-            slot.plan_done.wait(main.cuda_stream)
+        slot.plan_done.wait(main.cuda_stream)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled
         ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,

@@ -273,8 +273,7 @@ class HipKernels:
 
     def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss, prep=None):
         if prep is not None:  # the sorted (row, slot) plan is in the prepared workspace already
-            if not prep.done.query():
-                prep.done.wait(self.torch.cuda.current_stream().cuda_stream)
+            prep.done.wait(self.torch.cuda.current_stream().cuda_stream)
             self.ops.bpr_fwd_bwd_raw(fin, ego, users, pos, neg, n_users, reg_lambda, upstream, g_final, g_ego, loss,
                                      deterministic=2, ws=prep.ws)
         else:
@@ -311,8 +310,7 @@ class HipKernels:
 
     def wait_rows(self, prep):
         """The bitmap is first read by a product on the main stream."""
-        if not prep.rows_done.query():
-            prep.rows_done.wait(self.torch.cuda.current_stream().cuda_stream)
+        prep.rows_done.wait(self.torch.cuda.current_stream().cuda_stream)
 
     def release(self, prep):
         prep.busy = False  # its buffers go back to the pool; reuse is ordered by the fork event of the next prepare()
