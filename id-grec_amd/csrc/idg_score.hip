@@ -154,8 +154,8 @@ __device__ __forceinline__ void wave_sort128_desc(unsigned long long& k0, unsign
 // running best list lives in REGISTERS (lane L = rank L, 16 users x one 64-bit key per lane)
 // and its k-th key in scalar registers, so the steady state costs two LDS reads and two float
 // compares per user and slab; the rare candidate above the k-th key is inserted by a one-lane
-// shift.  The LDS slab (33 KB) is the only shared memory, which leaves room for 4 workgroups
-// per CU.  Scores never reach global memory.  Chunks of one user are merged by
+// shift.  The LDS slab (33 KB) is the only shared memory (registers, not LDS, bound the residency:
+// 3 workgroups per CU).  Scores never reach global memory.  Chunks of one user are merged by
 // topk_merge_kernel.
 // Selection is on RAW scores (sigmoid is monotone, it is applied to the k winners only):
 // order = (raw score descending, item id ascending) — a valid tie order for torch.topk.
@@ -410,8 +410,8 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
   return launch_dense(user_panel, item_panel, users, Bt, I, d, apply_sigmoid, rating, I, (hipStream_t)stream);
 }
 
-// Fused path geometry: 64 users per workgroup, the catalogue cut into n_chunks so that the grid has
-// roughly three workgroups per CU (what its register budget allows); scratch = one best-64 list per (user, chunk).
+// Fused path geometry: 64 users per workgroup, the catalogue cut into n_chunks so that the grid has about TOPK_WGS
+// workgroups (three are resident per CU, what the register budget allows); scratch = one best-64 list per (user, chunk).
 static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
   int64_t nc = (TOPK_WGS + user_tiles - 1) / user_tiles;
