@@ -35,7 +35,7 @@ class PropagationEngine:
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
         words = (self.n + 31) // 32
         # two slots: the batch being processed and the one prepared ahead (measured: 3 or 4 change nothing)
-        self._slots = [self._Slot(words, dev) for _ in range(2)] if graph is not None else None
+        self._slots = [self._Slot(words if graph is not None else 1, dev) for _ in range(2)] if self.deterministic else None
         self.touched = None
         self._stamp = 0
         self._loss3 = torch.zeros(3, **f32)  # [bpr, reg_lambda * reg, ssl_lambda * InfoNCE]
@@ -43,7 +43,7 @@ class PropagationEngine:
         self.step_count = 0
         self._final_version = -1  # step_count the cached propagation belongs to
         # side stream for index-only work, claimed at construction (ops.side_stream: hardware-queue placement)
-        self._side = ops.side_stream(dev) if (graph is not None and self.deterministic) else None
+        self._side = ops.side_stream(dev) if self.deterministic else None
         self._side_raw = self._side.cuda_stream if self._side is not None else None  # launches name their stream explicitly
         self._fork = ops.LocalEvent() if self._side is not None else None  # device-local events (ops.LocalEvent) throughout
         self._id_storage = None  # storages of the id tensors last ordered against the main stream
@@ -104,8 +104,9 @@ class PropagationEngine:
             self._id_storage = src
             self._fork.record(main.cuda_stream)
             self._fork.wait(self._side_raw)
-        ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap, stream=self._side_raw, clear_bits=self.n)
-        slot.rows_done.record(self._side_raw)  # needed by the last forward layer
+        if self.graph is not None:  # (without propagation nothing is restricted to the batch's rows: MFBPR)
+            ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap, stream=self._side_raw, clear_bits=self.n)
+            slot.rows_done.record(self._side_raw)  # needed by the last forward layer
         ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
         slot.plan_done.record(self._side_raw)  # needed by the gradient scatter
         slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
@@ -124,7 +125,7 @@ class PropagationEngine:
         """Optional one-batch lookahead: prepare the NEXT batch's row bitmap and scatter plan now, so
         they are ready long before its step starts (otherwise the step prepares them itself and the
         main stream waits a few microseconds for the side stream)."""
-        if self.deterministic and self.graph is not None:
+        if self.deterministic:
             self._prepare(self._take_slot(), users, pos, neg)
 
     # ---- forward + backward: losses [bpr, reg_lambda*reg] and d(sum)/dE0 into self.grad
@@ -140,8 +141,23 @@ class PropagationEngine:
         main = torch.cuda.current_stream()
         if self.graph is None:
             self.grad.zero_()
+            if not self.deterministic:
+                ops.bpr_fused_raw(self.params, self.params, users, pos, neg, self.U, self.reg_lambda, self.grad,
+                                  self.grad, loss=loss, deterministic=0)
+                return loss
+            # the sorted scatter plan depends on the indices only: prepared on the side stream (by prefetch() during the
+            # previous step, or right now) — in-call it is half of an MFBPR step
+            key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), users.shape[0])
+            slot = next((sl for sl in self._slots if sl.key == key), None)
+            if slot is None:
+                slot = self._take_slot()
+                self._prepare(slot, users, pos, neg)
+            slot.key = None
+            slot.plan_done.wait(main.cuda_stream)
             ops.bpr_fused_raw(self.params, self.params, users, pos, neg, self.U, self.reg_lambda, self.grad,
-                              self.grad, loss=loss, deterministic=int(self.deterministic))
+                              self.grad, loss=loss, deterministic=2, ws=slot.ws)
+            slot.free = slot.free_ev
+            slot.free.record(main.cuda_stream)
             self._final_version = -1
             return loss
         if not self.deterministic:

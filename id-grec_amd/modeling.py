@@ -157,8 +157,9 @@ class PackedRecommender(nn.Module):
         return True
 
     def prefetch_batch(self, users, pos, neg):
-        """One-batch lookahead for the fused step (row bitmap + scatter plan on the side stream)."""
-        if self.supports_fused_step and self.n_layers > 0:
+        """One-batch lookahead for the fused step (row bitmap + scatter plan on the side stream; the plan alone for
+        MFBPR)."""
+        if self.supports_fused_step:
             self.engine().prefetch(users, pos, neg)
 
     def final_panels(self):
