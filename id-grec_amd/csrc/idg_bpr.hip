@@ -262,24 +262,50 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
   const float up0 = a.upstream ? a.upstream[0] : 1.0f;
   const float up1 = a.upstream ? a.upstream[1] : 1.0f;
   if (a.touched && lane == 0) atomicOr(a.touched + (row >> 5), 1u << (row & 31));
-  for (int64_t f = lane; f < a.d; f += WAVE) {
+  // The run's slots are resolved 64 at a time by the lanes in parallel (slot -> triple -> coefficient and the one or two
+  // panel rows it reads): the sequential walk below then has ONE dependent load level per slot, with several slots'
+  // row loads in flight, instead of three (a hub item's run is the kernel's critical path).  The additions keep
+  // their order, so the result is bit-identical.
+  for (int64_t f0 = 0; f0 < a.d; f0 += WAVE) {
+    const int64_t f = f0 + lane;
+    const bool live = f < a.d;
     float acc = 0.f;
-    for (int64_t t = j; t < e; ++t) {
-      const int32_t s = sslots[t];
-      const int64_t i = s / 3;
-      const int kind = s - 3 * (int32_t)i;
-      const float c = a.coef[i] * up0;
-      float v;
-      if (kind == 0) {
-        const float p = a.fin[(a.num_users + a.pos[i]) * a.d + f];
-        const float n = a.fin[(a.num_users + a.neg[i]) * a.d + f];
-        v = c * (p - n);
-      } else {
-        const float u = a.fin[a.users[i] * a.d + f];
-        v = kind == 1 ? c * u : -c * u;
+    for (int64_t base = j; base < e; base += WAVE) {
+      const int cnt = (int)(e - base < WAVE ? e - base : WAVE);
+      int32_t my_a = 0, my_b = 0, my_kind = 1;
+      float my_c = 0.f;
+      if (lane < cnt) {
+        const int32_t s = sslots[base + lane];
+        const int64_t i = s / 3;
+        my_kind = s - 3 * (int32_t)i;
+        my_c = a.coef[i] * up0;
+        if (my_kind == 0) {
+          my_a = (int32_t)(a.num_users + a.pos[i]);
+          my_b = (int32_t)(a.num_users + a.neg[i]);
+        } else {
+          my_a = (int32_t)a.users[i];
+        }
       }
-      acc = t == j ? v : acc + v;
+#pragma unroll 4
+      for (int tt = 0; tt < cnt; ++tt) {
+        const int32_t ra = __shfl(my_a, tt, WAVE), rb = __shfl(my_b, tt, WAVE);
+        const int kind = __shfl(my_kind, tt, WAVE);
+        const float c = __shfl(my_c, tt, WAVE);
+        float v = 0.f;
+        if (live) {
+          if (kind == 0) {
+            const float p = a.fin[(int64_t)ra * a.d + f];
+            const float n = a.fin[(int64_t)rb * a.d + f];
+            v = c * (p - n);
+          } else {
+            const float u = a.fin[(int64_t)ra * a.d + f];
+            v = kind == 1 ? c * u : -c * u;
+          }
+        }
+        acc = (base == j && tt == 0) ? v : acc + v;
+      }
     }
+    if (!live) continue;
     const int64_t o = (int64_t)row * a.d + f;
     float reg = 0.f;
     if (a.g_ego) {
