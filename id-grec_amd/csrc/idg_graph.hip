@@ -49,7 +49,7 @@ struct __attribute__((aligned(16))) Tile {
   int16_t n_local;  // local rows (LocalRow entries) of this tile
   int32_t local_begin;
   int32_t row_first, row_last;  // the tile's vrows produce (pieces of) the consecutive rows row_first..row_last
-  int32_t pad_;
+  int32_t nnz_count;  // entries of the tile: lets a kernel stage them without first reading the tile's last vrow pointer
 };
 
 struct LocalRow {
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   if (DYNAMIC && tid == 0) s_next = GROUPS;
   for (int i = tid; i <= nv; i += BLOCK) s_ptr[i] = (int)(vptr[t.vrow_begin + i] - nz0);
   for (int i = tid; i < nv; i += BLOCK) s_tgt[i] = vtgt[t.vrow_begin + i];
-  const int cnt = (int)(vptr[t.vrow_begin + nv] - nz0);
+  const int cnt = t.nnz_count;
   {
     const ColVal* src = cv + nz0;
     for (int i = tid; i < cnt; i += BLOCK) s_cv[i] = src[i];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   if (tid == 0) s_next = GROUPS;
   for (int i = tid; i <= nv; i += BLOCK) s_ptr[i] = (int)(vptr[t.vrow_begin + i] - nz0);
   for (int i = tid; i < nv; i += BLOCK) s_tgt[i] = vtgt[t.vrow_begin + i];
-  const int cnt = (int)(vptr[t.vrow_begin + nv] - nz0);
+  const int cnt = t.nnz_count;
   const ColVal* src = cv + nz0;
   // flag + ordered compaction, BLOCK entries per round
   int base = 0;
@@ -652,15 +652,14 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
     const int at = atomicAdd(&s_nlive, (int)lr.n_seg);
     for (int q = 0; q < lr.n_seg; ++q) s_live[at + q] = lr.vrow - t.vrow_begin + q;
   }
-  __syncthreads();
-  const int nlive = s_nlive;
-  if (nlive == 0) return;
-  const int cnt = s_ptr[nv];
-  {
+  {  // the tile's entries are fetched beside the vrow tables (Tile::nnz_count): one dependent level and one barrier less
     const ColVal* src = cv + nz0;
+    const int cnt = t.nnz_count;
     for (int i = tid; i < cnt; i += BLOCK) s_cv[i] = src[i];
   }
   __syncthreads();
+  const int nlive = s_nlive;
+  if (nlive == 0) return;
 
   const int g = tid / LPR;
   const int l = tid % LPR;
@@ -743,15 +742,14 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_multi_kernel(const Tile*
     const int at = atomicAdd(&s_nlive, (int)lr.n_seg);
     for (int q = 0; q < lr.n_seg; ++q) s_live[at + q] = lr.vrow - t.vrow_begin + q;
   }
-  __syncthreads();
-  const int nlive = s_nlive;
-  if (nlive == 0) return;
-  const int cnt = s_ptr[nv];
-  {
+  {  // as in spmm_tile_rows_kernel: entries fetched beside the vrow tables
     const ColVal* src = cv + nz0;
+    const int cnt = t.nnz_count;
     for (int i = tid; i < cnt; i += BLOCK) s_cv[i] = src[i];
   }
   __syncthreads();
+  const int nlive = s_nlive;
+  if (nlive == 0) return;
 
   const int g = tid / LPR;
   const int l = tid % LPR;
@@ -1279,6 +1277,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
       t.local_begin = (int32_t)li0;
       t.row_first = vrow_row[(size_t)v];
       t.row_last = vrow_row[(size_t)w - 1];
+      t.nnz_count = (int32_t)(vptr[(size_t)w] - nz0);
       tiles.push_back(t);
       v = w;
     }
