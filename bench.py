@@ -225,6 +225,7 @@ def main():
             #                  exist before the timed region (at config-5 size: 2 x 15 GB of hipMalloc, ~1 s)
         eng.train_step(*batch(i), loss_out=losses[i])
 
+    S.ramp_clocks()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -156,6 +156,7 @@ def run_replicated_bench(args, rank, world, dist):
             rep.prefetch(tu[i + 1], tp[i + 1], tn[i + 1])
         return step_.train_step(tu[i], tp[i], tn[i])
 
+    S.ramp_clocks()
     for i in range(args.warmup):
         step(i)
     dist.barrier()

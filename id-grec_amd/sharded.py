@@ -601,6 +601,7 @@ def run_sharded_bench(args, rank, world, dist):
         s = slice(i * B, (i + 1) * B)
         return eng.train_step(tu[s], tp[s], tn[s], gB)
 
+    S.ramp_clocks()
     for i in range(args.warmup):
         step(i)
     dist.barrier()

@@ -136,3 +136,20 @@ def draw_triples(seed, users, items, num_users, num_items, need):
         t2 = rng.sample_epoch(su, si, pos_ptr, items32, num_items)
         tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
     return tri, rate, pos_ptr, items32
+
+
+def ramp_clocks(seconds=0.5):
+    """Half a second of untimed, unrelated GPU work before a bench's warm-up steps.  A GPU that has idled (a fresh box,
+    or the seconds of host-side graph construction) starts in a low power state, and the W warm-up steps of a small
+    workload (30 x 0.3 ms) can be over before the clocks are up: the first run on a fresh box measured 0.309 ms/step,
+    the following ones 0.301."""
+    import time
+
+    import torch
+
+    a = torch.randn(4096, 4096, device="cuda")
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            a = torch.tanh(a @ a * 1e-3)
+        torch.cuda.synchronize()
