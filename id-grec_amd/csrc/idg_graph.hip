@@ -539,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   __shared__ int s_pre[TILE_NNZ + 1];  // s_pre[i] = live entries among [0, i)
   __shared__ int s_ptr[TILE_VROWS + 1];
   __shared__ int s_tgt[TILE_VROWS];
-  __shared__ int s_wave[BLOCK / 64 + 1];
+  __shared__ int s_wave[(TILE_NNZ / BLOCK) * (BLOCK / 64)];
   __shared__ int s_next;
 
   const Tile t = tiles[blockIdx.x];
@@ -553,30 +553,44 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   for (int i = tid; i < nv; i += BLOCK) s_tgt[i] = vtgt[t.vrow_begin + i];
   const int cnt = t.nnz_count;
   const ColVal* src = cv + nz0;
-  // flag + ordered compaction, BLOCK entries per round
-  int base = 0;
-  for (int i0 = 0; i0 < cnt; i0 += BLOCK) {
-    const int i = i0 + tid;
-    ColVal e{};
-    bool live = false;
-    if (i < cnt) {
-      e = src[i];
-      live = mask_bit(x_mask, e.col);
-    }
-    const unsigned long long m = __ballot(live);
-    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wave] = __popcll(m);
-    __syncthreads();
-    int before = base;
-    for (int w = 0; w < wave; ++w) before += s_wave[w];
-    int total = 0;
-    for (int w = 0; w < BLOCK / 64; ++w) total += s_wave[w];
-    if (i < cnt) s_pre[i] = before + in_wave;
-    if (live) s_cv[before + in_wave] = e;
-    base += total;
-    __syncthreads();
+  // flag + ordered compaction.  Every thread takes its (up to PER) entries i = k * BLOCK + tid at once: all entry loads
+  // go out together, then all bitmap probes, and ONE barrier pair serves the whole tile (a round per BLOCK entries
+  // cost two dependent loads and two barriers each).  Position of a live entry = live entries with a smaller index.
+  constexpr int PER = TILE_NNZ / BLOCK;
+  ColVal e[PER];
+  bool live[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = k * BLOCK + tid;
+    e[k] = ColVal{};
+    if (i < cnt) e[k] = src[i];
   }
-  if (tid == 0) s_pre[cnt] = base;
+  int in_wave[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = k * BLOCK + tid;
+    live[k] = i < cnt && mask_bit(x_mask, e[k].col);
+    const unsigned long long m = __ballot(live[k]);
+    in_wave[k] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[k * (BLOCK / 64) + wave] = __popcll(m);
+  }
+  __syncthreads();
+  {
+    int before = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = k * BLOCK + tid;
+      int mine = before;
+      for (int w = 0; w < BLOCK / 64; ++w) {
+        const int c = s_wave[k * (BLOCK / 64) + w];
+        if (w < wave) mine += c;
+        before += c;
+      }
+      if (i < cnt) s_pre[i] = mine + in_wave[k];
+      if (live[k]) s_cv[mine + in_wave[k]] = e[k];
+    }
+    if (tid == 0) s_pre[cnt] = before;
+  }
   __syncthreads();
 
   const int g = tid / LPR;
