@@ -383,6 +383,7 @@ class NativeComm:
     unique id to the other ranks."""
 
     averages = True
+    _generation = 0
 
     def __init__(self, dist, device_index, overlap_bytes=64 << 20):
         """overlap_bytes: collectives of at least this many bytes run on a stream of their own, ordered after the
@@ -400,15 +401,27 @@ class NativeComm:
         self.check(self.lib.idg_comm_load(path.encode() if os.path.exists(path) else None), "idg_comm_load")
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         uid = torch.zeros(128, dtype=torch.uint8)
+        NativeComm._generation += 1
+        key = "idg_comm_unique_id_%d" % NativeComm._generation  # every rank constructs communicators in the same order
+        failure = None
         if self.rank == 0:
-            self.check(self.lib.idg_comm_unique_id(uid.data_ptr()), "idg_comm_unique_id")
+            try:
+                self.check(self.lib.idg_comm_unique_id(uid.data_ptr()), "idg_comm_unique_id")
+            except Exception as exc:  # noqa: BLE001 - the other ranks must learn of it instead of waiting for an id
+                failure = exc
         if self.world > 1:
-            # through the rendezvous store, not a collective: this communicator must be the FIRST RCCL communicator the
-            # process creates (measured: created after torch's, every collective on it costs ~30 us more)
+            # through the rendezvous store, not a collective (torch's own RCCL communicator and its streams are then
+            # created after this one's; see ops.side_stream for what stream order does to hardware-queue placement)
             store = dist.distributed_c10d._get_default_store()
             if self.rank == 0:
-                store.set("idg_comm_unique_id", bytes(uid.numpy().tobytes()))
-            uid = torch.frombuffer(bytearray(store.get("idg_comm_unique_id")), dtype=torch.uint8).clone()
+                store.set(key, b"FAILED" if failure is not None else bytes(uid.numpy().tobytes()))
+            got = bytes(store.get(key))
+            if got == b"FAILED" and failure is None:
+                failure = RuntimeError("rank 0 could not obtain an RCCL unique id")
+            if failure is None:
+                uid = torch.frombuffer(bytearray(got), dtype=torch.uint8).clone()
+        if failure is not None:
+            raise failure
         handle = C.c_void_p()
         self.check(self.lib.idg_comm_create(self.rank, self.world, uid.data_ptr(), int(device_index), C.byref(handle)),
                    "idg_comm_create")
