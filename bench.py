@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--layers", type=int, default=3)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MFBPR", "SimGCL"],
-                   help="SimGCL (BASELINE configs[3]): hyper-parameters from configure/SimGCL.txt, no CPU baseline leg")
+                   help="SimGCL (BASELINE configs[3]): hyper-parameters from configure/SimGCL.txt")
     p.add_argument("--atomic", action="store_true", help="float-atomic scatter instead of the deterministic one")
     p.add_argument("--split", type=int, default=0, help="row split threshold (0 = library default)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -46,6 +46,14 @@ def parse():
     p.add_argument("--separate-adam", action="store_true",
                    help="Adam as its own kernel instead of the last backward epilogue (PMC calibration runs)")
     p.add_argument("--seed", type=int, default=2024)
+    p.add_argument("--hbm-leg", default="auto", choices=["auto", "on", "off"],
+                   help="after the headline, time the dominant dense launch on the HBM-bound synth-1M d=64 graph (gathered "
+                        "panel 384 MB > the 256 MiB Infinity Cache) and report it as roofline.hbm_bound; auto = only "
+                        "for the default headline workload (yelp2018 LightGCN d=64)")
+    p.add_argument("--epoch-leg", default="auto", choices=["auto", "on", "off"],
+                   help="after the headline, run epochs through the plugin surface main.py uses (dataset files -> Data -> "
+                        "models.<Model>.Trainer.train(), native sampler included) and report E / epoch_time as `epoch`; "
+                        "auto = for graphs up to amazon-book size")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend of the sharded path: nccl (= RCCL over xGMI) for real runs; gloo only "
                         "to rehearse the multi-rank code path with several ranks sharing one GPU (host-staged collectives)")
@@ -95,8 +103,14 @@ def cpu_baseline(args, wl, W0):
     from oracle.torch_ref import RefStep
 
     U, I = wl["U"], wl["I"]
+    simgcl = None
+    if args.model == "SimGCL":
+        import utility.utility_function.tools as tools
+
+        c = tools.read_configuration(os.path.join(ROOT, "configure", "SimGCL.txt"), "SimGCL")
+        simgcl = (float(c["epsilon"]), float(c["temperature"]), float(c["ssl_lambda"]))
     ref = RefStep(wl["indptr"], wl["indices"], wl["values"], U, I, W0[:U], W0[U:], n_layers=args.layers,
-                  lr=1e-3, propagate=(args.model == "LightGCN"))
+                  lr=1e-3, propagate=(args.model != "MFBPR"), simgcl=simgcl)
     tri = torch.from_numpy(wl["triples"])
     B = args.batch
 
@@ -146,9 +160,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+        # a mislabelled scaling line is worse than none: the launcher's world size and --gpus must agree
+        if world == 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
+        sys.exit("bench.py: launched with WORLD_SIZE=%d but --gpus %d; pass --gpus %d" % (world, args.gpus, world))
     if args.parallel == "shard" and "GPU_MAX_HW_QUEUES" not in os.environ:
         # The sharded form runs several streams per process (step, batch preparation, communicators) and waits between
         # them 2K+1 times per step (the replicas wait once, and measure the same with 3 or 4 queues).  HIP spreads them
@@ -212,32 +228,27 @@ def main():
 
     last = args.warmup + args.steps - 1
 
-    collected = []
-
-    def step(i, timed=False):
+    def step(i):
         if i < last:
             eng.prefetch(*batch(i + 1))  # one-batch lookahead of the index-only work (as the trainer does)
-        # every 8th timed step runs its forward layer by layer with HIP events around each launch (the
-        # per-launch events cost ~10 % of a step, so they are sampled rather than always on)
-        eng.events = collected if (timed and graph is not None and (i - args.warmup) % 8 == 0) else None
-        if i == 0 and graph is not None and not timed:
-            eng.events = []  # the first warm-up step takes the instrumented path once, so that its two layer buffers
-            #                  exist before the timed region (at config-5 size: 2 x 15 GB of hipMalloc, ~1 s)
         eng.train_step(*batch(i), loss_out=losses[i])
 
     S.ramp_clocks()
+    if graph is not None and args.model == "LightGCN":
+        for k in range(1, K + 1):
+            eng.forward_layer(k)  # allocates the two layer buffers of the launch-timing leg BEFORE the timed region (at
+            #                       config-5 size: 2 x 15 GB of hipMalloc, ~1 s); results are overwritten by the steps
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
 
-    # timed region: exactly --steps steps
+    # timed region: exactly --steps steps, nothing else (no events, no instrumented launches)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        step(i, timed=True)
+        step(i)
     t_issue = time.perf_counter() - t0  # host time to issue the steps; < dt means the GPU, not the host, is the limit
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    events, eng.events = collected, None
 
     ms_per_step = dt / args.steps * 1e3
     value = B * args.steps / dt
@@ -256,48 +267,12 @@ def main():
         "host_issue_ms_per_step": t_issue / args.steps * 1e3,
     }
     if graph is not None:
-        # Inside the timed region the forward propagation runs one C-ABI call per layer with a HIP event
-        # pair (recorded on the launch stream) around each: layers 1..K-1 are launches of the dominant
-        # dense kernel (+ its split-row fix-up); the last layer is the row-restricted form and is
-        # reported separately.
-        dense = [(a, b) for kind, a, b in events if kind == "dense"]
-        rows = [(a, b) for kind, a, b in events if kind == "rows"]
-        if not dense:
-            # this step form does not run its products one call at a time (SimGCL shares its first product between the
-            # passes): time the same dense launch on its own, after the timed region
-            Y = torch.empty_like(eng.params)
-            for _ in range(3):
-                graph.spmm_raw(eng.params, out=Y)
-            for _ in range(20):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                graph.spmm_raw(eng.params, out=Y)
-                b.record()
-                dense.append((a, b))
-            torch.cuda.synchronize()
-        spmm_ms = sum(a.elapsed_time(b) for a, b in dense) / max(len(dense), 1)
-        rows_ms = sum(a.elapsed_time(b) for a, b in rows) / max(len(rows), 1)
-        gather, minimum = spmm_bytes(n, nnz, d)
-        achieved = gather / (spmm_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_%s_d%d.json" % (args.workload, d))
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        info = graph.info()
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "spmm_tile_kernel<%d,1,8,dyn> (split rows combined in-kernel)" % (d // 4),
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "us_per_launch": spmm_ms * 1e3, "launches_timed": len(dense),
-            # PMC-measured fabric-side bytes per launch over the launch time measured here: what the memory side of
-            # the L2s actually moved (Infinity-Cache hits included), as a rate and as a fraction of the HBM peak
-            "traffic_gbs": (traffic / (spmm_ms * 1e-3) / 1e9) if traffic else None,
-            "frac_traffic": (traffic / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "row_restricted_last_layer_us": rows_ms * 1e3,
-            "bytes_gather": gather, "bytes_min": minimum,
-            "frac_bytes_min": minimum / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "cache_resident": bool(4 * n * d < INFINITY_CACHE_BYTES),
-            "tiles": info["n_tiles"], "split_rows": info["n_long_rows"],
-        }
+        out["roofline"] = roofline(args, eng, graph, n, nnz, d, K, args.workload, in_step_form=(args.model == "LightGCN"),
+                                   bitmap=eng.touched)
+        hbm_leg = args.hbm_leg == "on" or (args.hbm_leg == "auto" and args.workload == "yelp2018" and d == 64
+                                           and args.model == "LightGCN")
+        if hbm_leg:
+            out["roofline"]["hbm_bound"] = hbm_bound_leg(args)
     # beside the headline: the host sampler's own rate, and full-rank evaluation (propagate + fused
     # score/mask/top-20 of every user against the train CSR) on the same tables — both outside the timed region
     out["sampler"] = {"value": wl["sampler_rate"], "unit": "triples/s", "what": "native MT19937 sampler + shuffle permutation, "
@@ -317,9 +292,167 @@ def main():
             t_e = (time.perf_counter() - t_e) / 3
         out["eval"] = {"value": U / t_e, "unit": "users/s", "ms_per_full_evaluation": t_e * 1e3,
                        "what": "propagate + score + train-positive mask + top-20 for all %d users x %d items" % (U, I)}
-    if not args.no_cpu_baseline and args.model != "SimGCL":
+    if args.epoch_leg == "on" or (args.epoch_leg == "auto" and wl["E"] <= 3_000_000):
+        out["epoch"] = epoch_leg(args)
+    if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl, W0.numpy())
     args.emit(out)
+
+
+def _time_launches(fn, launches_per_call, reps, warm=2):
+    """Average device time of one launch: `reps` calls of fn() (each `launches_per_call` back-to-back launches on
+    torch's current stream — the stream the library launches on) between ONE HIP event pair.  The figure includes the
+    kernel boundary between consecutive launches (~1.5 us each), not the ~5 us an event pair around every single
+    launch would add; rocprofv3's per-kernel average of the same command is the check (profiles/)."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / (reps * launches_per_call) * 1e-3  # seconds
+
+
+def roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form, bitmap=None, reps=None):
+    """SURVEY.md §8(d) for the dominant kernel, measured live AFTER the timed region: achieved = algorithmic gather
+    bytes of one Y = A.X over the average launch time of the dense tiled SpMM in the form a training step launches it
+    (layers 1..K-1 of the forward: product + running layer sum).  `traffic*` fields are NOT measured in this run: they
+    come from a builder-side rocprofv3 --pmc pass committed under profiles/ (traffic_source says which)."""
+    dense_layers = list(range(1, K)) if in_step_form and K >= 2 else []
+    reps = reps or max(3, min(40, int(2e-2 / max(1e-9, nnz * d * 4 / 6e12))))  # ~20 ms of launches, 3..40 calls
+    if dense_layers:
+        def fwd():
+            for k in dense_layers:
+                eng.forward_layer(k)
+        spmm_s = _time_launches(fwd, len(dense_layers), reps)
+        form = "layers 1..%d of the step's forward (product + running layer sum), %d launches between one HIP event pair" \
+               % (K - 1, reps * len(dense_layers))
+    else:
+        # this step form does not run its dense products one call per layer (SimGCL shares its first product between
+        # the passes): time the same dense launch on its own
+        Y = torch.empty_like(eng.params)
+        spmm_s = _time_launches(lambda: graph.spmm_raw(eng.params, out=Y), 1, reps)
+        form = "plain Y = A.X on the parameter panel, %d launches between one HIP event pair" % reps
+    rows_s = None
+    if in_step_form and bitmap is not None:
+        rows_s = _time_launches(lambda: eng.forward_layer(K, bitmap), 1, reps)
+    gather, minimum = spmm_bytes(n, nnz, d)
+    achieved = gather / spmm_s / 1e9
+    traffic, source = None, None
+    tname = "traffic_%s_d%d.json" % (workload, d)
+    for sub in ("r02", ""):
+        tfile = os.path.join(ROOT, "profiles", sub, tname)
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            source = "profiles/%s (builder-side rocprofv3 --pmc passes on an earlier run of this command; NOT measured in " \
+                     "this run; FETCH_SIZE x2 per the gfx950 guide + WRITE_SIZE, Infinity-Cache hits included)" \
+                     % os.path.join(sub, tname)
+            break
+    info = graph.info()
+    return {
+        "bound": "hbm", "kernel": "spmm_tile_kernel<%d,1,8,dyn> (split rows combined in-kernel)" % (d // 4),
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": source,
+        "us_per_launch": spmm_s * 1e6, "timing": form,
+        # PMC-measured fabric-side bytes per launch over the launch time measured here: what the memory side of
+        # the L2s moved (Infinity-Cache hits included), as a rate and as a fraction of the HBM peak
+        "traffic_gbs": (traffic / spmm_s / 1e9) if traffic else None,
+        "frac_traffic": (traffic / spmm_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "row_restricted_last_layer_us": rows_s * 1e6 if rows_s is not None else None,
+        "bytes_gather": gather, "bytes_min": minimum,
+        "frac_bytes_min": minimum / spmm_s / 1e9 / HBM_PEAK_GBS,
+        "cache_resident": bool(4 * n * d < INFINITY_CACHE_BYTES),
+        "tiles": info["n_tiles"], "split_rows": info["n_long_rows"],
+    }
+
+
+def hbm_bound_leg(args, workload="synth-1M", d=64, K=3):
+    """The same dense launch where it IS HBM-bound ("the d=64 >= 60 % of HBM peak target should be
+    demonstrated on a graph with 4nd > 256 MiB"): synth-1M, 1 M users x 0.5 M items, nnz 40 M, gathered panel 384 MB.
+    Built, timed and freed after the headline's timed region; same kernel, same in-step launch form."""
+    import idgrec_amd.host as H
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+
+    U, I, E = S.SHAPES[workload]
+    users, items = S.generate(U, I, E, seed=0)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n, nnz = U + I, len(ix)
+    graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
+    g = torch.Generator(device="cuda").manual_seed(args.seed)
+    params = (torch.rand((n, d), device="cuda", generator=g) * 2 - 1) * (6.0 / (U + d)) ** 0.5
+    eng = PropagationEngine(graph, U, I, d, K, include_layer0=True, deterministic=False, params=params)
+    r = roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form=True, reps=5)
+    r["workload"] = "%s: %d users x %d items, %d train edges, nnz(A)=%d, d=%d (gathered panel %.0f MB)" \
+                    % (workload, U, I, len(users), nnz, d, 4 * n * d / 1e6)
+    for k in ("bound", "kernel", "peak", "unit", "row_restricted_last_layer_us"):
+        r.pop(k, None)
+    del eng, graph, params
+    torch.cuda.empty_cache()
+    return r
+
+
+def epoch_leg(args, epochs=3):
+    """the end-to-end epoch rate E / epoch_time through the plugin surface main.py drives — dataset
+    files -> data_loader.Data -> models.<Model>.Trainer(...).train() — native sampler, shuffle, host->device copy of
+    the triples and the per-epoch loss read-back included; evaluation excluded (the trainer logs its training time
+    per epoch before it tests).  The fastest of epochs 2..N is reported (epoch 1 allocates)."""
+    import importlib
+    import logging
+    import re
+    import shutil
+    import tempfile
+
+    import idgrec_amd.synth as S
+    import utility.utility_data.data_loader as data_loader
+    import utility.utility_function.tools as tools
+
+    root = tempfile.mkdtemp(prefix="idg_bench_epoch_")
+    cwd = os.getcwd()
+    try:
+        os.chdir(ROOT)
+        S.make_dataset(root, args.workload, n_test=1)
+        cfg = tools.read_configuration("./configure/%s.txt" % args.model, args.model)
+        cfg.update(dataset=args.workload, dataset_path=root + "/", training_epochs=str(epochs), interval=str(10 ** 6),
+                   embedding_size=str(args.dim), batch_size=str(args.batch))
+        if "GCN_layer" in cfg:
+            cfg["GCN_layer"] = str(args.layers)
+        times = []
+
+        class Grab(logging.Handler):
+            def emit(self, record):
+                m = re.search(r"Training time: ([0-9.]+)", record.getMessage())
+                if m:
+                    times.append(float(m.group(1)))
+
+        logger = logging.getLogger("idg_bench_epoch")
+        logger.setLevel(logging.INFO)
+        logger.addHandler(Grab())
+        tools.set_seed(args.seed)
+        t0 = time.perf_counter()
+        data = data_loader.Data(cfg["dataset_path"] + cfg["dataset"], cfg)
+        t_data = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        trainer = importlib.import_module("models." + args.model).Trainer(None, cfg, data, torch.device("cuda"), logger)
+        t_init = time.perf_counter() - t0
+        import contextlib
+        import io
+
+        with contextlib.redirect_stderr(io.StringIO()):  # tqdm bars
+            trainer.train()
+        E = int(len(data.train_user))
+        best = min(times[1:]) if len(times) > 1 else times[0]
+        return {"value": E / best, "unit": "triples/s", "epoch_s": best, "epochs_timed": times, "train_edges": E,
+                "data_load_s": t_data, "model_and_graph_init_s": t_init,
+                "what": "E / epoch_time through models.%s.Trainer.train() (the path main.py drives): native sampler + shuffle "
+                        "+ upload + %d fused steps + one loss read-back per epoch; evaluation not included"
+                        % (args.model, E // args.batch + 1)}
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(root, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -869,6 +869,27 @@ __global__ __launch_bounds__(FIX_WAYS * LPR) void spmm_fixup_kernel(const LongRo
   }
 }
 
+// Any-width form of the perturbation (one wave per row, lane l owns features l, l + 64, ...): the row norm of the
+// uniforms depends on (seed, stream, row, d) only, so every wave forms it up front; all 64 lanes must call.
+__device__ __forceinline__ float generic_noise_scale(const Epilogue& ep, int64_t r, int64_t d, int lane) {
+  float ss = 0.f;
+  for (int64_t fb = lane; fb * 4 < d; fb += 64) {
+    const float4 u = noise4(ep, r, (int)fb);
+    const float uu[4] = {u.x, u.y, u.z, u.w};
+    for (int c = 0; c < 4; ++c)
+      if (fb * 4 + c < d) ss += uu[c] * uu[c];
+  }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  return ep.noise_eps / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+__device__ __forceinline__ float generic_perturb(const Epilogue& ep, int64_t r, int64_t f, float scale, float t) {
+  const float4 u = noise4(ep, r, (int)(f >> 2));
+  const int c = (int)(f & 3);
+  const float uf = c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
+  return __builtin_fmaf(sgn(t) * uf, scale, t);
+}
+
 __device__ __forceinline__ void generic_epilogue(const Epilogue& ep, int64_t r, int64_t f, float acc) {
   const int64_t o = r * ep.ldy + f;
   const bool live = ep.mask == nullptr || mask_bit(ep.mask, r);
@@ -895,6 +916,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
   const int64_t s = vptr[v], e = vptr[v + 1];
   const int tgt = vtgt[v];
   if (is_local(tgt)) return;  // spmm_generic_local_kernel
+  const float nscale = (ep.noise_eps != 0.f && tgt >= 0) ? generic_noise_scale(ep, tgt, d, l) : 0.f;
   for (int64_t f = l; f < d; f += 64) {
     float acc = 0.f;
     for (int64_t j = s; j < e; ++j)
@@ -903,6 +925,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_kernel(const int64_t* __re
       partials[(int64_t)(~tgt) * d + f] = acc;
       continue;
     }
+    if (ep.noise_eps != 0.f) acc = generic_perturb(ep, tgt, f, nscale, acc);
     generic_epilogue(ep, tgt, f, acc);
   }
 }
@@ -927,6 +950,18 @@ __global__ __launch_bounds__(BLOCK) void perturb_rows_kernel(const float* __rest
   }
 }
 
+// The stand-alone perturbation for any width: one wave per row.
+__global__ __launch_bounds__(BLOCK) void perturb_rows_generic_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                                     int64_t n, int64_t d, Epilogue ep,
+                                                                     const uint32_t* __restrict__ rows) {
+  const int64_t r = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  const int l = threadIdx.x % 64;
+  if (r >= n) return;
+  if (rows && !mask_bit(rows, r)) return;
+  const float scale = generic_noise_scale(ep, r, d, l);
+  for (int64_t f = l; f < d; f += 64) Y[r * d + f] = generic_perturb(ep, r, f, scale, X[r * d + f]);
+}
+
 // Any d: one wave per local row, its segments walked one after the other, combined in the published order.
 __global__ __launch_bounds__(BLOCK) void spmm_generic_local_kernel(const LocalRow* __restrict__ locals, int64_t n_local,
                                                                    const int64_t* __restrict__ vptr,
@@ -938,6 +973,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_local_kernel(const LocalRo
   const int l = threadIdx.x % 64;
   if (j >= n_local) return;
   const LocalRow lr = locals[j];
+  const float nscale = (ep.noise_eps != 0.f && lr.tgt >= 0) ? generic_noise_scale(ep, lr.tgt, d, l) : 0.f;
   for (int64_t f = l; f < d; f += 64) {
     float way[FIX_WAYS] = {0.f, 0.f, 0.f, 0.f};
     for (int sg = 0; sg < lr.n_seg; ++sg) {
@@ -948,10 +984,12 @@ __global__ __launch_bounds__(BLOCK) void spmm_generic_local_kernel(const LocalRo
     }
     float row = way[0];
     for (int q = 1; q < FIX_WAYS && q < lr.n_seg; ++q) row = row + way[q];
-    if (lr.tgt < 0)
+    if (lr.tgt < 0) {
       partials[(int64_t)(~lr.tgt) * d + f] = row;
-    else
+    } else {
+      if (ep.noise_eps != 0.f) row = generic_perturb(ep, lr.tgt, f, nscale, row);
       generic_epilogue(ep, lr.tgt, f, row);
+    }
   }
 }
 
@@ -962,6 +1000,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
   const int l = threadIdx.x % 64;
   if (g >= n_long) return;
   const LongRow lr = rows[g];
+  const float nscale = ep.noise_eps != 0.f ? generic_noise_scale(ep, lr.row, d, l) : 0.f;
   for (int64_t f = l; f < d; f += 64) {
     const float* p = partials + lr.slot_begin * d + f;
     float acc = 0.f;
@@ -970,6 +1009,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
       for (int sgm = q + FIX_WAYS; sgm < lr.n_seg; sgm += FIX_WAYS) a += p[(int64_t)sgm * d];
       acc = q == 0 ? a : acc + a;
     }
+    if (ep.noise_eps != 0.f) acc = generic_perturb(ep, lr.row, f, nscale, acc);
     generic_epilogue(ep, lr.row, f, acc);
   }
 }
@@ -1061,9 +1101,6 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
   if (ep.adam_p) return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: the fused Adam epilogue needs the tiled kernels");
   if (out_mask)
     return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: row-restricted output needs d in {32,64,128,256,512} and 16-byte aligned panels (d=%lld)",
-                     (long long)d);
-  if (ep.noise_eps != 0.f)
-    return idg::fail(IDG_E_UNSUPPORTED, "idg_propagate: the noise epilogue needs d in {32,64,128,256,512} and 16-byte aligned panels (d=%lld)",
                      (long long)d);
   if (g->n_vrows > 0) {
     const unsigned nb = (unsigned)((g->n_vrows + (BLOCK / 64) - 1) / (BLOCK / 64));
@@ -1474,8 +1511,7 @@ int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y
 
 int idg_perturb_f32(const float* X, float* Y, int64_t n, int64_t d, const uint32_t* rows, float eps, uint64_t seed,
                     uint64_t stream_id, void* stream) {
-  IDG_REQUIRE(X && Y && n >= 0, "idg_perturb_f32: NULL argument");
-  IDG_REQUIRE(((uintptr_t)X | (uintptr_t)Y) % 16 == 0, "idg_perturb_f32: panels must be 16-byte aligned");
+  IDG_REQUIRE(X && Y && n >= 0 && d > 0, "idg_perturb_f32: NULL argument");
   if (n == 0) return IDG_OK;
   Epilogue ep{};
   ep.noise_eps = eps;
@@ -1485,13 +1521,16 @@ int idg_perturb_f32(const float* X, float* Y, int64_t n, int64_t d, const uint32
 #define IDG_PERTURB(LPR, NB)                                                                                      \
   hipLaunchKernelGGL((perturb_rows_kernel<LPR, NB>), dim3((unsigned)((n + BLOCK / LPR - 1) / (BLOCK / LPR))),     \
                      dim3(BLOCK), 0, st, X, Y, n, d, ep, rows)
-  switch (d) {
+  const bool tiled = (d == 32 || d == 64 || d == 128 || d == 256 || d == 512) && ((uintptr_t)X | (uintptr_t)Y) % 16 == 0;
+  if (!tiled) {  // any width / alignment: one wave per row
+    hipLaunchKernelGGL(perturb_rows_generic_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, st, X,
+                       Y, n, d, ep, rows);
+  } else switch (d) {
     case 32: IDG_PERTURB(8, 1); break;
     case 64: IDG_PERTURB(16, 1); break;
     case 128: IDG_PERTURB(32, 1); break;
     case 256: IDG_PERTURB(64, 1); break;
-    case 512: IDG_PERTURB(64, 2); break;
-    default: return idg::fail(IDG_E_UNSUPPORTED, "idg_perturb_f32: d must be one of 32, 64, 128, 256, 512 (got %lld)", (long long)d);
+    default: IDG_PERTURB(64, 2); break;
   }
 #undef IDG_PERTURB
   IDG_HIP(hipGetLastError());

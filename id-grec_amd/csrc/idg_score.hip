@@ -204,7 +204,8 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
                                                                  int64_t I, int64_t d, int64_t chunk_items,
                                                                  const int64_t* __restrict__ excl_indptr,
                                                                  const int32_t* __restrict__ excl_items, int k,
-                                                                 unsigned long long* __restrict__ partial) {
+                                                                 unsigned long long* __restrict__ partial,
+                                                                 const unsigned long long* __restrict__ bound) {
   __shared__ float s_score[FT_USERS * FT_LD];
 
   const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
@@ -243,6 +244,10 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
   unsigned long long best[FT_UPW], tau[FT_UPW];  // per user of this wave: list (lane = rank) and its k-th key
 #pragma unroll
   for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull, tau[uu] = 0ull;
+  // k > 64 (idg_score_topk_f32 runs one pass per 64 ranks): only keys strictly below the user's bound — the last
+  // key the previous pass emitted — are candidates.  Lane uu keeps user uu's bound; no bound = every key passes.
+  unsigned long long my_bound = ~0ull;
+  if (bound && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_bound = bound[b0 + FT_UPW * wave + lane];
 
   for (int64_t slab = c_lo; slab < c_hi; slab += FT_SLAB) {
     // ---- (A) scores of this wave's 32-item column tile for both 32-user row tiles
@@ -330,6 +335,11 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
         const int u = FT_UPW * wave + uu;
         unsigned long long k0 = in0 ? make_key(s_score[u * FT_LD + lane], (uint32_t)(slab + lane)) : 0ull;
         unsigned long long k1 = in1 ? make_key(s_score[u * FT_LD + 64 + lane], (uint32_t)(slab + 64 + lane)) : 0ull;
+        if (bound) {
+          const unsigned long long bd = readlane_u64(my_bound, uu);
+          k0 = k0 < bd ? k0 : 0ull;
+          k1 = k1 < bd ? k1 : 0ull;
+        }
         wave_sort128_desc(k0, k1, lane);
         const unsigned long long t = readlane_u64(k0, k - 1);
 #pragma unroll
@@ -346,8 +356,15 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
         // columns past the chunk hold scores of a clamped item: the exact key test below drops them
         const float floor_ = tau_floor(tau[uu]);  // score of the k-th key (-inf while the list is short)
         if (__ballot(s0 >= floor_) | __ballot(s1 >= floor_)) {
-          list_offer(best[uu], tau[uu], in0 ? make_key(s0, (uint32_t)(slab + lane)) : 0ull, k, lane);
-          list_offer(best[uu], tau[uu], in1 ? make_key(s1, (uint32_t)(slab + 64 + lane)) : 0ull, k, lane);
+          unsigned long long c0 = in0 ? make_key(s0, (uint32_t)(slab + lane)) : 0ull;
+          unsigned long long c1 = in1 ? make_key(s1, (uint32_t)(slab + 64 + lane)) : 0ull;
+          if (bound) {
+            const unsigned long long bd = readlane_u64(my_bound, uu);
+            c0 = c0 < bd ? c0 : 0ull;
+            c1 = c1 < bd ? c1 : 0ull;
+          }
+          list_offer(best[uu], tau[uu], c0, k, lane);
+          list_offer(best[uu], tau[uu], c1, k, lane);
         }
       }
     }
@@ -365,7 +382,8 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
 template <bool SIGMOID>
 __global__ __launch_bounds__(BLOCK) void topk_merge_kernel(const unsigned long long* __restrict__ partial, int64_t Bt,
                                                            int n_chunks, int k, int64_t* __restrict__ out_idx,
-                                                           float* __restrict__ out_val) {
+                                                           float* __restrict__ out_val, int64_t ld_out, int64_t col0,
+                                                           unsigned long long* __restrict__ bound_out) {
   const int lane = threadIdx.x % WAVE;
   const int64_t b = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   if (b >= Bt) return;
@@ -376,13 +394,14 @@ __global__ __launch_bounds__(BLOCK) void topk_merge_kernel(const unsigned long l
     list_offer(best, tau, lane < k ? a : 0ull, k, lane);
   }
   if (lane < k) {
-    out_idx[b * k + lane] = (int64_t)key_item(best);
+    out_idx[b * ld_out + col0 + lane] = (int64_t)key_item(best);
     if (out_val) {
       float s = key_score(best);
       if (SIGMOID) s = s == -__builtin_inff() ? -1.0f : sigmoidf_(s);
-      out_val[b * k + lane] = s;
+      out_val[b * ld_out + col0 + lane] = s;
     }
   }
+  if (bound_out && lane == k - 1) bound_out[b] = best;  // ranks col0 + k ... of the next pass lie strictly below this key
 }
 
 }  // namespace
@@ -429,12 +448,12 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
 
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   (void)d;
-  (void)k;
   if (Bt <= 0 || I <= 0) return 0;
   int nc;
   int64_t ci;
   fused_geometry(Bt, I, &nc, &ci);
-  return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long);
+  // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes
+  return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0);
 }
 
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt,
@@ -442,7 +461,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
                        int apply_sigmoid, int64_t* out_idx, float* out_val, void* ws, void* stream) {
   IDG_REQUIRE(user_panel && item_panel && users && out_idx && ws, "idg_score_topk_f32: NULL argument");
   IDG_REQUIRE(Bt > 0 && I > 0 && d > 0, "idg_score_topk_f32: bad sizes");
-  IDG_REQUIRE(k >= 1 && k <= 64, "idg_score_topk_f32: k=%d outside [1,64]", k);
+  IDG_REQUIRE(k >= 1 && k <= 1024, "idg_score_topk_f32: k=%d outside [1,1024]", k);
   IDG_REQUIRE(k <= I, "idg_score_topk_f32: k=%d exceeds the item count %lld", k, (long long)I);
   IDG_REQUIRE(I < ((int64_t)1 << 32), "idg_score_topk_f32: more than 2^32 items");
   IDG_REQUIRE((excl_indptr == nullptr) == (excl_items == nullptr), "idg_score_topk_f32: excl_indptr and excl_items go together");
@@ -453,14 +472,25 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   unsigned long long* partial = reinterpret_cast<unsigned long long*>(ws);
   const dim3 grid((unsigned)nc, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
   const unsigned nbm = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
-  if (apply_sigmoid) {
-    hipLaunchKernelGGL(score_topk_fused_kernel<true>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
-                       Bt, I, d, ci, excl_indptr, excl_items, k, partial);
-    hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, k, out_idx, out_val);
-  } else {
-    hipLaunchKernelGGL(score_topk_fused_kernel<false>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
-                       Bt, I, d, ci, excl_indptr, excl_items, k, partial);
-    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, k, out_idx, out_val);
+  // k <= 64: one pass.  Larger k (the reference's torch.topk takes any k <= I, batch_test.py:68): one pass per 64
+  // ranks; pass p only admits keys strictly below the last key pass p - 1 emitted (keys are unique per item, so
+  // "below the 64p-th best" is exactly "not among the best 64p"), and its winners fill columns [64p, 64p + kk).
+  unsigned long long* bound = k > 64 ? partial + (size_t)Bt * (size_t)nc * 64 : nullptr;
+  for (int done = 0; done < k; done += 64) {
+    const int kk = k - done < 64 ? k - done : 64;
+    const unsigned long long* bd_in = done > 0 ? bound : nullptr;
+    unsigned long long* bd_out = done + kk < k ? bound : nullptr;
+    if (apply_sigmoid) {
+      hipLaunchKernelGGL(score_topk_fused_kernel<true>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
+                         Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in);
+      hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kk, out_idx, out_val,
+                         (int64_t)k, (int64_t)done, bd_out);
+    } else {
+      hipLaunchKernelGGL(score_topk_fused_kernel<false>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
+                         Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in);
+      hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kk, out_idx, out_val,
+                         (int64_t)k, (int64_t)done, bd_out);
+    }
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;

@@ -108,6 +108,18 @@ class PackedRecommender(nn.Module):
     supports_fused_step = False
     #: entries of the loss vector a fused step writes ([bpr, reg] + the model's own terms)
     n_fused_losses = 2
+    #: widths the row-restricted / masked / Adam-epilogue forms of the tiled SpMM exist for (idg_graph.hip,
+    #: spmm_dispatch): the fused step is built from them, any other width trains through forward() + autograd
+    FUSED_WIDTHS = (32, 64, 128, 256, 512)
+
+    def fused_step_available(self):
+        """True when the trainer may use fused_train_step(): the model offers one, lives on the GPU, and — if it
+        propagates — its embedding width is one the fused kernels are instantiated for.  embedding_size = 48 or 100
+        (values the reference's users run) then train through the generic-width kernels under autograd instead of
+        failing in the first step."""
+        if not self.supports_fused_step or self._storage is None or not self._storage.is_cuda:
+            return False
+        return self.n_layers == 0 or int(self._storage.shape[1]) in self.FUSED_WIDTHS
 
     def fused_loss_and_grad(self, users, pos, neg, loss_out=None):
         """Losses [bpr, reg_lambda*reg] (device tensor) and d(sum)/d(weights) written into the
@@ -159,7 +171,7 @@ class PackedRecommender(nn.Module):
     def prefetch_batch(self, users, pos, neg):
         """One-batch lookahead for the fused step (row bitmap + scatter plan on the side stream; the plan alone for
         MFBPR)."""
-        if self.supports_fused_step:
+        if self.fused_step_available():
             self.engine().prefetch(users, pos, neg)
 
     def final_panels(self):

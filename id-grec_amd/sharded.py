@@ -420,6 +420,16 @@ class NativeComm:
                 failure = RuntimeError("rank 0 could not obtain an RCCL unique id")
             if failure is None:
                 uid = torch.frombuffer(bytearray(got), dtype=torch.uint8).clone()
+        if self.world > 1:
+            # idg_comm_create is collective (ncclCommInitRank): a rank that cannot take part — no id, or a device
+            # index this process cannot open — must say so BEFORE the others enter it, or they wait there for good.
+            # Every rank publishes a verdict under this communicator's generation and reads everyone else's.
+            ready = failure is None and 0 <= int(device_index) < torch.cuda.device_count()
+            store.set("idg_comm_ready_%d_%d" % (NativeComm._generation, self.rank), b"1" if ready else b"0")
+            bad = [r for r in range(self.world)
+                   if bytes(store.get("idg_comm_ready_%d_%d" % (NativeComm._generation, r))) != b"1"]
+            if bad and failure is None:
+                failure = RuntimeError("libidgrec communicator: rank(s) %s cannot join (no unique id or no such device)" % bad)
         if failure is not None:
             raise failure
         handle = C.c_void_p()
@@ -526,8 +536,11 @@ def make_comm(dist, kind="auto"):
         store = dist.distributed_c10d._get_default_store()  # no collective yet: see NativeComm.__init__
     except Exception:  # noqa: BLE001 - private torch API: without it there is no collective-free way to agree
         return TorchComm(dist), "torch.distributed (rendezvous store not reachable)"
-    store.set("idg_comm_loaded_%d" % rank, b"1" if loaded else b"0")
-    if not all(bytes(store.get("idg_comm_loaded_%d" % r)) == b"1" for r in range(world)):
+    # keys carry the generation of the communicator about to be built (every rank calls make_comm in the same order),
+    # so a second make_comm on the same process group never reads the first one's verdicts
+    gen = NativeComm._generation + 1
+    store.set("idg_comm_loaded_%d_%d" % (gen, rank), b"1" if loaded else b"0")
+    if not all(bytes(store.get("idg_comm_loaded_%d_%d" % (gen, r))) == b"1" for r in range(world)):
         return TorchComm(dist), "torch.distributed (libidgrec could not load librccl)"
     why = ""
     try:

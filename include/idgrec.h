@@ -395,7 +395,9 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
  * masking) rank as the value -1 (batch_test.py:62-65).  The k best per row are returned sorted by
  * (raw score descending, item id ascending) — sigmoid is monotone, so this is one of the orders
  * torch.topk may return on the sigmoid values; out_val holds act(score), -1 for masked entries.
- * out_idx int64 [Bt,k], out_val fp32 [Bt,k] (may be NULL).  k <= 64.
+ * out_idx int64 [Bt,k], out_val fp32 [Bt,k] (may be NULL).  1 <= k <= min(I, 1024): k <= 64 is one pass;
+ * a larger k (torch.topk takes any k <= I, batch_test.py:68) runs one scoring pass per 64 ranks, each admitting only
+ * keys strictly below the last one the previous pass emitted (same order, same values as one pass would give).
  * ws: idg_score_topk_workspace_bytes (one 64-key list per user and item chunk: 512 B x Bt x chunks).
  * Throughput wants Bt large — hand over EVERY test user in one call (there is no [Bt, I] matrix to
  * bound): the catalogue is only cut into chunks when Bt/64 workgroups cannot fill the chip. */

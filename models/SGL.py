@@ -105,7 +105,7 @@ class Trainer():
             step_losses = torch.zeros((num_batch, 3), dtype=torch.float32, device=device)
             # one sub-graph per view ('ed' / 'nd'): the step runs as a fixed chain of kernels (PropagationEngine.sgl);
             # per-layer graph lists ('rw') go through forward() under autograd
-            fused = not isinstance(sub_graph_1, list) and torch.device(device).type == "cuda"
+            fused = not isinstance(sub_graph_1, list) and torch.device(device).type == "cuda" and model.fused_step_available()
             users, pos_items, neg_items = users.contiguous(), pos_items.contiguous(), neg_items.contiguous()
             batches = list(tools.mini_batch(users, pos_items, neg_items, batch_size=batch_size))
             for batch_i, (b_u, b_p, b_n) in enumerate(batches):

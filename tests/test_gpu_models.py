@@ -343,6 +343,35 @@ def test_simgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
     np.testing.assert_allclose(v_f, v_a, rtol=2e-3, atol=1e-6 * np.abs(v_a).max())
 
 
+@pytest.mark.parametrize("model_name", ["LightGCN", "SimGCL", "XSimGCL", "SGL", "MFBPR"])
+def test_embedding_size_without_tiled_kernels_trains(model_name, tmp_path, golden_small):
+    """embedding_size = 48 (the reference runs any width): the fused step is built from kernels that exist for
+    32/64/128/256/512 only, so the trainer must take the autograd path (any-width kernels) instead of failing in the
+    first step — two epochs train, the loss falls, evaluation runs.  top_K = [20, 100] also takes the evaluator past
+    the 64 ranks one top-K pass holds."""
+    import importlib
+
+    import utility.utility_function.tools as tools
+
+    g = golden_small
+    cfg = _cfg(model_name, embedding_size=48, batch_size=256, test_batch_size=64, training_epochs=2, interval=1,
+               top_K="[20, 100]", early_stopping=10, sparsity_test=0)
+    data = _data_with(tmp_path, g, cfg)
+    stream = io.StringIO()
+    logger = logging.getLogger("gpu_d48_" + model_name)
+    logger.setLevel(logging.INFO)
+    logger.handlers = [logging.StreamHandler(stream)]
+    tools.set_seed(2024)
+    tr = importlib.import_module("models." + model_name).Trainer(None, cfg, data, torch.device("cuda"), logger)
+    assert tr.model.fused_step_available() == (model_name == "MFBPR")
+    tr.train()
+    lines = stream.getvalue().splitlines()
+    losses = [_numbers(l.split("training loss:")[1])[0] for l in lines if "training loss" in l]
+    assert len(losses) == 2 and np.isfinite(losses).all() and losses[1] < losses[0]
+    recalls = [l for l in lines if "Test recall" in l]
+    assert len(recalls) >= 2
+
+
 # ----------------------------------------------------------------- next models (SURVEY §8f)
 @pytest.fixture(scope="module")
 def golden_next():

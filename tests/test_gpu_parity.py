@@ -740,6 +740,66 @@ def test_topk_ties_saturated_sigmoid_and_masked_fill(ops):
     assert val.cpu().numpy()[0, 2:].tolist() == [-1.0, -1.0, -1.0]
 
 
+@pytest.mark.parametrize("k", [65, 100, 128, 200])
+def test_topk_beyond_64_ranks(ops, k):
+    """torch.topk takes any k <= I (batch_test.py:68; the reference's sparsity_test comment suggests top_K up to
+    100): k > 64 runs one scoring pass per 64 ranks, each admitting only keys below the previous pass's last one.
+    Same order and values as the one-pass definition: (score descending, item ascending), train positives as -1."""
+    rng = np.random.default_rng(k)
+    U, I, d = 150, 1900, 64
+    Ue = rng.standard_normal((U, d)).astype(np.float32) * 0.5
+    Ie = rng.standard_normal((I, d)).astype(np.float32) * 0.5
+    Ie[700:760] = Ie[100]  # 61 items with identical scores for every user: ties across a pass boundary
+    rows = [np.sort(rng.choice(I, int(rng.integers(0, 60)) if u % 7 else I - k + 30, replace=False)) for u in range(U)]
+    ip = np.zeros(U + 1, dtype=np.int64)
+    ip[1:] = np.cumsum([len(r) for r in rows])
+    ix = np.concatenate(rows).astype(np.int32)
+    users_np = rng.permutation(U)
+    idx, val = ops.score_topk(dev(Ue), dev(Ie), dev(users_np), k, dev(ip), dev(ix), apply_sigmoid=False, return_values=True)
+    R = ops.score_dense(dev(Ue), dev(Ie), dev(users_np), apply_sigmoid=False).cpu().numpy()
+    for b, u in enumerate(users_np):
+        R[b, ix[ip[u]:ip[u + 1]]] = -1.0
+    want = oracle.topk_reference(R, k)
+    # masked entries rank as the VALUE -1 among raw scores (unmasked scores below -1 come after them)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(val.cpu().numpy(), np.take_along_axis(R, want, axis=1))
+    # through the evaluator's entry (sigmoid domain): first 64 columns equal the k = 64 call
+    idx_s = ops.score_topk(dev(Ue), dev(Ie), dev(users_np), k, dev(ip), dev(ix)).cpu().numpy()
+    idx_64 = ops.score_topk(dev(Ue), dev(Ie), dev(users_np), 64, dev(ip), dev(ix)).cpu().numpy()
+    assert np.array_equal(idx_s[:, :64], idx_64)
+    assert all(len(set(r.tolist())) == k for r in idx_s)
+
+
+def test_noise_and_perturbation_any_width(ops, golden_small):
+    """embedding_size = 48 / 100 (widths without a tiled instantiation): the perturbed product and the stand-alone
+    perturbation run in the any-width kernels with the same contract — clean product bit-equal to the fmaf chain, every
+    row moved by exactly eps along sign(X), reproducible per (seed, stream)."""
+    g = golden_small
+    n = int(g["num_users"]) + int(g["num_items"])
+    G = _graph(ops, g)
+    for d in (48, 100, 7):
+        X = torch.randn(n, d, device="cuda") * 0.1
+        clean = G.spmm_raw(X)
+        assert np.array_equal(clean.cpu().numpy(), oracle.spmm(*_adj(g), X.cpu().numpy(), *G.long_rows()))
+        Y1 = ops.spmm_noise_raw(G, X, 0.05, 99, 3)
+        Y2 = ops.spmm_noise_raw(G, X, 0.05, 99, 3)
+        Y3 = ops.spmm_noise_raw(G, X, 0.05, 99, 4)
+        assert torch.equal(Y1, Y2) and not torch.equal(Y1, Y3)
+        delta = Y1 - clean
+        livez = clean.abs().sum(1) > 0
+        if d > 8:  # (with a handful of features some of a row's entries can be exactly zero: sign(0) = 0)
+            np.testing.assert_allclose(delta[livez].norm(dim=1).cpu().numpy(), 0.05, rtol=5e-4)
+        assert torch.all(delta * torch.sign(clean) >= 0)
+        P = ops.perturb_raw(clean, 0.05, 99, 3)
+        assert torch.allclose(P, Y1, rtol=0, atol=1e-7)  # same uniforms, same scale: the epilogue's arithmetic on its own
+        # the K-layer perturbed pass and its backward (autograd path of SimGCL at this width)
+        E0 = X.clone().requires_grad_(True)
+        c, v1, v2 = ops.propagate_views(G, E0, 3, False, 0.05, n_views=2)
+        assert torch.equal(c, G.propagate_mean_raw(X, 3, False)) and not torch.equal(v1, v2)
+        (v1.sum() + v2.sum()).backward()
+        assert torch.isfinite(E0.grad).all()
+
+
 # ------------------------------------------------------------ full-size (BASELINE) properties
 @pytest.mark.parametrize("fused", ["0", "1"])
 def test_yelp_shape_full_size(ops, fused, monkeypatch):

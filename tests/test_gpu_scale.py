@@ -1,0 +1,250 @@
+"""GPU parity at the sizes BASELINE.json's configs name, where the oracle cannot restate a whole panel in seconds:
+
+* config 5 (LightGCN-3 d=256 on a 10M-user graph): a panel of MORE than 2^32 fp32 elements (n.d = 4.3e9, 17.2 GB) —
+  every 32-bit element or byte offset in a kernel would wrap here.  The oracle checks SAMPLED rows layer by layer
+  (a row of layer k needs only its neighbours' rows of layer k-1, which are read back from the device: by induction
+  over the layers every sampled row of the propagation is pinned to the sequential fmaf chain), the backward
+  propagation is pinned by its adjoint identity against the (verified) forward, BPR and Adam by the oracle on the
+  batch's rows.
+* config 4 (SimGCL-3 d=64, amazon-book shape): the shared-first-product / multi-panel row-restricted encoder passes
+  against the single-purpose kernels, and the fused step against the autograd composition.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _sampled_rows_problem(ip, ix, dv, rows, X_dev):
+    """The CSR rows `rows` of (ip, ix, dv) as a small CSR over a compact column space + the gathered panel rows of
+    X_dev they need (read back from the device).  Column order inside a row is preserved (the remap is monotone)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    lens = (ip[rows + 1] - ip[rows]).astype(np.int64)
+    sel = np.concatenate([np.arange(ip[r], ip[r + 1]) for r in rows]) if len(rows) else np.empty(0, np.int64)
+    cols = ix[sel].astype(np.int64)
+    uniq = np.unique(cols)
+    sub_ptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    sub_ptr[1:] = np.cumsum(lens)
+    sub_idx = np.searchsorted(uniq, cols).astype(np.int32)
+    Xs = X_dev.index_select(0, dev(uniq)).cpu().numpy()
+    return sub_ptr, sub_idx, dv[sel], Xs
+
+
+def _oracle_rows(ip, ix, dv, rows, X_dev, sched):
+    """(A.X)[rows] by the oracle's sequential fmaf chain (split rows in the handle's published schedule)."""
+    sub_ptr, sub_idx, sub_val, Xs = _sampled_rows_problem(ip, ix, dv, rows, X_dev)
+    long_rows, seg, chunk = sched
+    pos = {int(r): i for i, r in enumerate(long_rows)}
+    mine = [(i, pos[int(r)]) for i, r in enumerate(rows) if int(r) in pos]
+    if mine:
+        lr = np.array([i for i, _ in mine], dtype=np.int64)
+        sl = np.array([seg[j] for _, j in mine], dtype=np.int64)
+        cl = np.array([chunk[j] for _, j in mine], dtype=np.int64)
+        return oracle.spmm(sub_ptr, sub_idx, sub_val, Xs, lr, sl, cl)
+    return oracle.spmm(sub_ptr, sub_idx, sub_val, Xs)
+
+
+def test_config5_panel_beyond_2_pow_32_elements():
+    """LightGCN-3 d=256 on a graph whose [n, d] panel has more than 2^32 elements (n = 18 M, 18.4 GB per panel,
+    ~150 GB resident during the step; 1.2 M rows lie beyond element 2^32): every layer of the forward and of the
+    backward propagation, BPR and Adam of ONE training step, on sampled rows, bit for bit."""
+    import idgrec_amd.host as H
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+
+    free, total = torch.cuda.mem_get_info()
+    if free < 190 * (1 << 30):
+        pytest.skip("needs ~170 GB of free HBM (MI355X: 288 GB)")
+    U, I, E, d, K, B = 13_000_000, 5_000_000, 40_000_000, 256, 3, 1024
+    n = U + I
+    assert n * d > 2 ** 32
+    users, items = S.generate(U, I, E, seed=3, match_edges=False)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    G = ops.Graph(ip, ix, dv, n, n)
+    sched = G.long_rows()
+    assert len(sched[0]) > 0 and (np.asarray(sched[2]) > 0).any(), "the graph must exercise split and chunked rows"
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    X = (torch.rand((n, d), device="cuda", generator=gen) - 0.5) * 0.2
+
+    # the batch: reaches the far end of the panel (rows beyond 2^32 elements), with a duplicate user and item
+    rng = np.random.default_rng(0)
+    pos_ptr = np.zeros(U + 1, dtype=np.int64)
+    pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    pick = np.sort(rng.choice(len(users), 4 * B, replace=False))
+    tri = H.Rng(2024).sample_epoch(users[pick], items[pick], pos_ptr, items.astype(np.int32), I)
+    b = tri[rng.permutation(len(tri))[:B]].copy()
+    b[0] = [U - 1, I - 1, I - 2]
+    b[1] = [U - 1, I - 1, 0]
+    touched = np.unique(np.concatenate([b[:, 0], U + b[:, 1], U + b[:, 2]]))
+    touched_d = dev(touched)
+
+    # rows to check: around every 2^31 / 2^32 element and byte boundary of the panel, the panel's ends, the user/item
+    # seam, split rows (segments combined in LDS, chunks combined by the last arriver), part of the batch's rows (the
+    # live rows of the masked epilogues), neighbours of batch rows (rows the sparse-input backward product reaches),
+    # and a random sample
+    marks = [0, U - 1, U, n - 1, 2 ** 31 // d, 2 ** 32 // d, 2 ** 31 // (4 * d), 2 ** 32 // (4 * d), 2 ** 33 // (4 * d),
+             2 ** 34 // (4 * d)]
+    near = np.concatenate([np.arange(max(m - 3, 0), min(m + 4, n)) for m in marks])
+    longs = np.asarray(sched[0])
+    deg = np.diff(ip)
+    nbrs = np.concatenate([ix[ip[r]:ip[r + 1]][:4] for r in touched[::16]]).astype(np.int64)
+    rows = np.unique(np.concatenate([near, longs[:: max(1, len(longs) // 150)], longs[np.argsort(deg[longs])[-4:]],
+                                     touched[::8], nbrs, rng.integers(0, n, 1200), rng.integers(2 ** 32 // d, n, 300)]))
+    rows_d = dev(rows)
+    live = np.isin(rows, touched)
+
+    def at(t):
+        return t.index_select(0, rows_d).cpu().numpy()
+
+    eng = PropagationEngine(G, U, I, d, K, include_layer0=True, params=X)
+    ws = G._workspace("prop", d)  # the handle's two layer buffers: layer outputs stay there after a propagation
+    panel_bytes = (n * d * 4 + 255) // 256 * 256
+    L1 = ws[:n * d * 4].view(torch.float32).view(n, d)
+    L2 = ws[panel_bytes:panel_bytes + n * d * 4].view(torch.float32).view(n, d)
+
+    # ---- forward, layer by layer on the sampled rows
+    fin = eng.propagate(force=True)
+    y1 = _oracle_rows(ip, ix, dv, rows, X, sched)
+    assert np.array_equal(at(L1), y1), "forward layer 1 differs from the fmaf chain"
+    y2 = _oracle_rows(ip, ix, dv, rows, L1, sched)
+    assert np.array_equal(at(L2), y2), "forward layer 2 differs"
+    y3 = _oracle_rows(ip, ix, dv, rows, L2, sched)
+    x0 = at(X)
+    mean = (((x0 + y1) + y2) + y3) / np.float32(4.0)  # torch.mean(torch.stack([...])) order (SURVEY.md §8a note)
+    assert np.array_equal(at(fin), mean), "layer mean differs"
+    Y = G.spmm_raw(X)  # the plain product through the other entry point
+    assert np.array_equal(at(Y), y1)
+    del Y
+    fin_rows = fin.index_select(0, touched_d).cpu().numpy()
+    ego_rows = X.index_select(0, touched_d).cpu().numpy()
+    W_old = x0.copy()
+
+    # ---- one training step (row-restricted last forward layer, BPR, sparse-input first backward product, masked
+    #      epilogues, Adam in the last epilogue)
+    loss = eng.train_step(dev(b[:, 0]), dev(b[:, 1]), dev(b[:, 2])).cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.final.index_select(0, touched_d).cpu().numpy(), fin_rows), "row-restricted forward differs"
+    nu = int((touched < U).sum())  # compact problem: the touched rows renumbered 0.., users first (ids < U sort first)
+    cu = np.searchsorted(touched, b[:, 0])
+    cp = np.searchsorted(touched, U + b[:, 1]) - nu
+    cn = np.searchsorted(touched, U + b[:, 2]) - nu
+    loss_o, gf, ge = oracle.bpr(fin_rows, ego_rows, nu, cu, cp, cn, 1e-4)
+    np.testing.assert_allclose(loss, loss_o, rtol=1e-5)
+    gF = eng.g_final
+    np.testing.assert_allclose(gF.index_select(0, touched_d).cpu().numpy(), gf, rtol=1e-4, atol=1e-9)
+    # backward Horner chain, on the device's own g_final: h1 = A.g + g, h2 = A.h1 + g, grad = (g + A.h2)/4 (+ reg rows)
+    g_rows = at(gF)
+    g_rows[~live] = 0.0  # rows outside the batch are not part of g (never read: masked)
+    h1 = _oracle_rows(ip, ix, dv, rows, gF, sched)
+    h1[live] = h1[live] + g_rows[live]
+    assert np.array_equal(at(L1), h1), "backward step 1 differs"
+    h2 = _oracle_rows(ip, ix, dv, rows, L1, sched)
+    h2[live] = h2[live] + g_rows[live]
+    assert np.array_equal(at(L2), h2), "backward step 2 differs"
+    t3 = _oracle_rows(ip, ix, dv, rows, L2, sched)
+    want = t3.copy()
+    want[live] = g_rows[live] + t3[live]
+    want = want / np.float32(4.0)
+    ge_rows = np.zeros_like(want)
+    ge_rows[live] = ge[np.searchsorted(touched, rows[live])]
+    got = at(eng.grad)
+    assert np.array_equal(got[~live], want[~live]), "gradient differs outside the batch's rows"
+    np.testing.assert_allclose(got[live], ge_rows[live] + want[live], rtol=1e-5, atol=1e-10)
+    # Adam (first step) on the sampled rows, fed with the device's gradient rows
+    W, m, v = W_old.copy(), np.zeros_like(W_old), np.zeros_like(W_old)
+    oracle.adam(W, np.ascontiguousarray(got), m, v, 1e-3, 1)
+    np.testing.assert_allclose(at(eng.params), W, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(at(eng.exp_avg), m, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(at(eng.exp_avg_sq), v, rtol=1e-6, atol=1e-20)
+
+
+def test_simgcl_encoder_passes_and_fused_step_at_amazon_book_size():
+    """BASELINE configs[3] (SimGCL-3 d=64, amazon-book shape, B=2048): (i) idg_propagate_views_f32 — shared first
+    product, per-view perturbation, multi-panel row-restricted last layer — against the single-purpose kernels: the
+    clean pass bit-equal to propagate_mean over the whole panel, restricted outputs bit-equal to the unrestricted
+    ones on the requested rows (NaN poison everywhere else survives); (ii) the fused training step against the same
+    computation composed from the differentiable operators under autograd, same noise streams."""
+    import idgrec_amd.host as H
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+
+    U, I, E = S.SHAPES["amazon-book"]
+    d, K, B, eps, temperature, ssl_lambda = 64, 3, 2048, 0.05, 0.2, 0.5
+    users, items = S.generate(U, I, E, seed=0)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n = U + I
+    G = ops.Graph(ip, ix, dv, n, n)
+    W0 = S.xavier_uniform_panel(U, I, d, 2024).cuda()
+    pos_ptr = np.zeros(U + 1, dtype=np.int64)
+    pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    rng = H.Rng(2024)
+    tri = rng.sample_epoch(users, items, pos_ptr, items.astype(np.int32), I)
+    tri = tri[rng.shuffle_perm(len(tri))][:3 * B]
+    streams = [(1234, 1), (1234, 2)]
+
+    # (i) whole-panel passes
+    full = [torch.empty_like(W0) for _ in range(3)]
+    ops.propagate_views_raw(G, W0, K, False, eps, streams, full)
+    assert torch.equal(full[0], G.propagate_mean_raw(W0, K, False)), "clean pass differs from propagate_mean"
+    for v, (seed, sid) in zip(full[1:], streams):
+        # the composition from single-purpose entry points: A.E0, perturb, then K-1 perturbed layers
+        T = G.spmm_raw(W0)
+        X1 = ops.perturb_raw(T, eps, seed, sid * 64)
+        want = G.propagate_mean_noise_raw(X1, K - 1, True, eps, seed, sid)
+        assert torch.equal(v, want), "a perturbed view differs from its composition"
+        delta = (v - full[0]).norm(dim=1)
+        assert float(delta.max()) < K * eps * 1.01
+    b0 = tri[:B]
+    bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device="cuda")
+    ops.bpr_touch_rows_raw(dev(b0[:, 0]), dev(b0[:, 1]), dev(b0[:, 2]), U, bitmap)
+    rows = dev(np.unique(np.concatenate([b0[:, 0], U + b0[:, 1], U + b0[:, 2]])))
+    part = [torch.full_like(W0, float("nan")) for _ in range(3)]
+    ops.propagate_views_raw(G, W0, K, False, eps, streams, part, out_rows=bitmap)
+    for p, f in zip(part, full):
+        assert torch.equal(p.index_select(0, rows), f.index_select(0, rows)), "restricted rows differ from the full pass"
+        mask = torch.ones(n, dtype=torch.bool, device="cuda")
+        mask[rows] = False
+        assert bool(torch.isnan(p[mask]).all()), "a row outside the request was written"
+    del full, part
+
+    # (ii) fused step vs autograd composition, three steps
+    bt = [tuple(dev(tri[i * B:(i + 1) * B, c]) for c in range(3)) for i in range(3)]
+    res = []
+    for fused in (True, False):
+        torch.cuda.manual_seed(77)
+        ops.reset_noise_stream()
+        P = W0.clone()
+        loss = torch.zeros((3, 3), device="cuda")
+        if fused:
+            eng = PropagationEngine(G, U, I, d, K, include_layer0=False, reg_lambda=1e-4, lr=1e-3, params=P)
+            eng.ssl = (eps, temperature, ssl_lambda)
+            for i in range(3):
+                eng.train_step(*bt[i], loss_out=loss[i])
+            res.append((loss.cpu().numpy(), eng.grad.clone(), P))
+        else:
+            P.requires_grad_(True)
+            opt = ops.Adam([P], lr=1e-3)
+            for i in range(3):
+                u, p_, n_ = bt[i]
+                clean, v1, v2 = ops.propagate_views(G, P, K, False, eps, n_views=2)
+                bpr, reg = ops.bpr_loss(clean, P, u, p_, n_, U, 1e-4)
+                ssl = ssl_lambda * ops.infonce_pair(v1, v2, u, p_, U, temperature)
+                loss[i] = torch.stack([bpr.detach(), reg.detach(), ssl.detach()])
+                opt.zero_grad()
+                (bpr + reg + ssl).backward()
+                opt.step()
+            res.append((loss.cpu().numpy(), P.grad.clone(), P.detach()))
+    (l_f, g_f, w_f), (l_a, g_a, w_a) = res
+    np.testing.assert_allclose(l_f, l_a, rtol=2e-5)
+    gmax = float(g_a.abs().max())
+    assert float((g_f - g_a).abs().max()) <= 1e-3 * gmax
+    assert torch.allclose(w_f, w_a, rtol=1e-4, atol=1e-6)

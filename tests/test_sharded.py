@@ -12,10 +12,12 @@ from tests.ranks import run_ranks
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _problem(g, K, include0, B, steps, seed=0):
+def _problem(g, K, include0, B, steps, seed=0, d=64):
     U, I = int(g["num_users"]), int(g["num_items"])
     W0 = np.concatenate([g["d64_init_user"], g["d64_init_item"]])
     rng = np.random.default_rng(seed)
+    if d != 64:  # BASELINE config 5 is d = 256: xavier-uniform tables of that width (the checker is the oracle, not a golden)
+        W0 = np.concatenate([(rng.random((m, d)) * 2 - 1) * np.sqrt(6.0 / (m + d)) for m in (U, I)]).astype(np.float32)
     tri = g["sample1"][rng.permutation(len(g["sample1"]))][: B * steps]
     return dict(indptr=g["adj_indptr"], indices=g["adj_indices"], values=g["adj_data"], W0=W0, triples=tri, U=U, I=I,
                 K=K, B=B, include0=include0)
@@ -96,9 +98,9 @@ def test_shards_tile_the_global_adjacency(world, golden_small):
     assert (acc_iu != A[U:, :U]).nnz == 0
 
 
-@pytest.mark.parametrize("K,include0", [(3, True), (2, False), (1, True)])
-def test_two_ranks_gloo_cpu_match_single_device(K, include0, tmp_path, golden_small):
-    p = _problem(golden_small, K, include0, B=160, steps=3)
+@pytest.mark.parametrize("K,include0,d", [(3, True, 64), (2, False, 64), (1, True, 64), (3, True, 256)])
+def test_two_ranks_gloo_cpu_match_single_device(K, include0, d, tmp_path, golden_small):
+    p = _problem(golden_small, K, include0, B=160, steps=3, d=d)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
     outs = _launch("cpu", path, 3)
@@ -107,11 +109,12 @@ def test_two_ranks_gloo_cpu_match_single_device(K, include0, tmp_path, golden_sm
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["gpu", "gpu-dense"])
-@pytest.mark.parametrize("K,include0", [(3, True), (2, False), (1, True)])
-def test_two_ranks_hip_kernels_match_single_device(K, include0, mode, tmp_path, golden_small):
+@pytest.mark.parametrize("K,include0,d", [(3, True, 64), (2, False, 64), (1, True, 64), (3, True, 256), (2, False, 256)])
+def test_two_ranks_hip_kernels_match_single_device(K, include0, d, mode, tmp_path, golden_small):
     """mode "gpu": prepared batches (row-restricted last forward user product, sparse first backward product,
-    planned scatter, every other step through the one-batch lookahead); "gpu-dense": every product dense."""
-    p = _problem(golden_small, K, include0, B=160, steps=4)
+    planned scatter, every other step through the one-batch lookahead); "gpu-dense": every product dense.
+    d = 256 is the width of BASELINE config 5 (user-row shards, 8 GPUs)."""
+    p = _problem(golden_small, K, include0, B=160, steps=4, d=d)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
     outs = _launch(mode, path, 4)

@@ -33,3 +33,25 @@ def test_port_rating_matches_reference(golden_small):
     ref = RefStep(g["adj_indptr"], g["adj_indices"], g["adj_data"], U, I, g["d64_init_user"], g["d64_init_item"])
     R = ref.rating(torch.from_numpy(g["test_dict_users"][:48])).numpy()
     np.testing.assert_allclose(R, g["d64_lgcn_rating"], rtol=1e-6, atol=1e-7)
+
+
+def test_port_simgcl_pieces_match_reference(golden_small, golden_misc):
+    """The SimGCL leg of the CPU baseline: the clean encoder pass (no layer 0 in the mean) and InfoNCE reproduce the
+    imported reference's outputs bit for bit / to 1e-6; the perturbed passes draw from torch's CPU generator (nothing to
+    pin them to), so the whole step is only run once and asked for three finite losses."""
+    g = golden_small
+    torch.set_num_threads(1)
+    U, I = int(g["num_users"]), int(g["num_items"])
+    ref = RefStep(g["adj_indptr"], g["adj_indices"], g["adj_data"], U, I, g["d64_init_user"], g["d64_init_item"],
+                  simgcl=(0.1, 0.2, 0.5))
+    with torch.no_grad():
+        u, i = ref.aggregate(perturbed=False)
+        np.testing.assert_array_equal(u.numpy(), g["d64_simgcl_user"])
+        np.testing.assert_array_equal(i.numpy(), g["d64_simgcl_item"])
+        from oracle.torch_ref import info_nce
+
+        val = info_nce(torch.from_numpy(golden_misc["infonce_a"]), torch.from_numpy(golden_misc["infonce_b"]), 0.2)
+        np.testing.assert_allclose(val.item(), golden_misc["infonce_02"], rtol=1e-6)
+    b = torch.arange(64)
+    losses = ref.step(b % U, b % I, (b * 7) % I)
+    assert len(losses) == 3 and all(np.isfinite(losses))

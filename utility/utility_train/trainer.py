@@ -36,7 +36,11 @@ def universal_trainer(model, args, config, dataset, device, logger):
     batch_size = int(config['batch_size'])
     top_k = eval(config['top_K'])
     Optim = _make_optimizer(model, float(config['learn_rate']), device)
-    fused = bool(getattr(model, "supports_fused_step", False)) and torch.device(device).type == "cuda"
+    # the fused chain exists for the tiled embedding widths only: models say whether it applies (embedding_size = 48
+    # and the like fall back to forward() + autograd + the same Adam kernel)
+    available = getattr(model, "fused_step_available", None)
+    fused = torch.device(device).type == "cuda" and (available() if available is not None
+                                                     else bool(getattr(model, "supports_fused_step", False)))
 
     best_results = {'count': 0, 'epoch': 0, 'recall': [0. for _ in top_k], 'ndcg': [0. for _ in top_k], 'stop': 0}
 
