@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -127,6 +128,7 @@ struct idg_graph {
   int32_t* d_slot_long = nullptr;  // partial slot -> index into d_long
   int* d_long_cnt = nullptr;       // arrival tickets of the in-kernel split-row combine (zero between launches)
   int32_t* d_xl = nullptr;     // vrows too long for one tile (EXACT_ORDER only)
+  uint32_t* d_hot = nullptr;   // IDG_NT_COLD=H: bitmap of the H most gathered columns (the rest are loaded non-temporally)
   // host copies for the checker
   std::vector<int64_t> h_long_rows, h_seg_len, h_chunk_len;
 };
@@ -311,6 +313,50 @@ __device__ __forceinline__ float4 walk_masked(CVPtr cv, int s, int e, const floa
   return acc;
 }
 
+// The same walk with a cache-policy hint per entry (experiment, IDG_NT_COLD): columns outside the `hot` bitmap — the
+// rarely gathered rows of the panel — are fetched with a non-temporal load so that they do not displace the often
+// gathered rows from the XCD's L2.  Same values, same order: bits unchanged.
+using f32x4n = __attribute__((ext_vector_type(4))) float;
+// (The compiler folds `hot ? *a : __builtin_nontemporal_load(a)` into one plain load, so both flavours are spelled
+// in asm; the loads are invisible to the compiler's vmcnt bookkeeping and are drained explicitly before use.)
+__device__ __forceinline__ f32x4n load_hint(const float* a, bool hot) {
+  f32x4n x;
+  if (hot)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(a) : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(x) : "v"(a) : "memory");
+  return x;
+}
+template <int UNROLL, typename CVPtr>
+__device__ __forceinline__ float4 walk_nt(CVPtr cv, int s, int e, const float* __restrict__ Xl, int64_t ldx,
+                                          const uint32_t* __restrict__ hot, float4 acc) {
+  int j = s;
+  for (; j + UNROLL <= e; j += UNROLL) {
+    ColVal p[UNROLL];
+    bool h[UNROLL];
+    f32x4n x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) p[u] = cv[j + u];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) h[u] = mask_bit(hot, p[u].col);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler's own loads (bitmap probes) are done before ours start
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) x[u] = load_hint(Xl + (int64_t)p[u].col * ldx, h[u]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc = fma4(p[u].val, make_float4(x[u].x, x[u].y, x[u].z, x[u].w), acc);
+  }
+  for (; j < e; ++j) {
+    const ColVal p = cv[j];
+    const bool h = mask_bit(hot, p.col);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const f32x4n x = load_hint(Xl + (int64_t)p.col * ldx, h);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    acc = fma4(p.val, make_float4(x.x, x.y, x.z, x.w), acc);
+  }
+  return acc;
+}
+
 // ---- split rows combined inside the tile kernel (no separate fix-up launch) ---------------
 // A lane group that finishes a segment stores its partial WRITE-THROUGH (sc1), its wave drains
 // vmcnt(0), the group leader draws a ticket from the row's arrival counter (relaxed, agent
@@ -391,16 +437,17 @@ __device__ __forceinline__ int group_leader() {
   return lane & ~(LPR - 1);
 }
 
-template <int LPR, int NB, int UNROLL, int EPI, bool FUSED>
+template <int LPR, int NB, int UNROLL, int EPI, bool FUSED, bool NT = false>
 __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tgt, int l, const float* __restrict__ X,
                                         int64_t ldx, float* __restrict__ partials, int64_t d, const Epilogue& ep,
-                                        const FixCtx& fx, float4* s_part) {
+                                        const FixCtx& fx, float4* s_part, const uint32_t* __restrict__ hot = nullptr) {
   float nscale = 0.f;
   if (EPI == EPI_NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc = walk<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, acc);
+    acc = NT ? walk_nt<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, hot, acc)
+             : walk<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, acc);
     // the store addresses are rebuilt from the lane id once per vrow: hoisting them out of the vrow loop as
     // 64-bit per-lane pairs costs the registers that keep the kernel at 64 VGPRs (8 waves/SIMD)
     int lo = l;
@@ -471,7 +518,7 @@ __device__ __forceinline__ void combine_local(const Tile& t, const LocalRow* __r
 // One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
 // every feature block of width 4*LPR (d = NB * 4 * LPR).  DYNAMIC: lane groups draw the next
 // vrow from an LDS counter instead of a fixed stride (evens out skewed row lengths).
-template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, int EPI = EPI_PLAIN, bool FUSED = false>
+template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, int EPI = EPI_PLAIN, bool FUSED = false, bool NT = false>
 __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __restrict__ tiles,
                                                           const int64_t* __restrict__ vptr,
                                                           const int32_t* __restrict__ vtgt,
@@ -479,7 +526,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
                                                           const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ partials, int64_t d,
                                                           Epilogue ep, FixCtx fx,
-                                                          const LocalRow* __restrict__ locals) {
+                                                          const LocalRow* __restrict__ locals,
+                                                          const uint32_t* __restrict__ hot) {
   __shared__ ColVal s_cv[TILE_NNZ];
   __shared__ float4 s_part[LSLOTS * NB * LPR];
   __shared__ int s_ptr[TILE_VROWS + 1];
@@ -505,7 +553,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, UNROLL, EPI, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
+    do_vrow<LPR, NB, UNROLL, EPI, FUSED, NT>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part, hot);
     if (DYNAMIC) {
       int nxt = 0;
       if (l == 0) nxt = atomicAdd(&s_next, 1);
@@ -1033,10 +1081,10 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
   do {                                                                                                         \
     if (fused_fix)                                                                                             \
       hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, 1, EPI, true>  ), grid, block, 0, st, tile_order,  \
-                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);              \
+                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, nullptr);     \
     else                                                                                                       \
       hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, EPI, false>  ), grid, block, 0, st,          \
-                         tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);  \
+                         tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, nullptr);  \
   } while (0)
     if (out_mask && ep.noise_eps != 0.f) {  // flagged rows of a perturbed layer (the noise of a row depends on that row only)
       if (fused_fix)
@@ -1063,6 +1111,9 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       IDG_TILE(8, true, 1, EPI_NOISE);
     } else if (ep.adam_p) {  // last backward product of a training step: Adam applied to each finished gradient row
       IDG_TILE(8, true, 1, EPI_ADAM);
+    } else if (g->d_hot && fused_fix) {  // IDG_NT_COLD experiment: rarely gathered panel rows fetched non-temporally
+      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, 8, true, 1, EPI_PLAIN, true, true>), grid, block, 0, st, tile_order,
+                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, g->d_hot);
     } else switch (g->variant) {
       case 0: IDG_TILE(8, false, 1, EPI_PLAIN); break;
       case 1: IDG_TILE(8, true, 1, EPI_PLAIN); break;
@@ -1404,6 +1455,21 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK) rc = upload(&g->d_slot_long, slot_long);
   if (rc == IDG_OK) rc = upload(&g->d_long_cnt, std::vector<int>(longs.size() * MAX_PANELS, 0));  // one set per panel
   if (rc == IDG_OK) rc = upload(&g->d_xl, xl);
+  if (const char* v = std::getenv("IDG_NT_COLD")) {
+    const int64_t H = std::atoll(v);
+    if (H > 0 && rc == IDG_OK && nnz > 0) {
+      std::vector<int32_t> cnt((size_t)n_cols, 0);
+      for (int64_t k = 0; k < nnz; ++k) ++cnt[(size_t)indices[k]];
+      std::vector<int32_t> sorted(cnt);
+      const size_t kth = (size_t)std::min<int64_t>(H, n_cols) - 1;
+      std::nth_element(sorted.begin(), sorted.begin() + (std::ptrdiff_t)kth, sorted.end(), std::greater<int32_t>());
+      const int32_t thr = sorted[kth];
+      std::vector<uint32_t> hot((size_t)(n_cols + 31) / 32, 0u);
+      for (int64_t c = 0; c < n_cols; ++c)
+        if (cnt[(size_t)c] >= thr) hot[(size_t)c >> 5] |= 1u << (c & 31);
+      rc = upload(&g->d_hot, hot);
+    }
+  }
   if (rc != IDG_OK) {
     idg_graph_destroy(g);
     return rc;
@@ -1429,6 +1495,7 @@ int idg_graph_destroy(idg_graph* g) {
       (void)hipFree(g->d_slot_long);
       (void)hipFree(g->d_long_cnt);
       (void)hipFree(g->d_xl);
+      (void)hipFree(g->d_hot);
     }
   }
   delete g;

@@ -363,8 +363,8 @@ def test_embedding_size_without_tiled_kernels_trains(model_name, tmp_path, golde
     logger.handlers = [logging.StreamHandler(stream)]
     tools.set_seed(2024)
     tr = importlib.import_module("models." + model_name).Trainer(None, cfg, data, torch.device("cuda"), logger)
-    assert tr.model.fused_step_available() == (model_name == "MFBPR")
     tr.train()
+    assert tr.model.fused_step_available() == (model_name == "MFBPR")  # (plain matrix factorisation has no tiled kernel)
     lines = stream.getvalue().splitlines()
     losses = [_numbers(l.split("training loss:")[1])[0] for l in lines if "training loss" in l]
     assert len(losses) == 2 and np.isfinite(losses).all() and losses[1] < losses[0]
