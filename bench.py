@@ -25,7 +25,6 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INFINITY_CACHE_BYTES = 256 << 20
-REPLICA_BUDGET_BYTES = 200 << 30  # of the 288 GB of HBM3E: graphs whose training state fits are replicated, not sharded
 
 
 def parse():
@@ -33,8 +32,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=300)
     p.add_argument("--warmup", type=int, default=30)
-    p.add_argument("--workload", default="yelp2018")
-    p.add_argument("--dim", type=int, default=64)
+    p.add_argument("--workload", default=None,
+                   help="graph shape (idgrec_amd.synth.SHAPES).  Default: yelp2018 (BASELINE configs[1]) on one GPU; synth-10M "
+                        "(BASELINE configs[4]: 10M users x 5M items, 200M edges) for the user-row-sharded multi-GPU form")
+    p.add_argument("--dim", type=int, default=None, help="embedding width (default 64; 256 on synth-10M, as configs[4])")
     p.add_argument("--layers", type=int, default=3)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MFBPR", "SimGCL"],
@@ -58,11 +59,10 @@ def parse():
                    help="torch.distributed backend of the sharded path: nccl (= RCCL over xGMI) for real runs; gloo only "
                         "to rehearse the multi-rank code path with several ranks sharing one GPU (host-staged collectives)")
     p.add_argument("--parallel", default="auto", choices=["auto", "dp", "shard"],
-                   help="multi-GPU form: dp = replicas + one gradient exchange per step (small graphs), shard = user-row "
-                        "shards + per-layer all-reduces of the item panel; auto picks dp while the whole training state "
-                        "(~9 [n, d] panels + the graph) fits one GPU's HBM (all five BASELINE configs do: config 5 needs "
-                        "~140 of 288 GB) — replicas exchange a few MB of gradient rows per step whatever the graph's size, "
-                        "shards all-reduce the [I, d] item panel 2K+1 times")
+                   help="multi-GPU form: shard = user-row shards + per-layer all-reduces of the replicated item panel, ONE "
+                        "global batch of B triples per Adam step (the north-star split, SURVEY.md §8e); dp = replicas + one "
+                        "exchange of gradient rows per step, global batch N x B; auto (default) = shard as the headline and, "
+                        "on more than one GPU, the replica form on the yelp2018 shape as a second, labelled field")
     p.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                    help="collectives through libidgrec's RCCL communicator (native: on the step's own stream, or — from "
                         "64 MB — on a second stream the next product overlaps) or through torch.distributed (torch); auto = "
@@ -143,6 +143,30 @@ def cpu_baseline(args, wl, W0):
                       % (done, args.model, B, torch.__version__, t_used, ncpu)}
 
 
+def cpu_baseline_scaled(args):
+    """CPU leg of the multi-GPU lines (rank 0 only, after the timed region): the reference's step on torch CPU ops on
+    the named shape when that is small, else on a 1/64-scale graph of the same degree law ("for C5 the
+    CPU baseline times ... a 1/16-scale graph, stated explicitly" — 1/64 here to stay within ~30 s)."""
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    U, I, E = S.SHAPES[args.workload]
+    scale = 1
+    while E // scale > 4_000_000:
+        scale *= 2
+    U, I, E = U // scale, I // scale, E // scale
+    users, items = S.generate(U, I, E, seed=0)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    need = 64 * args.batch
+    tri = S.draw_triples(args.seed, users, items, U, I, need)[0]
+    wl = dict(U=U, I=I, indptr=ip, indices=ix, values=dv, triples=tri)
+    W0 = S.xavier_uniform_panel(U, I, args.dim, args.seed).numpy()
+    out = cpu_baseline(args, wl, W0)
+    out["sample"] += "; graph: %s at 1/%d scale (%d users x %d items, %d edges) — a step's cost grows with nnz, so the " \
+                     "full-size rate is about 1/%d of this" % (args.workload, scale, U, I, len(users), scale)
+    return out
+
+
 def main():
     args = parse()
     # stdout carries ONE line, the JSON.  Libraries print there too (RCCL announces its version on fd 1 when a
@@ -165,7 +189,7 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
         sys.exit("bench.py: launched with WORLD_SIZE=%d but --gpus %d; pass --gpus %d" % (world, args.gpus, world))
-    if args.parallel == "shard" and "GPU_MAX_HW_QUEUES" not in os.environ:
+    if (world > 1 or args.force_sharded) and args.parallel != "dp" and "GPU_MAX_HW_QUEUES" not in os.environ:
         # The sharded form runs several streams per process (step, batch preparation, communicators) and waits between
         # them 2K+1 times per step (the replicas wait once, and measure the same with 3 or 4 queues).  HIP spreads them
         # over GPU_MAX_HW_QUEUES (default 4) hardware queues in order of first use, and waits between streams on
@@ -187,19 +211,37 @@ def main():
     import idgrec_amd.synth as S
     from idgrec_amd.engine import PropagationEngine
 
-    if world > 1 or args.force_sharded:
-        U_, I_, _ = S.SHAPES[args.workload]
-        # replicas need the whole training state on every GPU: 9 [n, d] fp32 panels (parameters, two Adam moments,
-        # gradient, layer mean and its gradient, two layer buffers, messages/partials) + ~16 B per stored entry
-        resident = 9 * 4 * (U_ + I_) * args.dim + 16 * 2 * S.SHAPES[args.workload][2]
-        small = resident <= REPLICA_BUDGET_BYTES
-        if args.parallel == "dp" or (args.parallel == "auto" and small and not args.force_sharded):
-            from idgrec_amd.replicated import run_replicated_bench
+    multi = world > 1 or args.force_sharded
+    form = "single" if not multi else ("dp" if args.parallel == "dp" else "shard")
+    if args.workload is None:
+        args.workload = "synth-10M" if (form == "shard" and world > 1) else "yelp2018"
+    if args.dim is None:
+        args.dim = 256 if args.workload == "synth-10M" else 64
+    if multi:
+        from idgrec_amd.replicated import run_replicated_bench
+        from idgrec_amd.sharded import make_comm, run_sharded_bench
 
-            return run_replicated_bench(args, rank, world, dist)
-        from idgrec_amd.sharded import run_sharded_bench
-
-        return run_sharded_bench(args, rank, world, dist)
+        comm, comm_name = make_comm(dist, args.comm)
+        if form == "dp":
+            out = run_replicated_bench(args, rank, world, dist, comm, comm_name)
+        else:
+            out = run_sharded_bench(args, rank, world, dist, comm, comm_name)
+            if args.parallel == "auto" and world > 1:
+                rep = run_replicated_bench(args, rank, world, dist, comm, comm_name, workload="yelp2018", dim=64)
+                if rank == 0:
+                    out["replicas"] = {k: rep[k] for k in ("value", "unit", "ms_per_step", "config", "replicas_bit_identical")}
+                    out["replicas"]["what"] = ("NOT the headline: %d replicas of the yelp2018-shape graph, global batch %d x B — "
+                                               "%d x the reference's batch_size per Adam step (trainer.py:36); one all-gather of "
+                                               "gradient rows per step" % (world, world, world))
+        if rank == 0 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_scaled(args)
+        dist.barrier()
+        if rank == 0:
+            args.emit(out)
+        if hasattr(comm, "close"):
+            comm.close()
+        dist.destroy_process_group()
+        return
 
     wl = build_workload(args, rank, world)
     U, I, d, K, B = wl["U"], wl["I"], args.dim, args.layers, args.batch

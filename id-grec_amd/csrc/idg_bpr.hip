@@ -405,6 +405,32 @@ __global__ __launch_bounds__(BLOCK) void adam_kernel(float* __restrict__ p, cons
 #undef IDG_ADAM1
 }
 
+// dst[t] = idx[t] >= 0 ? src[idx[t]] : 0   (rows of d floats; one wave per row)
+__global__ __launch_bounds__(BLOCK) void rows_gather_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                            const int64_t* __restrict__ idx, int64_t count, int64_t d) {
+  const int64_t t = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  if (t >= count) return;
+  const int64_t r = idx[t];
+  for (int64_t f = threadIdx.x % 64; f < d; f += 64) dst[t * d + f] = r >= 0 ? src[r * d + f] : 0.f;
+}
+
+// For every t with idx[t] >= 0 (the head of a chain): dst[idx[t]] += src[t] + src[next[t]] + src[next[next[t]]] + ...
+// added in chain order (the caller links the occurrences of one destination in list order), one wave per chain: no
+// atomics, run-to-run identical bits.
+__global__ __launch_bounds__(BLOCK) void rows_chain_add_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                               const int64_t* __restrict__ idx,
+                                                               const int64_t* __restrict__ next, int64_t count, int64_t d) {
+  const int64_t t = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  if (t >= count) return;
+  const int64_t r = idx[t];
+  if (r < 0) return;
+  for (int64_t f = threadIdx.x % 64; f < d; f += 64) {
+    float acc = dst[r * d + f];
+    for (int64_t j = t; j >= 0; j = next[j]) acc += src[j * d + f];
+    dst[r * d + f] = acc;
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void lincomb_kernel(float* __restrict__ out, const float* x, float a,
                                                         const float* y, float b, int64_t n4, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
@@ -803,6 +829,25 @@ int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b
   const int64_t n4 = count / 4;
   int64_t nb = std::max<int64_t>(1, std::min<int64_t>((n4 + BLOCK - 1) / BLOCK, 256 * 8));
   hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, out, x, a, y, b, n4, count);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_rows_gather_f32(float* dst, const float* src, const int64_t* idx, int64_t count, int64_t d, void* stream) {
+  IDG_REQUIRE(dst && src && idx && count >= 0 && d > 0, "idg_rows_gather_f32: bad argument");
+  if (count == 0) return IDG_OK;
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)((count + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, dst, src, idx, count, d);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_rows_chain_add_f32(float* dst, const float* src, const int64_t* idx, const int64_t* next, int64_t count, int64_t d,
+                           void* stream) {
+  IDG_REQUIRE(dst && src && idx && next && count >= 0 && d > 0, "idg_rows_chain_add_f32: bad argument");
+  if (count == 0) return IDG_OK;
+  hipLaunchKernelGGL(rows_chain_add_kernel, dim3((unsigned)((count + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, dst, src, idx, next, count, d);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }

@@ -230,6 +230,19 @@ def lincomb_raw(out, x, a, y=None, b=0.0):
     check(lib.idg_lincomb_f32(_ptr(out), _ptr(x), float(a), _ptr(y), float(b), out.numel(), _stream()), "idg_lincomb_f32")
 
 
+def rows_gather_raw(dst, src, idx):
+    """idg_rows_gather_f32: dst[t] = src[idx[t]] (zeros where idx[t] < 0)."""
+    _require_device(dst, src, idx)
+    check(lib.idg_rows_gather_f32(_ptr(dst), _ptr(src), _ptr(idx), idx.shape[0], src.shape[1], _stream()), "idg_rows_gather_f32")
+
+
+def rows_chain_add_raw(dst, src, idx, nxt):
+    """idg_rows_chain_add_f32: dst[idx[t]] += src[t] + src[nxt[t]] + ... for every chain head t (idx[t] >= 0)."""
+    _require_device(dst, src, idx, nxt)
+    check(lib.idg_rows_chain_add_f32(_ptr(dst), _ptr(src), _ptr(idx), _ptr(nxt), idx.shape[0], src.shape[1], _stream()),
+          "idg_rows_chain_add_f32")
+
+
 _noise_stream = [0]
 
 
@@ -537,6 +550,12 @@ def bpr_touch_rows_raw(users, pos, neg, num_users, bitmap, stream=None, clear_bi
         check(lib.idg_bitmap_clear(_ptr(bitmap), int(clear_bits), st), "idg_bitmap_clear")
     check(lib.idg_bpr_touch_rows(_ptr(users), _ptr(pos), _ptr(neg), users.shape[0], int(num_users), _ptr(bitmap), st),
           "idg_bpr_touch_rows")
+
+
+def bitmap_clear_raw(bitmap, n_bits, stream=None):
+    """idg_bitmap_clear: zero the first n_bits bits of an int32 bitmap tensor."""
+    _require_device(bitmap)
+    check(lib.idg_bitmap_clear(_ptr(bitmap), int(n_bits), _stream() if stream is None else stream), "idg_bitmap_clear")
 
 
 def bpr_plan_raw(users, pos, neg, num_users, n, d, ws=None, stream=None):

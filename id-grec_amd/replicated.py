@@ -118,10 +118,11 @@ class HipReplica:
         self.ops.adam_step_raw(e.params, e.grad, e.exp_avg, e.exp_avg_sq, e.lr, e.step_count, e.betas[0], e.betas[1], e.eps)
 
 
-def run_replicated_bench(args, rank, world, dist):
-    """bench.py --gpus N, small graphs: N replicas of the BASELINE-shape graph, B triples per GPU and step out of
-    one globally shuffled epoch (global batch N x B); value = N*B*steps / max-over-ranks time."""
-    import json
+def run_replicated_bench(args, rank, world, dist, comm, comm_name, workload=None, dim=None):
+    """bench.py --gpus N, replica form: N replicas of the BASELINE-shape graph, B triples per GPU and step out of
+    one globally shuffled epoch — a GLOBAL batch of N x B, i.e. N times the reference's batch_size per Adam step
+    (trainer.py:36): a different optimisation than the reference's, reported for what it is.  value = N*B*steps /
+    max-over-ranks time.  Returns the bench line (rank 0) or None."""
     import time
 
     import torch
@@ -129,17 +130,17 @@ def run_replicated_bench(args, rank, world, dist):
     from . import host as H
     from . import ops
     from . import synth as S
-    from .sharded import make_comm
 
-    U, I, E = S.SHAPES[args.workload]
+    workload = workload or args.workload
+    dim = dim or args.dim
+    U, I, E = S.SHAPES[workload]
     users, items = S.generate(U, I, E, seed=0)               # every rank derives the same graph and the same epoch
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
     n, nnz, n_edges = U + I, len(ix), len(users)
     graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
-    W0 = S.xavier_uniform_panel(U, I, args.dim, args.seed)
-    rep = HipReplica(graph, U, I, args.dim, args.layers, True, 1e-4, 1e-3, params=W0.cuda(), world=world)
+    W0 = S.xavier_uniform_panel(U, I, dim, args.seed)
+    rep = HipReplica(graph, U, I, dim, args.layers, True, 1e-4, 1e-3, params=W0.cuda(), world=world)
     rows = getattr(args, "dp_exchange", "rows") == "rows"
-    comm, comm_name = make_comm(dist, getattr(args, "comm", "auto"))
     step_ = (RowExchangeStep if rows else ReplicatedStep)(rep, comm, world)
     B, gB = args.batch, args.batch * world
     need = (args.steps + args.warmup) * gB
@@ -177,9 +178,10 @@ def run_replicated_bench(args, rank, world, dist):
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    out = None
     if rank == 0:
         out = {
-            "metric": "BPR triples/sec, LightGCN-%d dim=%d" % (args.layers, args.dim),
+            "metric": "BPR triples/sec, LightGCN-%d dim=%d" % (args.layers, dim),
             "value": gB * args.steps / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -187,19 +189,19 @@ def run_replicated_bench(args, rank, world, dist):
                                    "LightGCN K=%d d=%d, B=%d per GPU (global batch %d, slices of one shuffled epoch); step = "
                                    "propagate + fused BPR on every replica, %s over %s, backward propagate + identical "
                                    "dense Adam on every replica"
-                                   % (args.workload, world, U, I, n_edges, nnz, args.layers, args.dim, B, gB,
+                                   % (workload, world, U, I, n_edges, nnz, args.layers, dim, B, gB,
                                       ("ONE all-gather of the batches' gradient rows (%d fp32 words per rank) BEFORE the "
-                                       "backward propagation" % ops.bpr_rows_message_floats(B, args.dim)) if rows else
-                                      ("ONE all-reduce of the [%d,%d] fp32 gradient AFTER the backward propagation" % (n, args.dim)),
+                                       "backward propagation" % ops.bpr_rows_message_floats(B, dim)) if rows else
+                                      ("ONE all-reduce of the [%d,%d] fp32 gradient AFTER the backward propagation" % (n, dim)),
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
-                       "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "dp%d" % world,
+                       "batch": B, "dim": dim, "layers": args.layers, "parallelism": "dp%d" % world,
+                       "global_batch": gB, "note": "global batch N x B = %d: N x the reference's batch_size per Adam step" % gB,
                        "exchange": "gradient rows (all-gather)" if rows else "dense gradient (all-reduce)",
                        "comm": comm_name},
             "loss_last": [float(x) for x in rep.loss_row.cpu()],
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "replicas_bit_identical": bool(lo.item() == hi.item()),
         }
-        getattr(args, "emit", lambda o: print(json.dumps(o)))(out)
-    if hasattr(comm, "close"):
-        comm.close()
-    dist.destroy_process_group()
+    del rep, step_, graph
+    torch.cuda.empty_cache()
+    return out

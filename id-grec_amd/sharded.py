@@ -69,45 +69,130 @@ def shard_adjacency(indptr, indices, values, num_users, num_items, u_lo, u_hi):
 
 
 # --------------------------------------------------------------------------- the step
+class GlobalBatch:
+    """Index-only description of ONE global batch as one rank sees it (built on the host by ShardedEngine.make_batch
+    from the batch's global ids; every array lives where the kernels want it).  B triples; triple t owns guest row t.
+      pos, neg   int64 [B]  global item ids
+      own_src    int64 [B]  local id of triple t's user if this rank owns it, else -1 (fills the guest rows)
+      head_dst   int64 [B]  the same id for the FIRST owned occurrence of a user in the batch, else -1
+      nxt        int64 [B]  batch position of the next occurrence of triple t's user, -1 at the end of its chain
+      own_users / own_pos / own_neg  int64 [B_g]  the owned triples (local user ids): the rows this rank's restricted
+                 products have to produce / may gather from"""
+    __slots__ = ("B", "pos", "neg", "own_src", "head_dst", "nxt", "own_users", "own_pos", "own_neg", "n_owned", "key")
+
+
 class ShardedEngine:
-    """One rank's share of the LightGCN step.  Arrays are whatever `kernels` allocates
-    (torch CUDA tensors in the product); row layout of every local panel: this rank's users
-    first ([0, U_g)), then ALL items ([U_g, U_g + I))."""
+    """One rank's share of the LightGCN step.  Arrays are whatever `kernels` allocates (torch CUDA tensors in the
+    product).  Row layout of every local panel: this rank's users [0, U_g), then B GUEST rows [U_g, U_g + B) — row
+    U_g + t carries triple t's user, whoever owns it — then ALL items [U_g + B, U_g + B + I).
+
+    The batch is GLOBAL (every rank sees all B triples, as the single-device step does): after the forward
+    propagation the owners copy the batch users' final and ego rows into the guest rows, two all-reduces of [B, d]
+    (x + 0 + ... + 0: exact) hand them to every rank, and every rank evaluates the WHOLE batch's BPR loss — so the
+    loss and the item-side gradient g_I are complete and bit-identical on every rank without any [I, d] exchange, and
+    the user-side gradient rows flow back from the guest rows to their owners' rows (chained adds in batch order).
+    Per step: K forward + K backward all-reduces of the [I, d] item panel, cut into slices that overlap the products
+    (SURVEY.md §8e), plus the two [B, d] ones."""
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
-                 reg_lambda=1e-4, lr=1e-3, batch_sparsity=True):
+                 reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None):
         """batch_sparsity: use what a prepared batch (kernels.prepare) knows — the user side of the last forward
-        layer is produced for the batch's users only, the first backward product gathers its live rows only, the
-        gradient scatter follows a plan sorted ahead of time.  Exact; FIN's user rows outside the batch are then
-        stale, which no consumer reads."""
+        layer is produced for the batch's owned users only, the first backward product gathers its live rows only,
+        the gradient scatter follows a plan sorted ahead of time.  Exact; FIN's user rows outside the batch are then
+        stale, which no consumer reads.  batch_size: capacity of the guest rows (the global batch size).
+        user_lo: global id of this rank's first user.  n_slices: row slices of R_g^T whose all-reduces overlap the
+        following slices' products (default: 4 once the item panel reaches 256 MB, else 1); item_cuts: the slices' row
+        bounds — they MUST be the same on every rank (the slices are what the ranks all-reduce); default: equal row
+        counts (callers that know the global item degrees pass entry-balanced cuts)."""
         self.k, self.comm = kernels, comm
         self.batch_sparsity = bool(batch_sparsity)
         self._prepared = {}
         self.Ug, self.I, self.d, self.K = int(n_local_users), int(num_items), int(dim), int(n_layers)
+        self.B, self.lo = int(batch_size), int(user_lo)
         self.c0 = 1 if include_layer0 else 0
         self.cnt = float(self.K + self.c0)
         self.reg_lambda, self.lr = float(reg_lambda), float(lr)
         self.G_ui = kernels.make_graph(*ui_csr, self.Ug, self.I)
-        self.G_iu = kernels.make_graph(*iu_csr, self.I, self.Ug)
-        n = self.Ug + self.I
+        if n_slices is None:
+            n_slices = 4 if self.I * self.d * 4 >= (256 << 20) else 1
+        iu_ptr, iu_idx, iu_val = iu_csr
+        iu_ptr = np.asarray(iu_ptr, dtype=np.int64)
+        if item_cuts is None:
+            item_cuts = np.linspace(0, self.I, max(1, min(int(n_slices), self.I)) + 1).astype(np.int64)
+        cuts = np.asarray(item_cuts, dtype=np.int64)
+        assert cuts[0] == 0 and cuts[-1] == self.I and (np.diff(cuts) >= 0).all(), "item_cuts must tile [0, I]"
+        self.G_iu = []
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            r0, r1 = int(r0), int(r1)
+            if r1 == r0:
+                continue
+            e0, e1 = int(iu_ptr[r0]), int(iu_ptr[r1])
+            self.G_iu.append((kernels.make_graph(iu_ptr[r0:r1 + 1] - e0, iu_idx[e0:e1], iu_val[e0:e1], r1 - r0, self.Ug), r0, r1))
+        n = self.Ug + self.B + self.I
         z = kernels.zeros
         self.P, self.G, self.M, self.V = z((n, dim)), z((n, dim)), z((n, dim)), z((n, dim))
         self.FIN = z((n, dim))
-        # d loss / d FIN, plus ONE extra row: its first two floats are this rank's share of the two losses, so the
-        # loss rides in the first backward all-reduce (item rows of GF) instead of needing a collective of its own
-        self._gf = z((n + 1, dim))
-        self.GF = self._gf[:n]
+        self.GF = z((n, dim))   # d loss / d FIN
         self.XU = [z((self.Ug, dim)), z((self.Ug, dim))]
         self.XI = [z((self.I, dim)), z((self.I, dim)), z((self.I, dim))]
-        self.loss = self._gf[n, :2]
+        self.loss = z((2,))
         self.upstream = z((2,))
+        kernels.fill(self.upstream, 1.0)
+        self.guest_ids = kernels.to_device(np.arange(self.Ug, self.Ug + self.B, dtype=np.int64))
         self.step_count = 0
 
     def _u(self, a):
         return a[: self.Ug]
 
+    def _guest(self, a, count=None):
+        return a[self.Ug: self.Ug + (self.B if count is None else count)]
+
     def _i(self, a):
-        return a[self.Ug:]
+        return a[self.Ug + self.B:]
+
+    # ---- index-only preparation of a global batch (host)
+    def make_batch(self, users, pos, neg):
+        """users: GLOBAL user ids [B' <= B] (numpy), pos / neg: global item ids."""
+        users = np.asarray(users, dtype=np.int64)
+        Bc = len(users)
+        assert 0 < Bc <= self.B, "batch of %d triples, engine built for up to %d" % (Bc, self.B)
+        local = users - self.lo
+        owned = (local >= 0) & (local < self.Ug)
+        own_src = np.where(owned, local, -1)
+        # chains over the occurrences of one user, in batch order (stable sort by user, then by position)
+        order = np.argsort(users, kind="stable")
+        su = users[order]
+        nxt = np.full(Bc, -1, dtype=np.int64)
+        same = su[1:] == su[:-1]
+        nxt[order[:-1][same]] = order[1:][same]
+        first = np.ones(Bc, dtype=bool)
+        first[order[1:][same]] = False
+        gb = GlobalBatch()
+        to = self.k.to_device
+        gb.B = Bc
+        gb.pos, gb.neg = to(np.asarray(pos, dtype=np.int64)), to(np.asarray(neg, dtype=np.int64))
+        gb.own_src = to(own_src.astype(np.int64))
+        gb.head_dst = to(np.where(owned & first, local, -1).astype(np.int64))
+        gb.nxt = to(nxt)
+        gb.n_owned = int(owned.sum())
+        gb.own_users = to(local[owned].astype(np.int64))
+        gb.own_pos, gb.own_neg = to(np.asarray(pos, dtype=np.int64)[owned]), to(np.asarray(neg, dtype=np.int64)[owned])
+        gb.key = id(gb)
+        return gb
+
+    # ---- item-side product, slice by slice; each slice's all-reduce starts as soon as the slice is produced
+    def _item_side(self, X_u, Y_i, x_rows=None, after_first=None):
+        works = []
+        for j, (g, r0, r1) in enumerate(self.G_iu):
+            self.k.spmm(g, X_u, Y=Y_i[r0:r1], x_rows=x_rows)
+            if j == 0 and after_first is not None:
+                after_first()
+            works.append(self.comm.all_reduce_async(Y_i[r0:r1]))
+        return works
+
+    def _wait_all(self, works):
+        for w in works:
+            self.comm.wait(w)
 
     # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
     def propagate(self, prep=None):
@@ -117,11 +202,14 @@ class ShardedEngine:
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
         fin_u, fin_i = self._u(self.FIN), self._i(self.FIN)
         xu_prev, xi_prev = self._u(self.P), self._i(self.P)
-        pending = None  # (work, xi_new, layer) of the all-reduce whose result has not been folded in yet
+        pending = [None]  # (works, xi_new, layer, xi_before) of the all-reduce whose result has not been folded in yet
 
-        def finish(pending):
-            work, xi_new, layer, xi_before = pending
-            self.comm.wait(work)
+        def finish():
+            if pending[0] is None:
+                return
+            works, xi_new, layer, xi_before = pending[0]
+            pending[0] = None
+            self._wait_all(works)
             scale = 1.0 / cnt if layer == K else 1.0
             if layer == 1:
                 base = self._i(self.P) if c0 else None
@@ -132,10 +220,8 @@ class ShardedEngine:
         for layer in range(1, K + 1):
             last = layer == K
             xi_new = self.XI[layer % 3]
-            k.spmm(self.G_iu, xu_prev, Y=xi_new)                       # item-side partial of this layer
-            if pending is not None:
-                finish(pending)                                        # X_I(layer-1) is needed from here on
-            work = self.comm.all_reduce_async(xi_new)
+            # item-side partial of this layer; X_I(layer-1) (the previous collective) is folded in under its first slice
+            works = self._item_side(xu_prev, xi_new, after_first=finish)
             if layer == 1:
                 sum_in = self._u(self.P) if c0 else None
             else:
@@ -143,13 +229,13 @@ class ShardedEngine:
             xu_new = None if last else self.XU[layer & 1]
             k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0,
                    out_rows=prep.bitmap if (last and prep is not None) else None)  # BPR reads the batch's users only
-            pending = (work, xi_new, layer, xi_prev)
+            pending[0] = (works, xi_new, layer, xi_prev)
             xu_prev, xi_prev = xu_new, xi_new
-        finish(pending)
+        finish()
         return self.FIN
 
-    # ---- backward of the above given GF = d loss / d FIN (item rows still per-rank partials),
-    #      accumulated onto G (which already holds the regulariser gradient, item rows partial)
+    # ---- backward of the above given GF = d loss / d FIN (g_I complete on every rank, g_U at the owners' rows),
+    #      accumulated onto G (which already holds the regulariser gradient: item rows complete, user rows owned)
     def propagate_backward(self, prep=None):
         """Horner steps h <- A.h + g, k = K..2, then gE0 = (A.h + c0.g)/cnt.  In block form
         (A.h)_U = R_g h_I (local), (A.h)_I = all-reduce(R_g^T h_U).  As in the forward pass the item-side
@@ -157,82 +243,105 @@ class ShardedEngine:
         all-reduce; the user-side product is what waits for it."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
         g_u, g_i = self._u(self.GF), self._i(self.GF)
-        first = self.comm.all_reduce_async(self._gf[self.Ug:])  # completes the item-side gradient g_I (+ the loss row)
         h_u = g_u
-        pending = ("g", first, g_i)                           # h_I of the coming step, not yet usable
+        pending = [("g", [], g_i)]                            # h_I of the coming step: g_I itself, nothing to wait for
+        h_i = [None]
 
-        def finish(p):                                        # -> h_I usable
-            kind, work, buf = p
-            self.comm.wait(work)
+        def finish():                                         # -> h_I usable
+            kind, works, buf = pending[0]
+            self._wait_all(works)
             if kind == "t":
                 k.lincomb(buf, buf, 1.0, g_i, 1.0)            # (A h)_I + g_I
-            return buf
+            h_i[0] = buf
 
-        live = prep.bitmap if prep is not None else None      # h_U = g_U has the batch's users as its only live rows
+        live = prep.bitmap if prep is not None else None      # h_U = g_U has the batch's owned users as its only live rows
         for layer in range(K, 1, -1):
             t_i = self.XI[layer % 3]
-            k.spmm(self.G_iu, h_u, Y=t_i, x_rows=live)        # partial of (A h)_I: needs h_U only
+            works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)   # partial of (A h)_I: needs h_U only
             live = None
-            h_i = finish(pending)                             # previous all-reduce (+ g_I) -> h_I
-            work = self.comm.all_reduce_async(t_i)
             t_u = self.XU[layer & 1]
-            k.spmm(self.G_ui, h_i, Y=t_u, addend=g_u)         # (A h)_U + g_U
-            pending = ("t", work, t_i)
+            k.spmm(self.G_ui, h_i[0], Y=t_u, addend=g_u)      # (A h)_U + g_U
+            pending[0] = ("t", works, t_i)
             h_u = t_u
-        # last Horner step, scaled by 1/cnt; regulariser gradients ride along
+        # last Horner step, scaled by 1/cnt
         t_i = self.XI[1]  # 3-buffer rotation: never the buffer of the all-reduce still in flight (layer 2 -> XI[2])
-        k.spmm(self.G_iu, h_u, Y=t_i, x_rows=live)            # (live only when K == 1: h_U is still g_U)
-        h_i = finish(pending)
-        k.lincomb(t_i, t_i, 1.0 / cnt, self._i(self.G), 1.0)  # partial/cnt + this rank's item reg grads
-        work = self.comm.all_reduce_async(t_i)
-        k.spmm(self.G_ui, h_i, sum_in=g_u if c0 else None, sum_out=self._u(self.G), div=cnt, accumulate=True)
-        self.comm.wait(work)
-        k.lincomb(self._i(self.G), t_i, 1.0, g_i if c0 else None, 1.0 / cnt)
+        works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)       # (live only when K == 1: h_U is still g_U)
+        k.spmm(self.G_ui, h_i[0], sum_in=g_u if c0 else None, sum_out=self._u(self.G), div=cnt, accumulate=True)
+        if c0:
+            k.lincomb(self._i(self.G), self._i(self.G), 1.0, g_i, 1.0 / cnt)     # reg_I + g_I/cnt, under the collective
+        self._wait_all(works)
+        k.lincomb(self._i(self.G), t_i, 1.0 / cnt, self._i(self.G), 1.0)         # + (sum of the ranks' partials)/cnt
         return self.G
 
-    def train_step(self, users_local, pos, neg, global_batch):
-        """users_local: ids re-based to this rank's block; pos/neg: global item ids;
-        global_batch: total triples over all ranks this step (the mean's divisor)."""
+    def train_step(self, gb):
+        """gb: a GlobalBatch from make_batch() — the same global batch on every rank."""
         k = self.k
-        B = len(users_local)
+        Bc = gb.B
         prep = None
-        if self.batch_sparsity and B > 0:
-            prep = self._prepared.pop(_batch_key(users_local, pos, neg), None)
+        if self.batch_sparsity:
+            prep = self._prepared.pop(gb.key, None)
             if prep is None:
-                prep = k.prepare(users_local, pos, neg, self.Ug, self.Ug + self.I, self.d)  # None for kernels without one
+                prep = k.prepare(self, gb)  # None for kernels without one
             if prep is not None:
                 k.wait_rows(prep)
         self.propagate(prep)
+        # the batch's user rows (final and ego) travel through the guest rows: owners fill, everybody else adds zeros
+        fin_g, ego_g = self._guest(self.FIN, Bc), self._guest(self.P, Bc)
+        k.gather_rows(fin_g, self._u(self.FIN), gb.own_src)
+        k.gather_rows(ego_g, self._u(self.P), gb.own_src)
+        w1 = self.comm.all_reduce_async(fin_g)
+        w2 = self.comm.all_reduce_async(ego_g)
         k.fill(self.G, 0.0)
-        k.fill(self._gf, 0.0)
-        ratio = float(B) / float(global_batch)
-        if B > 0:
-            k.fill(self.upstream, ratio)
-            k.bpr(self.FIN, self.P, self.Ug, users_local, pos, neg, self.reg_lambda, self.upstream, self.GF, self.G,
-                  self.loss, prep)
-            k.lincomb(self.loss, self.loss, ratio, None, 0.0)         # local mean -> share of the global mean
-        self.propagate_backward(prep)                          # its first all-reduce also sums the loss shares
+        k.fill(self.GF, 0.0)
+        self.comm.wait(w1)
+        self.comm.wait(w2)
+        k.bpr(self.FIN, self.P, self.Ug + self.B, self.guest_ids[:Bc], gb.pos, gb.neg, self.reg_lambda, self.upstream,
+              self.GF, self.G, self.loss, prep)
+        # gradients of the guest rows go home: every owned user's occurrences are added in batch order
+        k.chain_add_rows(self._u(self.GF), self._guest(self.GF, Bc), gb.head_dst, gb.nxt)
+        k.chain_add_rows(self._u(self.G), self._guest(self.G, Bc), gb.head_dst, gb.nxt)
+        self.propagate_backward(prep)
         if prep is not None:
             k.release(prep)
         self.step_count += 1
-        k.adam(self.P, self.G, self.M, self.V, self.lr, self.step_count)
+        for sl in (slice(0, self.Ug), slice(self.Ug + self.B, None)):  # (the guest rows are not parameters)
+            k.adam(self.P[sl], self.G[sl], self.M[sl], self.V[sl], self.lr, self.step_count)
         return self.loss
 
-
-    def prefetch(self, users_local, pos, neg):
+    def prefetch(self, gb):
         """One-batch lookahead of the index-only work of the NEXT step (row bitmap + sorted scatter plan), on
         the kernels' side stream while this step's products run."""
-        if self.batch_sparsity and len(users_local) > 0:
+        if self.batch_sparsity:
             while len(self._prepared) >= 2:  # lookaheads nobody came for (a skipped batch)
                 self.k.release(self._prepared.pop(next(iter(self._prepared))))
-            prep = self.k.prepare(users_local, pos, neg, self.Ug, self.Ug + self.I, self.d)
+            prep = self.k.prepare(self, gb)
             if prep is not None:
-                self._prepared[_batch_key(users_local, pos, neg)] = prep
+                self._prepared[gb.key] = prep
 
+    # ---- evaluation: users by owner, items replicated, metric sums exchanged (SURVEY.md §8e)
+    def evaluate(self, test_users, test_items, excl_indptr, excl_items, top_k, reduce_sums):
+        """batch_test.Test (utility/utility_train/batch_test.py:37-93) for this rank's users.
+        test_users: global ids of this rank's test users (ascending), test_items: their held-out item lists;
+        excl_indptr / excl_items: train CSR of THIS rank's users (local ids); reduce_sums(np.float64 array) -> the
+        element-wise sum over ranks.  Returns the reference's result dict, identical on every rank."""
+        import utility.utility_function.metrics as metrics
 
-def _batch_key(users, pos, neg):
-    ptr = (lambda t: t.data_ptr()) if hasattr(users, "data_ptr") else (lambda t: t.__array_interface__["data"][0])
-    return (ptr(users), ptr(pos), ptr(neg), len(users))
+        self.propagate(None)
+        local = np.asarray(test_users, dtype=np.int64) - self.lo
+        kmax = max(top_k)
+        sums = np.zeros(3 * len(top_k) + 1, dtype=np.float64)
+        if len(local):
+            top = self.k.topk(self._u(self.FIN), self._i(self.FIN), local, kmax, excl_indptr, excl_items)
+            r = metrics.get_label(test_items, top)
+            for j, kk in enumerate(top_k):
+                sums[3 * j + 0] = metrics.recall_at_k(r, kk, test_items)
+                sums[3 * j + 1] = metrics.precision_at_k(r, kk, test_items)
+                sums[3 * j + 2] = metrics.ndcg_at_k(r, kk, test_items)
+            sums[-1] = len(local)
+        sums = reduce_sums(sums)
+        n_users = float(sums[-1])
+        return {"recall": sums[0:-1:3] / n_users, "precision": sums[1:-1:3] / n_users, "ndcg": sums[2:-1:3] / n_users,
+                "hit": np.zeros(len(top_k))}
 
 
 # --------------------------------------------------------------------------- product bindings
@@ -280,31 +389,54 @@ class HipKernels:
             self.ops.bpr_fwd_bwd_raw(fin, ego, users, pos, neg, n_users, reg_lambda, upstream, g_final, g_ego, loss,
                                      self.deterministic)
 
+    def to_device(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def gather_rows(self, dst, src, idx):
+        self.ops.rows_gather_raw(dst, src, idx)
+
+    def chain_add_rows(self, dst, src, idx, nxt):
+        self.ops.rows_chain_add_raw(dst, src, idx, nxt)
+
+    def topk(self, user_panel, item_panel, users, k, excl_indptr, excl_items):
+        """Top-k item ids [len(users), k] (numpy) for local user ids `users`, train items excluded."""
+        torch = self.torch
+        idx = self.ops.score_topk(user_panel, item_panel, self.to_device(np.asarray(users, dtype=np.int64)), int(k),
+                                  self.to_device(np.asarray(excl_indptr, dtype=np.int64)),
+                                  self.to_device(np.asarray(excl_items, dtype=np.int32)), apply_sigmoid=True)
+        torch.cuda.synchronize()
+        return idx.cpu().numpy()
+
     class _Prepared:
         __slots__ = ("bitmap", "ws", "rows_done", "done", "free", "B", "busy")
 
-    def prepare(self, users, pos, neg, n_users, n, d):
-        """Index-only work of a batch on a side stream: bitmap of the panel rows it touches, and the sorted
-        scatter plan.  Returns None when the scatter is not the deterministic one.  Host cost matters here (the
-        sharded step issues ~50 calls): raw stream handles and events allocated once, no stream context manager."""
+    def prepare(self, eng, gb):
+        """Index-only work of a global batch on a side stream: bitmap of the LOCAL user rows this rank owns in it (the
+        rows its restricted products produce / gather), and the sorted scatter plan of the whole batch over the guest
+        rows.  Returns None when the scatter is not the deterministic one.  Host cost matters here (the sharded step
+        issues ~50 calls): raw stream handles and events allocated once, no stream context manager."""
         if not self.deterministic:
             return None
         torch, ops = self.torch, self.ops
-        B = users.shape[0]
-        prep = next((p for p in self._pool if p.B == B and not p.busy), None)
+        cap, n_users, n, d = eng.B, eng.Ug + eng.B, eng.Ug + eng.B + eng.I, eng.d
+        prep = next((p for p in self._pool if p.B == cap and not p.busy), None)
         if prep is None:
             prep = self._Prepared()
             prep.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=self.device)
-            prep.ws, prep.B = ops.bpr_workspace(B, d, self.device), B
+            prep.ws, prep.B = ops.bpr_workspace(cap, d, self.device), cap
             prep.rows_done, prep.done, prep.free = ops.LocalEvent(), ops.LocalEvent(), None  # device-local events
             self._pool.append(prep)
         prep.busy = True
         main = torch.cuda.current_stream()
         self._fork.record(main.cuda_stream)  # the id tensors may have just been produced on the main stream,
         self._fork.wait(self._side_raw)      # and the step that last used these buffers is ordered before it
-        ops.bpr_touch_rows_raw(users, pos, neg, n_users, prep.bitmap, stream=self._side_raw, clear_bits=n)
+        if gb.n_owned > 0:
+            ops.bpr_touch_rows_raw(gb.own_users, gb.own_pos, gb.own_neg, n_users, prep.bitmap, stream=self._side_raw,
+                                   clear_bits=n)
+        else:
+            ops.bitmap_clear_raw(prep.bitmap, n, stream=self._side_raw)
         prep.rows_done.record(self._side_raw)
-        ops.bpr_plan_raw(users, pos, neg, n_users, n, d, ws=prep.ws, stream=self._side_raw)
+        ops.bpr_plan_raw(eng.guest_ids[:gb.B], gb.pos, gb.neg, n_users, n, d, ws=prep.ws, stream=self._side_raw)
         prep.done.record(self._side_raw)
         return prep
 
@@ -573,11 +705,11 @@ class NoComm:
 
 
 # --------------------------------------------------------------------------- bench driver
-def run_sharded_bench(args, rank, world, dist):
-    """bench.py --gpus N (N > 1): weak scaling — every rank owns a block of the BASELINE-shape
-    user set (U = N x the named shape's users, items fixed), B triples of its own users per
-    step; value = N*B*steps / max-over-ranks time."""
-    import json
+def run_sharded_bench(args, rank, world, dist, comm, comm_name):
+    """bench.py --gpus N (N > 1), the north-star split: ONE graph of the named shape cut across the
+    ranks by nnz-balanced user-row blocks, item table replicated, ONE global batch of B triples per step (the
+    reference takes one Adam step per batch_size triples, trainer.py:36-56) — strong scaling: value = B*steps /
+    max-over-ranks time.  Returns the bench line (rank 0) or None; the caller emits it and ends the process group."""
     import time
 
     import torch
@@ -585,47 +717,42 @@ def run_sharded_bench(args, rank, world, dist):
     from . import host as H
     from . import synth as S
 
-    U1, I, E1 = S.SHAPES[args.workload]
-    # weak scaling in the graph: one named-shape user block per rank — unless that would exceed any sensible host
-    # budget (BASELINE config 5 is ONE 10M-user graph cut across the ranks, not eight of them)
-    blocks = world if U1 * world <= 20_000_000 else 1
-    U, E = U1 * blocks, E1 * blocks
+    U, I, E = S.SHAPES[args.workload]
+    d, K, B = args.dim, args.layers, args.batch
     users, items = S.generate(U, I, E, seed=0)           # every rank derives the same global graph
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
-    deg_u = np.bincount(users, minlength=U)
-    bounds = partition_users_by_nnz(deg_u, world)
+    bounds = partition_users_by_nnz(np.bincount(users, minlength=U), world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     ui, iu = shard_adjacency(ip, ix, dv, U, I, lo, hi)
-    kern = HipKernels(deterministic=not args.atomic)
-    comm, comm_name = make_comm(dist, getattr(args, "comm", "auto"))
-    eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, args.dim, args.layers, True, 1e-4, 1e-3)
-    W0 = S.xavier_uniform_panel(U, I, args.dim, args.seed)  # same initialisation as the single-GPU run
-    eng.P[: hi - lo].copy_(W0[lo:hi])
-    eng.P[hi - lo:].copy_(W0[U:])
-    # this rank's triples: the native sampler over its own users' edges
-    sel = (users >= lo) & (users < hi)
-    lu, li = users[sel] - lo, items[sel]
-    pos_ptr = np.zeros(hi - lo + 1, dtype=np.int64)
-    pos_ptr[1:] = np.cumsum(np.bincount(lu, minlength=hi - lo))
-    rng = H.Rng(args.seed + rank)
-    B = args.batch
+    nnz_global, n_edges = len(ix), len(users)
+    n_slices = 4 if I * d * 4 >= (256 << 20) else 1
+    cuts = partition_users_by_nnz(np.bincount(items, minlength=I), n_slices)  # same cuts on every rank: global item degrees
     need = (args.steps + args.warmup) * B
-    tri = np.empty((0, 3), dtype=np.int64)
-    while len(tri) < need:
-        t2 = rng.sample_epoch(lu, li, pos_ptr, li.astype(np.int32), I)
-        tri = np.concatenate([tri, t2[rng.shuffle_perm(len(t2))]])
-    tri = torch.from_numpy(tri).cuda()
-    tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
-    gB = B * world
-
+    tri = S.draw_triples(args.seed, users, items, U, I, need)[0]  # the same global sequence on every rank
+    del ip, ix, dv, users, items
+    kern = HipKernels(deterministic=not args.atomic)
+    eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
+                        n_slices=n_slices, item_cuts=cuts)
+    nnz_ui, nnz_iu = len(ui[1]), len(iu[1])
+    del ui, iu
+    Ug = hi - lo
+    # same initialisation as a single-device run of this graph would draw; the item block on every rank
+    g = torch.Generator().manual_seed(args.seed)
+    bu, bi = (6.0 / (U + d)) ** 0.5, (6.0 / (I + d)) ** 0.5
+    for r in range(world):  # the user table is drawn block by block so that no rank holds all of it
+        blk = (torch.rand(int(bounds[r + 1] - bounds[r]), d, generator=g) * 2 - 1) * bu
+        if r == rank:
+            eng.P[:Ug].copy_(blk)
+        del blk
+    eng.P[Ug + B:].copy_((torch.rand(I, d, generator=g) * 2 - 1) * bi)
+    batches = [eng.make_batch(tri[i * B:(i + 1) * B, 0], tri[i * B:(i + 1) * B, 1], tri[i * B:(i + 1) * B, 2])
+               for i in range(args.steps + args.warmup)]
     last = args.warmup + args.steps - 1
 
     def step(i):
         if i < last:
-            n = slice((i + 1) * B, (i + 2) * B)
-            eng.prefetch(tu[n], tp[n], tn[n])  # index-only work of the next batch, off the critical path
-        s = slice(i * B, (i + 1) * B)
-        return eng.train_step(tu[s], tp[s], tn[s], gB)
+            eng.prefetch(batches[i + 1])  # index-only work of the next batch, off the critical path
+        return eng.train_step(batches[i])
 
     S.ramp_clocks()
     for i in range(args.warmup):
@@ -642,23 +769,66 @@ def run_sharded_bench(args, rank, world, dist):
                       device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    # coherence of the replicated item table: a checksum must agree on every rank
+    chk = eng.P[Ug + B:].double().sum().reshape(1)
+    chk = chk if dist.get_backend() == "nccl" else chk.cpu()
+    c_lo, c_hi = chk.clone(), chk.clone()
+    dist.all_reduce(c_lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(c_hi, op=dist.ReduceOp.MAX)
+
+    # per-rank roofline of the two products a layer consists of (after the timed region, this rank only)
+    def timed(fn, reps=5):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+
+    t_ui = timed(lambda: kern.spmm(eng.G_ui, eng._i(eng.P), Y=eng.XU[0]))
+
+    def item_side():
+        for gph, r0, r1 in eng.G_iu:
+            kern.spmm(gph, eng._u(eng.P), Y=eng.XI[0][r0:r1])
+
+    t_iu = timed(item_side)
+    bytes_ui = 4 * (Ug + 1) + 8 * nnz_ui + 4 * nnz_ui * d + 4 * Ug * d
+    bytes_iu = 4 * (I + 1) + 8 * nnz_iu + 4 * nnz_iu * d + 4 * I * d
+    out = None
     if rank == 0:
-        n, nnz = U + I, len(ix)
+        n = U + I
         out = {
-            "metric": "BPR triples/sec, LightGCN-%d dim=%d" % (args.layers, args.dim),
-            "value": gB * args.steps / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "BPR triples/sec, LightGCN-%d dim=%d" % (K, d),
+            "value": B * args.steps / dt, "unit": "triples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d x %s-shape user blocks (graph cut across the ranks by user rows): %d users x %d items, %d train edges, nnz(A)=%d; "
-                                   "LightGCN K=%d d=%d, B=%d per GPU (global %d); user rows sharded, item table "
-                                   "replicated, %d all-reduces of [%d,%d] fp32 per step over %s"
-                                   % (blocks, args.workload, U, I, len(users), nnz, args.layers, args.dim, B, gB,
-                                      2 * args.layers + 1, I, args.dim,
+            "config": {"workload": "%s graph cut across %d ranks by nnz-balanced user-row blocks: %d users x %d items, %d train "
+                                   "edges, nnz(A)=%d; LightGCN K=%d d=%d, ONE global batch of B=%d triples per Adam step (as "
+                                   "the reference, trainer.py:36); item table replicated; per step %d all-reduces of the "
+                                   "[%d,%d] fp32 item panel in %d slices that overlap the products + 2 of [%d,%d] (the "
+                                   "batch's user rows) over %s"
+                                   % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, 2 * K, I, d, len(eng.G_iu), B, d,
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
-                       "batch": B, "dim": args.dim, "layers": args.layers, "parallelism": "user-row shard x%d" % world,
-                       "comm": comm_name},
+                       "batch": B, "dim": d, "layers": K, "parallelism": "user-row shard x%d" % world,
+                       "comm": comm_name, "item_panel_slices": len(eng.G_iu)},
             "loss_last": [float(x) for x in eng.loss.cpu()],
             "host_issue_ms_per_step": t_enqueue / args.steps * 1e3,
+            "item_table_coherent": bool(c_lo.item() == c_hi.item()),
+            "roofline": {
+                "bound": "hbm", "kernel": "spmm_tile_kernel<%d,...> on rank 0's two blocks: R_g (users x items) and R_g^T "
+                                          "(items x users, %d row slices)" % (min(d // 4, 64), len(eng.G_iu)),
+                "achieved": (bytes_ui + bytes_iu) / (t_ui + t_iu) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": (bytes_ui + bytes_iu) / (t_ui + t_iu) / 1e9 / 8000.0, "traffic": None,
+                "us_user_side": t_ui * 1e6, "us_item_side": t_iu * 1e6, "bytes_gather_user_side": bytes_ui,
+                "bytes_gather_item_side": bytes_iu, "rank0_users": Ug, "rank0_nnz": nnz_ui,
+                "cache_resident": bool(4 * max(I, Ug) * d < (256 << 20)),
+                "exchange_bytes_per_step_per_rank": 2 * K * 4 * I * d + 2 * 4 * B * d,
+            },
+            "single_gpu_reference": "the same workload on ONE MI355X, unsharded: profiles/r01/k_c5_single_gpu_bench.json "
+                                    "(builder-run, round 1; not measured in this run)" if args.workload == "synth-10M" else None,
         }
-        getattr(args, "emit", lambda o: print(json.dumps(o)))(out)
-    dist.destroy_process_group()
+    del eng, batches
+    torch.cuda.empty_cache()
+    return out

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 113 /* 0.1.11: + gradient-row messages for data-parallel replicas, RCCL communicator */
+#define IDG_VERSION 114 /* 0.1.12: + row gather / chained row add (user-row shards), top-K beyond 64 ranks */
 
 /* error classes */
 #define IDG_OK 0
@@ -377,6 +377,16 @@ int idg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* ex
  * 1/(K+1) scaling, folding the replicated layer-0 term. */
 int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b, int64_t count,
                     void* stream);
+
+/* Row movers of the user-row-sharded step (no counterpart in the single-device reference): the ranks
+ * exchange the batch's user rows through "guest" rows of their panels.
+ * idg_rows_gather_f32: dst[t, :] = idx[t] >= 0 ? src[idx[t], :] : 0 for t < count (rows of d floats).
+ * idg_rows_chain_add_f32: for every t with idx[t] >= 0, dst[idx[t], :] += src[t, :] + src[next[t], :] + ... following
+ * `next` until -1, added in that order by one wave (the caller chains the occurrences of one destination in list
+ * order): deterministic, no atomics.  idx / next: int64 device arrays. */
+int idg_rows_gather_f32(float* dst, const float* src, const int64_t* idx, int64_t count, int64_t d, void* stream);
+int idg_rows_chain_add_f32(float* dst, const float* src, const int64_t* idx, const int64_t* next, int64_t count,
+                           int64_t d, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: full-rank scoring, train-positive masking, top-K

@@ -29,8 +29,28 @@ class OracleKernels:
     def make_graph(self, indptr, indices, values, n_rows, n_cols):
         return (np.asarray(indptr), np.asarray(indices), np.asarray(values), n_rows, n_cols)
 
-    def prepare(self, users, pos, neg, n_users, n, d):
+    def prepare(self, eng, gb):
         return None  # no batch lookahead in the checker-backed stub: every product is the dense one
+
+    def to_device(self, a):
+        return np.ascontiguousarray(a)
+
+    def gather_rows(self, dst, src, idx):
+        dst[...] = np.where((idx >= 0)[:, None], src[np.maximum(idx, 0)], np.float32(0))
+
+    def chain_add_rows(self, dst, src, idx, nxt):
+        for t in np.nonzero(idx >= 0)[0]:
+            acc, j = dst[idx[t]].copy(), t
+            while j >= 0:
+                acc = acc + src[j]
+                j = nxt[j]
+            dst[idx[t]] = acc
+
+    def topk(self, user_panel, item_panel, users, k, excl_indptr, excl_items):
+        R = self.o.score(user_panel, item_panel, np.asarray(users))
+        for b, u in enumerate(users):
+            R[b, excl_items[excl_indptr[u]:excl_indptr[u + 1]]] = -1
+        return self.o.topk_reference(R, k)
 
     def spmm(self, graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False, out_rows=None,
              x_rows=None):
@@ -84,30 +104,51 @@ def run(rank, world, port, mode, path, steps):
         kern = sh.HipKernels()
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         to_np = lambda a: a.cpu().numpy()  # noqa: E731
+    n_slices = int(z["n_slices"]) if "n_slices" in z.files else 1
     eng = sh.ShardedEngine(kern, sh.TorchComm(dist), ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
-                           batch_sparsity=(mode != "gpu-dense"))
+                           batch_sparsity=(mode != "gpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices)
+    Ug = hi - lo
     if mode == "cpu":
-        eng.P[: hi - lo] = W0[lo:hi]
-        eng.P[hi - lo:] = W0[U:]
+        eng.P[:Ug] = W0[lo:hi]
+        eng.P[Ug + B:] = W0[U:]
     else:
-        eng.P[: hi - lo].copy_(to_dev(W0[lo:hi]))
-        eng.P[hi - lo:].copy_(to_dev(W0[U:]))
+        eng.P[:Ug].copy_(to_dev(W0[lo:hi]))
+        eng.P[Ug + B:].copy_(to_dev(W0[U:]))
     losses = []
+
     def batch(s):
-        b = tri[s * B:(s + 1) * B]
-        mine = b[(b[:, 0] >= lo) & (b[:, 0] < hi)]
-        return to_dev(mine[:, 0] - lo), to_dev(mine[:, 1]), to_dev(mine[:, 2]), mine
+        b = tri[s * B:(s + 1) * B]  # the GLOBAL batch: every rank sees all of it
+        return eng.make_batch(b[:, 0], b[:, 1], b[:, 2]), b
 
     nxt = batch(0)
     for s in range(steps):
         cur, nxt = nxt, (batch(s + 1) if s + 1 < steps else None)
         if nxt is not None and s % 2 == 0:  # every other step through the lookahead, the rest prepared in-step
-            eng.prefetch(*nxt[:3])
-        loss = eng.train_step(cur[0], cur[1], cur[2], B)
+            eng.prefetch(nxt[0])
+        loss = eng.train_step(cur[0])
         losses.append(to_np(loss).copy())
-    touched = np.unique(cur[3][:, 0] - lo)  # local user rows of the LAST batch: the only FIN user rows guaranteed fresh
-    np.savez(path + ".out%d.npz" % rank, P=to_np(eng.P), FIN=to_np(eng.FIN), G=to_np(eng.G), losses=np.stack(losses),
-             lo=lo, hi=hi, fin_rows=touched)
+    mine = cur[1][(cur[1][:, 0] >= lo) & (cur[1][:, 0] < hi)]
+    touched = np.unique(mine[:, 0] - lo)  # local user rows of the LAST batch: the only FIN user rows guaranteed fresh
+
+    def strip(a):  # (drop the guest rows: users, then items)
+        a = to_np(a)
+        return np.concatenate([a[:Ug], a[Ug + B:]])
+
+    out = dict(P=strip(eng.P), FIN=strip(eng.FIN), G=strip(eng.G), losses=np.stack(losses), lo=lo, hi=hi, fin_rows=touched)
+    if "test_users" in z.files:  # sharded evaluation: this rank's test users, its train rows as the exclusion lists
+        tu, tptr, titems = z["test_users"], z["test_ptr"], z["test_items"]
+        own = [(int(u), titems[tptr[j]:tptr[j + 1]].tolist()) for j, u in enumerate(tu) if lo <= u < hi]
+        ex_ptr = z["train_ptr"][lo:hi + 1] - z["train_ptr"][lo]
+        ex_items = z["train_items"][z["train_ptr"][lo]:z["train_ptr"][hi]]
+
+        def reduce_sums(a):
+            t = torch.from_numpy(a)
+            dist.all_reduce(t)
+            return t.numpy()
+
+        res = eng.evaluate([u for u, _ in own], [t for _, t in own], ex_ptr, ex_items, [5, 10], reduce_sums)
+        out.update(ev_recall=res["recall"], ev_precision=res["precision"], ev_ndcg=res["ndcg"])
+    np.savez(path + ".out%d.npz" % rank, **out)
     dist.barrier()
     dist.destroy_process_group()
 

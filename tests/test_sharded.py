@@ -12,15 +12,20 @@ from tests.ranks import run_ranks
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _problem(g, K, include0, B, steps, seed=0, d=64):
+def _problem(g, K, include0, B, steps, seed=0, d=64, n_slices=1):
     U, I = int(g["num_users"]), int(g["num_items"])
     W0 = np.concatenate([g["d64_init_user"], g["d64_init_item"]])
     rng = np.random.default_rng(seed)
     if d != 64:  # BASELINE config 5 is d = 256: xavier-uniform tables of that width (the checker is the oracle, not a golden)
         W0 = np.concatenate([(rng.random((m, d)) * 2 - 1) * np.sqrt(6.0 / (m + d)) for m in (U, I)]).astype(np.float32)
     tri = g["sample1"][rng.permutation(len(g["sample1"]))][: B * steps]
+    # held-out items per test user (file order of test.txt) and the train CSR: what a sharded evaluation needs
+    tu = g["test_dict_users"]
+    t_items = [g["test_item"][g["test_user"] == u] for u in tu]
+    t_ptr = np.concatenate([[0], np.cumsum([len(t) for t in t_items])]).astype(np.int64)
     return dict(indptr=g["adj_indptr"], indices=g["adj_indices"], values=g["adj_data"], W0=W0, triples=tri, U=U, I=I,
-                K=K, B=B, include0=include0)
+                K=K, B=B, include0=include0, n_slices=n_slices, test_users=tu, test_ptr=t_ptr,
+                test_items=np.concatenate(t_items).astype(np.int64), train_ptr=g["pos_indptr"], train_items=g["pos_indices"])
 
 
 def _single_device_reference(p, steps):
@@ -60,6 +65,29 @@ def _check(p, outs, steps, rtol, atol, sparse=False):
     # replicated item table: bit-identical across ranks (coherence without an extra exchange)
     a, b = outs[0], outs[1]
     assert np.array_equal(a["P"][int(a["hi"]) - int(a["lo"]):], b["P"][int(b["hi"]) - int(b["lo"]):])
+    assert np.array_equal(a["losses"], b["losses"])  # every rank evaluates the whole batch's loss: same bits
+    # sharded evaluation (users by owner, items replicated, metric sums exchanged) == the single-device Test()
+    want = _single_device_test(p, W, [5, 10])
+    for o in outs:
+        for name in ("recall", "precision", "ndcg"):
+            np.testing.assert_allclose(o["ev_" + name], want[name], rtol=1e-9, atol=1e-12)
+
+
+def _single_device_test(p, W, top_k):
+    """batch_test.Test (utility/utility_train/batch_test.py:37-93) on the trained tables, by the oracle."""
+    adj = (p["indptr"], p["indices"], p["values"])
+    fin = oracle.propagate_mean(*adj, W, p["K"], p["include0"])
+    users = p["test_users"]
+    R = oracle.score(fin[: p["U"]], fin[p["U"]:], users)
+    for b, u in enumerate(users):
+        R[b, p["train_items"][p["train_ptr"][u]:p["train_ptr"][u + 1]]] = -1
+    top = oracle.topk_reference(R, max(top_k))
+    truth = [p["test_items"][p["test_ptr"][j]:p["test_ptr"][j + 1]].tolist() for j in range(len(users))]
+    r = oracle.get_label(truth, top)
+    n = float(len(users))
+    return {"recall": np.array([oracle.recall_at_k(r, k, truth) for k in top_k]) / n,
+            "precision": np.array([oracle.precision_at_k(r, k, truth) for k in top_k]) / n,
+            "ndcg": np.array([oracle.ndcg_at_k(r, k, truth) for k in top_k]) / n}
 
 
 def test_partition_is_contiguous_and_balanced():
@@ -98,9 +126,10 @@ def test_shards_tile_the_global_adjacency(world, golden_small):
     assert (acc_iu != A[U:, :U]).nnz == 0
 
 
-@pytest.mark.parametrize("K,include0,d", [(3, True, 64), (2, False, 64), (1, True, 64), (3, True, 256)])
-def test_two_ranks_gloo_cpu_match_single_device(K, include0, d, tmp_path, golden_small):
-    p = _problem(golden_small, K, include0, B=160, steps=3, d=d)
+@pytest.mark.parametrize("K,include0,d,n_slices", [(3, True, 64, 1), (2, False, 64, 3), (1, True, 64, 2), (3, True, 256, 2)])
+def test_two_ranks_gloo_cpu_match_single_device(K, include0, d, n_slices, tmp_path, golden_small):
+    """n_slices > 1: the item-side products run slice by slice, each slice's all-reduce issued as soon as it exists."""
+    p = _problem(golden_small, K, include0, B=160, steps=3, d=d, n_slices=n_slices)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
     outs = _launch("cpu", path, 3)
@@ -114,7 +143,7 @@ def test_two_ranks_hip_kernels_match_single_device(K, include0, d, mode, tmp_pat
     """mode "gpu": prepared batches (row-restricted last forward user product, sparse first backward product,
     planned scatter, every other step through the one-batch lookahead); "gpu-dense": every product dense.
     d = 256 is the width of BASELINE config 5 (user-row shards, 8 GPUs)."""
-    p = _problem(golden_small, K, include0, B=160, steps=4, d=d)
+    p = _problem(golden_small, K, include0, B=160, steps=4, d=d, n_slices=1 + (K + d) % 3)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
     outs = _launch(mode, path, 4)
