@@ -128,7 +128,8 @@ struct idg_graph {
   int32_t* d_slot_long = nullptr;  // partial slot -> index into d_long
   int* d_long_cnt = nullptr;       // arrival tickets of the in-kernel split-row combine (zero between launches)
   int32_t* d_xl = nullptr;     // vrows too long for one tile (EXACT_ORDER only)
-  uint32_t* d_hot = nullptr;   // IDG_NT_COLD=H: bitmap of the H most gathered columns (the rest are loaded non-temporally)
+  int32_t* d_vrow_row = nullptr; // vrow -> the CSR row it is (a piece of) (entry -> row, for idg_graph_masked_copy)
+  bool borrowed = false;       // a masked copy: everything but d_cv / d_long_cnt belongs to the handle it was made from
   // host copies for the checker
   std::vector<int64_t> h_long_rows, h_seg_len, h_chunk_len;
 };
@@ -313,50 +314,6 @@ __device__ __forceinline__ float4 walk_masked(CVPtr cv, int s, int e, const floa
   return acc;
 }
 
-// The same walk with a cache-policy hint per entry (experiment, IDG_NT_COLD): columns outside the `hot` bitmap — the
-// rarely gathered rows of the panel — are fetched with a non-temporal load so that they do not displace the often
-// gathered rows from the XCD's L2.  Same values, same order: bits unchanged.
-using f32x4n = __attribute__((ext_vector_type(4))) float;
-// (The compiler folds `hot ? *a : __builtin_nontemporal_load(a)` into one plain load, so both flavours are spelled
-// in asm; the loads are invisible to the compiler's vmcnt bookkeeping and are drained explicitly before use.)
-__device__ __forceinline__ f32x4n load_hint(const float* a, bool hot) {
-  f32x4n x;
-  if (hot)
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(a) : "memory");
-  else
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(x) : "v"(a) : "memory");
-  return x;
-}
-template <int UNROLL, typename CVPtr>
-__device__ __forceinline__ float4 walk_nt(CVPtr cv, int s, int e, const float* __restrict__ Xl, int64_t ldx,
-                                          const uint32_t* __restrict__ hot, float4 acc) {
-  int j = s;
-  for (; j + UNROLL <= e; j += UNROLL) {
-    ColVal p[UNROLL];
-    bool h[UNROLL];
-    f32x4n x[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) p[u] = cv[j + u];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) h[u] = mask_bit(hot, p[u].col);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler's own loads (bitmap probes) are done before ours start
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) x[u] = load_hint(Xl + (int64_t)p[u].col * ldx, h[u]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) acc = fma4(p[u].val, make_float4(x[u].x, x[u].y, x[u].z, x[u].w), acc);
-  }
-  for (; j < e; ++j) {
-    const ColVal p = cv[j];
-    const bool h = mask_bit(hot, p.col);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const f32x4n x = load_hint(Xl + (int64_t)p.col * ldx, h);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    acc = fma4(p.val, make_float4(x.x, x.y, x.z, x.w), acc);
-  }
-  return acc;
-}
-
 // ---- split rows combined inside the tile kernel (no separate fix-up launch) ---------------
 // A lane group that finishes a segment stores its partial WRITE-THROUGH (sc1), its wave drains
 // vmcnt(0), the group leader draws a ticket from the row's arrival counter (relaxed, agent
@@ -437,17 +394,16 @@ __device__ __forceinline__ int group_leader() {
   return lane & ~(LPR - 1);
 }
 
-template <int LPR, int NB, int UNROLL, int EPI, bool FUSED, bool NT = false>
+template <int LPR, int NB, int UNROLL, int EPI, bool FUSED>
 __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tgt, int l, const float* __restrict__ X,
                                         int64_t ldx, float* __restrict__ partials, int64_t d, const Epilogue& ep,
-                                        const FixCtx& fx, float4* s_part, const uint32_t* __restrict__ hot = nullptr) {
+                                        const FixCtx& fx, float4* s_part) {
   float nscale = 0.f;
   if (EPI == EPI_NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc = NT ? walk_nt<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, hot, acc)
-             : walk<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, acc);
+    acc = walk<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, acc);
     // the store addresses are rebuilt from the lane id once per vrow: hoisting them out of the vrow loop as
     // 64-bit per-lane pairs costs the registers that keep the kernel at 64 VGPRs (8 waves/SIMD)
     int lo = l;
@@ -518,7 +474,7 @@ __device__ __forceinline__ void combine_local(const Tile& t, const LocalRow* __r
 // One workgroup per tile.  LPR lanes per vrow, each lane owns 4 consecutive features of
 // every feature block of width 4*LPR (d = NB * 4 * LPR).  DYNAMIC: lane groups draw the next
 // vrow from an LDS counter instead of a fixed stride (evens out skewed row lengths).
-template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, int EPI = EPI_PLAIN, bool FUSED = false, bool NT = false>
+template <int LPR, int NB, int UNROLL, bool DYNAMIC, int MINW = 1, int EPI = EPI_PLAIN, bool FUSED = false>
 __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __restrict__ tiles,
                                                           const int64_t* __restrict__ vptr,
                                                           const int32_t* __restrict__ vtgt,
@@ -526,8 +482,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
                                                           const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ partials, int64_t d,
                                                           Epilogue ep, FixCtx fx,
-                                                          const LocalRow* __restrict__ locals,
-                                                          const uint32_t* __restrict__ hot) {
+                                                          const LocalRow* __restrict__ locals) {
   __shared__ ColVal s_cv[TILE_NNZ];
   __shared__ float4 s_part[LSLOTS * NB * LPR];
   __shared__ int s_ptr[TILE_VROWS + 1];
@@ -553,7 +508,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, UNROLL, EPI, FUSED, NT>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part, hot);
+    do_vrow<LPR, NB, UNROLL, EPI, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
     if (DYNAMIC) {
       int nxt = 0;
       if (l == 0) nxt = atomicAdd(&s_next, 1);
@@ -1081,10 +1036,10 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
   do {                                                                                                         \
     if (fused_fix)                                                                                             \
       hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, 1, EPI, true>  ), grid, block, 0, st, tile_order,  \
-                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, nullptr);     \
+                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);              \
     else                                                                                                       \
       hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, EPI, false>  ), grid, block, 0, st,          \
-                         tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, nullptr);  \
+                         tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);  \
   } while (0)
     if (out_mask && ep.noise_eps != 0.f) {  // flagged rows of a perturbed layer (the noise of a row depends on that row only)
       if (fused_fix)
@@ -1111,9 +1066,6 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       IDG_TILE(8, true, 1, EPI_NOISE);
     } else if (ep.adam_p) {  // last backward product of a training step: Adam applied to each finished gradient row
       IDG_TILE(8, true, 1, EPI_ADAM);
-    } else if (g->d_hot && fused_fix) {  // IDG_NT_COLD experiment: rarely gathered panel rows fetched non-temporally
-      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, 8, true, 1, EPI_PLAIN, true, true>), grid, block, 0, st, tile_order,
-                         g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, g->d_hot);
     } else switch (g->variant) {
       case 0: IDG_TILE(8, false, 1, EPI_PLAIN); break;
       case 1: IDG_TILE(8, true, 1, EPI_PLAIN); break;
@@ -1440,6 +1392,51 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
 
   std::vector<ColVal> cv((size_t)nnz);
   for (int64_t k = 0; k < nnz; ++k) cv[(size_t)k] = ColVal{indices[k], values[k]};
+  // Inside every tile the work units — a plain vrow, or a split row's run of segments — are laid out LONGEST FIRST.
+  // The lane groups of a wave walk their vrows in lockstep (a round lasts as long as its longest walk) and draw
+  // consecutive units from the tile's counter: sorted by length, the four (d = 64) walks of a round are of similar
+  // length instead of random ones, and the tile ends with its short rows (longest-first list scheduling).  Only the
+  // order of whole rows inside a tile changes: every row's entries, segments and summation order are untouched.
+  bool sort_tiles = true;
+  if (const char* v = std::getenv("IDG_TILE_SORT")) sort_tiles = std::atoi(v) != 0;
+  if (sort_tiles && !tiles_plain.empty()) {
+    std::vector<int64_t> vptr2(vptr);
+    std::vector<int32_t> vtgt2(vtgt), vrow_row2(vrow_row);
+    std::vector<size_t> local_of(vtgt.size(), SIZE_MAX);  // first segment's vrow -> its LocalRow
+    for (size_t li = 0; li < locals.size(); ++li) local_of[(size_t)locals[li].vrow] = li;
+    struct Unit {
+      int32_t v, n;
+      int64_t len;
+    };
+    std::vector<Unit> units;
+    for (const Tile& t : tiles_plain) {
+      units.clear();
+      for (int32_t v = t.vrow_begin; v < t.vrow_begin + t.n_vrows;) {
+        const int32_t nseg = local_of[(size_t)v] != SIZE_MAX ? (int32_t)locals[local_of[(size_t)v]].n_seg : 1;
+        units.push_back(Unit{v, nseg, vptr[(size_t)(v + nseg)] - vptr[(size_t)v]});
+        v += nseg;
+      }
+      std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.len > b.len; });
+      int64_t pos = t.nnz_begin;
+      int32_t nv = t.vrow_begin;
+      for (const Unit& u : units) {
+        if (local_of[(size_t)u.v] != SIZE_MAX) locals[local_of[(size_t)u.v]].vrow = nv;
+        for (int32_t q = 0; q < u.n; ++q) {
+          const int64_t b = vptr[(size_t)(u.v + q)], e = vptr[(size_t)(u.v + q) + 1];
+          vptr2[(size_t)nv] = pos;
+          vtgt2[(size_t)nv] = vtgt[(size_t)(u.v + q)];
+          vrow_row2[(size_t)nv] = vrow_row[(size_t)(u.v + q)];
+          for (int64_t k = b; k < e; ++k) cv[(size_t)(pos + (k - b))] = ColVal{indices[k], values[k]};
+          pos += e - b;
+          ++nv;
+        }
+      }
+      vptr2[(size_t)nv] = pos;  // == the next tile's first entry (or an xl vrow's start)
+    }
+    vptr.swap(vptr2);
+    vtgt.swap(vtgt2);
+    vrow_row.swap(vrow_row2);
+  }
 
   DeviceGuard guard;
   int rc = guard.enter(device);
@@ -1455,21 +1452,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK) rc = upload(&g->d_slot_long, slot_long);
   if (rc == IDG_OK) rc = upload(&g->d_long_cnt, std::vector<int>(longs.size() * MAX_PANELS, 0));  // one set per panel
   if (rc == IDG_OK) rc = upload(&g->d_xl, xl);
-  if (const char* v = std::getenv("IDG_NT_COLD")) {
-    const int64_t H = std::atoll(v);
-    if (H > 0 && rc == IDG_OK && nnz > 0) {
-      std::vector<int32_t> cnt((size_t)n_cols, 0);
-      for (int64_t k = 0; k < nnz; ++k) ++cnt[(size_t)indices[k]];
-      std::vector<int32_t> sorted(cnt);
-      const size_t kth = (size_t)std::min<int64_t>(H, n_cols) - 1;
-      std::nth_element(sorted.begin(), sorted.begin() + (std::ptrdiff_t)kth, sorted.end(), std::greater<int32_t>());
-      const int32_t thr = sorted[kth];
-      std::vector<uint32_t> hot((size_t)(n_cols + 31) / 32, 0u);
-      for (int64_t c = 0; c < n_cols; ++c)
-        if (cnt[(size_t)c] >= thr) hot[(size_t)c >> 5] |= 1u << (c & 31);
-      rc = upload(&g->d_hot, hot);
-    }
-  }
+  if (rc == IDG_OK) rc = upload(&g->d_vrow_row, vrow_row);
   if (rc != IDG_OK) {
     idg_graph_destroy(g);
     return rc;
@@ -1484,21 +1467,79 @@ int idg_graph_destroy(idg_graph* g) {
     DeviceGuard guard;
     if (guard.enter(g->device) == IDG_OK) {
       (void)hipFree(g->d_cv);
-      (void)hipFree(g->d_vptr);
-      (void)hipFree(g->d_vtgt);
-      (void)hipFree(g->d_tiles);
-      (void)hipFree(g->d_tiles_banded);
-      (void)hipFree(g->d_tiles_seq);
-      (void)hipFree(g->d_local);
-      (void)hipFree(g->d_long);
-      (void)hipFree(g->d_slot_row);
-      (void)hipFree(g->d_slot_long);
       (void)hipFree(g->d_long_cnt);
-      (void)hipFree(g->d_xl);
-      (void)hipFree(g->d_hot);
+      if (!g->borrowed) {
+        (void)hipFree(g->d_vptr);
+        (void)hipFree(g->d_vtgt);
+        (void)hipFree(g->d_tiles);
+        (void)hipFree(g->d_tiles_banded);
+        (void)hipFree(g->d_tiles_seq);
+        (void)hipFree(g->d_local);
+        (void)hipFree(g->d_long);
+        (void)hipFree(g->d_slot_row);
+        (void)hipFree(g->d_slot_long);
+        (void)hipFree(g->d_xl);
+        (void)hipFree(g->d_vrow_row);
+      }
     }
   }
   delete g;
+  return IDG_OK;
+}
+
+// values of a copy of the handle: entry (r, c) keeps v / divisor when floor(u(r, c) + add) != 0, u ~ U[0,1) from
+// Philox4x32-10(seed; stream; r, c) — or u(c, r) for the transposed mask — and becomes an explicit zero otherwise
+__global__ __launch_bounds__(BLOCK) void mask_values_kernel(const ColVal* __restrict__ src, ColVal* __restrict__ dst,
+                                                            const int64_t* __restrict__ vptr,
+                                                            const int32_t* __restrict__ vrow_row, int64_t n_vrows, int64_t nnz,
+                                                            float add, float divisor, uint64_t seed, uint64_t stream_id,
+                                                            int transpose) {
+  const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= nnz) return;
+  int64_t lo = 0, hi = n_vrows;  // the vrow v with vptr[v] <= k < vptr[v + 1] (the entry list is in vrow order)
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (vptr[mid] <= k) lo = mid;
+    else hi = mid;
+  }
+  const uint32_t row = (uint32_t)vrow_row[lo];
+  const ColVal e = src[k];
+  const uint32_t i = transpose ? (uint32_t)e.col : row, j = transpose ? row : (uint32_t)e.col;
+  const uint4 x = philox4x32_10(make_uint4(i, j, (uint32_t)stream_id, (uint32_t)(stream_id >> 32)),
+                                make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  const float u = (x.x >> 8) * (1.0f / 16777216.0f);
+  const bool keep = (int)(u + add) != 0;  // torch.rand(...) + (1 - keep_prob) truncated to int (models/NGCF.py:60-61)
+  dst[k] = ColVal{e.col, keep ? e.val / divisor : 0.f};
+}
+
+int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t seed, uint64_t stream_id, int transpose,
+                          void* stream, idg_graph** out) {
+  IDG_REQUIRE(g && out, "idg_graph_masked_copy: NULL argument");
+  IDG_REQUIRE(divisor != 0.f, "idg_graph_masked_copy: divisor must be non-zero");
+  IDG_REQUIRE(!transpose || g->n_rows == g->n_cols, "idg_graph_masked_copy: the transposed mask needs a square graph");
+  IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_masked_copy: handle without a vrow -> row table");
+  idg_graph* c = new (std::nothrow) idg_graph(*g);  // metadata and (borrowed) device pointers
+  if (!c) return idg::fail(IDG_E_NOMEM, "idg_graph_masked_copy: out of memory");
+  c->borrowed = true;
+  c->d_cv = nullptr;
+  c->d_long_cnt = nullptr;
+  c->flags &= ~(uint32_t)IDG_GRAPH_SYMMETRIC;  // (r, c) and (c, r) are drawn independently
+  DeviceGuard guard;
+  int rc = guard.enter(g->device);
+  if (rc == IDG_OK && g->nnz > 0) {
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_cv), (size_t)g->nnz * sizeof(ColVal)) != hipSuccess)
+      rc = idg::fail(IDG_E_NOMEM, "idg_graph_masked_copy: hipMalloc of %lld entries failed", (long long)g->nnz);
+  }
+  if (rc == IDG_OK) rc = upload(&c->d_long_cnt, std::vector<int>((size_t)g->n_long * MAX_PANELS, 0));
+  if (rc != IDG_OK) {
+    idg_graph_destroy(c);
+    return rc;
+  }
+  if (g->nnz > 0)
+    hipLaunchKernelGGL(mask_values_kernel, dim3((unsigned)((g->nnz + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       g->d_cv, c->d_cv, g->d_vptr, g->d_vrow_row, g->n_vrows, g->nnz, add, divisor, seed, stream_id, transpose);
+  IDG_HIP(hipGetLastError());
+  *out = c;
   return IDG_OK;
 }
 

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "idg_graph_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.c_uint32,
                                    C.c_int64, C.POINTER(c_vp)]),
     "idg_graph_destroy": (C.c_int, [c_vp]),
+    "idg_graph_masked_copy": (C.c_int, [c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp, C.POINTER(c_vp)]),
     "idg_graph_info": (C.c_int, [c_vp, c_i64p]),
     "idg_graph_long_rows": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p]),
     "idg_spmm_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
@@ -67,6 +68,8 @@ PROTOTYPES = {
     "idg_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "idg_linear_wgrad_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_int, c_vp,
                                        c_vp]),
+    "idg_ngcf_transform_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, c_vp]),
+    "idg_ngcf_transform_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, c_vp]),
     "idg_ngcf_tail_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
                                     c_vp, c_vp, c_vp]),
     "idg_ngcf_tail_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64,

@@ -110,6 +110,29 @@ class Graph:
     def T(self):
         return self if self.symmetric else self._T
 
+    def dropout_copy(self, keep_prob, stream=None):
+        """NGCF.node_dropout (models/NGCF.py:56-65) of a SYMMETRIC graph as a new Graph on the same tile schedule:
+        every stored entry is kept where int(u + (1 - keep_prob)) != 0, u ~ U[0, 1) — i.e. with probability
+        1 - keep_prob, the reference's own (inverted-looking) rule — and divided by (1 - keep_prob); its `.T` (used by
+        the backward of spmm) carries the transposed mask.  stream: (seed, stream id) of the draw; default: the next
+        one of the device seed's sequence."""
+        if not self.symmetric:
+            raise ValueError("dropout_copy needs a symmetric graph (the transposed mask is read off the same structure)")
+        seed, sid = _next_noise_stream() if stream is None else stream
+        add = 1.0 - float(keep_prob)
+        out = []
+        for transpose in (0, 1):
+            g = Graph.__new__(Graph)
+            g.device, g.n_rows, g.n_cols, g.nnz, g.symmetric = self.device, self.n_rows, self.n_cols, self.nnz, False
+            g._ws, g._base = self._ws, self  # same workspaces (same schedule); keeps the base handle alive
+            h = C.c_void_p()
+            check(lib.idg_graph_masked_copy(self._h, add, add, C.c_uint64(seed), C.c_uint64(sid), transpose, _stream(),
+                                            C.byref(h)), "idg_graph_masked_copy")
+            g._h = h
+            out.append(g)
+        out[0]._T, out[1]._T = out[1], out[0]
+        return out[0]
+
     def info(self):
         a = (C.c_int64 * 8)()
         check(lib.idg_graph_info(self._h, a), "idg_graph_info")
@@ -678,6 +701,52 @@ def tall_linear(X, W):
     return _TallLinear.apply(X, W)
 
 
+class _NgcfTransform(torch.autograd.Function):
+    """S = side @ W1 + (ego * side) @ W2 on the fp32 matrix cores in one pass over the rows (idg_ngcf_transform_f32);
+    backward: input gradients by idg_ngcf_transform_bwd_f32, weight gradients by idg_linear_wgrad_f32."""
+
+    @staticmethod
+    def forward(ctx, side, ego, W1, W2):
+        _require_device(side, ego, W1, W2)
+        side, ego, W1, W2 = _f32c(side, "side"), _f32c(ego, "ego"), _f32c(W1, "W1"), _f32c(W2, "W2")
+        n, d1 = side.shape
+        d2 = W1.shape[1]
+        S = torch.empty((n, d2), dtype=torch.float32, device=side.device)
+        need_w = ctx.needs_input_grad[3]
+        BI = torch.empty_like(side) if need_w else None
+        check(lib.idg_ngcf_transform_f32(_ptr(side), _ptr(ego), _ptr(W1), _ptr(W2), n, d1, d2, _ptr(S), _ptr(BI), _stream()),
+              "idg_ngcf_transform_f32")
+        ctx.save_for_backward(side, ego, W1, W2, BI if need_w else side)
+        ctx.has_bi = need_w
+        return S
+
+    @staticmethod
+    def backward(ctx, gS):
+        side, ego, W1, W2, BI = ctx.saved_tensors
+        gS = _f32c(gS, "gS")
+        n, d1 = side.shape
+        d2 = W1.shape[1]
+        g_side = g_ego = gW1 = gW2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g_side, g_ego = torch.empty_like(side), torch.empty_like(side)
+            check(lib.idg_ngcf_transform_bwd_f32(_ptr(gS), _ptr(side), _ptr(ego), _ptr(W1), _ptr(W2), n, d1, d2, _ptr(g_side),
+                                                 _ptr(g_ego), _stream()), "idg_ngcf_transform_bwd_f32")
+        if ctx.needs_input_grad[2]:
+            gW1 = linear_wgrad_raw(side, gS)
+        if ctx.needs_input_grad[3]:
+            gW2 = linear_wgrad_raw(BI if ctx.has_bi else ego * side, gS)
+        return g_side, g_ego, gW1, gW2
+
+
+def ngcf_transform(side, ego, W1, W2):
+    """torch.matmul(side, W1) + torch.matmul(ego * side, W2) (models/NGCF.py:88-99, biases left to ngcf_layer_tail).
+    MFMA kernel when the widths allow it (d1 % 64 == 0 and d2 % 64 == 0), the two thin GEMMs otherwise."""
+    d1, d2 = W1.shape
+    if d1 % 64 == 0 and d2 % 64 == 0 and side.is_cuda:
+        return _NgcfTransform.apply(side, ego, W1, W2)
+    return tall_linear(side, W1) + tall_linear(torch.mul(ego, side), W2)
+
+
 class _NgcfTail(torch.autograd.Function):
     """(E, N) = NGCF's layer tail of (S1, S2, b1, b2): leaky_relu((S1 + b1) + (S2 + b2)) -> dropout -> (itself,
     its row-normalised copy) in one kernel; backward in one kernel + the bias column sums."""
@@ -685,7 +754,7 @@ class _NgcfTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, S1, S2, b1, b2, slope, p, stream):
         _require_device(S1, S2, b1, b2)
-        S1, S2 = _f32c(S1, "S1"), _f32c(S2, "S2")
+        S1, S2 = _f32c(S1, "S1"), (None if S2 is None else _f32c(S2, "S2"))
         n, d = S1.shape
         E, N = torch.empty_like(S1), torch.empty_like(S1)
         seed, sid = stream
@@ -707,11 +776,12 @@ class _NgcfTail(torch.autograd.Function):
         check(lib.idg_ngcf_tail_bwd_f32(_ptr(E), _ptr(gE), _ptr(gN), n, d, slope, p, C.c_uint64(seed), C.c_uint64(sid),
                                         _ptr(gT), _stream()), "idg_ngcf_tail_bwd_f32")
         gb = gT.sum(dim=0)
-        return gT, gT, gb.reshape(shape1), gb.reshape(shape2), None, None, None
+        return gT, (gT if ctx.needs_input_grad[1] else None), gb.reshape(shape1), gb.reshape(shape2), None, None, None
 
 
 def ngcf_layer_tail(S1, S2, b1, b2, negative_slope=0.2, p=0.0, stream=None):
-    """(next ego, its L2-normalised copy) of one NGCF layer from the two transformed panels (models/NGCF.py:95-108).
+    """(next ego, its L2-normalised copy) of one NGCF layer from the two transformed panels (models/NGCF.py:95-108);
+    S2 = None: S1 already holds their sum (ngcf_transform).
     stream: (seed, stream id) of the dropout mask; default: the next one of the device seed's sequence."""
     return _NgcfTail.apply(S1, S2, b1, b2, negative_slope, p, _next_noise_stream() if stream is None else stream)
 

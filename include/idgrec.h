@@ -137,6 +137,17 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
                      const int32_t* indices, const float* values, uint32_t flags,
                      int64_t split_threshold, idg_graph** out);
 int idg_graph_destroy(idg_graph* g);
+
+/* A copy of `g` whose stored entry (r, c) keeps values[k] / divisor when floor(u + add) != 0 and becomes an explicit
+ * zero otherwise, u ~ U[0, 1) drawn by Philox4x32-10 from (seed, stream_id, r, c) — with transpose != 0 from (c, r):
+ * for a symmetric `g` that copy is the TRANSPOSE of the first one, which is what the backward of a product with the
+ * first one multiplies by.  This is NGCF.node_dropout (models/NGCF.py:56-65: keep where int(rand + (1 - keep_prob))
+ * is non-zero, survivors divided by (1 - keep_prob)) with add = divisor = 1 - keep_prob; the zeros stay in the
+ * structure (fmaf(0, x, acc) == acc), so the tile schedule, split schedule and summation order are those of `g`.
+ * The copy shares g's schedule (g must outlive it) and owns its entry list; destroy it with idg_graph_destroy.
+ * The mask is written on `stream`, in order with the products that follow. */
+int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t seed, uint64_t stream_id,
+                          int transpose, void* stream, idg_graph** out);
 /* info[0..7] = n_rows, n_cols, nnz, n_tiles, n_long_rows, n_long_chunks, split_threshold, flags */
 int idg_graph_info(const idg_graph* g, int64_t info[8]);
 /* The split schedule, so a checker can restate the exact summation order.  Define
@@ -324,9 +335,22 @@ int idg_linear_wgrad_f32(const float* X, int64_t ldx, const float* G, int64_t ld
                          int64_t d1, int64_t d2, float* w_grad, int accumulate, void* ws,
                          void* stream);
 
+/* NGCF's two per-layer transforms (models/NGCF.py:88-99: torch.matmul(side, W_gcn) and torch.matmul(ego * side, W_bi))
+ * on the fp32 matrix cores in one pass over the rows: S[n, d2] = side . W1 + (ego * side) . W2 (the two bias rows are
+ * added by idg_ngcf_tail_f32, which takes S as its S1 with S2 = NULL); BI (nullable) receives ego * side [n, d1], the
+ * left operand of W2's weight gradient.  Backward: g_side = gS . W1^T + (gS . W2^T) * ego, g_ego = (gS . W2^T) * side
+ * (weight gradients: idg_linear_wgrad_f32 on (side, gS) and (BI, gS)).  W1, W2: [d1, d2] row-major.
+ * Forward needs d1 % 64 == 0 and d2 % 32 == 0, backward d2 % 64 == 0 and d1 % 32 == 0, panels 16-byte aligned. */
+int idg_ngcf_transform_f32(const float* side, const float* ego, const float* W1, const float* W2, int64_t n,
+                           int64_t d1, int64_t d2, float* S, float* BI, void* stream);
+int idg_ngcf_transform_bwd_f32(const float* gS, const float* side, const float* ego, const float* W1,
+                               const float* W2, int64_t n, int64_t d1, int64_t d2, float* g_side, float* g_ego,
+                               void* stream);
+
 /* NGCF's per-layer tail after the two thin GEMMs (models/NGCF.py:95-108), one pass over the rows:
  *   t = (S1 + b1) + (S2 + b2);  a = leaky_relu(t, negative_slope);  E = dropout(a, p);  N = normalize(E, dim=1)
- * (S1 = side.W_gcn, S2 = (ego * side).W_bi, all [n, d] row-major; b1, b2 [d]).  The dropout mask is a counter-based
+ * (S1 = side.W_gcn, S2 = (ego * side).W_bi, all [n, d] row-major; b1, b2 [d]; S2 = NULL: S1 already holds the sum of
+ * the two, as idg_ngcf_transform_f32 produces it).  The dropout mask is a counter-based
  * function of (seed, stream_id, row, feature) — always applied, as in the reference, where nn.Dropout is built
  * inside aggregate() — and regenerated by the backward call, which needs only E:
  *   gT = d loss / d t  given  gE (gradient through E as the next layer's input, nullable) and gN (through N, nullable);

@@ -1,7 +1,8 @@
 """NGCF (Wang et al., SIGIR'19) on MI355X.  The sparse product with the self-loop adjacency
 D^-1/2 (A + I) D^-1/2 runs on the library's SpMM operator (symmetric graph: backward reuses the
-handle); the per-layer d x d transforms, LeakyReLU, message dropout, L2 normalisation and layer
-concatenation are stock torch ops as in the reference (models/NGCF.py:67-111).  Regularisation
+handle; with node_dropout a re-drawn masked copy of the handle per training forward); the two
+per-layer d x d transforms run on the fp32 matrix cores in one pass (idg_ngcf_transform_f32), bias adds,
+LeakyReLU, message dropout and L2 normalisation in one more (idg_ngcf_tail_f32) (models/NGCF.py:67-111).  Regularisation
 covers the positive and negative item rows only (models/NGCF.py:125)."""
 import torch
 from torch import nn
@@ -25,26 +26,28 @@ class NGCF(PackedRecommender):
                 self.weight_dict[name % layer] = nn.Parameter(nn.init.xavier_uniform_(torch.empty(*shape)))
         if eval(config['mess_dropout']):
             self.mess_dropout = eval(config['mess_drop_prob'])
-        if eval(config['node_dropout']):
-            raise NotImplementedError("NGCF node_dropout re-samples the sparse graph every forward; only the shipped "
-                                      "configuration (node_dropout = False) is supported on the MI355X path.")
+        self.node_dropout = bool(eval(config['node_dropout']))
+        self.node_keep_prob = float(config['node_keep_prob']) if self.node_dropout else 1.0
         self.attach_graph(data_graph.sparse_adjacency_matrix_with_self(dataset))
         self.activation_layer = nn.Tanh()
 
     def aggregate(self):
         ego = self.ego_panel()
         layers = [ego]
+        # node dropout (models/NGCF.py:56-65, 73-79): ONE re-drawn edge mask per training forward, shared by the layers;
+        # on the device it is a masked copy of the handle (same tile schedule; backward multiplies by the transposed mask)
+        graph = self.Graph.dropout_copy(self.node_keep_prob) if (self.node_dropout and self.training) else self.Graph
         for layer in range(self.n_layers):
-            side = ops.spmm(self.Graph, ego)
+            side = ops.spmm(graph, ego)
             w = self.weight_dict
-            # [n, d] x [d, d]: forward / input gradient are small GEMMs, the weight gradient (all reduction over the
-            # n rows) is the library's slice-summed kernel
-            s1 = ops.tall_linear(side, w['W_gcn_%d' % layer])
-            s2 = ops.tall_linear(torch.mul(ego, side), w['W_bi_%d' % layer])
+            # side . W_gcn + (ego * side) . W_bi (models/NGCF.py:88-99): both [n, d] x [d, d] products in ONE pass over
+            # the rows on the fp32 matrix cores, into one accumulator; input gradients likewise, weight gradients (all
+            # reduction over the n rows) by the library's slice-summed kernel
+            s = ops.ngcf_transform(side, ego, w['W_gcn_%d' % layer], w['W_bi_%d' % layer])
             # bias adds, LeakyReLU(0.2), message dropout and the L2-normalised copy in one kernel.  The reference
             # instantiates nn.Dropout inside aggregate() (models/NGCF.py:104): a fresh module is always in training
             # mode, so message dropout is applied during evaluation as well — kept as is
-            ego, normed = ops.ngcf_layer_tail(s1, s2, w['b_gcn_%d' % layer], w['b_bi_%d' % layer], 0.2,
+            ego, normed = ops.ngcf_layer_tail(s, None, w['b_gcn_%d' % layer], w['b_bi_%d' % layer], 0.2,
                                               self.mess_dropout[layer])
             layers.append(normed)
         final = torch.cat(layers, dim=1)

@@ -6,5 +6,7 @@ for line in sys.stdin:
         continue
     d = json.loads(line)
     r = d.get("roofline", {})
-    print("%-14s ms/step %.4f  triples/s %.0f  dense launch %.1f us  rows layer %.1f us  tiles %s" % (
-        tag, d["ms_per_step"], d["value"], r.get("us_per_launch", 0), r.get("row_restricted_last_layer_us", 0), r.get("tiles")))
+    h = r.get("hbm_bound") or {}
+    print("%-14s ms/step %.4f  triples/s %.0f  dense launch %.1f us  rows layer %.1f us  tiles %s  hbm-bound launch %.1f us" % (
+        tag, d["ms_per_step"], d["value"], r.get("us_per_launch", 0), r.get("row_restricted_last_layer_us") or 0, r.get("tiles"),
+        h.get("us_per_launch", 0)))

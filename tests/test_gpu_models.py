@@ -432,6 +432,43 @@ def test_ngcf_vs_reference(tmp_path, golden_small, golden_next):
     assert idx.shape == (32, 10)
 
 
+def test_ngcf_node_dropout_trains(tmp_path, golden_small):
+    """node_dropout = True (models/NGCF.py:56-79; the reference reads config['node_keep_prob'], a key its shipped
+    config file does not have): a re-drawn edge mask per training forward, the plain graph in evaluation."""
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.NGCF import NGCF
+
+    g = golden_small
+    cfg = _cfg("NGCF", node_dropout=True)
+    data = _data_with(tmp_path, g, cfg)
+    with pytest.raises(KeyError):
+        NGCF(cfg, data, torch.device("cuda"))
+    cfg["node_keep_prob"] = "0.2"  # survivors: probability 0.8 (the reference's rule), scaled by 1 / 0.8
+    tools.set_seed(2024)
+    model = NGCF(cfg, data, torch.device("cuda")).to("cuda")
+    batch = torch.from_numpy(g["d64_batch"]).cuda()
+    opt = ops.Adam(model.parameters(), lr=1e-3)
+    model.train()
+    with torch.no_grad():
+        a1 = torch.cat(model.aggregate())
+        a2 = torch.cat(model.aggregate())
+    assert not torch.equal(a1[:, 64:], a2[:, 64:])  # a fresh mask (and fresh message dropout) per forward
+    losses_seen = []
+    for _ in range(12):
+        ll = model(batch[:, 0], batch[:, 1], batch[:, 2])
+        assert all(torch.isfinite(x) for x in ll)
+        opt.zero_grad()
+        sum(ll).backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses_seen.append(float(sum(ll).detach()))
+    assert np.mean(losses_seen[-3:]) < np.mean(losses_seen[:3])
+    model.eval()
+    r = model.get_rating_for_test(torch.arange(8, device="cuda"))
+    assert torch.isfinite(r).all()
+
+
 def test_sgl_three_views_vs_reference(tmp_path, golden_small, golden_next):
     import scipy.sparse as sp
 

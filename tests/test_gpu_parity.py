@@ -518,6 +518,31 @@ def test_ngcf_layer_tail_vs_torch_ops(ops, p):
         assert torch.allclose(m, t.grad, rtol=2e-4, atol=2e-5 * float(t.grad.abs().max()))
 
 
+@pytest.mark.parametrize("n,d1,d2", [(3001, 64, 64), (517, 128, 64), (70000, 64, 128)])
+def test_ngcf_transform_vs_float64(ops, n, d1, d2):
+    """side @ W1 + (ego * side) @ W2 on the fp32 matrix cores (models/NGCF.py:88-99: the two torch.matmul calls of a
+    layer) and its four gradients, against the same expression in float64; rows not a multiple of the 32-row tile."""
+    rng = np.random.default_rng(n)
+    side = dev(rng.standard_normal((n, d1)).astype(np.float32)).requires_grad_()
+    ego = dev(rng.standard_normal((n, d1)).astype(np.float32)).requires_grad_()
+    W1 = dev((rng.standard_normal((d1, d2)) * 0.2).astype(np.float32)).requires_grad_()
+    W2 = dev((rng.standard_normal((d1, d2)) * 0.2).astype(np.float32)).requires_grad_()
+    S = ops.ngcf_transform(side, ego, W1, W2)
+    w = dev(rng.standard_normal((n, d2)).astype(np.float32))
+    (S * w).sum().backward()
+    mine = [t.grad.clone() for t in (side, ego, W1, W2)]
+    s64, e64, a64, b64 = (t.detach().double().requires_grad_() for t in (side, ego, W1, W2))
+    R = s64 @ a64 + (e64 * s64) @ b64
+    (R * w.double()).sum().backward()
+    assert torch.allclose(S.double(), R, rtol=1e-5, atol=1e-5)
+    for m, t in zip(mine, (s64, e64, a64, b64)):
+        scale = float(t.grad.abs().max())
+        assert torch.allclose(m.double(), t.grad, rtol=1e-4, atol=1e-5 * scale)
+    # the same values as the two thin GEMMs it replaces, to fp32 rounding
+    S2 = ops.tall_linear(side.detach(), W1.detach()) + ops.tall_linear(ego.detach() * side.detach(), W2.detach())
+    assert torch.allclose(S, S2, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("d,K,n_views", [(64, 3, 2), (64, 2, 1), (256, 3, 2), (32, 4, 2)])
 def test_propagate_views_one_call_equals_composition(ops, d, K, n_views, monkeypatch):
     """idg_propagate_views_f32 (shared first product, ONE multi-panel restricted launch for the last layer of all
@@ -798,6 +823,38 @@ def test_noise_and_perturbation_any_width(ops, golden_small):
         assert torch.equal(c, G.propagate_mean_raw(X, 3, False)) and not torch.equal(v1, v2)
         (v1.sum() + v2.sum()).backward()
         assert torch.isfinite(E0.grad).all()
+
+
+@pytest.mark.parametrize("keep_prob", [0.9, 0.3])
+def test_node_dropout_masked_copy(ops, golden_small, keep_prob):
+    """NGCF.node_dropout (models/NGCF.py:56-65) as a masked copy of the handle: an entry survives where
+    int(u + (1 - keep_prob)) != 0 — probability 1 - keep_prob, the reference's own rule — and is divided by
+    (1 - keep_prob); the copy's .T carries the transposed mask (what backward multiplies by); products run on the
+    base handle's schedule, so on the surviving entries they are the base product's bits scaled."""
+    g = golden_small
+    n = int(g["num_users"]) + int(g["num_items"])
+    G = _graph(ops, g)
+    eye = torch.eye(n, device="cuda")
+    A = G.spmm_raw(eye).cpu().numpy()
+    D = G.dropout_copy(keep_prob, stream=(4321, 7))
+    Dd, Dt = D.spmm_raw(eye).cpu().numpy(), D.T.spmm_raw(eye).cpu().numpy()
+    assert np.array_equal(Dt, Dd.T) and D.T.T is D
+    stored = A != 0
+    kept = Dd != 0
+    assert not (kept & ~stored).any()
+    p = 1.0 - keep_prob
+    frac, sigma = kept.sum() / stored.sum(), np.sqrt(p * (1 - p) / stored.sum())
+    assert abs(frac - p) < 5 * sigma, (frac, p)
+    np.testing.assert_allclose(Dd[kept], A[kept] / np.float32(p), rtol=2e-7)
+    assert not np.array_equal(kept, kept.T)  # (r, c) and (c, r) are drawn independently, as in the reference
+    again = G.dropout_copy(keep_prob, stream=(4321, 7)).spmm_raw(eye).cpu().numpy()
+    other = G.dropout_copy(keep_prob, stream=(4321, 8)).spmm_raw(eye).cpu().numpy()
+    assert np.array_equal(again, Dd) and not np.array_equal(other, Dd)
+    # autograd through ops.spmm uses the transposed mask
+    X = torch.randn(n, 64, device="cuda", requires_grad=True)
+    W = torch.randn(n, 64, device="cuda")
+    (ops.spmm(D, X) * W).sum().backward()
+    np.testing.assert_allclose(X.grad.cpu().numpy(), Dd.T @ W.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
 # ------------------------------------------------------------ full-size (BASELINE) properties
