@@ -277,9 +277,9 @@ def main():
 
     S.ramp_clocks()
     if graph is not None and args.model == "LightGCN":
-        for k in range(1, K + 1):
+        for k in range(1, K):
             eng.forward_layer(k)  # allocates the two layer buffers of the launch-timing leg BEFORE the timed region (at
-            #                       config-5 size: 2 x 15 GB of hipMalloc, ~1 s); results are overwritten by the steps
+            #                       config-5 size: 2 x 15 GB of hipMalloc, ~1 s)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -369,8 +369,8 @@ def roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form, bitmap=None
             for k in dense_layers:
                 eng.forward_layer(k)
         spmm_s = _time_launches(fwd, len(dense_layers), reps)
-        form = "layers 1..%d of the step's forward (product + running layer sum), %d launches between one HIP event pair" \
-               % (K - 1, reps * len(dense_layers))
+        form = "layers 1..%d of the step's forward (plain products into the layer buffers; the layer sum is formed by the " \
+               "last product's epilogue), %d launches between one HIP event pair" % (K - 1, reps * len(dense_layers))
     else:
         # this step form does not run its dense products one call per layer (SimGCL shares its first product between
         # the passes): time the same dense launch on its own
@@ -378,8 +378,10 @@ def roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form, bitmap=None
         spmm_s = _time_launches(lambda: graph.spmm_raw(eng.params, out=Y), 1, reps)
         form = "plain Y = A.X on the parameter panel, %d launches between one HIP event pair" % reps
     rows_s = None
-    if in_step_form and bitmap is not None:
-        rows_s = _time_launches(lambda: eng.forward_layer(K, bitmap), 1, reps)
+    if in_step_form and bitmap is not None and dense_layers:
+        # the row-restricted last layer (+ the layer sum in its epilogue): the whole restricted forward minus its dense layers
+        fwd_s = _time_launches(lambda: graph.propagate_mean_raw(eng.params, K, eng.inc, out=eng.final, out_rows=bitmap), 1, reps)
+        rows_s = max(fwd_s - len(dense_layers) * spmm_s, 0.0)
     gather, minimum = spmm_bytes(n, nnz, d)
     achieved = gather / spmm_s / 1e9
     traffic, source = None, None

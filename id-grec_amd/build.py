@@ -43,7 +43,7 @@ def build(force=False, verbose=False):
     # contracts a*b+c differently in different instantiations of the same source, and paths that must agree bit for
     # bit (single- vs multi-panel kernels, epilogue vs stand-alone perturbation) then differ in the last place
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-ffp-contract=off",
-              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("IDG_BUILD_DEFS", "").split()
     jobs = []
     objs = []
     for src in SOURCES:

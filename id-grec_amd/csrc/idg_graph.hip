@@ -30,6 +30,13 @@
 
 #include "idg_common.h"
 
+#ifndef IDG_ROWS_UNROLL
+#define IDG_ROWS_UNROLL 8  // panel rows in flight per lane group in the row-restricted / sparse-input kernels (few lane groups
+#endif                     // are busy there: the walk of a long row is a chain of dependent rounds, wider rounds shorten it)
+#ifndef IDG_WALK_TAIL
+#define IDG_WALK_TAIL 1  // 0: the remainder of a row as a 4-batch + single loads (the round-1 form; kept for A/B timing)
+#endif
+
 namespace {
 
 constexpr int TILE_NNZ = 1024;    // LDS capacity: entries staged per workgroup (8 KiB)
@@ -80,6 +87,8 @@ struct Epilogue {
   float* Y;             // [n_rows, ldy]   (nullable)
   const float* addend;  // acc += addend[r] (nullable)
   const float* sum_in;  // s = sum_in[r] + acc (nullable -> s = acc)
+  const float* sum_in2; // with sum_in: s = ((sum_in[r] + sum_in2[r]) + sum_in3[r]) + acc, left to right (each nullable):
+  const float* sum_in3; // the layer mean's additions in torch's order when the earlier layers are summed only at the end
   float* sum_out;       // sum_out[r] = s / div (nullable)
   int64_t ldy;          // leading dimension of Y/addend/sum_in/sum_out
   float div;            // 1 = no division
@@ -213,7 +222,12 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, in
   if (ep.Y) *reinterpret_cast<float4*>(ep.Y + o) = acc;
   if (ep.sum_out) {
     float4 s = acc;
-    if (ep.sum_in && live) s = add4(*reinterpret_cast<const float4*>(ep.sum_in + o), acc);
+    if (ep.sum_in && live) {
+      float4 t = *reinterpret_cast<const float4*>(ep.sum_in + o);
+      if (ep.sum_in2) t = add4(t, *reinterpret_cast<const float4*>(ep.sum_in2 + o));
+      if (ep.sum_in3) t = add4(t, *reinterpret_cast<const float4*>(ep.sum_in3 + o));
+      s = add4(t, acc);
+    }
     if (ep.div != 1.0f) {
       s.x = s.x / ep.div;
       s.y = s.y / ep.div;
@@ -255,6 +269,29 @@ __device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __re
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) acc = fma4(p[u].val, x[u], acc);
   }
+#if IDG_WALK_TAIL
+  // The last (e - j) < UNROLL entries of the row as ONE more round instead of a 4-batch plus up to three dependent
+  // single loads: every slot loads a valid entry of this row (slots past the end re-read the row's last entry: an L1
+  // hit), and a slot past the end leaves the accumulator as it is — a select on the fmaf's result, so the chain is the
+  // same sequence of operations on the same operands (no 0 * x terms: exact for any panel contents).
+  if (j < e) {
+    ColVal p[UNROLL];
+    float4 x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) p[u] = cv[j + u < e ? j + u : e - 1];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const float4 t = fma4(p[u].val, x[u], acc);
+      const bool in = j + u < e;
+      acc.x = in ? t.x : acc.x;
+      acc.y = in ? t.y : acc.y;
+      acc.z = in ? t.z : acc.z;
+      acc.w = in ? t.w : acc.w;
+    }
+  }
+#else
   if (UNROLL > 8 && j + 8 <= e) {
     ColVal p[8];
     float4 x[8];
@@ -282,6 +319,7 @@ __device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __re
     float4 x = *reinterpret_cast<const float4*>(Xl + (int64_t)p.col * ldx);
     acc = fma4(p.val, x, acc);
   }
+#endif
   return acc;
 }
 
@@ -600,7 +638,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, 8, EPI_PLAIN, FUSED>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx,
+    do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI_PLAIN, FUSED>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx,
                                       s_part);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
@@ -683,7 +721,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   int q = g;
   while (q < nlive) {
     const int v = s_live[q];
-    do_vrow<LPR, NB, 8, EPI, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
+    do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
     q = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
@@ -779,9 +817,9 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_multi_kernel(const Tile*
       FixCtx f = fx;
       f.cnt = mp.cnt[p];
       if (p == 0)
-        do_vrow<LPR, NB, 8, EPI0, true>(s_cv, vs, ve, tg, l, mp.X[p], ldx, mp.partials[p], d, mp.ep[p], f, s_part + p * SLAB);
+        do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI0, true>(s_cv, vs, ve, tg, l, mp.X[p], ldx, mp.partials[p], d, mp.ep[p], f, s_part + p * SLAB);
       else
-        do_vrow<LPR, NB, 8, EPI_NOISE, true>(s_cv, vs, ve, tg, l, mp.X[p], ldx, mp.partials[p], d, mp.ep[p], f,
+        do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI_NOISE, true>(s_cv, vs, ve, tg, l, mp.X[p], ldx, mp.partials[p], d, mp.ep[p], f,
                                              s_part + p * SLAB);
     }
     int nxt = 0;
@@ -899,7 +937,13 @@ __device__ __forceinline__ void generic_epilogue(const Epilogue& ep, int64_t r, 
   if (ep.addend && live) acc += ep.addend[o];
   if (ep.Y) ep.Y[o] = acc;
   if (ep.sum_out) {
-    float sres = (ep.sum_in && live) ? ep.sum_in[o] + acc : acc;
+    float sres = acc;
+    if (ep.sum_in && live) {
+      float t = ep.sum_in[o];
+      if (ep.sum_in2) t = t + ep.sum_in2[o];
+      if (ep.sum_in3) t = t + ep.sum_in3[o];
+      sres = t + acc;
+    }
     if (ep.div != 1.0f) sres = sres / ep.div;
     if (ep.accumulate && live) sres = ep.sum_out[o] + sres;
     ep.sum_out[o] = sres;
@@ -1090,7 +1134,8 @@ int spmm_dispatch(const idg_graph* g, const float* X, int64_t ldx, int64_t d, vo
   if (g->n_slots > 0 && !partials) return idg::fail(IDG_E_INVALID, "idg_spmm: workspace is NULL but the graph has split rows");
   const bool aligned = (ldx % 4 == 0) && (ep.ldy % 4 == 0) && ((uintptr_t)X % 16 == 0) &&
                        ((uintptr_t)ep.Y % 16 == 0) && ((uintptr_t)ep.addend % 16 == 0) &&
-                       ((uintptr_t)ep.sum_in % 16 == 0) && ((uintptr_t)ep.sum_out % 16 == 0);
+                       ((uintptr_t)ep.sum_in % 16 == 0) && ((uintptr_t)ep.sum_in2 % 16 == 0) &&
+                       ((uintptr_t)ep.sum_in3 % 16 == 0) && ((uintptr_t)ep.sum_out % 16 == 0);
   if (aligned) {
     switch (d) {
       case 32: return launch_fast<8, 1>(g, X, ldx, partials, d, ep, x_mask, out_mask, st);
@@ -1677,8 +1722,24 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
       ep.noise_seed = noise_seed;
       ep.noise_stream = noise_stream * 64 + (uint64_t)k;  // a fresh stream per layer
     }
-    if (!backward) {
-      // forward: running sum lives in `out`; the last layer divides.
+    if (!backward && K <= 3) {
+      // forward, up to three layers: the layer outputs X_1..X_{K-1} stay in the two layer buffers, and only the LAST
+      // product's epilogue forms the mean, (((E0 + X_1) + X_2) + X_K) / cnt — torch.mean(torch.stack(...))'s order — so
+      // the earlier layers are plain products (no running-sum panel read and written per layer) and, with out_rows,
+      // the sum is formed for the requested rows only.
+      if (!last) {
+        ep.Y = P[(k - 1) & 1];
+      } else {
+        const float* terms[3] = {nullptr, nullptr, nullptr};
+        int nt = 0;
+        if (include0) terms[nt++] = in;
+        for (int j = 1; j < K; ++j) terms[nt++] = P[(j - 1) & 1];
+        ep.sum_in = terms[0], ep.sum_in2 = terms[1], ep.sum_in3 = terms[2];
+        ep.sum_out = out;
+        ep.div = cnt;
+      }
+    } else if (!backward) {
+      // forward, deeper stacks: running sum lives in `out`; the last layer divides.
       if (!last) ep.Y = P[(k - 1) & 1];
       if (k == 1) {
         if (include0 || last) {
@@ -1777,8 +1838,16 @@ int idg_propagate_views_f32(const idg_graph* g, const float* E0, int K, int64_t 
       ep.div = last ? (float)K : 1.0f;
       const float* Xp = P[p][(k - 2) & 1];
       if (!last) ep.Y = P[p][(k - 1) & 1];
-      ep.sum_in = (k == 2) ? P[p][0] : outs[p];
-      ep.sum_out = outs[p];
+      if (K <= 3) {  // as in propagate_common: X_1 (and X_2) stay in the pass's two buffers, the last epilogue sums them
+        if (last) {
+          ep.sum_in = P[p][0];
+          ep.sum_in2 = K == 3 ? P[p][1] : nullptr;
+          ep.sum_out = outs[p];
+        }
+      } else {
+        ep.sum_in = (k == 2) ? P[p][0] : outs[p];
+        ep.sum_out = outs[p];
+      }
       if (p > 0) {
         ep.noise_eps = eps;
         ep.noise_seed = seeds[p - 1];

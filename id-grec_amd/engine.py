@@ -207,10 +207,8 @@ class PropagationEngine:
                                                 out_rows=slot.bitmap)
             seed1, sid1 = ops.layer_noise_stream(stream, 1)  # layer 1 again, on its own, for the rows of the batch
             ops.spmm_noise_raw(self.graph, self.params, eps, seed1, sid1, out=self._views[0], out_rows=slot.bitmap)
-        elif self.events is None:
-            self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
         else:
-            self._forward_layer_by_layer(slot.bitmap)
+            self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
         if self.sgl is not None:
             # SGL (models/SGL.py:75-101): the same encoder on two edge-dropped sub-graphs of this epoch; their layer
             # means are contrasted at the batch's users / positives (raw ids, duplicates count)
@@ -299,37 +297,16 @@ class PropagationEngine:
                           self.betas[0], self.betas[1], self.eps)
         return loss
 
-    def _forward_layer_by_layer(self, out_rows):
-        """The same forward as idg_propagate_mean_f32, one idg_spmm_ex_f32 call per layer, with a HIP
-        event pair around every launch.  self.events collects ("dense" | "rows", start, end)."""
-        for k in range(1, self.K + 1):
-            a = torch.cuda.Event(enable_timing=True)
-            b = torch.cuda.Event(enable_timing=True)
-            a.record()
-            self.forward_layer(k, out_rows)
-            b.record()
-            self.events.append(("rows" if k == self.K else "dense", a, b))
-
     def forward_layer(self, k, out_rows=None):
-        """Layer k (1-based) of the forward propagation as ONE idg_spmm_ex_f32 call, in exactly the form
-        idg_propagate_mean_f32 launches it inside a training step (running layer sum in self.final, the last layer
-        divides and — with out_rows — is restricted to the batch's rows).  bench.py times the dominant dense launch
-        through this, outside its timed region: layers 1..K-1 are launches of spmm_tile_kernel, layer K is the
-        row-restricted form."""
-        K, c0 = self.K, 1 if self.inc else 0
+        """Layer k (1-based, k < K) of the forward propagation as ONE idg_spmm_ex_f32 call, in the form
+        idg_propagate_mean_f32 launches it inside a training step: a plain product into a layer buffer (for K <= 3 the
+        layer sum is formed by the last product's epilogue only).  bench.py times the dominant dense launch through
+        this, outside its timed region."""
+        assert 1 <= k < self.K
         if self._pp is None:
             self._pp = [torch.empty_like(self.params), torch.empty_like(self.params)]
         X = self.params if k == 1 else self._pp[(k - 2) & 1]
-        last = k == K
-        if k == 1:
-            sum_in = self.params if c0 else None
-            sum_out = self.final if (c0 or last) else None
-        else:
-            sum_in = self.final if (c0 or k > 2) else X
-            sum_out = self.final
-        Y = None if last else self._pp[(k - 1) & 1]
-        ops.spmm_ex_raw(self.graph, X, Y=Y, sum_in=sum_in, sum_out=sum_out, div=float(K + c0) if last else 1.0,
-                        out_rows=out_rows if last else None)
+        ops.spmm_ex_raw(self.graph, X, Y=self._pp[(k - 1) & 1])
 
     def _mark(self, start=None):
         if self.events is None:
