@@ -33,6 +33,9 @@
 #ifndef IDG_ROWS_UNROLL
 #define IDG_ROWS_UNROLL 8  // panel rows in flight per lane group in the row-restricted / sparse-input kernels (few lane groups
 #endif                     // are busy there: the walk of a long row is a chain of dependent rounds, wider rounds shorten it)
+#ifndef IDG_FUSED_MINW
+#define IDG_FUSED_MINW 1   // __launch_bounds__ minimum waves per SIMD of the dense kernel with in-kernel split-row combine
+#endif
 #ifndef IDG_WALK_TAIL
 #define IDG_WALK_TAIL 1  // 0: the remainder of a row as a 4-batch + single loads (the round-1 form; kept for A/B timing)
 #endif
@@ -1079,7 +1082,7 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
 #define IDG_TILE(U, DYN, MINW, EPI)                                                                            \
   do {                                                                                                         \
     if (fused_fix)                                                                                             \
-      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, 1, EPI, true>  ), grid, block, 0, st, tile_order,  \
+      hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, IDG_FUSED_MINW, EPI, true>  ), grid, block, 0, st, tile_order,  \
                          g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);              \
     else                                                                                                       \
       hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, EPI, false>  ), grid, block, 0, st,          \
@@ -1557,29 +1560,107 @@ __global__ __launch_bounds__(BLOCK) void mask_values_kernel(const ColVal* __rest
   dst[k] = ColVal{e.col, keep ? e.val / divisor : 0.f};
 }
 
+// values of a copy of the handle, looked up in a CSR of the same structure: entry (r, c) of the handle's list takes
+// values[k] where k is c's position in row r of (indptr, indices) (ascending columns: a binary search)
+__global__ __launch_bounds__(BLOCK) void revalue_kernel(const ColVal* __restrict__ src, ColVal* __restrict__ dst,
+                                                        const int64_t* __restrict__ vptr, const int32_t* __restrict__ vrow_row,
+                                                        int64_t n_vrows, int64_t nnz, const int64_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices, const float* __restrict__ values) {
+  const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= nnz) return;
+  int64_t lo = 0, hi = n_vrows;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (vptr[mid] <= k) lo = mid;
+    else hi = mid;
+  }
+  const int64_t r = vrow_row[lo];
+  const int32_t c = src[k].col;
+  int64_t a = indptr[r], b = indptr[r + 1];  // first position with indices[pos] >= c
+  while (a < b) {
+    const int64_t mid = (a + b) >> 1;
+    if (indices[mid] < c) a = mid + 1;
+    else b = mid;
+  }
+  dst[k] = ColVal{c, values[a]};
+}
+
+// kept(edge_of_entry[k]) ? dinv[row_of_entry[k]] * dinv[col_of_entry[k]] : 0 for every entry of a normalised bipartite
+// adjacency (tools.create_adj_mat, tools.py:67-92: D^-1/2 (A' + A'^T) D^-1/2 on the kept interactions, float32)
+__global__ __launch_bounds__(BLOCK) void subgraph_values_kernel(int64_t nnz, const int32_t* __restrict__ row_of_entry,
+                                                                const int32_t* __restrict__ col_of_entry,
+                                                                const int32_t* __restrict__ edge_of_entry,
+                                                                const uint32_t* __restrict__ kept,
+                                                                const float* __restrict__ dinv, float* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= nnz) return;
+  const int32_t e = edge_of_entry[k];
+  const bool keep = (kept[e >> 5] >> (e & 31)) & 1u;
+  // (d_r * 1) * d_c: the two float32 products of degree_matrix.dot(adjacency).dot(degree_matrix)
+  out[k] = keep ? (dinv[row_of_entry[k]] * 1.0f) * dinv[col_of_entry[k]] : 0.f;
+}
+
+static int graph_copy_shell(const idg_graph* g, idg_graph** out, const char* who) {
+  idg_graph* c = new (std::nothrow) idg_graph(*g);  // metadata and (borrowed) device pointers
+  if (!c) return idg::fail(IDG_E_NOMEM, "%s: out of memory", who);
+  c->borrowed = true;
+  c->d_cv = nullptr;
+  c->d_long_cnt = nullptr;
+  int rc = IDG_OK;
+  if (g->nnz > 0 && hipMalloc(reinterpret_cast<void**>(&c->d_cv), (size_t)g->nnz * sizeof(ColVal)) != hipSuccess)
+    rc = idg::fail(IDG_E_NOMEM, "%s: hipMalloc of %lld entries failed", who, (long long)g->nnz);
+  if (rc == IDG_OK) rc = upload(&c->d_long_cnt, std::vector<int>((size_t)g->n_long * MAX_PANELS, 0));
+  if (rc != IDG_OK) {
+    idg_graph_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return IDG_OK;
+}
+
+int idg_subgraph_values_f32(int64_t nnz, const int32_t* row_of_entry, const int32_t* col_of_entry, const int32_t* edge_of_entry,
+                            const uint32_t* kept_bits, const float* dinv, float* values_out, void* stream) {
+  IDG_REQUIRE(nnz >= 0 && (nnz == 0 || (row_of_entry && col_of_entry && edge_of_entry && kept_bits && dinv && values_out)),
+              "idg_subgraph_values_f32: NULL argument");
+  if (nnz == 0) return IDG_OK;
+  hipLaunchKernelGGL(subgraph_values_kernel, dim3((unsigned)((nnz + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, nnz,
+                     row_of_entry, col_of_entry, edge_of_entry, kept_bits, dinv, values_out);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_graph_revalued_copy(const idg_graph* g, const int64_t* d_indptr, const int32_t* d_indices, const float* d_values,
+                            void* stream, idg_graph** out) {
+  IDG_REQUIRE(g && out, "idg_graph_revalued_copy: NULL argument");
+  IDG_REQUIRE(g->nnz == 0 || (d_indptr && d_indices && d_values), "idg_graph_revalued_copy: NULL CSR array");
+  IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_revalued_copy: handle without a vrow -> row table");
+  DeviceGuard guard;
+  int rc = guard.enter(g->device);
+  if (rc != IDG_OK) return rc;
+  idg_graph* c = nullptr;
+  rc = graph_copy_shell(g, &c, "idg_graph_revalued_copy");
+  if (rc != IDG_OK) return rc;
+  if (g->nnz > 0)
+    hipLaunchKernelGGL(revalue_kernel, dim3((unsigned)((g->nnz + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       g->d_cv, c->d_cv, g->d_vptr, g->d_vrow_row, g->n_vrows, g->nnz, d_indptr, d_indices, d_values);
+  IDG_HIP(hipGetLastError());
+  *out = c;
+  return IDG_OK;
+}
+
 int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t seed, uint64_t stream_id, int transpose,
                           void* stream, idg_graph** out) {
   IDG_REQUIRE(g && out, "idg_graph_masked_copy: NULL argument");
   IDG_REQUIRE(divisor != 0.f, "idg_graph_masked_copy: divisor must be non-zero");
   IDG_REQUIRE(!transpose || g->n_rows == g->n_cols, "idg_graph_masked_copy: the transposed mask needs a square graph");
   IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_masked_copy: handle without a vrow -> row table");
-  idg_graph* c = new (std::nothrow) idg_graph(*g);  // metadata and (borrowed) device pointers
-  if (!c) return idg::fail(IDG_E_NOMEM, "idg_graph_masked_copy: out of memory");
-  c->borrowed = true;
-  c->d_cv = nullptr;
-  c->d_long_cnt = nullptr;
-  c->flags &= ~(uint32_t)IDG_GRAPH_SYMMETRIC;  // (r, c) and (c, r) are drawn independently
   DeviceGuard guard;
   int rc = guard.enter(g->device);
-  if (rc == IDG_OK && g->nnz > 0) {
-    if (hipMalloc(reinterpret_cast<void**>(&c->d_cv), (size_t)g->nnz * sizeof(ColVal)) != hipSuccess)
-      rc = idg::fail(IDG_E_NOMEM, "idg_graph_masked_copy: hipMalloc of %lld entries failed", (long long)g->nnz);
-  }
-  if (rc == IDG_OK) rc = upload(&c->d_long_cnt, std::vector<int>((size_t)g->n_long * MAX_PANELS, 0));
-  if (rc != IDG_OK) {
-    idg_graph_destroy(c);
-    return rc;
-  }
+  if (rc != IDG_OK) return rc;
+  idg_graph* c = nullptr;
+  rc = graph_copy_shell(g, &c, "idg_graph_masked_copy");
+  if (rc != IDG_OK) return rc;
+  c->flags &= ~(uint32_t)IDG_GRAPH_SYMMETRIC;  // (r, c) and (c, r) are drawn independently
   if (g->nnz > 0)
     hipLaunchKernelGGL(mask_values_kernel, dim3((unsigned)((g->nnz + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                        g->d_cv, c->d_cv, g->d_vptr, g->d_vrow_row, g->n_vrows, g->nnz, add, divisor, seed, stream_id, transpose);

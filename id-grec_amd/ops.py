@@ -110,6 +110,21 @@ class Graph:
     def T(self):
         return self if self.symmetric else self._T
 
+    def revalued_copy(self, d_indptr, d_indices, d_values):
+        """A Graph on this handle's structure and tile schedule with the values of the DEVICE CSR (d_indptr int64,
+        d_indices int32, d_values fp32) — idg_graph_revalued_copy.  No host work: SGL's per-epoch edge-dropped views."""
+        _require_device(d_indptr, d_indices, d_values)
+        if d_indptr.dtype != torch.int64 or d_indices.dtype != torch.int32 or d_values.dtype != torch.float32:
+            raise TypeError("revalued_copy: indptr int64, indices int32, values float32")
+        g = Graph.__new__(Graph)
+        g.device, g.n_rows, g.n_cols, g.nnz, g.symmetric = self.device, self.n_rows, self.n_cols, self.nnz, self.symmetric
+        g._ws, g._base, g._T = self._ws, self, None
+        h = C.c_void_p()
+        check(lib.idg_graph_revalued_copy(self._h, _ptr(d_indptr), _ptr(d_indices), _ptr(d_values), _stream(), C.byref(h)),
+              "idg_graph_revalued_copy")
+        g._h = h
+        return g
+
     def dropout_copy(self, keep_prob, stream=None):
         """NGCF.node_dropout (models/NGCF.py:56-65) of a SYMMETRIC graph as a new Graph on the same tile schedule:
         every stored entry is kept where int(u + (1 - keep_prob)) != 0, u ~ U[0, 1) — i.e. with probability
@@ -251,6 +266,16 @@ def lincomb_raw(out, x, a, y=None, b=0.0):
     """out = a*x + b*y (y may be None)."""
     _require_device(out, x, y)
     check(lib.idg_lincomb_f32(_ptr(out), _ptr(x), float(a), _ptr(y), float(b), out.numel(), _stream()), "idg_lincomb_f32")
+
+
+def subgraph_values_raw(row_of_entry, col_of_entry, edge_of_entry, kept_bits, dinv, out=None):
+    """idg_subgraph_values_f32: the normalised values of an edge-dropped bipartite adjacency, in CSR entry order."""
+    _require_device(row_of_entry, col_of_entry, edge_of_entry, kept_bits, dinv, out)
+    nnz = row_of_entry.shape[0]
+    out = torch.empty(nnz, dtype=torch.float32, device=dinv.device) if out is None else out
+    check(lib.idg_subgraph_values_f32(nnz, _ptr(row_of_entry), _ptr(col_of_entry), _ptr(edge_of_entry), _ptr(kept_bits),
+                                      _ptr(dinv), _ptr(out), _stream()), "idg_subgraph_values_f32")
+    return out
 
 
 def rows_gather_raw(dst, src, idx):

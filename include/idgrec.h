@@ -148,6 +148,24 @@ int idg_graph_destroy(idg_graph* g);
  * The mask is written on `stream`, in order with the products that follow. */
 int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t seed, uint64_t stream_id,
                           int transpose, void* stream, idg_graph** out);
+
+/* A copy of `g` with NEW VALUES on the same structure and schedule, taken from a DEVICE CSR (indptr int64 [n_rows+1],
+ * indices int32 ascending per row, values fp32) that holds every entry of g (it may hold more): entry (r, c) takes the
+ * value stored for (r, c) there.  This is how a per-epoch sub-graph gets onto the device without a host-side tile
+ * schedule: SGL's edge-dropped views (tools.create_adj_mat, tools.py:67-92; models/SGL.py:130-143) are the full
+ * adjacency's handle with dropped interactions as explicit zeros and the kept ones re-normalised.  Same ownership
+ * rules as idg_graph_masked_copy; the flags (symmetry) are g's — the caller passes symmetric values. */
+int idg_graph_revalued_copy(const idg_graph* g, const int64_t* d_indptr, const int32_t* d_indices,
+                            const float* d_values, void* stream, idg_graph** out);
+
+/* values_out[k] = kept(edge_of_entry[k]) ? (dinv[row_of_entry[k]] * 1.0f) * dinv[col_of_entry[k]] : 0 for the nnz
+ * entries of a bipartite adjacency in CSR order (all arrays on the device): the float32 arithmetic of
+ * degree_matrix.dot(adjacency_matrix).dot(degree_matrix) in tools.create_adj_mat (tools.py:84-90) on the interactions
+ * whose bit is set in kept_bits (bit e = interaction e of inter_graph.nonzero()'s order); dinv = d^-1/2 of the kept
+ * graph, formed by the caller with the reference's own np.power expression. */
+int idg_subgraph_values_f32(int64_t nnz, const int32_t* row_of_entry, const int32_t* col_of_entry,
+                            const int32_t* edge_of_entry, const uint32_t* kept_bits, const float* dinv,
+                            float* values_out, void* stream);
 /* info[0..7] = n_rows, n_cols, nnz, n_tiles, n_long_rows, n_long_chunks, split_threshold, flags */
 int idg_graph_info(const idg_graph* g, int64_t info[8]);
 /* The split schedule, so a checker can restate the exact summation order.  Define

@@ -1,9 +1,11 @@
 """SGL (Wu et al., SIGIR'21) on MI355X: LightGCN encoder on the full graph plus two
 edge-dropped views rebuilt every epoch, InfoNCE between the views (reference: models/SGL.py,
-including its own epoch loop `SGL_trainer`).  Every view is a device graph handle; the
-per-epoch sub-graph normalisation runs in the native adjacency builder instead of SciPy."""
+including its own epoch loop `SGL_trainer`).  Every view is a device graph handle made ON the
+device from the full adjacency's handle (dropped interactions become explicit zeros, kept ones are
+re-normalised: idg_graph_revalued_copy) — no per-epoch host-side graph or tile-schedule build."""
 from time import time
 
+import numpy as np
 import torch
 
 import utility.utility_data.data_graph as data_graph
@@ -73,9 +75,63 @@ class Trainer():
     def train(self):
         self.SGL_trainer()
 
+    def _subgraph_state(self):
+        """Once per dataset: the full adjacency's CSR structure on the device and, per stored entry, its row and the
+        interaction (position in inter_graph.nonzero()'s order, tools.py:70) it stands for."""
+        st = getattr(self, "_sub_state", None)
+        if st is None:
+            import scipy.sparse as sp
+
+            R = self.dataset.user_item_net.tocsr()
+            R.sort_indices()
+            U, I = R.shape
+            E = R.nnz
+            user_index, item_index = R.nonzero()  # CSR order: interaction e is the e-th stored entry of R
+            ids = sp.csr_matrix((np.arange(1, E + 1, dtype=np.int64), R.indices, R.indptr), shape=R.shape)
+            Rt = ids.T.tocsr()
+            Rt.sort_indices()
+            # A = [[0, R], [R^T, 0]]: user rows keep R's entry order, item rows R^T's
+            indptr = np.concatenate([R.indptr.astype(np.int64), E + Rt.indptr[1:].astype(np.int64)])
+            indices = np.concatenate([R.indices.astype(np.int32) + U, Rt.indices.astype(np.int32)])
+            edge = np.concatenate([np.arange(E, dtype=np.int32), (Rt.data - 1).astype(np.int32)])
+            row = np.repeat(np.arange(U + I, dtype=np.int32), np.diff(indptr))
+            dev = torch.device(self.device)
+            st = self._sub_state = dict(
+                U=U, I=I, E=E, user_index=np.asarray(user_index), item_index=np.asarray(item_index),
+                indptr=torch.from_numpy(indptr).to(dev), indices=torch.from_numpy(indices).to(dev),
+                edge=torch.from_numpy(edge).to(dev), row=torch.from_numpy(row).to(dev))
+            full = self.model.Graph
+            assert full.nnz == len(indices) and full.n_rows == U + I, "the model's graph is not the plain bipartite adjacency"
+        return st
+
     def _view(self):
-        mat = tools.create_adj_mat(self.dataset.user_item_net, self.aug_type, self.ssl_ratio)
-        return tools.convert_sp_mat_to_graph(mat, self.device)
+        """One edge-dropped view (tools.create_adj_mat, tools.py:67-92).  The draw — random.sample on Python's own
+        stream, restated natively — and the kept graph's d^-1/2 (the reference's np.power expression on its degree
+        counts) are host work on index lists; the view itself never exists on the host: it is the full adjacency's
+        device handle with dropped interactions as explicit zeros and the kept ones re-normalised
+        (idg_subgraph_values_f32 + idg_graph_revalued_copy: same tile schedule, no per-epoch schedule build)."""
+        if self.aug_type == 'nd':
+            raise NotImplementedError("The method does not implemented.")
+        if torch.device(self.device).type != "cuda" or self.model.Graph is None:
+            mat = tools.create_adj_mat(self.dataset.user_item_net, self.aug_type, self.ssl_ratio)
+            return tools.convert_sp_mat_to_graph(mat, self.device)
+        import idgrec_amd.host as host
+
+        st = self._subgraph_state()
+        E, U, I = st["E"], st["U"], st["I"]
+        keep = host.py_random_sample(E, int((1 - self.ssl_ratio) * E))  # == random.sample(range(E), k) (tools.py:77)
+        kept = np.zeros((E + 31) // 32 * 32, dtype=bool)
+        kept[keep] = True
+        bits = np.packbits(kept, bitorder="little").view(np.int32)  # bit e of the little-endian bitmap = interaction e
+        deg = np.concatenate([np.bincount(st["user_index"][keep], minlength=U),
+                              np.bincount(st["item_index"][keep], minlength=I)]).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            d_inv = np.power(deg, -0.5)  # tools.py:85
+        d_inv[np.isinf(d_inv)] = 0.
+        dev = torch.device(self.device)
+        values = ops.subgraph_values_raw(st["row"], st["indices"], st["edge"], torch.from_numpy(bits).to(dev),
+                                         torch.from_numpy(d_inv.astype(np.float32)).to(dev))
+        return self.model.Graph.revalued_copy(st["indptr"], st["indices"], values)
 
     def _views(self):
         if self.aug_type in ['nd', 'ed']:

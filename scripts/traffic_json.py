@@ -1,5 +1,5 @@
 """Turn a scripts/pmc.sh summary into profiles/traffic_<workload>_d<d>.json (read by bench.py's
-roofline.traffic).  usage: python scripts/traffic_json.py gpurun_out/pmc_<tag>/summary.json <workload> <d>
+roofline.traffic).  usage: python scripts/traffic_json.py gpurun_out/pmc_<tag>/summary.json <workload> <d> [round dir, default r02]
 
 HBM-side bytes per launch of the dominant kernel = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md,
 HBM/rocprofv3 section: gfx950 tallies its 128-byte read requests as 64 B; WRITE_SIZE is exact).  The
@@ -35,6 +35,8 @@ out["method"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_H
                  "(scripts/pmc.sh, bench.py --separate-adam), per-dispatch average; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                  "(gfx950 tallies 128-B read requests at 64 B), checked on adam_kernel in the same run. Fabric-side bytes: "
                  "Infinity Cache hits are included, so for a cache-resident panel this is not DRAM traffic.")
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_%s_d%d.json" % (workload, d))
+sub = sys.argv[4] if len(sys.argv) > 4 else "r02"  # profiles/<round>/: bench.py reads the newest round's file
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", sub, "traffic_%s_d%d.json" % (workload, d))
+os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))

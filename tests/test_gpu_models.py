@@ -536,6 +536,47 @@ def test_sgl_fused_step_equals_autograd_step(tmp_path, golden_small, golden_next
     np.testing.assert_allclose(w_f, w_a, rtol=1e-4, atol=1e-6)
 
 
+def test_sgl_device_views_equal_create_adj_mat(tmp_path, golden_small):
+    """The trainer's per-epoch views — built on the device from the full graph's handle (idg_subgraph_values_f32 +
+    idg_graph_revalued_copy) — against tools.create_adj_mat (tools.py:67-92) on the same draws of Python's `random`
+    stream: the same matrix bit for bit (dropped interactions are explicit zeros), the same final stream state."""
+    import random
+
+    import utility.utility_function.tools as tools
+    from models.SGL import Trainer
+
+    g = golden_small
+    cfg = _cfg("SGL", aug_type="ed", ssl_ratio=0.1)
+    data = _data_with(tmp_path, g, cfg)
+    tools.set_seed(2024)
+    tr = Trainer(None, cfg, data, torch.device("cuda"), logging.getLogger("sgl_views"))
+    tr.model.to("cuda")
+    n = data.num_users + data.num_items
+    eye = torch.eye(n, device="cuda")
+    random.seed(99)
+    state = random.getstate()
+    want = [tools.create_adj_mat(data.user_item_net, "ed", 0.1).toarray() for _ in range(2)]
+    end_state = random.getstate()
+    random.setstate(state)
+    views = tr._views()
+    assert random.getstate() == end_state
+    for v, w in zip(views, want):
+        got = v.spmm_raw(eye).cpu().numpy()
+        assert np.array_equal(got, w.astype(np.float32))
+        assert v.symmetric and abs(float((w != 0).sum()) / float((tr.model.Graph.spmm_raw(eye) != 0).sum().item()) - 0.9) < 0.01
+    # the views propagate (forward and backward) on the full graph's schedule
+    X = torch.randn(n, 64, device="cuda")
+    out = views[0].propagate_mean_raw(X, 3, True).cpu().numpy()
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix(want[0].astype(np.float32))
+    x = X.cpu().numpy()
+    layers = [x]
+    for _ in range(3):
+        layers.append(A @ layers[-1])
+    np.testing.assert_allclose(out, np.mean(np.stack(layers, 1), 1), rtol=1e-4, atol=1e-6)
+
+
 def test_sgl_trainer_loop_runs(tmp_path, golden_small):
     import utility.utility_function.tools as tools
     from models.SGL import Trainer
