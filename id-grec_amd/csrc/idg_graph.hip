@@ -52,6 +52,7 @@ constexpr int64_t DEFAULT_SPLIT = 128;
 constexpr int DEFAULT_TILE_CAP = 512;  // entries per tile: small tiles even out work per CU (measured, profiles/r01)
 constexpr int64_t BAND_PANEL_BYTES = (int64_t)128 << 20;  // use XCD band placement up to this gathered-panel size
 constexpr int FIX_WAYS = 4;            // lane groups that share one split row in the fix-up pass
+constexpr int32_t UNIT_LONG = INT32_MIN;  // row_unit code of a chunked row: UNIT_LONG + its LongRow index
 
 struct __attribute__((aligned(16))) Tile {
   int64_t nnz_begin;
@@ -124,6 +125,7 @@ struct idg_graph {
   // selects the separate fix-up launch instead (same bits; measured 6 us per product slower on the benchmark
   // graphs now that only ~1 % of the rows and a few hundred partials go through the protocol).
   bool no_fused_fix = false;
+  bool no_units = false;  // IDG_LIVE_UNITS=0: ignore registered live-unit lists (restricted launches visit the tiles)
   int64_t tile_cap = DEFAULT_TILE_CAP;  // entries per tile (IDG_TILE_NNZ, <= TILE_NNZ)
   // device
   ColVal* d_cv = nullptr;
@@ -142,6 +144,18 @@ struct idg_graph {
   int32_t* d_xl = nullptr;     // vrows too long for one tile (EXACT_ORDER only)
   int32_t* d_vrow_row = nullptr; // vrow -> the CSR row it is (a piece of) (entry -> row, for idg_graph_masked_copy)
   bool borrowed = false;       // a masked copy: everything but d_cv / d_long_cnt belongs to the handle it was made from
+  // row -> work unit (idg_graph_live_units): >= 0 the row's vrow; ~li a split row combined in LDS (LocalRow li);
+  // UNIT_LONG + i a chunked row (LongRow i; one unit per chunk: d_slot_unit[slot], a vrow or ~LocalRow whose target is
+  // the chunk's global partial slot)
+  int32_t* d_row_unit = nullptr;
+  int32_t* d_slot_unit = nullptr;
+  // bitmaps whose live-unit lists are known (idg_graph_live_units): a restricted launch naming one of them walks the
+  // listed units, one wave each, instead of visiting every tile
+  static constexpr int MAX_BOUND = 8;
+  mutable const uint32_t* bound_bitmap[MAX_BOUND] = {};
+  mutable const int32_t* bound_units[MAX_BOUND] = {};
+  mutable int64_t bound_cap[MAX_BOUND] = {};
+  mutable int bound_next = 0;
   // host copies for the checker
   std::vector<int64_t> h_long_rows, h_seg_len, h_chunk_len;
 };
@@ -844,6 +858,131 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_multi_kernel(const Tile*
   }
 }
 
+// ---- row-restricted product over a LIST of live work units (round 2) ------------------------------------------
+// The tile form above visits every tile to find the few vrows of the batch's rows and stages a whole tile for one or
+// two of them.  With the batch's row bitmap turned into a list of work units ahead of time (idg_graph_live_units, on
+// the side stream with the rest of the batch's index-only work) the launch has one WAVE per unit and nothing else:
+//   * a plain vrow: lane group 0 walks its entries straight from global memory;
+//   * a split row whose segments the tile form combines in LDS (a LocalRow; also one chunk of a chunked row): the
+//     wave's lane groups take the segments round-robin, partials go to a wave-private LDS slab and lane group 0 adds
+//     them in the published 4-way order — the same operations on the same operands as combine_local;
+//   * chunks hand their sums to the last-arriver combine exactly as in the tile form.
+// Same fmaf chains, same combine orders: bit-identical to the tile form (and to the full product on those rows).
+__global__ __launch_bounds__(BLOCK) void live_units_kernel(const uint32_t* __restrict__ bitmap, int64_t n_rows,
+                                                           const int32_t* __restrict__ row_unit,
+                                                           const LongRow* __restrict__ longs,
+                                                           const int32_t* __restrict__ slot_unit, int32_t* __restrict__ out,
+                                                           int64_t cap) {
+  // out[0] = number of units, out[1..] = the units (order irrelevant)
+  const int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (w * 32 >= n_rows) return;
+  uint32_t m = bitmap[w];
+  while (m) {
+    const int b = __builtin_ctz(m);
+    m &= m - 1;
+    const int64_t r = w * 32 + b;
+    if (r >= n_rows) break;
+    const int32_t u = row_unit[r];
+    if (u > UNIT_LONG / 2) {  // a vrow (>= 0) or ~LocalRow
+      const int pos = atomicAdd(out, 1);
+      if (pos < cap) out[1 + pos] = u;
+    } else {
+      const LongRow lr = longs[u - UNIT_LONG];
+      const int pos = atomicAdd(out, lr.n_seg);
+      for (int k = 0; k < lr.n_seg; ++k)
+        if (pos + k < cap) out[1 + pos + k] = slot_unit[lr.slot_begin + k];
+    }
+  }
+}
+
+template <int LPR, int NB, int EPI>
+__global__ __launch_bounds__(BLOCK) void spmm_units_kernel(const int32_t* __restrict__ units, int64_t cap,
+                                                           const int64_t* __restrict__ vptr,
+                                                           const int32_t* __restrict__ vtgt,
+                                                           const ColVal* __restrict__ cv, const float* __restrict__ X,
+                                                           int64_t ldx, float* __restrict__ partials, int64_t d, Epilogue ep,
+                                                           FixCtx fx, const LocalRow* __restrict__ locals) {
+  constexpr int GPW = 64 / LPR;  // lane groups per wave
+  constexpr int W = NB * LPR;
+  __shared__ float4 s_part[BLOCK / 64][LSLOTS * W];
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int64_t u_idx = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+  int64_t count = units[0];
+  if (count > cap) count = cap;
+  if (u_idx >= count) return;  // whole waves leave together
+  const int32_t unit = units[1 + u_idx];
+  const int g = lane / LPR, l = lane % LPR;
+  if (unit >= 0) {  // a plain vrow: one lane group.  Its target is a row, or (a short last chunk) a global partial slot
+    if (g != 0) return;
+    const int64_t s = vptr[unit], e = vptr[unit + 1];
+    const int tgt = vtgt[unit];
+    float nscale = 0.f;
+    if (EPI == EPI_NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int off = (b * LPR + l) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t c = s; c < e; c += (1 << 20)) {
+        const int len = (int)((e - c) < (1 << 20) ? (e - c) : (1 << 20));
+        acc = walk<8>(cv + c, 0, len, X + off, ldx, acc);
+      }
+      if (tgt >= 0) {
+        if (EPI == EPI_NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
+        epilogue_store<EPI>(ep, tgt, off, acc);
+      } else {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)fx.part_bytes, 0x00020000);
+        u32x4 u;
+        u.x = __float_as_uint(acc.x), u.y = __float_as_uint(acc.y), u.z = __float_as_uint(acc.z), u.w = __float_as_uint(acc.w);
+        __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (unsigned)(((int64_t)(~tgt) * d + off) * 4), 0, 16);  // aux 16 = sc1
+      }
+    }
+    if (tgt < 0) combine_if_last<LPR, NB, EPI>(ep, partials, d, fx, ~tgt, l);
+    return;
+  }
+  const LocalRow lr = locals[~unit];
+  float4* part = s_part[wave];
+  for (int q = g; q < lr.n_seg; q += GPW) {  // segments round-robin over the wave's lane groups
+    const int64_t s = vptr[lr.vrow + q], e = vptr[lr.vrow + q + 1];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = walk<8>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, acc);
+      part[q * W + b * LPR + l] = acc;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (g != 0) return;
+  float nscale = 0.f;
+  if (EPI == EPI_NOISE && lr.tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, lr.tgt, l);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int off = (b * LPR + l) * 4;
+    const float4* p = part + b * LPR + l;
+    float4 sq[FIX_WAYS];
+#pragma unroll
+    for (int q = 0; q < FIX_WAYS; ++q) sq[q] = q < lr.n_seg ? p[q * W] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < FIX_WAYS; ++q)
+      if (q + FIX_WAYS < lr.n_seg) sq[q] = add4(sq[q], p[(q + FIX_WAYS) * W]);
+    float4 row = sq[0];
+#pragma unroll
+    for (int q = 1; q < FIX_WAYS; ++q)
+      if (q < lr.n_seg) row = add4(row, sq[q]);
+    if (lr.tgt >= 0) {
+      if (EPI == EPI_NOISE) row = perturb(ep, lr.tgt, b * LPR + l, nscale, row);
+      epilogue_store<EPI>(ep, lr.tgt, off, row);
+    } else {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)fx.part_bytes, 0x00020000);
+      u32x4 u;
+      u.x = __float_as_uint(row.x), u.y = __float_as_uint(row.y), u.z = __float_as_uint(row.z), u.w = __float_as_uint(row.w);
+      __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, (unsigned)(((int64_t)(~lr.tgt) * d + off) * 4), 0, 16);  // aux 16 = sc1
+    }
+  }
+  if (lr.tgt < 0) combine_if_last<LPR, NB, EPI>(ep, partials, d, fx, ~lr.tgt, l);
+}
+
 // EXACT_ORDER rows longer than a tile: one lane group streams the row from global memory.
 template <int LPR, int NB>
 __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__ xl,
@@ -1088,6 +1227,23 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       hipLaunchKernelGGL((spmm_tile_kernel<LPR, NB, U, DYN, MINW, EPI, false>  ), grid, block, 0, st,          \
                          tile_order, g->d_vptr, g->d_vtgt, g->d_cv, X, ldx, partials, d, ep, fx, g->d_local);  \
   } while (0)
+    const int32_t* units = nullptr;
+    int64_t ucap = 0;
+    if (out_mask)
+      for (int i = 0; i < idg_graph::MAX_BOUND; ++i)
+        if (g->bound_bitmap[i] == out_mask) units = g->bound_units[i], ucap = g->bound_cap[i];
+    if (units && ucap > 0 && (g->n_long == 0 || fused_fix) && !g->no_units) {
+      // the bitmap's live work units are listed: one wave per unit, no tile is visited (spmm_units_kernel)
+      const dim3 ugrid((unsigned)((ucap + BLOCK / 64 - 1) / (BLOCK / 64)));
+      if (ep.noise_eps != 0.f)
+        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_NOISE>), ugrid, block, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
+                           X, ldx, partials, d, ep, fx, g->d_local);
+      else
+        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_PLAIN>), ugrid, block, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
+                           X, ldx, partials, d, ep, fx, g->d_local);
+      IDG_HIP(hipGetLastError());
+      return IDG_OK;
+    }
     if (out_mask && ep.noise_eps != 0.f) {  // flagged rows of a perturbed layer (the noise of a row depends on that row only)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true, EPI_NOISE>), grid, block, 0, st, tile_order, g->d_vptr,
@@ -1261,6 +1417,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   g->flags = flags;
   if (const char* v = std::getenv("IDG_SPMM_VARIANT")) g->variant = std::atoi(v);
   if (const char* v = std::getenv("IDG_FUSED_FIX")) g->no_fused_fix = std::atoi(v) == 0;
+  if (const char* v = std::getenv("IDG_LIVE_UNITS")) g->no_units = std::atoi(v) == 0;
   if (const char* v = std::getenv("IDG_TILE_NNZ")) g->tile_cap = std::min<int64_t>(std::max(64, std::atoi(v)), TILE_NNZ);
   const bool exact = (flags & IDG_GRAPH_EXACT_ORDER) != 0;
   int64_t T = split_threshold > 0 ? split_threshold : DEFAULT_SPLIT;
@@ -1501,6 +1658,20 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   if (rc == IDG_OK) rc = upload(&g->d_long_cnt, std::vector<int>(longs.size() * MAX_PANELS, 0));  // one set per panel
   if (rc == IDG_OK) rc = upload(&g->d_xl, xl);
   if (rc == IDG_OK) rc = upload(&g->d_vrow_row, vrow_row);
+  if (rc == IDG_OK) {  // row -> work unit, chunk slot -> its LocalRow (idg_graph_live_units)
+    std::vector<int32_t> row_unit((size_t)n_rows, 0), slot_unit((size_t)slots, 0);
+    for (size_t v = 0; v < vtgt.size(); ++v) {
+      if (vtgt[v] >= 0) row_unit[(size_t)vtgt[v]] = (int32_t)v;
+      else if (vtgt[v] >= LOCAL_CODE + LSLOTS) slot_unit[(size_t)(~vtgt[v])] = (int32_t)v;  // a chunk that is one plain vrow
+    }
+    for (size_t li = 0; li < locals.size(); ++li) {
+      if (locals[li].tgt >= 0) row_unit[(size_t)locals[li].tgt] = ~(int32_t)li;
+      else slot_unit[(size_t)(~locals[li].tgt)] = ~(int32_t)li;
+    }
+    for (size_t i = 0; i < longs.size(); ++i) row_unit[(size_t)longs[i].row] = UNIT_LONG + (int32_t)i;
+    rc = upload(&g->d_row_unit, row_unit);
+    if (rc == IDG_OK) rc = upload(&g->d_slot_unit, slot_unit);
+  }
   if (rc != IDG_OK) {
     idg_graph_destroy(g);
     return rc;
@@ -1528,6 +1699,8 @@ int idg_graph_destroy(idg_graph* g) {
         (void)hipFree(g->d_slot_long);
         (void)hipFree(g->d_xl);
         (void)hipFree(g->d_vrow_row);
+        (void)hipFree(g->d_row_unit);
+        (void)hipFree(g->d_slot_unit);
       }
     }
   }
@@ -1667,6 +1840,43 @@ int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t
   IDG_HIP(hipGetLastError());
   *out = c;
   return IDG_OK;
+}
+
+size_t idg_graph_live_units_bytes(const idg_graph* g, int64_t max_rows) {
+  if (!g || max_rows < 0) return 0;
+  return sizeof(int32_t) * (size_t)(1 + max_rows + g->n_slots);
+}
+
+int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows) {
+  IDG_REQUIRE(g && bitmap && units_ws && max_rows >= 0, "idg_graph_bind_live_units: bad argument");
+  int at = -1;
+  for (int i = 0; i < idg_graph::MAX_BOUND; ++i)
+    if (g->bound_bitmap[i] == bitmap) at = i;
+  if (at < 0) at = g->bound_next, g->bound_next = (g->bound_next + 1) % idg_graph::MAX_BOUND;
+  g->bound_bitmap[at] = bitmap;
+  g->bound_units[at] = reinterpret_cast<const int32_t*>(units_ws);
+  g->bound_cap[at] = max_rows + g->n_slots;
+  return IDG_OK;
+}
+
+int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap) {
+  IDG_REQUIRE(g, "idg_graph_forget_live_units: NULL handle");
+  for (int i = 0; i < idg_graph::MAX_BOUND; ++i)
+    if (g->bound_bitmap[i] == bitmap || bitmap == nullptr) g->bound_bitmap[i] = nullptr, g->bound_units[i] = nullptr;
+  return IDG_OK;
+}
+
+int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream) {
+  IDG_REQUIRE(g && bitmap && units_ws && max_rows >= 0, "idg_graph_live_units: bad argument");
+  IDG_REQUIRE(g->d_row_unit || g->n_rows == 0, "idg_graph_live_units: handle without a row -> unit table");
+  hipStream_t st = (hipStream_t)stream;
+  IDG_HIP(hipMemsetAsync(units_ws, 0, sizeof(int32_t), st));
+  const int64_t words = (g->n_rows + 31) / 32;
+  if (words > 0)
+    hipLaunchKernelGGL(live_units_kernel, dim3((unsigned)((words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, bitmap, g->n_rows,
+                       g->d_row_unit, g->d_long, g->d_slot_unit, reinterpret_cast<int32_t*>(units_ws), max_rows + g->n_slots);
+  IDG_HIP(hipGetLastError());
+  return idg_graph_bind_live_units(g, bitmap, units_ws, max_rows);
 }
 
 int idg_graph_info(const idg_graph* g, int64_t info[8]) {
@@ -1908,7 +2118,10 @@ int idg_propagate_views_f32(const idg_graph* g, const float* E0, int K, int64_t 
     if (rc != IDG_OK) return rc;
   }
   // layers 2..K: mean(X1..XK) = propagate_mean(X1, K - 1, include_layer0 = 1), per pass
-  const bool multi_ok = out_rows && g->n_tiles > 0 && g->n_xl == 0 && !g->no_fused_fix &&
+  bool listed = false;  // a live-unit list for this bitmap: the per-panel launches take the one-wave-per-unit form
+  if (out_rows && !g->no_units)
+    for (int i = 0; i < idg_graph::MAX_BOUND; ++i) listed = listed || g->bound_bitmap[i] == out_rows;
+  const bool multi_ok = out_rows && !listed && g->n_tiles > 0 && g->n_xl == 0 && !g->no_fused_fix &&
                         (g->n_slots * d * (int64_t)sizeof(float)) < ((int64_t)1 << 31);
   for (int k = 2; k <= K; ++k) {
     const bool last = (k == K);

@@ -16,6 +16,7 @@
 // and catalogue chunk fills the list at the start.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "idg_common.h"
@@ -480,17 +481,18 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     const int kk = k - done < 64 ? k - done : 64;
     const unsigned long long* bd_in = done > 0 ? bound : nullptr;
     unsigned long long* bd_out = done + kk < k ? bound : nullptr;
-    if (apply_sigmoid) {
+    if (apply_sigmoid)
       hipLaunchKernelGGL(score_topk_fused_kernel<true>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
                          Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in);
-      hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kk, out_idx, out_val,
-                         (int64_t)k, (int64_t)done, bd_out);
-    } else {
+    else
       hipLaunchKernelGGL(score_topk_fused_kernel<false>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
                          Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in);
+    if (apply_sigmoid)
+      hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kk, out_idx, out_val,
+                         (int64_t)k, (int64_t)done, bd_out);
+    else
       hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kk, out_idx, out_val,
                          (int64_t)k, (int64_t)done, bd_out);
-    }
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;

@@ -57,6 +57,16 @@ class PropagationEngine:
         #                        the average over all ranks' batches before the (linear) backward propagation
         self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
+    def __del__(self):
+        # the graph may outlive this engine: its registered bitmaps must not (a later buffer at the same address would
+        # inherit a stale unit list)
+        try:
+            if self.graph is not None and self._slots:
+                for sl in self._slots:
+                    self.graph.forget_live_units(sl.bitmap)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
     # ---- views handed to nn.Embedding
     def user_weight(self):
         return self.params[: self.U]
@@ -81,6 +91,7 @@ class PropagationEngine:
     class _Slot:
         def __init__(self, words, device):
             self.bitmap = torch.zeros(words, dtype=torch.int32, device=device)
+            self.units, self.units_B = None, -1  # live work units of the bitmap (Graph.live_units), rebuilt with it
             self.ws = None
             self.key = None
             self.rows_done = self.plan_done = None
@@ -106,6 +117,11 @@ class PropagationEngine:
             self._fork.wait(self._side_raw)
         if self.graph is not None:  # (without propagation nothing is restricted to the batch's rows: MFBPR)
             ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap, stream=self._side_raw, clear_bits=self.n)
+            # the bitmap's rows as a list of work units: the row-restricted last layer then runs one wave per unit
+            # instead of visiting every tile (same bits)
+            slot.units = self.graph.live_units(slot.bitmap, 3 * B, ws=slot.units if slot.units_B == B else None,
+                                               stream=self._side_raw)
+            slot.units_B = B
             slot.rows_done.record(self._side_raw)  # needed by the last forward layer
         ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
         slot.plan_done.record(self._side_raw)  # needed by the gradient scatter
@@ -216,6 +232,9 @@ class PropagationEngine:
             if self._views is None:
                 self._views = tuple(torch.empty_like(self.params) for _ in range(4))  # two views, their gradients
                 self._ssl_loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+            for sub in (sub_1, sub_2):  # copies of the full graph's handle share its schedule: the same unit list serves
+                if getattr(sub, "_base", None) is self.graph and slot.units is not None:
+                    sub.bind_live_units(slot.bitmap, slot.units, 3 * users.shape[0])
             sub_1.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[0], out_rows=slot.bitmap)
             sub_2.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[1], out_rows=slot.bitmap)
         assert self.exchange is None or not three, "gradient-row exchange: LightGCN-family steps only"

@@ -40,6 +40,10 @@ PROTOTYPES = {
     "idg_graph_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.c_uint32,
                                    C.c_int64, C.POINTER(c_vp)]),
     "idg_graph_destroy": (C.c_int, [c_vp]),
+    "idg_graph_live_units_bytes": (C.c_size_t, [c_vp, C.c_int64]),
+    "idg_graph_live_units": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
+    "idg_graph_bind_live_units": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64]),
+    "idg_graph_forget_live_units": (C.c_int, [c_vp, c_vp]),
     "idg_graph_revalued_copy": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(c_vp)]),
     "idg_subgraph_values_f32": (C.c_int, [C.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "idg_graph_masked_copy": (C.c_int, [c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp, C.POINTER(c_vp)]),

@@ -110,6 +110,28 @@ class Graph:
     def T(self):
         return self if self.symmetric else self._T
 
+    # ---- live work units of a row bitmap (idg_graph_live_units): restricted launches naming the bitmap then run one
+    #      wave per unit instead of visiting every tile
+    def live_units(self, bitmap, max_rows, ws=None, stream=None):
+        """Build (on `stream`, default: current) and register the unit list of `bitmap` (int32 tensor); returns the
+        list's buffer, which the caller keeps alive while the bitmap is in use — and re-builds whenever the bitmap's
+        contents change."""
+        _require_device(bitmap, ws)
+        if ws is None:
+            ws = torch.empty(int(lib.idg_graph_live_units_bytes(self._h, int(max_rows))) // 4, dtype=torch.int32,
+                             device=self.device)
+        check(lib.idg_graph_live_units(self._h, _ptr(bitmap), _ptr(ws), int(max_rows), _stream() if stream is None else stream),
+              "idg_graph_live_units")
+        return ws
+
+    def bind_live_units(self, bitmap, ws, max_rows):
+        """Register an existing list (built on a handle with the same schedule: the base of a masked / revalued copy)."""
+        check(lib.idg_graph_bind_live_units(self._h, _ptr(bitmap), _ptr(ws), int(max_rows)), "idg_graph_bind_live_units")
+
+    def forget_live_units(self, bitmap=None):
+        if getattr(self, "_h", None):
+            lib.idg_graph_forget_live_units(self._h, _ptr(bitmap))
+
     def revalued_copy(self, d_indptr, d_indices, d_values):
         """A Graph on this handle's structure and tile schedule with the values of the DEVICE CSR (d_indptr int64,
         d_indices int32, d_values fp32) — idg_graph_revalued_copy.  No host work: SGL's per-epoch edge-dropped views."""

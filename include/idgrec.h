@@ -149,6 +149,22 @@ int idg_graph_destroy(idg_graph* g);
 int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t seed, uint64_t stream_id,
                           int transpose, void* stream, idg_graph** out);
 
+/* Live work units of a row bitmap (optional accelerator of the row-restricted launches; round 2).  A launch given
+ * `out_rows` normally visits every tile to find the few rows wanted.  idg_graph_live_units turns the bitmap into the list
+ * of work units behind its rows — on `stream`: meant for the side stream that prepares a batch's index-only work — and
+ * registers (bitmap pointer -> list) on the handle; from then on every restricted launch on this handle that names THIS
+ * bitmap pointer runs one wave per listed unit and visits no tile.  Results are bit-identical to the tile form.  The
+ * list is valid for the bitmap's contents at the time of the call: call again after changing the bitmap (same units_ws:
+ * the registration is replaced), or idg_graph_forget_live_units (bitmap = NULL: all).  max_rows: upper bound on the set
+ * bits (3 x batch size); more set bits than that is the caller's error (the surplus rows would not be produced).
+ * units_ws: idg_graph_live_units_bytes(g, max_rows) bytes of device memory owned by the caller, alive while registered.
+ * Copies of a handle (masked / revalued) share its schedule: idg_graph_bind_live_units registers an existing list on them.
+ * At most 8 bitmaps are registered per handle (oldest replaced). */
+size_t idg_graph_live_units_bytes(const idg_graph* g, int64_t max_rows);
+int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream);
+int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows);
+int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap);
+
 /* A copy of `g` with NEW VALUES on the same structure and schedule, taken from a DEVICE CSR (indptr int64 [n_rows+1],
  * indices int32 ascending per row, values fp32) that holds every entry of g (it may hold more): entry (r, c) takes the
  * value stored for (r, c) there.  This is how a per-epoch sub-graph gets onto the device without a host-side tile

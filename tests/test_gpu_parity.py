@@ -825,6 +825,57 @@ def test_noise_and_perturbation_any_width(ops, golden_small):
         assert torch.isfinite(E0.grad).all()
 
 
+@pytest.mark.parametrize("d", [32, 64, 256])
+@pytest.mark.parametrize("exact", [False, True])
+def test_live_unit_list_equals_tile_form(ops, d, exact):
+    """idg_graph_live_units: a restricted launch that finds its bitmap registered runs one wave per listed work unit
+    (plain vrows, split rows combined in a wave-private LDS slab, chunks through the last-arriver combine) instead of
+    visiting every tile — the same bits on the requested rows, nothing else written; plain and perturbed products,
+    hub rows of every kind, an EXACT_ORDER handle (rows beyond a tile are plain units)."""
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    U, I, E = 6000, 2500, 260000  # item hubs far beyond 512 entries (chunked), many rows of 129..512 (LDS-combined)
+    users, items = S.generate(U, I, E, seed=5)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n = U + I
+    G = ops.Graph(ip, ix, dv, n, n, exact_order=exact)
+    deg = np.diff(ip)
+    if not exact:
+        _, seg, chunk = G.long_rows()
+        assert (np.asarray(chunk) > 0).any() and (np.asarray(chunk) == 0).any()
+    rng = np.random.default_rng(d)
+    rows = np.unique(np.concatenate([rng.integers(0, n, 700), np.argsort(deg)[-40:], np.argsort(deg)[:5], [0, n - 1]]))
+    bitmap = np.zeros((n + 31) // 32, dtype=np.uint32)
+    np.bitwise_or.at(bitmap, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
+    bm = dev(bitmap.view(np.int32))
+    X = torch.randn(n, d, device="cuda") * 0.1
+    rows_d = dev(rows)
+    others = torch.ones(n, dtype=torch.bool, device="cuda")
+    others[rows_d] = False
+
+    def run():
+        out = torch.full((n, d), float("nan"), device="cuda")
+        G.propagate_mean_raw(X, 3, True, out=out, out_rows=bm)
+        noisy = torch.full((n, d), float("nan"), device="cuda")
+        ops.spmm_noise_raw(G, X, 0.05, 77, 3, out=noisy, out_rows=bm)
+        return out, noisy
+
+    tile_out, tile_noisy = run()
+    ws = G.live_units(bm, len(rows))
+    torch.cuda.synchronize()
+    listed = int(ws[0].item())
+    assert listed >= len(rows)  # chunked rows contribute one unit per chunk
+    unit_out, unit_noisy = run()
+    G.forget_live_units(bm)
+    again, _ = run()  # (tile form once more: the registration is gone)
+    full = G.propagate_mean_raw(X, 3, True)
+    for a, b in ((unit_out, tile_out), (unit_noisy, tile_noisy), (again, tile_out)):
+        assert torch.equal(a.index_select(0, rows_d), b.index_select(0, rows_d))
+        assert bool(torch.isnan(a[others]).all())
+    assert torch.equal(unit_out.index_select(0, rows_d), full.index_select(0, rows_d))
+
+
 @pytest.mark.parametrize("keep_prob", [0.9, 0.3])
 def test_node_dropout_masked_copy(ops, golden_small, keep_prob):
     """NGCF.node_dropout (models/NGCF.py:56-65) as a masked copy of the handle: an entry survives where
