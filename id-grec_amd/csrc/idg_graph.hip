@@ -36,6 +36,9 @@
 #ifndef IDG_FUSED_MINW
 #define IDG_FUSED_MINW 1   // __launch_bounds__ minimum waves per SIMD of the dense kernel with in-kernel split-row combine
 #endif
+#ifndef IDG_UNITS_UNROLL
+#define IDG_UNITS_UNROLL 8  // panel rows in flight per lane group in the one-wave-per-unit kernel
+#endif
 #ifndef IDG_WALK_TAIL
 #define IDG_WALK_TAIL 1  // 0: the remainder of a row as a 4-batch + single loads (the round-1 form; kept for A/B timing)
 #endif
@@ -924,7 +927,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_units_kernel(const int32_t* __rest
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int64_t c = s; c < e; c += (1 << 20)) {
         const int len = (int)((e - c) < (1 << 20) ? (e - c) : (1 << 20));
-        acc = walk<8>(cv + c, 0, len, X + off, ldx, acc);
+        acc = walk<IDG_UNITS_UNROLL>(cv + c, 0, len, X + off, ldx, acc);
       }
       if (tgt >= 0) {
         if (EPI == EPI_NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_units_kernel(const int32_t* __rest
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = walk<8>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, acc);
+      acc = walk<IDG_UNITS_UNROLL>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, acc);
       part[q * W + b * LPR + l] = acc;
     }
   }
