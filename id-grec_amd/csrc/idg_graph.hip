@@ -39,6 +39,9 @@
 #ifndef IDG_UNITS_UNROLL
 #define IDG_UNITS_UNROLL 8  // panel rows in flight per lane group in the one-wave-per-unit kernel
 #endif
+#ifndef IDG_UNITS_UNROLL
+#define IDG_UNITS_UNROLL 8  // panel rows in flight per lane group in the one-wave-per-unit kernel (16 / 32 measured: no gain)
+#endif
 #ifndef IDG_WALK_TAIL
 #define IDG_WALK_TAIL 1  // 0: the remainder of a row as a 4-batch + single loads (the round-1 form; kept for A/B timing)
 #endif
