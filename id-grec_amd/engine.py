@@ -55,7 +55,6 @@ class PropagationEngine:
         self._views = self._ssl_loss = None
         self.exchange = None   # replicas (replicated.py): hook(slot, loss) -> bitmap, swaps this batch's gradient rows for
         #                        the average over all ranks' batches before the (linear) backward propagation
-        self.events = None  # bench.py: list collecting (start, end) HIP events around each propagation
 
     def __del__(self):
         # the graph may outlive this engine: its registered bitmaps must not (a later buffer at the same address would
@@ -179,14 +178,10 @@ class PropagationEngine:
         if not self.deterministic:
             self.grad.zero_()
             self.g_final.zero_()
-            ev = self._mark()
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final)
-            self._mark(ev)
             ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
                               self.grad, loss=loss, deterministic=0)
-            ev = self._mark()
             self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True)
-            self._mark(ev)
             self._final_version = -1
             return loss
         # deterministic path.  The batch's rows are flagged in a bitmap and its (row, slot) pairs sorted —
@@ -326,15 +321,6 @@ class PropagationEngine:
             self._pp = [torch.empty_like(self.params), torch.empty_like(self.params)]
         X = self.params if k == 1 else self._pp[(k - 2) & 1]
         ops.spmm_ex_raw(self.graph, X, Y=self._pp[(k - 1) & 1])
-
-    def _mark(self, start=None):
-        if self.events is None:
-            return None
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()  # torch's current stream == the stream the kernels are launched on
-        if start is not None:
-            self.events.append((start, e))
-        return e
 
     # ---- evaluation
     @torch.no_grad()

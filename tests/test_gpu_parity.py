@@ -825,6 +825,42 @@ def test_noise_and_perturbation_any_width(ops, golden_small):
         assert torch.isfinite(E0.grad).all()
 
 
+@pytest.mark.parametrize("d", [7, 64, 256])
+def test_guest_row_movers(ops, d):
+    """idg_rows_gather_f32 / idg_rows_chain_add_f32 (the sharded step's guest rows) against their numpy statement:
+    gathered rows bit-equal, zeros where not owned; chained adds in list order (bit-equal to the sequential float32 sums)."""
+    rng = np.random.default_rng(d)
+    n, B = 500, 300
+    src = rng.standard_normal((n, d)).astype(np.float32)
+    idx = rng.integers(-1, n, B).astype(np.int64)
+    dst = torch.full((B, d), float("nan"), device="cuda")
+    ops.rows_gather_raw(dst, dev(src), dev(idx))
+    want = np.where((idx >= 0)[:, None], src[np.maximum(idx, 0)], np.float32(0))
+    assert np.array_equal(dst.cpu().numpy(), want)
+    # chains: occurrences of one destination linked in list order, heads carry the destination
+    users = rng.integers(0, 40, B)
+    owned = users < 30
+    order = np.argsort(users, kind="stable")
+    nxt = np.full(B, -1, dtype=np.int64)
+    same = users[order][1:] == users[order][:-1]
+    nxt[order[:-1][same]] = order[1:][same]
+    first = np.ones(B, dtype=bool)
+    first[order[1:][same]] = False
+    head = np.where(owned & first, users, -1).astype(np.int64)
+    g = rng.standard_normal((B, d)).astype(np.float32)
+    base = rng.standard_normal((40, d)).astype(np.float32)
+    out = dev(base.copy())
+    ops.rows_chain_add_raw(out, dev(g), dev(head), dev(nxt))
+    want = base.copy()
+    for t in np.nonzero(head >= 0)[0]:
+        acc, j = want[head[t]].copy(), t
+        while j >= 0:
+            acc = acc + g[j]
+            j = nxt[j]
+        want[head[t]] = acc
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("d", [32, 64, 256])
 @pytest.mark.parametrize("exact", [False, True])
 def test_live_unit_list_equals_tile_form(ops, d, exact):

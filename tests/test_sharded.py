@@ -102,6 +102,41 @@ def test_partition_is_contiguous_and_balanced():
     assert sh.partition_users_by_nnz(np.zeros(5, dtype=int), 2).tolist()[0::2] == [0, 5]
 
 
+def test_global_batch_chains_and_guest_row_movers():
+    """ShardedEngine.make_batch: ownership, first occurrences and the per-user chains in batch order; the two row
+    movers restated in numpy (tests/sharded_worker.OracleKernels) move exactly the owned rows and add duplicates in
+    list order."""
+    import idgrec_amd.sharded as sh
+    from tests.sharded_worker import OracleKernels
+
+    class Eng(sh.ShardedEngine):
+        def __init__(self):  # only what make_batch needs
+            self.k, self.B, self.lo, self.Ug = OracleKernels(), 8, 10, 5
+
+    users = np.array([12, 3, 12, 14, 10, 12, 99, 14])  # owned block: global users 10..14
+    gb = Eng().make_batch(users, np.arange(8), np.arange(8) + 1)
+    assert gb.B == 8 and gb.n_owned == 6
+    assert gb.own_src.tolist() == [2, -1, 2, 4, 0, 2, -1, 4]
+    assert gb.head_dst.tolist() == [2, -1, -1, 4, 0, -1, -1, -1]       # first owned occurrence of each user
+    assert gb.nxt.tolist() == [2, -1, 5, 7, -1, -1, -1, -1]            # 0 -> 2 -> 5 (user 12), 3 -> 7 (user 14)
+    assert gb.own_users.tolist() == [2, 2, 4, 0, 2, 4]
+    k = OracleKernels()
+    src = np.arange(5 * 3, dtype=np.float32).reshape(5, 3) + 1
+    guest = np.full((8, 3), np.nan, dtype=np.float32)
+    k.gather_rows(guest, src, gb.own_src)
+    assert np.array_equal(guest[[0, 2, 5]], np.tile(src[2], (3, 1))) and np.all(guest[[1, 6]] == 0)
+    g_guest = np.random.default_rng(0).standard_normal((8, 3)).astype(np.float32)
+    dst = np.zeros((5, 3), dtype=np.float32)
+    k.chain_add_rows(dst, g_guest, gb.head_dst, gb.nxt)
+    want = np.zeros_like(dst)
+    for t in (0, 2, 5):
+        want[2] = want[2] + g_guest[t]
+    for t in (3, 7):
+        want[4] = want[4] + g_guest[t]
+    want[0] = g_guest[4]
+    assert np.array_equal(dst, want)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_shards_tile_the_global_adjacency(world, golden_small):
     import scipy.sparse as sp
