@@ -193,9 +193,26 @@ class PackedRecommender(nn.Module):
             ue, ie = self.final_panels()
             return ops.score_dense(ue, ie, user.long(), apply_sigmoid=True)
 
+    #: ranks one call of the fused scoring / top-K entry point returns (idg_score_topk_f32: one pass per 64 ranks)
+    FUSED_TOPK_MAX = 1024
+
     def topk_for_test(self, user, k):
-        """Top-k unseen items per user without materialising the rating matrix."""
+        """Top-k unseen items per user without materialising the rating matrix (k up to FUSED_TOPK_MAX; beyond that —
+        torch.topk takes any k <= num_items, batch_test.py:68 — the dense rating matrix, the reference's mask and
+        torch.topk, batch by batch)."""
         with torch.no_grad():
             ue, ie = self.final_panels()
             ip, ix = self.dataset.train_csr_on(ue.device)
-            return ops.score_topk(ue, ie, user.long(), k, ip, ix, apply_sigmoid=True)
+            user = user.long()
+            if k <= self.FUSED_TOPK_MAX:
+                return ops.score_topk(ue, ie, user, k, ip, ix, apply_sigmoid=True)
+            out = []
+            for lo in range(0, user.shape[0], 256):
+                u = user[lo:lo + 256]
+                rating = ops.score_dense(ue, ie, u, apply_sigmoid=True)
+                cnt = ip[u + 1] - ip[u]
+                rows = torch.repeat_interleave(torch.arange(u.shape[0], device=u.device), cnt)
+                cols = torch.cat([ix[int(a):int(b)] for a, b in zip(ip[u].tolist(), ip[u + 1].tolist())]).long() if int(cnt.sum()) else rows
+                rating[rows, cols] = -1
+                out.append(torch.topk(rating, k=k)[1])
+            return torch.cat(out)

@@ -239,6 +239,33 @@ def test_evaluator_fused_vs_dense_path(tmp_path, golden_small):
     np.testing.assert_allclose(R, g["d64_lgcn_rating"], rtol=1e-5, atol=1e-6)
 
 
+def test_topk_for_test_any_k(tmp_path):
+    """model.topk_for_test for k below, at and beyond what the fused entry point returns in one call (64 ranks per pass,
+    1024 per call; beyond: dense rating + the reference's mask + torch.topk): the same lists as ranking the dense
+    rating matrix by (score descending, item ascending) wherever scores are distinct."""
+    import idgrec_amd.synth as S
+    import utility.utility_data.data_loader as data_loader
+    import utility.utility_function.tools as tools
+    from models.LightGCN import LightGCN
+
+    S.make_dataset(str(tmp_path), "medium", n_test=2)
+    cfg = _cfg("LightGCN", dataset="medium", dataset_path=str(tmp_path) + "/")
+    data = data_loader.Data(str(tmp_path / "medium"), cfg)
+    tools.set_seed(2024)
+    model = LightGCN(cfg, data, torch.device("cuda")).to("cuda").eval()
+    users = torch.arange(0, 97, device="cuda")
+    rating = model.get_rating_for_test(users).cpu().numpy()
+    for b, u in enumerate(users.tolist()):
+        rating[b, data.get_user_pos_items([u])[0]] = -1
+    order = np.lexsort((np.arange(rating.shape[1])[None, :].repeat(len(users), 0), -rating), axis=1)
+    for k in (20, 64, 65, 1024, 1100):
+        got = model.topk_for_test(users, k).cpu().numpy()
+        assert got.shape == (len(users), k)
+        vals = np.take_along_axis(rating, got, axis=1)
+        np.testing.assert_allclose(vals, np.take_along_axis(rating, order[:, :k], axis=1), rtol=0, atol=2e-6)
+        assert all(len(set(r.tolist())) == k for r in got)
+
+
 def test_simgcl_runs_and_clean_view_matches_reference(tmp_path, golden_small):
     import utility.utility_function.tools as tools
     from idgrec_amd import ops
