@@ -191,7 +191,7 @@ def main():
         sys.exit("bench.py: launched with WORLD_SIZE=%d but --gpus %d; pass --gpus %d" % (world, args.gpus, world))
     if (world > 1 or args.force_sharded) and args.parallel != "dp" and "GPU_MAX_HW_QUEUES" not in os.environ:
         # The sharded form runs several streams per process (step, batch preparation, communicators) and waits between
-        # them 2K+1 times per step (the replicas wait once, and measure the same with 3 or 4 queues).  HIP spreads them
+        # them ~2K times per step (the replicas wait once, and measure the same with 3 or 4 queues).  HIP spreads them
         # over GPU_MAX_HW_QUEUES (default 4) hardware queues in order of first use, and waits between streams on
         # DIFFERENT queues cost the host tens of microseconds each: measured on the sharded step at world size 1,
         # 0.53 ms with 2-3 queues, 0.59-0.70 ms (depending on which stream met which queue) with 4, 0.90 ms with 8.
