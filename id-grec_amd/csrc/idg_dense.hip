@@ -6,6 +6,7 @@
 // slice order — deterministic, HBM-bound (reads X and G once).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "idg_common.h"
@@ -250,95 +251,108 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// grid: ceil(row_tiles * (d2 / 32) / 4) workgroups of 4 waves; wave task t -> (row tile t / nct, column tile t % nct)
+// Persistent waves: wave w of the launch owns output column tile w % nct (forward) / input feature tile w % nkt
+// (backward) and keeps that tile's weights — 32 of W1 and 32 of W2 per lane — in registers while it walks the row tiles
+// w / nct, w / nct + stride, ...: per row tile it loads only the row operands (one contiguous 128-byte run per lane).
+constexpr int NGCF_WGS = 256 * 3;  // workgroups per launch (4 waves each; ~110 VGPRs: 4 waves per SIMD fit)
+
 __global__ __launch_bounds__(BLOCK) void ngcf_transform_fwd_kernel(const float* __restrict__ side, const float* __restrict__ ego,
                                                                    const float* __restrict__ W1, const float* __restrict__ W2,
                                                                    int64_t n, int64_t d1, int64_t d2, float* __restrict__ S,
                                                                    float* __restrict__ BI) {
   const int lane = threadIdx.x % 64, i = lane & 31, h = lane >> 5;
-  const int64_t nct = d2 / 32;
-  const int64_t task = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
-  const int64_t rt = task / nct, ct = task % nct;
-  const int64_t r0 = rt * 32;
-  if (r0 >= n) return;  // whole waves leave together
-  const int64_t row = r0 + i < n ? r0 + i : n - 1;
-  const int64_t c0 = ct * 32;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int64_t kc = 0; kc < d1; kc += 64) {
+  const int64_t nct = d2 / 32, n_rt = (n + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (BLOCK / 64);
+  const int64_t ct = wave % nct, c0 = ct * 32;
+  const int64_t rt_stride = n_waves / nct;  // (n_waves is a multiple of nct: see the launch)
+  for (int64_t kc = 0; kc < d1; kc += 64) {  // d1 = 64: one pass, weights loaded once; wider layers re-walk the rows per chunk
     const int64_t k0 = kc + 32 * h;
-    float a[32], b[32];
+    float w1[32], w2[32];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 x = *reinterpret_cast<const float4*>(side + row * d1 + k0 + 4 * q);
-      const float4 y = *reinterpret_cast<const float4*>(ego + row * d1 + k0 + 4 * q);
-      a[4 * q + 0] = x.x, a[4 * q + 1] = x.y, a[4 * q + 2] = x.z, a[4 * q + 3] = x.w;
-      b[4 * q + 0] = x.x * y.x, b[4 * q + 1] = x.y * y.y, b[4 * q + 2] = x.z * y.z, b[4 * q + 3] = x.w * y.w;
+    for (int s = 0; s < 32; ++s) w1[s] = W1[(k0 + s) * d2 + c0 + i], w2[s] = W2[(k0 + s) * d2 + c0 + i];
+    for (int64_t rt = wave / nct; rt < n_rt; rt += rt_stride) {
+      const int64_t r0 = rt * 32;
+      const int64_t row = r0 + i < n ? r0 + i : n - 1;
+      float a[32], b[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(side + row * d1 + k0 + 4 * q);
+        const float4 y = *reinterpret_cast<const float4*>(ego + row * d1 + k0 + 4 * q);
+        a[4 * q + 0] = x.x, a[4 * q + 1] = x.y, a[4 * q + 2] = x.z, a[4 * q + 3] = x.w;
+        b[4 * q + 0] = x.x * y.x, b[4 * q + 1] = x.y * y.y, b[4 * q + 2] = x.z * y.z, b[4 * q + 3] = x.w * y.w;
+      }
+      if (BI && ct == 0 && r0 + i < n) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          *reinterpret_cast<float4*>(BI + row * d1 + k0 + 4 * q) = make_float4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w1[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], w2[s], acc, 0, 0, 0);
+      }
+      // C/D map: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (rr < n) {
+          float* o = S + rr * d2 + c0 + i;
+          *o = kc == 0 ? acc[r] : *o + acc[r];  // further 64-deep chunks of a wide layer add to the first one's sums
+        }
+      }
     }
-    if (BI && ct == 0 && r0 + i < n) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        *reinterpret_cast<float4*>(BI + row * d1 + k0 + 4 * q) = make_float4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
-    }
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const float w1 = W1[(k0 + s) * d2 + c0 + i], w2 = W2[(k0 + s) * d2 + c0 + i];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], w2, acc, 0, 0, 0);
-    }
-  }
-  // C/D map: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (rr < n) S[rr * d2 + c0 + i] = acc[r];
   }
 }
 
-// wave task t -> (row tile, 32 input features k1_0 ..): A1 = gS . W1^T, A2 = gS . W2^T over d2
+// A1 = gS . W1^T, A2 = gS . W2^T over d2; gSide = A1 + A2 * ego, gEgo = A2 * side
 __global__ __launch_bounds__(BLOCK) void ngcf_transform_bwd_kernel(const float* __restrict__ gS, const float* __restrict__ side,
                                                                    const float* __restrict__ ego, const float* __restrict__ W1,
                                                                    const float* __restrict__ W2, int64_t n, int64_t d1,
                                                                    int64_t d2, float* __restrict__ gSide,
                                                                    float* __restrict__ gEgo) {
   const int lane = threadIdx.x % 64, i = lane & 31, h = lane >> 5;
-  const int64_t nkt = d1 / 32;
-  const int64_t task = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
-  const int64_t rt = task / nkt, kt = task % nkt;
-  const int64_t r0 = rt * 32;
-  if (r0 >= n) return;
-  const int64_t row = r0 + i < n ? r0 + i : n - 1;
-  const int64_t k1 = kt * 32;  // this tile's input features; lane i supplies the weights of feature k1 + i
-  f32x16 acc1, acc2;
+  const int64_t nkt = d1 / 32, n_rt = (n + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (BLOCK / 64);
+  const int64_t k1 = (wave % nkt) * 32;  // this wave's input features; lane i supplies the weights of feature k1 + i
+  const int64_t rt_stride = n_waves / nkt;
+  for (int64_t rt = wave / nkt; rt < n_rt; rt += rt_stride) {
+    const int64_t r0 = rt * 32;
+    const int64_t row = r0 + i < n ? r0 + i : n - 1;
+    f32x16 acc1, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc1[r] = 0.f, acc2[r] = 0.f;
-  for (int64_t cc = 0; cc < d2; cc += 64) {
-    const int64_t c0 = cc + 32 * h;
-    float a[32], w1[32], w2[32];
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f, acc2[r] = 0.f;
+    for (int64_t cc = 0; cc < d2; cc += 64) {  // (d2 = 64: one pass; the weight runs are L1 / L2 hits after the first tile)
+      const int64_t c0 = cc + 32 * h;
+      float a[32], w1[32], w2[32];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 x = *reinterpret_cast<const float4*>(gS + row * d2 + c0 + 4 * q);
-      const float4 u = *reinterpret_cast<const float4*>(W1 + (k1 + i) * d2 + c0 + 4 * q);
-      const float4 v = *reinterpret_cast<const float4*>(W2 + (k1 + i) * d2 + c0 + 4 * q);
-      a[4 * q + 0] = x.x, a[4 * q + 1] = x.y, a[4 * q + 2] = x.z, a[4 * q + 3] = x.w;
-      w1[4 * q + 0] = u.x, w1[4 * q + 1] = u.y, w1[4 * q + 2] = u.z, w1[4 * q + 3] = u.w;
-      w2[4 * q + 0] = v.x, w2[4 * q + 1] = v.y, w2[4 * q + 2] = v.z, w2[4 * q + 3] = v.w;
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(gS + row * d2 + c0 + 4 * q);
+        const float4 u = *reinterpret_cast<const float4*>(W1 + (k1 + i) * d2 + c0 + 4 * q);
+        const float4 v = *reinterpret_cast<const float4*>(W2 + (k1 + i) * d2 + c0 + 4 * q);
+        a[4 * q + 0] = x.x, a[4 * q + 1] = x.y, a[4 * q + 2] = x.z, a[4 * q + 3] = x.w;
+        w1[4 * q + 0] = u.x, w1[4 * q + 1] = u.y, w1[4 * q + 2] = u.z, w1[4 * q + 3] = u.w;
+        w2[4 * q + 0] = v.x, w2[4 * q + 1] = v.y, w2[4 * q + 2] = v.z, w2[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w1[s], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2[s], acc2, 0, 0, 0);
+      }
     }
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w1[s], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2[s], acc2, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (rr < n) {
-      const int64_t o = rr * d1 + k1 + i;
-      const float e = ego[o], sd = side[o];
-      gSide[o] = __builtin_fmaf(acc2[r], e, acc1[r]);
-      gEgo[o] = acc2[r] * sd;
+    for (int r = 0; r < 16; ++r) {
+      const int64_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (rr < n) {
+        const int64_t o = rr * d1 + k1 + i;
+        const float e = ego[o], sd = side[o];
+        gSide[o] = __builtin_fmaf(acc2[r], e, acc1[r]);
+        gEgo[o] = acc2[r] * sd;
+      }
     }
   }
 }
@@ -354,9 +368,12 @@ int idg_ngcf_transform_f32(const float* side, const float* ego, const float* W1,
               "idg_ngcf_transform_f32: needs d1 %% 64 == 0 and d2 %% 32 == 0 (got %lld, %lld)", (long long)d1, (long long)d2);
   IDG_REQUIRE(((uintptr_t)side | (uintptr_t)ego | (uintptr_t)BI) % 16 == 0, "idg_ngcf_transform_f32: panels must be 16-byte aligned");
   if (n == 0) return IDG_OK;
-  const int64_t tasks = (n + 31) / 32 * (d2 / 32);
-  hipLaunchKernelGGL(ngcf_transform_fwd_kernel, dim3((unsigned)((tasks + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
-                     (hipStream_t)stream, side, ego, W1, W2, n, d1, d2, S, BI);
+  // persistent waves: a multiple of the column-tile count, no more than the work needs
+  const int64_t nct = d2 / 32, tasks = (n + 31) / 32 * nct;
+  int64_t waves = std::min<int64_t>((int64_t)NGCF_WGS * (BLOCK / 64), tasks);
+  waves = std::max<int64_t>(nct * (BLOCK / 64), waves / (nct * (BLOCK / 64)) * (nct * (BLOCK / 64)));
+  hipLaunchKernelGGL(ngcf_transform_fwd_kernel, dim3((unsigned)(waves / (BLOCK / 64))), dim3(BLOCK), 0, (hipStream_t)stream, side, ego,
+                     W1, W2, n, d1, d2, S, BI);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }
@@ -368,9 +385,11 @@ int idg_ngcf_transform_bwd_f32(const float* gS, const float* side, const float* 
               "idg_ngcf_transform_bwd_f32: needs d2 %% 64 == 0 and d1 %% 32 == 0 (got %lld, %lld)", (long long)d2, (long long)d1);
   IDG_REQUIRE(((uintptr_t)gS | (uintptr_t)W1 | (uintptr_t)W2) % 16 == 0, "idg_ngcf_transform_bwd_f32: panels must be 16-byte aligned");
   if (n == 0) return IDG_OK;
-  const int64_t tasks = (n + 31) / 32 * (d1 / 32);
-  hipLaunchKernelGGL(ngcf_transform_bwd_kernel, dim3((unsigned)((tasks + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
-                     (hipStream_t)stream, gS, side, ego, W1, W2, n, d1, d2, g_side, g_ego);
+  const int64_t nkt = d1 / 32, tasks = (n + 31) / 32 * nkt;
+  int64_t waves = std::min<int64_t>((int64_t)NGCF_WGS * (BLOCK / 64), tasks);
+  waves = std::max<int64_t>(nkt * (BLOCK / 64), waves / (nkt * (BLOCK / 64)) * (nkt * (BLOCK / 64)));
+  hipLaunchKernelGGL(ngcf_transform_bwd_kernel, dim3((unsigned)(waves / (BLOCK / 64))), dim3(BLOCK), 0, (hipStream_t)stream, gS, side,
+                     ego, W1, W2, n, d1, d2, g_side, g_ego);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }

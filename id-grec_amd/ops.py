@@ -788,8 +788,10 @@ class _NgcfTransform(torch.autograd.Function):
 def ngcf_transform(side, ego, W1, W2):
     """torch.matmul(side, W1) + torch.matmul(ego * side, W2) (models/NGCF.py:88-99, biases left to ngcf_layer_tail).
     MFMA kernel when the widths allow it (d1 % 64 == 0 and d2 % 64 == 0), the two thin GEMMs otherwise."""
+    import os
+
     d1, d2 = W1.shape
-    if d1 % 64 == 0 and d2 % 64 == 0 and side.is_cuda:
+    if d1 % 64 == 0 and d2 % 64 == 0 and side.is_cuda and os.environ.get("IDG_NGCF_MFMA", "1") != "0":
         return _NgcfTransform.apply(side, ego, W1, W2)
     return tall_linear(side, W1) + tall_linear(torch.mul(ego, side), W2)
 
