@@ -91,6 +91,7 @@ class PropagationEngine:
         def __init__(self, words, device):
             self.bitmap = torch.zeros(words, dtype=torch.int32, device=device)
             self.units, self.units_B = None, -1  # live work units of the bitmap (Graph.live_units), rebuilt with it
+            self.ids = None
             self.ws = None
             self.key = None
             self.rows_done = self.plan_done = None
@@ -125,6 +126,8 @@ class PropagationEngine:
         ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
         slot.plan_done.record(self._side_raw)  # needed by the gradient scatter
         slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
+        slot.ids = (users, pos, neg)  # keeps the id tensors alive until the side stream has read them (a caller's temporaries
+        #                               would otherwise return to the allocator, and be rewritten, while still being read)
 
     def _take_slot(self):
         """Next slot of the ring: one whose batch has been consumed the longest ago (or never filled); when every slot

@@ -276,3 +276,42 @@ def test_topk_at_full_catalogue_geometry():
         # a user's list does not depend on who shares its launch
         part = ops.score_topk(ue, ie, dev(sample), k, ip, ix).cpu().numpy()
         assert np.array_equal(part, idx[sample])
+
+
+def test_training_trajectory_at_yelp_size_vs_cpu_port():
+    """BASELINE configs[1] at size: 24 training steps (B = 1024) of the fused engine against the reference's op sequence
+    on torch CPU (oracle/torch_ref.py, pinned to the imported reference by tests/test_torch_ref.py), same graph, same
+    initial tables, same native-sampler batches: every step's two losses and the tables after the last step."""
+    import idgrec_amd.host as H
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+    from oracle.torch_ref import RefStep
+
+    U, I, E = S.SHAPES["yelp2018"]
+    users, items = S.generate(U, I, E, seed=0)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n, d, K, B, steps = U + I, 64, 3, 1024, 24
+    W0 = S.xavier_uniform_panel(U, I, d, 2024)
+    tri = S.draw_triples(2024, users, items, U, I, steps * B)[0][: steps * B]
+    G = ops.Graph(ip, ix, dv, n, n)
+    eng = PropagationEngine(G, U, I, d, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3, params=W0.cuda())
+    t = dev(tri)
+    tu, tp, tn = t[:, 0].contiguous(), t[:, 1].contiguous(), t[:, 2].contiguous()  # epoch-long id tensors, as the trainer's
+    losses = torch.zeros((steps, 2), device="cuda")
+    for s in range(steps):
+        cur, nxt = slice(s * B, (s + 1) * B), slice((s + 1) * B, (s + 2) * B)
+        if s + 1 < steps:
+            eng.prefetch(tu[nxt], tp[nxt], tn[nxt])
+        eng.train_step(tu[cur], tp[cur], tn[cur], loss_out=losses[s])
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = RefStep(ip, ix, dv, U, I, W0[:U].numpy(), W0[U:].numpy(), n_layers=K, lr=1e-3)
+    tc = torch.from_numpy(tri)
+    ref_losses = [ref.step(tc[s * B:(s + 1) * B, 0], tc[s * B:(s + 1) * B, 1], tc[s * B:(s + 1) * B, 2]) for s in range(steps)]
+    np.testing.assert_allclose(losses.cpu().numpy(), np.array(ref_losses), rtol=1e-4)
+    Wr = np.concatenate([ref.user_w.detach().numpy(), ref.item_w.detach().numpy()])
+    Wg = eng.params.cpu().numpy()
+    # Adam's first steps move every touched weight by ~lr: compare the MOVEMENT, where it is above rounding level
+    moved = np.abs(Wr - W0.numpy()) > 1e-4
+    np.testing.assert_allclose((Wg - W0.numpy())[moved], (Wr - W0.numpy())[moved], rtol=2e-2, atol=2e-5)
+    np.testing.assert_allclose(Wg, Wr, rtol=1e-4, atol=2e-5)
