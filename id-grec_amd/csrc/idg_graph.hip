@@ -1827,6 +1827,18 @@ int idg_graph_revalued_copy(const idg_graph* g, const int64_t* d_indptr, const i
   return IDG_OK;
 }
 
+int idg_graph_remask(const idg_graph* g, idg_graph* copy, float add, float divisor, uint64_t seed, uint64_t stream_id,
+                     int transpose, void* stream) {
+  IDG_REQUIRE(g && copy && copy->borrowed && copy->nnz == g->nnz && copy->d_vptr == g->d_vptr,
+              "idg_graph_remask: `copy` is not a masked / revalued copy of `g`");
+  IDG_REQUIRE(divisor != 0.f, "idg_graph_remask: divisor must be non-zero");
+  if (g->nnz > 0)
+    hipLaunchKernelGGL(mask_values_kernel, dim3((unsigned)((g->nnz + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       g->d_cv, copy->d_cv, g->d_vptr, g->d_vrow_row, g->n_vrows, g->nnz, add, divisor, seed, stream_id, transpose);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
 int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t seed, uint64_t stream_id, int transpose,
                           void* stream, idg_graph** out) {
   IDG_REQUIRE(g && out, "idg_graph_masked_copy: NULL argument");

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "idg_graph_forget_live_units": (C.c_int, [c_vp, c_vp]),
     "idg_graph_revalued_copy": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(c_vp)]),
     "idg_subgraph_values_f32": (C.c_int, [C.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "idg_graph_remask": (C.c_int, [c_vp, c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp]),
     "idg_graph_masked_copy": (C.c_int, [c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp, C.POINTER(c_vp)]),
     "idg_graph_info": (C.c_int, [c_vp, c_i64p]),
     "idg_graph_long_rows": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p]),

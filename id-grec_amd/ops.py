@@ -147,16 +147,22 @@ class Graph:
         g._h = h
         return g
 
-    def dropout_copy(self, keep_prob, stream=None):
+    def dropout_copy(self, keep_prob, stream=None, reuse=None):
         """NGCF.node_dropout (models/NGCF.py:56-65) of a SYMMETRIC graph as a new Graph on the same tile schedule:
         every stored entry is kept where int(u + (1 - keep_prob)) != 0, u ~ U[0, 1) — i.e. with probability
         1 - keep_prob, the reference's own (inverted-looking) rule — and divided by (1 - keep_prob); its `.T` (used by
         the backward of spmm) carries the transposed mask.  stream: (seed, stream id) of the draw; default: the next
-        one of the device seed's sequence."""
+        one of the device seed's sequence.  reuse: a Graph an earlier call on this handle returned — its two entry
+        lists are redrawn in place (no allocation, nothing synchronous: the per-forward form)."""
         if not self.symmetric:
             raise ValueError("dropout_copy needs a symmetric graph (the transposed mask is read off the same structure)")
         seed, sid = _next_noise_stream() if stream is None else stream
         add = 1.0 - float(keep_prob)
+        if reuse is not None and getattr(reuse, "_base", None) is self and reuse._T is not None:
+            for g, transpose in ((reuse, 0), (reuse._T, 1)):
+                check(lib.idg_graph_remask(self._h, g._h, add, add, C.c_uint64(seed), C.c_uint64(sid), transpose, _stream()),
+                      "idg_graph_remask")
+            return reuse
         out = []
         for transpose in (0, 1):
             g = Graph.__new__(Graph)

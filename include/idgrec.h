@@ -148,6 +148,10 @@ int idg_graph_destroy(idg_graph* g);
  * The mask is written on `stream`, in order with the products that follow. */
 int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t seed, uint64_t stream_id,
                           int transpose, void* stream, idg_graph** out);
+/* A new draw into an EXISTING copy of g (one made by idg_graph_masked_copy / idg_graph_revalued_copy): no allocation,
+ * asynchronous on `stream` — the per-forward form of node dropout. */
+int idg_graph_remask(const idg_graph* g, idg_graph* copy, float add, float divisor, uint64_t seed,
+                     uint64_t stream_id, int transpose, void* stream);
 
 /* Live work units of a row bitmap (optional accelerator of the row-restricted launches; round 2).  A launch given
  * `out_rows` normally visits every tile to find the few rows wanted.  idg_graph_live_units turns the bitmap into the list

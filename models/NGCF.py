@@ -36,7 +36,9 @@ class NGCF(PackedRecommender):
         layers = [ego]
         # node dropout (models/NGCF.py:56-65, 73-79): ONE re-drawn edge mask per training forward, shared by the layers;
         # on the device it is a masked copy of the handle (same tile schedule; backward multiplies by the transposed mask)
-        graph = self.Graph.dropout_copy(self.node_keep_prob) if (self.node_dropout and self.training) else self.Graph
+        graph = self.Graph
+        if self.node_dropout and self.training:  # (the pair of masked entry lists is allocated once and redrawn in place)
+            graph = self._dropped = self.Graph.dropout_copy(self.node_keep_prob, reuse=getattr(self, "_dropped", None))
         for layer in range(self.n_layers):
             side = ops.spmm(graph, ego)
             w = self.weight_dict

@@ -934,6 +934,9 @@ def test_node_dropout_masked_copy(ops, golden_small, keep_prob):
     assert abs(frac - p) < 5 * sigma, (frac, p)
     np.testing.assert_allclose(Dd[kept], A[kept] / np.float32(p), rtol=2e-7)
     assert not np.array_equal(kept, kept.T)  # (r, c) and (c, r) are drawn independently, as in the reference
+    redrawn = G.dropout_copy(keep_prob, stream=(4321, 9), reuse=G.dropout_copy(keep_prob, stream=(4321, 1)))
+    fresh = G.dropout_copy(keep_prob, stream=(4321, 9))
+    assert torch.equal(redrawn.spmm_raw(eye), fresh.spmm_raw(eye)) and torch.equal(redrawn.T.spmm_raw(eye), fresh.T.spmm_raw(eye))
     again = G.dropout_copy(keep_prob, stream=(4321, 7)).spmm_raw(eye).cpu().numpy()
     other = G.dropout_copy(keep_prob, stream=(4321, 8)).spmm_raw(eye).cpu().numpy()
     assert np.array_equal(again, Dd) and not np.array_equal(other, Dd)
