@@ -37,11 +37,12 @@
 #define IDG_FUSED_MINW 1   // __launch_bounds__ minimum waves per SIMD of the dense kernel with in-kernel split-row combine
 #endif
 #ifndef IDG_UNITS_UNROLL
-#define IDG_UNITS_UNROLL 8  // panel rows in flight per lane group in the one-wave-per-unit kernel
-#endif
-#ifndef IDG_UNITS_UNROLL
 #define IDG_UNITS_UNROLL 8  // panel rows in flight per lane group in the one-wave-per-unit kernel (16 / 32 measured: no gain)
 #endif
+#ifndef IDG_UNITS_BLOCK
+#define IDG_UNITS_BLOCK 64  // threads per workgroup of the one-wave-per-unit kernel.  One wave: the chunks of a hub row are
+#endif                      // consecutive units, and a workgroup's waves share a CU — whose miss path, not the chip's, then
+                            // bounds the row (measured: 256 -> 64 threads 24.4 -> 20.4 us for a yelp2018-size batch)
 #ifndef IDG_WALK_TAIL
 #define IDG_WALK_TAIL 1  // 0: the remainder of a row as a 4-batch + single loads (the round-1 form; kept for A/B timing)
 #endif
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(BLOCK) void live_units_kernel(const uint32_t* __res
 }
 
 template <int LPR, int NB, int EPI>
-__global__ __launch_bounds__(BLOCK) void spmm_units_kernel(const int32_t* __restrict__ units, int64_t cap,
+__global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32_t* __restrict__ units, int64_t cap,
                                                            const int64_t* __restrict__ vptr,
                                                            const int32_t* __restrict__ vtgt,
                                                            const ColVal* __restrict__ cv, const float* __restrict__ X,
@@ -910,9 +911,9 @@ __global__ __launch_bounds__(BLOCK) void spmm_units_kernel(const int32_t* __rest
                                                            FixCtx fx, const LocalRow* __restrict__ locals) {
   constexpr int GPW = 64 / LPR;  // lane groups per wave
   constexpr int W = NB * LPR;
-  __shared__ float4 s_part[BLOCK / 64][LSLOTS * W];
+  __shared__ float4 s_part[IDG_UNITS_BLOCK / 64][LSLOTS * W];
   const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-  const int64_t u_idx = (int64_t)blockIdx.x * (BLOCK / 64) + wave;
+  const int64_t u_idx = (int64_t)blockIdx.x * (IDG_UNITS_BLOCK / 64) + wave;
   int64_t count = units[0];
   if (count > cap) count = cap;
   if (u_idx >= count) return;  // whole waves leave together
@@ -1240,12 +1241,12 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
         if (g->bound_bitmap[i] == out_mask) units = g->bound_units[i], ucap = g->bound_cap[i];
     if (units && ucap > 0 && (g->n_long == 0 || fused_fix) && !g->no_units) {
       // the bitmap's live work units are listed: one wave per unit, no tile is visited (spmm_units_kernel)
-      const dim3 ugrid((unsigned)((ucap + BLOCK / 64 - 1) / (BLOCK / 64)));
+      const dim3 ugrid((unsigned)((ucap + IDG_UNITS_BLOCK / 64 - 1) / (IDG_UNITS_BLOCK / 64))), ublock(IDG_UNITS_BLOCK);
       if (ep.noise_eps != 0.f)
-        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_NOISE>), ugrid, block, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
+        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_NOISE>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
                            X, ldx, partials, d, ep, fx, g->d_local);
       else
-        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_PLAIN>), ugrid, block, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
+        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_PLAIN>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
                            X, ldx, partials, d, ep, fx, g->d_local);
       IDG_HIP(hipGetLastError());
       return IDG_OK;

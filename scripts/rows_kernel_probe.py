@@ -47,6 +47,11 @@ clear, batch, full = bitmap(np.zeros(0, dtype=np.int64)), bitmap(rows), bitmap(n
 timeit("dense", lambda: ops.spmm_ex_raw(g, X, Y=Y))
 timeit("out_rows: no row flagged", lambda: ops.spmm_ex_raw(g, X, Y=Y, out_rows=clear))
 timeit("out_rows: %d batch rows" % len(rows), lambda: ops.spmm_ex_raw(g, X, Y=Y, out_rows=batch))
+ws = g.live_units(batch, len(rows))
+torch.cuda.synchronize()
+timeit("out_rows: %d batch rows, live-unit list" % len(rows), lambda: ops.spmm_ex_raw(g, X, Y=Y, out_rows=batch))
+print("units in the list:", int(ws[0].item()))
+g.forget_live_units(batch)
 timeit("out_rows: every row", lambda: ops.spmm_ex_raw(g, X, Y=Y, out_rows=full))
 timeit("x_rows: no live row", lambda: ops.spmm_ex_raw(g, X, Y=Y, x_rows=clear))
 timeit("x_rows: %d batch rows" % len(rows), lambda: ops.spmm_ex_raw(g, X, Y=Y, x_rows=batch))
