@@ -167,14 +167,17 @@ def build_norm_adj(num_users, num_items, users, items, self_loops=False, numpy_p
         dinv_p = np_ptr(dinv, C.c_double)
     nnz = C.c_int64()
     up, ip = np_ptr(users, C.c_int64), np_ptr(items, C.c_int64)
-    check(lib.idg_build_norm_adj(U, I, E, up, ip, int(bool(self_loops)), dinv_p, C.byref(nnz), None, None, None),
-          "idg_build_norm_adj")
+    # one call into arrays sized for the case without duplicate pairs (2E entries + the diagonal): the size query
+    # (NULL outputs) would run the whole sort + de-duplication pass a second time
+    cap = 2 * E + (U + I if self_loops else 0)
     indptr = np.empty(U + I + 1, dtype=np.int64)
-    indices = np.empty(nnz.value, dtype=np.int32)
-    values = np.empty(nnz.value, dtype=np.float32)
+    indices = np.empty(cap, dtype=np.int32)
+    values = np.empty(cap, dtype=np.float32)
     check(lib.idg_build_norm_adj(U, I, E, up, ip, int(bool(self_loops)), dinv_p, C.byref(nnz),
                                  np_ptr(indptr, C.c_int64), np_ptr(indices, C.c_int32), np_ptr(values, C.c_float)),
           "idg_build_norm_adj")
+    if nnz.value != cap:  # duplicate pairs were merged
+        indices, values = indices[:nnz.value].copy(), values[:nnz.value].copy()
     return indptr, indices, values
 
 

@@ -33,9 +33,31 @@ def _draw(num_users, num_items, target, seed, zipf_a):
     cdf /= cdf[-1]
     perm = rng.permutation(I)
     total = int(deg.sum())
-    users = np.repeat(np.arange(U, dtype=np.int64), deg)
-    items = perm[np.searchsorted(cdf, rng.random(total), side="right").clip(0, I - 1)].astype(np.int64)
-    key = np.unique(users * I + items)
+    r = rng.random(total)
+    if total < (1 << 22):
+        users = np.repeat(np.arange(U, dtype=np.int64), deg)
+        items = perm[np.searchsorted(cdf, r, side="right").clip(0, I - 1)].astype(np.int64)
+        key = np.unique(users * I + items)
+        return key // I, key % I
+    # The same arithmetic in blocks of whole users on a few threads (NumPy's search, gather and sort release the GIL):
+    # draws belong to users in order, so the sorted unique keys of a block of users are a contiguous piece of the
+    # sorted unique keys of all of them — identical output, ~8x sooner on the 2e8-edge shape.
+    from concurrent.futures import ThreadPoolExecutor
+
+    ends = np.cumsum(deg)
+    n_blocks = int(min(U, max(1, total >> 22)))
+    cut_users = np.searchsorted(ends, np.linspace(0, total, n_blocks + 1)[1:-1], side="left") + 1
+    cut_users = np.unique(np.concatenate([[0], cut_users, [U]]))
+
+    def block(b):
+        u0, u1 = int(cut_users[b]), int(cut_users[b + 1])
+        e0, e1 = (int(ends[u0 - 1]) if u0 else 0), int(ends[u1 - 1])
+        it = perm[np.searchsorted(cdf, r[e0:e1], side="right").clip(0, I - 1)].astype(np.int64)
+        us = np.repeat(np.arange(u0, u1, dtype=np.int64), deg[u0:u1])
+        return np.unique(us * I + it)
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        key = np.concatenate(list(ex.map(block, range(len(cut_users) - 1))))
     return key // I, key % I
 
 
