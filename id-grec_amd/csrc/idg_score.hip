@@ -378,6 +378,325 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
   }
 }
 
+// ---- the same computation with the two phases on DIFFERENT waves (round 2) ------------------------------------
+// In the kernel above every wave alternates between the matrix pipe (A) and the vector pipe (B), two barriers per
+// slab, and the waves of a workgroup reach each phase together: measured, the matrix phase alone takes 2.04 of the
+// 2.65 ms of a yelp2018-size evaluation and the select phase adds its 0.6 ms serially.  Here a 512-thread workgroup
+// has four PRODUCER waves (one per SIMD: the 64 x 32 score tile of their column tile, written to one of TWO LDS
+// slabs, plus one compare per accumulator register that flags the users with a possible candidate) and four CONSUMER
+// waves (one per SIMD: masking + streaming select for 16 users each out of the other slab, flagged users only).
+// One barrier per slab: barrier t says "slab t is written and slab t - 1 is consumed", so producers compute slab
+// t + 1 while consumers select from slab t — the two pipes of a SIMD work at the same time.  Same MFMA sequence per
+// score and same selection order as above: results are identical.  LDS 2 x 33 KB: two workgroups (16 waves) per CU.
+// Where the time goes (cycle counters inside the kernel, profiles/r02/topk_roles.txt): the select is a chain of
+// dependent scalar-ish steps — one instruction per ~20 cycles on its wave — and the consumers, not the producers,
+// set the pace (producers wait at the barrier for 64 % of their cycles; alone they would finish in 1.5 ms).
+constexpr int SP_BLOCK = 2 * BLOCK;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Producer side of the select: which users of the block have, among this wave's 32 items of the slab, a score that
+// reaches their floor (the score of their k-th key as last published by their consumer wave — floors only rise, so a
+// stale one flags too many users, never too few).  One compare per accumulator register (64 scores), in the issue
+// slots the wave has between its MFMAs' completions; consumers then look at flagged users only.
+__device__ __forceinline__ void flag_candidates(const f32x16& acc0, const f32x16& acc1, const float* s_floor,
+                                                uint32_t* flag, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 f0 = *reinterpret_cast<const float4*>(s_floor + 8 * g + 4 * h);
+    const float4 f1 = *reinterpret_cast<const float4*>(s_floor + 32 + 8 * g + 4 * h);
+    const float fa[4] = {f0.x, f0.y, f0.z, f0.w}, fb[4] = {f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (acc0[4 * g + c] >= fa[c]) flag[8 * g + 4 * h + c] = 1u;
+      if (acc1[4 * g + c] >= fb[c]) flag[32 + 8 * g + 4 * h + c] = 1u;
+    }
+  }
+}
+
+template <bool SIGMOID, bool D64>
+__global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const float* __restrict__ U,
+                                                                    const float* __restrict__ V,
+                                                                    const int64_t* __restrict__ users, int64_t Bt,
+                                                                    int64_t I, int64_t d, int64_t chunk_items,
+                                                                    const int64_t* __restrict__ excl_indptr,
+                                                                    const int32_t* __restrict__ excl_items, int k,
+                                                                    unsigned long long* __restrict__ partial,
+                                                                    const unsigned long long* __restrict__ bound) {
+  __shared__ float s_buf[2][FT_USERS * FT_LD];
+  __shared__ __attribute__((aligned(16))) float s_floor[FT_USERS];  // per user: score of its k-th key (consumers publish)
+  __shared__ uint32_t s_flag[2][FT_USERS];                          // per slab buffer and user: a candidate may exist
+
+  const int tid = threadIdx.x, lane = tid % WAVE;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid / WAVE);  // scalar: the role branch below is wave-uniform
+  if (tid < FT_USERS) s_floor[tid] = -__builtin_inff(), s_flag[0][tid] = 0u, s_flag[1][tid] = 0u;
+  __syncthreads();
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t b0 = (int64_t)blockIdx.y * FT_USERS;
+  const int64_t c_lo = (int64_t)blockIdx.x * chunk_items;
+  const int64_t c_hi = c_lo + chunk_items < I ? c_lo + chunk_items : I;
+  const int n_chunks = gridDim.x;
+  const int n_slabs = c_hi > c_lo ? (int)((c_hi - c_lo + FT_SLAB - 1) / FT_SLAB) : 0;
+
+  if (wave8 < BLOCK / WAVE) {
+    // ================= producers: wave p computes items slab + 32p .. slab + 32p + 31 for the block's 64 users
+    const int wave = wave8;
+    const int64_t bu0 = b0 + i < Bt ? b0 + i : Bt - 1;
+    const int64_t bu1 = b0 + 32 + i < Bt ? b0 + 32 + i : Bt - 1;
+    const float* urow0 = U + users[bu0] * d;
+    const float* urow1 = U + users[bu1] * d;
+    const bool d4 = (d % 4 == 0);
+    if (D64) {
+      // d = 64: this lane's 32 features of its two users stay in registers for the whole chunk, and the item operand
+      // arrives 8 features at a time, one piece AHEAD of the MFMAs that use it (the piece after a slab's last is the
+      // next slab's first, so it is in flight across the LDS writes and the barrier).  Per slab the wave then issues
+      // 8 loads instead of 24: every float4 load here touches 64 cache lines (one row per lane), and the address
+      // path of the CU, not the matrix pipe, was what bounded the three-operand form.
+      float a0[32], a1[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(urow0 + 32 * h + 4 * q);
+        const float4 y = *reinterpret_cast<const float4*>(urow1 + 32 * h + 4 * q);
+        a0[4 * q + 0] = x.x, a0[4 * q + 1] = x.y, a0[4 * q + 2] = x.z, a0[4 * q + 3] = x.w;
+        a1[4 * q + 0] = y.x, a1[4 * q + 1] = y.y, a1[4 * q + 2] = y.z, a1[4 * q + 3] = y.w;
+      }
+      const int64_t j0 = c_lo + 32 * wave + i;
+      const float* vnext = V + (j0 < I ? j0 : I - 1) * 64 + 32 * h;
+      // The item loads are issued by hand (asm) and waited for by hand: left to the compiler, each load is scheduled
+      // right before the MFMAs that use it (it reuses the registers) and the wave waits out the whole latency every
+      // 8 MFMAs.  Two register pairs alternate; the wait before a piece's MFMAs leaves the two newest loads in flight.
+      f32x4 pa0, pa1, pb0, pb1;
+#define IDG_LD(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr) : "memory")
+#define IDG_WAIT2(x, y) asm volatile("s_waitcnt vmcnt(2)" : "+v"(x), "+v"(y) : : "memory")
+#define IDG_MM(A0, A1, B)                                               \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B, acc0, 0, 0, 0);   \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B, acc1, 0, 0, 0)
+#define IDG_PIECE(pc, X0, X1)                                                                                        \
+  IDG_MM(a0[8 * pc + 0], a1[8 * pc + 0], X0.x); IDG_MM(a0[8 * pc + 1], a1[8 * pc + 1], X0.y);                        \
+  IDG_MM(a0[8 * pc + 2], a1[8 * pc + 2], X0.z); IDG_MM(a0[8 * pc + 3], a1[8 * pc + 3], X0.w);                        \
+  IDG_MM(a0[8 * pc + 4], a1[8 * pc + 4], X1.x); IDG_MM(a0[8 * pc + 5], a1[8 * pc + 5], X1.y);                        \
+  IDG_MM(a0[8 * pc + 6], a1[8 * pc + 6], X1.z); IDG_MM(a0[8 * pc + 7], a1[8 * pc + 7], X1.w)
+      // the user operands have arrived before the first hand-issued load goes out: empty asm statements that "use"
+      // them make the compiler wait for its own loads HERE (it does not count the asm loads; left alone it sinks the
+      // operand loads to the loop entry and re-waits for them, down to vmcnt(0), in every trip)
+#define IDG_PIN8(a, o) asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), "+v"(a[o + 7]))
+      IDG_PIN8(a0, 0); IDG_PIN8(a0, 8); IDG_PIN8(a0, 16); IDG_PIN8(a0, 24);
+      IDG_PIN8(a1, 0); IDG_PIN8(a1, 8); IDG_PIN8(a1, 16); IDG_PIN8(a1, 24);
+#undef IDG_PIN8
+      IDG_LD(pa0, vnext, 0);
+      IDG_LD(pa1, vnext, 16);
+      for (int t = 0; t < n_slabs; ++t) {
+        const float* vrow = vnext;
+        {
+          const int64_t jn = j0 + (int64_t)(t + 1) * FT_SLAB;
+          vnext = V + (jn < I ? jn : I - 1) * 64 + 32 * h;
+        }
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+        IDG_LD(pb0, vrow, 32);
+        IDG_LD(pb1, vrow, 48);
+        IDG_WAIT2(pa0, pa1);
+        IDG_PIECE(0, pa0, pa1);
+        IDG_LD(pa0, vrow, 64);
+        IDG_LD(pa1, vrow, 80);
+        IDG_WAIT2(pb0, pb1);
+        IDG_PIECE(1, pb0, pb1);
+        IDG_LD(pb0, vrow, 96);
+        IDG_LD(pb1, vrow, 112);
+        IDG_WAIT2(pa0, pa1);
+        IDG_PIECE(2, pa0, pa1);
+        IDG_LD(pa0, vnext, 0);  // (past the last slab: a clamped, valid row nobody uses)
+        IDG_LD(pa1, vnext, 16);
+        IDG_WAIT2(pb0, pb1);
+        IDG_PIECE(3, pb0, pb1);
+        float* s_score = s_buf[t & 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          s_score[row * FT_LD + 32 * wave + i] = acc0[r];
+          s_score[(32 + row) * FT_LD + 32 * wave + i] = acc1[r];
+        }
+        flag_candidates(acc0, acc1, s_floor, s_flag[t & 1], h);
+        __syncthreads();  // barrier t
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa0), "+v"(pa1) : : "memory");
+#undef IDG_LD
+#undef IDG_WAIT2
+#undef IDG_MM
+#undef IDG_PIECE
+      return;
+    }
+    for (int t = 0; t < n_slabs; ++t) {
+      const int64_t slab = c_lo + (int64_t)t * FT_SLAB;
+      const int64_t j = slab + 32 * wave + i;
+      const float* vrow = V + (j < I ? j : I - 1) * d;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+#pragma unroll 1
+      for (int64_t kq = 0; kq < (d + 63) / 64 * 64; kq += 16) {
+        const int64_t k0 = (kq / 64) * 64 + 32 * h + (kq % 64) / 2;  // kq%64 in {0,16,32,48} -> offset {0,8,16,24}
+        float a0[8], a1[8], bb[8];
+        if (d4 && k0 + 8 <= d) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float4 x = *reinterpret_cast<const float4*>(urow0 + k0 + 4 * q);
+            const float4 y = *reinterpret_cast<const float4*>(urow1 + k0 + 4 * q);
+            const float4 z = *reinterpret_cast<const float4*>(vrow + k0 + 4 * q);
+            a0[4 * q + 0] = x.x, a0[4 * q + 1] = x.y, a0[4 * q + 2] = x.z, a0[4 * q + 3] = x.w;
+            a1[4 * q + 0] = y.x, a1[4 * q + 1] = y.y, a1[4 * q + 2] = y.z, a1[4 * q + 3] = y.w;
+            bb[4 * q + 0] = z.x, bb[4 * q + 1] = z.y, bb[4 * q + 2] = z.z, bb[4 * q + 3] = z.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const bool in = k0 + q < d;
+            a0[q] = in ? urow0[k0 + q] : 0.f;
+            a1[q] = in ? urow1[k0 + q] : 0.f;
+            bb[q] = in ? vrow[k0 + q] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bb[q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bb[q], acc1, 0, 0, 0);
+        }
+      }
+      // slab t goes to buffer t & 1, last read (slab t - 2) before barrier t - 1, which this wave has passed
+      float* s_score = s_buf[t & 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        s_score[row * FT_LD + 32 * wave + i] = acc0[r];
+        s_score[(32 + row) * FT_LD + 32 * wave + i] = acc1[r];
+      }
+      flag_candidates(acc0, acc1, s_floor, s_flag[t & 1], h);
+      __syncthreads();  // barrier t
+    }
+    return;
+  }
+
+  // ================= consumers: wave w owns users 16w .. 16w+15 of the block
+  const int wave = wave8 - BLOCK / WAVE;
+  // Exclusion lists are ascending: lane uu (< FT_UPW) keeps a cursor into the list of user FT_UPW*wave+uu, parked at
+  // the first train item >= c_lo; every slab it advances past the items that fall inside the slab, and those entries
+  // of the LDS score slab are overwritten before selection (batch_test.py:62-65).
+  int64_t my_ex_cur = 0, my_ex_end = 0;
+  if (excl_indptr && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) {
+    const int64_t uid = users[b0 + FT_UPW * wave + lane];
+    int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
+    my_ex_end = hi;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
+      else hi = mid;
+    }
+    my_ex_cur = lo;
+  }
+  int32_t win[FT_UPW / 2];  // per PAIR of users of this wave: their next 32 train items each (halves of the wave)
+#pragma unroll
+  for (int p = 0; p < FT_UPW / 2; ++p) {
+    const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h);
+    const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
+    win[p] = (excl_indptr && cur + i < end) ? excl_items[cur + i] : 0x7fffffff;
+  }
+  unsigned long long best[FT_UPW], tau[FT_UPW];  // per user of this wave: list (lane = rank) and its k-th key
+#pragma unroll
+  for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull, tau[uu] = 0ull;
+  unsigned long long my_bound = ~0ull;
+  if (bound && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_bound = bound[b0 + FT_UPW * wave + lane];
+
+  for (int t = 0; t < n_slabs; ++t) {
+    const int64_t slab = c_lo + (int64_t)t * FT_SLAB;
+    __syncthreads();  // barrier t: slab t is complete in buffer t & 1
+    float* s_score = s_buf[t & 1];
+    const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
+    if (excl_indptr) {
+      const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
+#pragma unroll
+      for (int p = 0; p < FT_UPW / 2; ++p) {
+        unsigned long long below = __ballot(win[p] < (int32_t)slab_end);
+        if (below == 0ull) continue;  // nothing of these two users up to the end of the slab
+        const int row = FT_UPW * wave + 2 * p + h;
+        if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
+        while ((uint32_t)below == 0xffffffffu || (uint32_t)(below >> 32) == 0xffffffffu) {  // a half used up (rare)
+          const bool reload = h == 0 ? (uint32_t)below == 0xffffffffu : (uint32_t)(below >> 32) == 0xffffffffu;
+          const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h) + (reload ? 32 : 0);
+          const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
+          if (reload) {
+            win[p] = cur + i < end ? excl_items[cur + i] : 0x7fffffff;
+            if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
+          }
+          const unsigned long long moved = __ballot(reload);
+          if (lane == 2 * p && (uint32_t)moved) my_ex_cur += 32;
+          if (lane == 2 * p + 1 && (uint32_t)(moved >> 32)) my_ex_cur += 32;
+          below = __ballot(win[p] < (int32_t)slab_end);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const bool in0 = slab + lane < c_hi, in1 = slab + 64 + lane < c_hi;
+    if (t == 0) {
+      // first slab of the chunk: one 128-key sorting network per user fills its list
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        const int u = FT_UPW * wave + uu;
+        unsigned long long k0 = in0 ? make_key(s_score[u * FT_LD + lane], (uint32_t)(slab + lane)) : 0ull;
+        unsigned long long k1 = in1 ? make_key(s_score[u * FT_LD + 64 + lane], (uint32_t)(slab + 64 + lane)) : 0ull;
+        if (bound) {
+          const unsigned long long bd = shfl_u64(my_bound, uu);
+          k0 = k0 < bd ? k0 : 0ull;
+          k1 = k1 < bd ? k1 : 0ull;
+        }
+        wave_sort128_desc(k0, k1, lane);
+        const unsigned long long tk = readlane_u64(k0, k - 1);
+        if (lane == 0) s_floor[u] = tau_floor(tk);
+#pragma unroll
+        for (int q = 0; q < FT_UPW; ++q) {
+          best[q] = q == uu ? k0 : best[q];
+          tau[q] = q == uu ? tk : tau[q];
+        }
+      }
+      if (lane < FT_UPW) s_flag[0][FT_UPW * wave + lane] = 0u;  // (slab 0 flagged everybody: floors were -inf)
+      continue;
+    }
+    // the producers have flagged the users that may have a candidate in this slab (flag_candidates): one LDS read for
+    // the wave's users; the flags are cleared for the slab after next, which reuses this buffer
+    uint32_t fl = 0u;
+    if (lane < FT_UPW) {
+      fl = s_flag[t & 1][FT_UPW * wave + lane];
+      s_flag[t & 1][FT_UPW * wave + lane] = 0u;
+    }
+    const uint32_t cand = (uint32_t)__ballot(fl != 0u);
+    if (cand == 0) continue;
+#pragma unroll
+    for (int uu = 0; uu < FT_UPW; ++uu) {
+      if (!((cand >> uu) & 1u)) continue;
+      const int u = FT_UPW * wave + uu;
+      const float s0 = s_score[u * FT_LD + lane], s1 = s_score[u * FT_LD + 64 + lane];
+      // columns past the chunk hold scores of a clamped item: the exact key test below drops them
+      const float floor_ = tau_floor(tau[uu]);  // score of the k-th key (-inf while the list is short)
+      if (__ballot(s0 >= floor_) | __ballot(s1 >= floor_)) {
+        const unsigned long long tau_was = tau[uu];
+        unsigned long long c0 = in0 ? make_key(s0, (uint32_t)(slab + lane)) : 0ull;
+        unsigned long long c1 = in1 ? make_key(s1, (uint32_t)(slab + 64 + lane)) : 0ull;
+        if (bound) {
+          const unsigned long long bd = readlane_u64(my_bound, uu);
+          c0 = c0 < bd ? c0 : 0ull;
+          c1 = c1 < bd ? c1 : 0ull;
+        }
+        list_offer(best[uu], tau[uu], c0, k, lane);
+        list_offer(best[uu], tau[uu], c1, k, lane);
+        if (tau[uu] != tau_was && lane == 0) s_floor[u] = tau_floor(tau[uu]);
+      }
+    }
+  }
+#pragma unroll
+  for (int uu = 0; uu < FT_UPW; ++uu) {
+    const int64_t b = b0 + FT_UPW * wave + uu;
+    if (b < Bt) partial[(b * n_chunks + blockIdx.x) * 64 + lane] = best[uu];
+  }
+}
+
 // one wave per batch row: fold the per-chunk lists (each holds its chunk's true top-k in lanes < k),
 // emit ids and values
 template <bool SIGMOID>
@@ -432,14 +751,23 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 
 // Fused path geometry: 64 users per workgroup, the catalogue cut into n_chunks so that the grid has about TOPK_WGS
 // workgroups (three are resident per CU, what the register budget allows); scratch = one best-64 list per (user, chunk).
-static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items) {
+// Which kernel, and into how many catalogue chunks.  The producer / consumer kernel pays a sort and a burst of list
+// insertions at the start of every chunk (its consumers set the pace there), so it wants the FEWEST chunks that still
+// fill its 512 workgroup slots (2 per CU) — measured at yelp2018 size: 1 chunk 2.40 ms, 3 chunks 3.00 ms — and it only
+// pays with many user tiles; small batches (the reference's test_batch_size of 100 users: 2 tiles) keep the
+// alternating kernel with its ~1024 short workgroups (8.4 vs 12.5 ms for the 31,668 users in 317 calls).
+static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
-  int64_t nc = (TOPK_WGS + user_tiles - 1) / user_tiles;
+  const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 forces a kernel
+  const int forced = fv && *fv ? std::atoi(fv) : -1;
+  const int form = forced >= 0 ? forced : (user_tiles >= 256 ? 1 : 0);
+  if (form_out) *form_out = form;
+  int64_t nc = form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
   if (const char* v = std::getenv("IDG_TOPK_WGS"))
     if (*v) nc = (std::atoll(v) + user_tiles - 1) / user_tiles;  // testing knob
   const int64_t max_nc = (I + 1023) / 1024;
   if (const char* v = std::getenv("IDG_TOPK_CHUNKS"))
-    if (*v) nc = std::atoll(v);  // testing knob
+    if (*v && std::atoll(v) > 0) nc = std::atoll(v);  // testing knob
   nc = nc < 1 ? 1 : (nc > max_nc ? max_nc : nc);
   int64_t ci = ((I + nc - 1) / nc + FT_SLAB - 1) / FT_SLAB * FT_SLAB;
   nc = (I + ci - 1) / ci;
@@ -467,9 +795,9 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   IDG_REQUIRE(I < ((int64_t)1 << 32), "idg_score_topk_f32: more than 2^32 items");
   IDG_REQUIRE((excl_indptr == nullptr) == (excl_items == nullptr), "idg_score_topk_f32: excl_indptr and excl_items go together");
   hipStream_t st = (hipStream_t)stream;
-  int nc;
+  int nc, form;
   int64_t ci;
-  fused_geometry(Bt, I, &nc, &ci);
+  fused_geometry(Bt, I, &nc, &ci, &form);
   unsigned long long* partial = reinterpret_cast<unsigned long long*>(ws);
   const dim3 grid((unsigned)nc, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
   const unsigned nbm = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
@@ -481,7 +809,17 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     const int kk = k - done < 64 ? k - done : 64;
     const unsigned long long* bd_in = done > 0 ? bound : nullptr;
     unsigned long long* bd_out = done + kk < k ? bound : nullptr;
-    if (apply_sigmoid)
+    if (form == 1) {  // producer / consumer waves (many user tiles); 0: every wave alternates between the two phases
+      const bool d64 = d == 64 && (uintptr_t)user_panel % 16 == 0 && (uintptr_t)item_panel % 16 == 0;
+#define IDG_SPEC(SIG, D64)                                                                                           \
+  hipLaunchKernelGGL((score_topk_spec_kernel<SIG, D64>), grid, dim3(SP_BLOCK), 0, st, user_panel, item_panel, users, \
+                     Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in)
+      if (apply_sigmoid && d64) IDG_SPEC(true, true);
+      else if (apply_sigmoid) IDG_SPEC(true, false);
+      else if (d64) IDG_SPEC(false, true);
+      else IDG_SPEC(false, false);
+#undef IDG_SPEC
+    } else if (apply_sigmoid)
       hipLaunchKernelGGL(score_topk_fused_kernel<true>, grid, dim3(BLOCK), 0, st, user_panel, item_panel, users,
                          Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in);
     else

@@ -662,8 +662,16 @@ def test_score_dense_widths_and_ragged_shapes(ops, d):
         np.testing.assert_allclose(R, oracle.score(Uu, Vv, users, sig), rtol=2e-5, atol=2e-5)
 
 
+@pytest.fixture(params=["alternating", "producer-consumer"])
+def topk_form(request, monkeypatch):
+    """The fused top-K has two kernels (every wave alternating between scoring and selecting; producer and consumer
+    waves) chosen by the number of user tiles: every contract test runs on both (IDG_TOPK_FORM forces one)."""
+    monkeypatch.setenv("IDG_TOPK_FORM", "0" if request.param == "alternating" else "1")
+    return request.param
+
+
 @pytest.mark.parametrize("k", [1, 10, 20, 40, 64])
-def test_topk_masked_vs_reference_contract(ops, k, golden_small):
+def test_topk_masked_vs_reference_contract(ops, k, golden_small, topk_form):
     g = golden_small
     users_np = g["test_dict_users"][:48]
     ref = g["d64_lgcn_rating"].copy()
@@ -693,7 +701,7 @@ def test_topk_masked_vs_reference_contract(ops, k, golden_small):
 
 
 @pytest.mark.parametrize("d", [64, 256, 40])
-def test_topk_is_independent_of_item_chunking(ops, d, golden_small, monkeypatch):
+def test_topk_is_independent_of_item_chunking(ops, d, golden_small, monkeypatch, topk_form):
     """The catalogue is cut into chunks across workgroups and the per-chunk best lists are merged:
     any chunk count gives the same answer (incl. ragged last slabs and d not a multiple of 64)."""
     g = golden_small
@@ -720,7 +728,7 @@ def test_topk_is_independent_of_item_chunking(ops, d, golden_small, monkeypatch)
 
 
 @pytest.mark.parametrize("d", [64, 100])
-def test_topk_dense_exclusion_runs_and_batch_independence(ops, d):
+def test_topk_dense_exclusion_runs_and_batch_independence(ops, d, topk_form):
     """More than 64 train items inside one 128-item slab (the cursor's refill loop), rows that mask
     almost the whole catalogue, and: a user's list does not depend on which users share its launch."""
     rng = np.random.default_rng(7 + d)
@@ -749,7 +757,7 @@ def test_topk_dense_exclusion_runs_and_batch_independence(ops, d):
     assert np.array_equal(np.concatenate(parts), whole)
 
 
-def test_topk_ties_saturated_sigmoid_and_masked_fill(ops):
+def test_topk_ties_saturated_sigmoid_and_masked_fill(ops, topk_form):
     # sigmoid saturates to exactly 1.0f: ties broken by lowest item id
     Uu = np.full((3, 64), 1.0, dtype=np.float32)
     Vv = np.full((500, 64), 1.0, dtype=np.float32)
@@ -766,7 +774,7 @@ def test_topk_ties_saturated_sigmoid_and_masked_fill(ops):
 
 
 @pytest.mark.parametrize("k", [65, 100, 128, 200])
-def test_topk_beyond_64_ranks(ops, k):
+def test_topk_beyond_64_ranks(ops, k, topk_form):
     """torch.topk takes any k <= I (batch_test.py:68; the reference's sparsity_test comment suggests top_K up to
     100): k > 64 runs one scoring pass per 64 ranks, each admitting only keys below the previous pass's last one.
     Same order and values as the one-pass definition: (score descending, item ascending), train positives as -1."""

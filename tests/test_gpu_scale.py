@@ -248,7 +248,7 @@ def test_simgcl_encoder_passes_and_fused_step_at_amazon_book_size():
     assert torch.allclose(w_f, w_a, rtol=1e-4, atol=1e-6)
 
 
-def test_topk_at_full_catalogue_geometry():
+def test_topk_at_full_catalogue_geometry(monkeypatch):
     """Full-rank evaluation at amazon-book size in ONE call (52,643 users x 91,599 items: the launch geometry of a real
     evaluation — catalogue chunks, per-chunk lists, merge; train-item masking from the full train CSR) against the
     oracle's dense scores for a sample of users: tie-aware top-20 / top-100 (two passes) equality."""
@@ -276,6 +276,13 @@ def test_topk_at_full_catalogue_geometry():
         # a user's list does not depend on who shares its launch
         part = ops.score_topk(ue, ie, dev(sample), k, ip, ix).cpu().numpy()
         assert np.array_equal(part, idx[sample])
+        # 823 user tiles run the producer / consumer kernel, the 160-user call above the alternating one; here all
+        # users through the alternating kernel too: same ids, same values, bit for bit
+        vals = ops.score_topk(ue, ie, all_users, k, ip, ix, return_values=True)[1]
+        monkeypatch.setenv("IDG_TOPK_FORM", "0")
+        idx0, val0 = ops.score_topk(ue, ie, all_users, k, ip, ix, return_values=True)
+        monkeypatch.delenv("IDG_TOPK_FORM")
+        assert np.array_equal(idx0.cpu().numpy(), idx) and torch.equal(val0, vals)
 
 
 def test_training_trajectory_at_yelp_size_vs_cpu_port():
