@@ -17,5 +17,10 @@ python bench.py --workload amazon-book --model SimGCL --batch 2048 --steps 400 -
 python bench.py --no-cpu-baseline --model MFBPR --batch 2048 > gpurun_out/r2h/bench_mfbpr.json 2> gpurun_out/r2h/bench_mfbpr.err
 python bench.py --no-cpu-baseline --workload synth-1M --steps 60 --warmup 10 > gpurun_out/r2h/bench_synth1m.json 2> gpurun_out/r2h/bench_synth1m.err
 python bench.py --no-cpu-baseline --workload synth-10M --dim 256 --steps 12 --warmup 4 > gpurun_out/r2h/bench_c5_single_gpu.json 2> gpurun_out/r2h/bench_c5_single_gpu.err
+python scripts/eval_bench.py > gpurun_out/r2h/eval_yelp.txt 2>&1
+python scripts/eval_bench.py amazon-book > gpurun_out/r2h/eval_amazon.txt 2>&1
+IDG_TOPK_FORM=0 python scripts/eval_bench.py > gpurun_out/r2h/eval_yelp_alternating_kernel.txt 2>&1
+python scripts/rows_kernel_probe.py > gpurun_out/r2h/restricted_probe.txt 2>&1
+grep -h "evaluation\|identical" gpurun_out/r2h/eval_*.txt; grep "us$" gpurun_out/r2h/restricted_probe.txt
 for f in bench_default bench_amazon bench_simgcl_amazon bench_mfbpr bench_synth1m bench_c5_single_gpu; do echo "== $f"; python scripts/brief.py < gpurun_out/r2h/$f.json; tail -n 1 gpurun_out/r2h/$f.err; done
 ls gpurun_out/prof_r02_yelp/*/ 2>/dev/null | head; cat gpurun_out/r2h/traffic_yelp.log | head -30
