@@ -396,8 +396,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Producer side of the select: which users of the block have, among this wave's 32 items of the slab, a score that
 // reaches their floor (the score of their k-th key as last published by their consumer wave — floors only rise, so a
-// stale one flags too many users, never too few).  One compare per accumulator register (64 scores), in the issue
-// slots the wave has between its MFMAs' completions; consumers then look at flagged users only.
+// stale one flags too many users, never too few).  One compare per accumulator register (64 scores); consumers then
+// look at flagged users only.  (Queues of (user, column) pairs filled here with LDS atomics, so that consumers read
+// the listed columns only, were measured: the same 2.07 ms — the work just moves to the producers.)
 __device__ __forceinline__ void flag_candidates(const f32x16& acc0, const f32x16& acc1, const float* s_floor,
                                                 uint32_t* flag, int h) {
 #pragma unroll
@@ -504,11 +505,15 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
         IDG_LD(pb0, vrow, 96);
         IDG_LD(pb1, vrow, 112);
         IDG_WAIT2(pa0, pa1);
+#if !defined(IDG_TOPK_PROBE) || IDG_TOPK_PROBE != 4
         IDG_PIECE(2, pa0, pa1);
+#endif
         IDG_LD(pa0, vnext, 0);  // (past the last slab: a clamped, valid row nobody uses)
         IDG_LD(pa1, vnext, 16);
         IDG_WAIT2(pb0, pb1);
+#if !defined(IDG_TOPK_PROBE) || IDG_TOPK_PROBE != 4
         IDG_PIECE(3, pb0, pb1);
+#endif
         float* s_score = s_buf[t & 1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -578,33 +583,66 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
 
   // ================= consumers: wave w owns users 16w .. 16w+15 of the block
   const int wave = wave8 - BLOCK / WAVE;
-  // Exclusion lists are ascending: lane uu (< FT_UPW) keeps a cursor into the list of user FT_UPW*wave+uu, parked at
-  // the first train item >= c_lo; every slab it advances past the items that fall inside the slab, and those entries
-  // of the LDS score slab are overwritten before selection (batch_test.py:62-65).
-  int64_t my_ex_cur = 0, my_ex_end = 0;
-  if (excl_indptr && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) {
-    const int64_t uid = users[b0 + FT_UPW * wave + lane];
+#ifndef IDG_TOPK_CONS_PRIO
+#define IDG_TOPK_CONS_PRIO 2
+#endif
+  // Vector issue on a SIMD is arbitrated by priority, then age: the consumers are the younger half of the workgroup
+  // and would get what the producers' MFMA stream leaves over.  Their chains of short dependent instructions are what
+  // the slab time hangs on, and an MFMA that issues a few cycles late costs the paced matrix pipe nothing.
+  __builtin_amdgcn_s_setprio(IDG_TOPK_CONS_PRIO);
+  // Train-item masking (batch_test.py:62-65).  Exclusion lists are ascending.  Lane (mu, mj) = (lane / 4, lane % 4)
+  // holds entry mj of a 4-entry window into the list of user mu of this wave, starting at the user's cursor (parked at
+  // the first train item >= c_lo).  Per slab ONE compare pair finds the window entries inside the slab (their LDS
+  // scores are overwritten before selection), one ballot counts how many entries each user has passed (a prefix of
+  // its window: ascending), cursors advance and the windows of users that advanced are re-read — a load whose result
+  // is first needed at the next slab.  A user that used up all four entries may have more inside this slab: rare, the
+  // loop then goes round again.  (The alternating kernel's 32-entry windows per user PAIR cost 8 dependent
+  // compare / ballot / branch rounds per slab: 6,500 of this wave's ~16,000 cycles per slab, measured.)
+  const int mu = lane >> 2, mj = lane & 3;
+  int64_t m_cur = 0, m_end = 0;
+  if (excl_indptr && b0 + FT_UPW * wave + mu < Bt) {
+    const int64_t uid = users[b0 + FT_UPW * wave + mu];
     int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
-    my_ex_end = hi;
+    m_end = hi;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
       if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
       else hi = mid;
     }
-    my_ex_cur = lo;
+    m_cur = lo;
   }
-  int32_t win[FT_UPW / 2];  // per PAIR of users of this wave: their next 32 train items each (halves of the wave)
+  int32_t m_win = (excl_indptr && m_cur + mj < m_end) ? excl_items[m_cur + mj] : 0x7fffffff;
+  // Per user of this wave: the list (lane = rank).  Its k-th key is wave-uniform, but it is fetched where needed with
+  // ds_bpermute into VECTOR registers on purpose: an fp32 MFMA runs on the SIMD's own FMA lanes (the fp32 matrix and
+  // vector peaks are the same number), so while the producers' MFMAs execute no other vector instruction of this SIMD
+  // does — every vector-class instruction of the select waits for an MFMA boundary (measured: halving the MFMAs takes
+  // exactly their pipe time off the kernel; ~2,800 cycles for the ~85 vector instructions of one (user, slab) pair).
+  // Scalar and LDS-class instructions do not wait, so the select is written to use them: thresholds broadcast with
+  // ds_bpermute instead of v_readlane pairs, no scalar-register spills (v_readlane / v_writelane are vector-class),
+  // keys built in three vector instructions.
+  unsigned long long best[FT_UPW];
 #pragma unroll
-  for (int p = 0; p < FT_UPW / 2; ++p) {
-    const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h);
-    const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
-    win[p] = (excl_indptr && cur + i < end) ? excl_items[cur + i] : 0x7fffffff;
-  }
-  unsigned long long best[FT_UPW], tau[FT_UPW];  // per user of this wave: list (lane = rank) and its k-th key
-#pragma unroll
-  for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull, tau[uu] = 0ull;
+  for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull;
   unsigned long long my_bound = ~0ull;
   if (bound && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_bound = bound[b0 + FT_UPW * wave + lane];
+  auto key_of = [](float sc, uint32_t not_item) {  // make_key with the item id already complemented
+    const uint32_t ub = __float_as_uint(sc);
+    const uint32_t hi = ub ^ ((uint32_t)((int32_t)ub >> 31) | 0x80000000u);
+    return ((unsigned long long)hi << 32) | not_item;
+  };
+  auto floor_of = [](unsigned long long tk) { return tk ? key_score(tk) : -__builtin_inff(); };
+  // feed the keys of this wave's lanes (0 = none) that beat the k-th key into the list; true if the list changed
+  auto offer = [&](unsigned long long& list, unsigned long long& tk, unsigned long long key) {
+    unsigned long long m = __ballot(key > tk);
+    const bool any = m != 0ull;
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      list_insert(list, readlane_u64(key, src), lane);
+      tk = shfl_u64(list, k - 1);
+      m = (m & (m - 1)) & __ballot(key > tk);
+    }
+    return any;
+  };
 
   for (int t = 0; t < n_slabs; ++t) {
     const int64_t slab = c_lo + (int64_t)t * FT_SLAB;
@@ -613,81 +651,71 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
     const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
     if (excl_indptr) {
       const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
-#pragma unroll
-      for (int p = 0; p < FT_UPW / 2; ++p) {
-        unsigned long long below = __ballot(win[p] < (int32_t)slab_end);
-        if (below == 0ull) continue;  // nothing of these two users up to the end of the slab
-        const int row = FT_UPW * wave + 2 * p + h;
-        if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
-        while ((uint32_t)below == 0xffffffffu || (uint32_t)(below >> 32) == 0xffffffffu) {  // a half used up (rare)
-          const bool reload = h == 0 ? (uint32_t)below == 0xffffffffu : (uint32_t)(below >> 32) == 0xffffffffu;
-          const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h) + (reload ? 32 : 0);
-          const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
-          if (reload) {
-            win[p] = cur + i < end ? excl_items[cur + i] : 0x7fffffff;
-            if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
-          }
-          const unsigned long long moved = __ballot(reload);
-          if (lane == 2 * p && (uint32_t)moved) my_ex_cur += 32;
-          if (lane == 2 * p + 1 && (uint32_t)(moved >> 32)) my_ex_cur += 32;
-          below = __ballot(win[p] < (int32_t)slab_end);
-        }
+      while (true) {
+        const bool passed = m_win < (int32_t)slab_end;
+        if (passed && m_win >= (int32_t)slab) s_score[(FT_UPW * wave + mu) * FT_LD + (m_win - (int32_t)slab)] = masked;
+        const unsigned long long pm = __ballot(passed);
+        if (pm == 0ull) break;  // nobody has a train item up to the end of this slab
+        const int adv = __popc((uint32_t)(pm >> (4 * mu)) & 0xFu);  // entries user mu has passed
+        m_cur += adv;
+        const bool again = __ballot(adv == 4) != 0ull;  // a whole window used up: that user may have more in this slab
+        if (adv > 0) m_win = m_cur + mj < m_end ? excl_items[m_cur + mj] : 0x7fffffff;
+        if (!again) break;
       }
       __builtin_amdgcn_wave_barrier();
     }
     const bool in0 = slab + lane < c_hi, in1 = slab + 64 + lane < c_hi;
+    const uint32_t not_item0 = ~(uint32_t)(slab + lane), not_item1 = ~(uint32_t)(slab + 64 + lane);
     if (t == 0) {
       // first slab of the chunk: one 128-key sorting network per user fills its list
       for (int uu = 0; uu < FT_UPW; ++uu) {
         const int u = FT_UPW * wave + uu;
-        unsigned long long k0 = in0 ? make_key(s_score[u * FT_LD + lane], (uint32_t)(slab + lane)) : 0ull;
-        unsigned long long k1 = in1 ? make_key(s_score[u * FT_LD + 64 + lane], (uint32_t)(slab + 64 + lane)) : 0ull;
+        unsigned long long k0 = in0 ? key_of(s_score[u * FT_LD + lane], not_item0) : 0ull;
+        unsigned long long k1 = in1 ? key_of(s_score[u * FT_LD + 64 + lane], not_item1) : 0ull;
         if (bound) {
           const unsigned long long bd = shfl_u64(my_bound, uu);
           k0 = k0 < bd ? k0 : 0ull;
           k1 = k1 < bd ? k1 : 0ull;
         }
         wave_sort128_desc(k0, k1, lane);
-        const unsigned long long tk = readlane_u64(k0, k - 1);
-        if (lane == 0) s_floor[u] = tau_floor(tk);
+        const unsigned long long tk = shfl_u64(k0, k - 1);
+        if (lane == 0) s_floor[u] = floor_of(tk);
 #pragma unroll
-        for (int q = 0; q < FT_UPW; ++q) {
-          best[q] = q == uu ? k0 : best[q];
-          tau[q] = q == uu ? tk : tau[q];
-        }
+        for (int q = 0; q < FT_UPW; ++q) best[q] = q == uu ? k0 : best[q];
       }
       if (lane < FT_UPW) s_flag[0][FT_UPW * wave + lane] = 0u;  // (slab 0 flagged everybody: floors were -inf)
       continue;
     }
     // the producers have flagged the users that may have a candidate in this slab (flag_candidates): one LDS read for
     // the wave's users; the flags are cleared for the slab after next, which reuses this buffer
-    uint32_t fl = 0u;
+    uint32_t fl_ = 0u;
     if (lane < FT_UPW) {
-      fl = s_flag[t & 1][FT_UPW * wave + lane];
+      fl_ = s_flag[t & 1][FT_UPW * wave + lane];
       s_flag[t & 1][FT_UPW * wave + lane] = 0u;
     }
-    const uint32_t cand = (uint32_t)__ballot(fl != 0u);
+    const uint32_t cand = (uint32_t)__ballot(fl_ != 0u);
+#if defined(IDG_TOPK_PROBE) && IDG_TOPK_PROBE == 1
+    continue;
+#endif
     if (cand == 0) continue;
 #pragma unroll
     for (int uu = 0; uu < FT_UPW; ++uu) {
       if (!((cand >> uu) & 1u)) continue;
       const int u = FT_UPW * wave + uu;
       const float s0 = s_score[u * FT_LD + lane], s1 = s_score[u * FT_LD + 64 + lane];
-      // columns past the chunk hold scores of a clamped item: the exact key test below drops them
-      const float floor_ = tau_floor(tau[uu]);  // score of the k-th key (-inf while the list is short)
-      if (__ballot(s0 >= floor_) | __ballot(s1 >= floor_)) {
-        const unsigned long long tau_was = tau[uu];
-        unsigned long long c0 = in0 ? make_key(s0, (uint32_t)(slab + lane)) : 0ull;
-        unsigned long long c1 = in1 ? make_key(s1, (uint32_t)(slab + 64 + lane)) : 0ull;
-        if (bound) {
-          const unsigned long long bd = readlane_u64(my_bound, uu);
-          c0 = c0 < bd ? c0 : 0ull;
-          c1 = c1 < bd ? c1 : 0ull;
-        }
-        list_offer(best[uu], tau[uu], c0, k, lane);
-        list_offer(best[uu], tau[uu], c1, k, lane);
-        if (tau[uu] != tau_was && lane == 0) s_floor[u] = tau_floor(tau[uu]);
+      // columns past the chunk hold scores of a clamped item: in0 / in1 drop them.  No float pre-filter: the keys
+      // are three vector instructions each and the offer's own first compare is the filter
+      unsigned long long c0 = in0 ? key_of(s0, not_item0) : 0ull;
+      unsigned long long c1 = in1 ? key_of(s1, not_item1) : 0ull;
+      if (bound) {
+        const unsigned long long bd = shfl_u64(my_bound, uu);
+        c0 = c0 < bd ? c0 : 0ull;
+        c1 = c1 < bd ? c1 : 0ull;
       }
+      unsigned long long tk = shfl_u64(best[uu], k - 1);
+      const bool ch0 = offer(best[uu], tk, c0);
+      const bool ch1 = offer(best[uu], tk, c1);
+      if ((ch0 || ch1) && lane == 0) s_floor[u] = floor_of(tk);
     }
   }
 #pragma unroll
