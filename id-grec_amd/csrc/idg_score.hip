@@ -780,15 +780,16 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 // Fused path geometry: 64 users per workgroup, the catalogue cut into n_chunks so that the grid has about TOPK_WGS
 // workgroups (three are resident per CU, what the register budget allows); scratch = one best-64 list per (user, chunk).
 // Which kernel, and into how many catalogue chunks.  The producer / consumer kernel pays a sort and a burst of list
-// insertions at the start of every chunk (its consumers set the pace there), so it wants the FEWEST chunks that still
-// fill its 512 workgroup slots (2 per CU) — measured at yelp2018 size: 1 chunk 2.40 ms, 3 chunks 3.00 ms — and it only
-// pays with many user tiles; small batches (the reference's test_batch_size of 100 users: 2 tiles) keep the
-// alternating kernel with its ~1024 short workgroups (8.4 vs 12.5 ms for the 31,668 users in 317 calls).
+// insertions at the start of every chunk, so it wants the FEWEST chunks that still fill its 512 workgroup slots (2 per
+// CU) — measured at yelp2018 size, all users in one call: 1 chunk 1.95 ms, 2 chunks 2.41, 3 chunks 2.68 — and it pays
+// from about 16 user tiles on (calls of 1024 users: 7.9 vs 8.4 ms for the 31,668 users; of 4096: 3.9 vs 5.2 ms);
+// below that the two kernels tie at the launch floor (calls of 100 users, the reference's test_batch_size: 66 vs 69 ms
+// for 317 calls) and the alternating kernel, with its ~1024 short workgroups, is kept.
 static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
   const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 forces a kernel
   const int forced = fv && *fv ? std::atoi(fv) : -1;
-  const int form = forced >= 0 ? forced : (user_tiles >= 256 ? 1 : 0);
+  const int form = forced >= 0 ? forced : (user_tiles >= 16 ? 1 : 0);
   if (form_out) *form_out = form;
   int64_t nc = form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
   if (const char* v = std::getenv("IDG_TOPK_WGS"))
