@@ -275,7 +275,7 @@ def main():
             eng.prefetch(*batch(i + 1))  # one-batch lookahead of the index-only work (as the trainer does)
         eng.train_step(*batch(i), loss_out=losses[i])
 
-    S.ramp_clocks()
+    S.ramp_clocks(graph=graph if graph is not None and nnz * d <= 4e9 else None, d=d)
     if graph is not None and args.model == "LightGCN":
         for k in range(1, K):
             eng.forward_layer(k)  # allocates the two layer buffers of the launch-timing leg BEFORE the timed region (at

@@ -160,17 +160,29 @@ def draw_triples(seed, users, items, num_users, num_items, need):
     return tri, rate, pos_ptr, items32
 
 
-def ramp_clocks(seconds=0.5):
-    """Half a second of untimed, unrelated GPU work before a bench's warm-up steps.  A GPU that has idled (a fresh box,
-    or the seconds of host-side graph construction) starts in a low power state, and the W warm-up steps of a small
-    workload (30 x 0.3 ms) can be over before the clocks are up: the first run on a fresh box measured 0.309 ms/step,
-    the following ones 0.301."""
+def ramp_clocks(seconds=0.5, graph=None, d=64):
+    """Half a second of untimed GPU work before a bench's warm-up steps.  A GPU that has idled (a fresh box, or the
+    seconds of host-side graph construction) starts in a low power state, and the W warm-up steps of a small workload
+    (5 x 0.3 ms at the driver's flags) are over before the clocks are up.  With a graph handle the work is that
+    graph's own product on a scratch panel — what the steps will run, so the clocks settle where the steps hold them
+    (measured, steps 5-24 after the ramp: 276 us; after a GEMM ramp or none at all 282 us; steady state 274 us;
+    scripts/step_trend.py) — otherwise a dense GEMM loop."""
     import time
 
     import torch
 
-    a = torch.randn(4096, 4096, device="cuda")
     t0 = time.perf_counter()
+    if graph is not None:
+        from . import ops
+
+        x = torch.randn(graph.n_cols, d, device="cuda")
+        y = torch.empty(graph.n_rows, d, device="cuda")
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                ops.spmm_ex_raw(graph, x, Y=y)
+            torch.cuda.synchronize()
+        return
+    a = torch.randn(4096, 4096, device="cuda")
     while time.perf_counter() - t0 < seconds:
         for _ in range(8):
             a = torch.tanh(a @ a * 1e-3)
