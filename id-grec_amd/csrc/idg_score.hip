@@ -220,28 +220,27 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
   const float* urow0 = U + users[bu0] * d;
   const float* urow1 = U + users[bu1] * d;
   const bool d4 = (d % 4 == 0);
-  // Exclusion lists are ascending: lane uu (< 16) keeps a cursor into the list of user 16*wave+uu, parked
-  // at the first train item >= c_lo; every slab it advances past the items that fall inside the slab,
-  // and those entries of the LDS score slab are overwritten before selection (batch_test.py:62-65).
-  int64_t my_ex_cur = 0, my_ex_end = 0;
-  if (excl_indptr && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) {
-    const int64_t uid = users[b0 + FT_UPW * wave + lane];
+  // Train-item masking (batch_test.py:62-65).  Exclusion lists are ascending.  Lane (mu, mj) = (lane / 4, lane % 4)
+  // holds entry mj of a 4-entry window into the list of user mu of this wave, starting at the user's cursor (parked at
+  // the first train item >= c_lo).  Per slab ONE compare pair finds the window entries inside the slab (their LDS
+  // scores are overwritten before selection), one ballot counts how many entries each user has passed, cursors advance
+  // and the windows of users that advanced are re-read; a user that used up all four entries may have more inside this
+  // slab: the loop then goes round again.  (Round 1's 32-entry windows per user PAIR took 8 dependent compare / ballot
+  // / branch rounds per slab: 40 % of the select's cycles, measured in the producer / consumer kernel below.)
+  const int mu = lane >> 2, mj = lane & 3;
+  int64_t m_cur = 0, m_end = 0;
+  if (excl_indptr && b0 + FT_UPW * wave + mu < Bt) {
+    const int64_t uid = users[b0 + FT_UPW * wave + mu];
     int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
-    my_ex_end = hi;
+    m_end = hi;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
       if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
       else hi = mid;
     }
-    my_ex_cur = lo;
+    m_cur = lo;
   }
-  int32_t win[FT_UPW / 2];  // per PAIR of users of this wave: their next 32 train items each (see the masking step)
-#pragma unroll
-  for (int p = 0; p < FT_UPW / 2; ++p) {
-    const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h);
-    const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
-    win[p] = (excl_indptr && cur + i < end) ? excl_items[cur + i] : 0x7fffffff;
-  }
+  int32_t m_win = (excl_indptr && m_cur + mj < m_end) ? excl_items[m_cur + mj] : 0x7fffffff;
   unsigned long long best[FT_UPW], tau[FT_UPW];  // per user of this wave: list (lane = rank) and its k-th key
 #pragma unroll
   for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull, tau[uu] = 0ull;
@@ -303,29 +302,16 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
     const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
     if (excl_indptr) {
       const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
-      // win[p]: lanes 0-31 hold the next 32 train items of user 2p, lanes 32-63 those of user 2p+1 (entry = cursor +
-      // (lane & 31)), loaded once and kept across slabs: the lists are ascending, so the entries inside this slab are
-      // those in [slab, slab_end); a half is re-read only when its 32 entries have all been passed (users average ~40
-      // train items over the whole catalogue)
-#pragma unroll
-      for (int p = 0; p < FT_UPW / 2; ++p) {
-        unsigned long long below = __ballot(win[p] < (int32_t)slab_end);
-        if (below == 0ull) continue;  // nothing of these two users up to the end of the slab
-        const int row = FT_UPW * wave + 2 * p + h;
-        if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
-        while ((uint32_t)below == 0xffffffffu || (uint32_t)(below >> 32) == 0xffffffffu) {  // a half used up (rare)
-          const bool reload = h == 0 ? (uint32_t)below == 0xffffffffu : (uint32_t)(below >> 32) == 0xffffffffu;
-          const int64_t cur = (int64_t)shfl_u64((unsigned long long)my_ex_cur, 2 * p + h) + (reload ? 32 : 0);
-          const int64_t end = (int64_t)shfl_u64((unsigned long long)my_ex_end, 2 * p + h);
-          if (reload) {
-            win[p] = cur + i < end ? excl_items[cur + i] : 0x7fffffff;
-            if (win[p] < (int32_t)slab_end && win[p] >= (int32_t)slab) s_score[row * FT_LD + (win[p] - (int32_t)slab)] = masked;
-          }
-          const unsigned long long moved = __ballot(reload);
-          if (lane == 2 * p && (uint32_t)moved) my_ex_cur += 32;
-          if (lane == 2 * p + 1 && (uint32_t)(moved >> 32)) my_ex_cur += 32;
-          below = __ballot(win[p] < (int32_t)slab_end);
-        }
+      while (true) {
+        const bool passed = m_win < (int32_t)slab_end;
+        if (passed && m_win >= (int32_t)slab) s_score[(FT_UPW * wave + mu) * FT_LD + (m_win - (int32_t)slab)] = masked;
+        const unsigned long long pm = __ballot(passed);
+        if (pm == 0ull) break;  // nobody has a train item up to the end of this slab
+        const int adv = __popc((uint32_t)(pm >> (4 * mu)) & 0xFu);  // entries user mu has passed
+        m_cur += adv;
+        const bool again = __ballot(adv == 4) != 0ull;  // a whole window used up: that user may have more in this slab
+        if (adv > 0) m_win = m_cur + mj < m_end ? excl_items[m_cur + mj] : 0x7fffffff;
+        if (!again) break;
       }
       __builtin_amdgcn_wave_barrier();
     }
