@@ -68,6 +68,35 @@ def shard_adjacency(indptr, indices, values, num_users, num_items, u_lo, u_hi):
     return (ui_ptr, ui_idx, ui_val), (iu_ptr, iu_idx, iu_val)
 
 
+def shard_adjacency_from_edges(users, items, num_users, num_items, u_lo, u_hi):
+    """The same two pieces as shard_adjacency, straight from the interaction list — sorted by (user, item), no
+    duplicate pairs (what synth.generate returns) — without building the global [U+I, U+I] CSR first: at configs[4]
+    size that build is 4e8 entries and ~55 s per rank, of which a rank keeps 1/N.  Values are the reference's float32
+    arithmetic (data_graph.py:46-51: np.power(rowsum, -0.5) in float32, (D.A).D left to right), i.e. bit for bit what
+    host.build_norm_adj + shard_adjacency give (tests/test_sharded.py)."""
+    U, I = int(num_users), int(num_items)
+    users = np.asarray(users, dtype=np.int64)
+    items = np.asarray(items, dtype=np.int64)
+    if len(users) > 1:
+        du = np.diff(users)
+        if (du < 0).any() or ((du == 0) & (np.diff(items) <= 0)).any():
+            raise ValueError("shard_adjacency_from_edges needs edges sorted by (user, item) without duplicates")
+    deg = np.concatenate([np.bincount(users, minlength=U), np.bincount(items, minlength=I)]).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, np.float32(-0.5))
+    dinv[np.isinf(dinv)] = 0.0
+    s, e = np.searchsorted(users, [u_lo, u_hi], side="left")
+    su, si = users[s:e], items[s:e]
+    ui_ptr = np.concatenate([[0], np.cumsum(np.bincount(su - u_lo, minlength=u_hi - u_lo))]).astype(np.int64)
+    ui_idx = si.astype(np.int32)
+    ui_val = (dinv[su] * np.float32(1.0)) * dinv[U + si]
+    order = np.argsort(si, kind="stable")  # item rows, users ascending inside each
+    iu_ptr = np.concatenate([[0], np.cumsum(np.bincount(si, minlength=I))]).astype(np.int64)
+    iu_idx = (su[order] - u_lo).astype(np.int32)
+    iu_val = (dinv[U + si[order]] * np.float32(1.0)) * dinv[su[order]]
+    return (ui_ptr, ui_idx, ui_val.astype(np.float32)), (iu_ptr, iu_idx, iu_val.astype(np.float32))
+
+
 # --------------------------------------------------------------------------- the step
 class GlobalBatch:
     """Index-only description of ONE global batch as one rank sees it (built on the host by ShardedEngine.make_batch
@@ -719,17 +748,20 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
 
     U, I, E = S.SHAPES[args.workload]
     d, K, B = args.dim, args.layers, args.batch
-    users, items = S.generate(U, I, E, seed=0)           # every rank derives the same global graph
-    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    # every rank needs the same global graph: large ones are drawn once per machine, then loaded
+    if world > 1 and E >= int(os.environ.get("IDG_SYNTH_SHARED_MIN_EDGES", "50000000")):
+        users, items = S.generate_shared(U, I, E, 0, rank, dist.barrier)
+    else:
+        users, items = S.generate(U, I, E, seed=0)
     bounds = partition_users_by_nnz(np.bincount(users, minlength=U), world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    ui, iu = shard_adjacency(ip, ix, dv, U, I, lo, hi)
-    nnz_global, n_edges = len(ix), len(users)
+    ui, iu = shard_adjacency_from_edges(users, items, U, I, lo, hi)  # this rank's rows only: no global CSR
+    nnz_global, n_edges = 2 * len(users), len(users)
     n_slices = 4 if I * d * 4 >= (256 << 20) else 1
     cuts = partition_users_by_nnz(np.bincount(items, minlength=I), n_slices)  # same cuts on every rank: global item degrees
     need = (args.steps + args.warmup) * B
     tri = S.draw_triples(args.seed, users, items, U, I, need)[0]  # the same global sequence on every rank
-    del ip, ix, dv, users, items
+    del users, items
     kern = HipKernels(deterministic=not args.atomic)
     eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
                         n_slices=n_slices, item_cuts=cuts)

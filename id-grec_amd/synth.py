@@ -79,6 +79,42 @@ def generate(num_users, num_items, num_edges, seed=0, zipf_a=0.8, match_edges=Tr
     return users, items
 
 
+GENERATOR_VERSION = 2  # part of generate_shared's cache file name: bump when generate()'s output changes
+
+
+def generate_shared(num_users, num_items, num_edges, seed, rank, barrier, cache_dir=None):
+    """generate() for the ranks of one multi-process run on one host: rank 0 draws the graph (or finds it already drawn
+    by an earlier run on this machine) and leaves it in a cache file under the temporary directory, the others load
+    it — the 2e8-edge shape costs ~45 s and 10 GB of host memory to draw, per process.  `barrier` is the process
+    group's barrier (called twice by every rank).  Any trouble with the file (no space, unreadable, wrong length)
+    falls back to drawing in this process: the result is the same arrays either way."""
+    import tempfile
+
+    d = cache_dir or os.environ.get("IDG_SYNTH_CACHE") or tempfile.gettempdir()
+    path = os.path.join(d, "idgrec_synth_v%d_%d_%d_%d_%d.npy" % (GENERATOR_VERSION, num_users, num_items, num_edges, seed))
+    drawn = None
+    barrier()
+    if rank == 0 and not os.path.exists(path):
+        drawn = generate(num_users, num_items, num_edges, seed=seed)
+        try:
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "wb") as f:
+                np.save(f, np.stack(drawn))
+            os.replace(tmp, path)
+        except OSError:
+            pass
+    barrier()
+    if drawn is not None:
+        return drawn
+    try:
+        both = np.load(path)
+        if both.ndim == 2 and both.shape[0] == 2 and both.dtype == np.int64:
+            return both[0], both[1]
+    except (OSError, ValueError):
+        pass
+    return generate(num_users, num_items, num_edges, seed=seed)
+
+
 def split_test(users, items, num_users, n_test=1, seed=1):
     """Hold out up to n_test items per user (never a user's last train item).
     Returns train (users, items) and test (users, items)."""

@@ -161,6 +161,38 @@ def test_shards_tile_the_global_adjacency(world, golden_small):
     assert (acc_iu != A[U:, :U]).nnz == 0
 
 
+@pytest.mark.parametrize("world", [1, 3, 4])
+def test_shards_straight_from_the_edge_list(world, golden_small):
+    """shard_adjacency_from_edges (what the multi-GPU bench uses: no global CSR per rank) gives, array for array and
+    bit for bit, the pieces shard_adjacency cuts out of the reference-exact global adjacency — on the golden graph
+    (whose adjacency the reference itself produced) and on a generated one with empty users and items."""
+    import idgrec_amd.host as H
+    import idgrec_amd.sharded as sh
+    import idgrec_amd.synth as S
+
+    g = golden_small
+    cases = [(int(g["num_users"]), int(g["num_items"]), g["train_user"].astype(np.int64), g["train_item"].astype(np.int64),
+              (g["adj_indptr"], g["adj_indices"], g["adj_data"]))]
+    U2, I2 = 700, 900
+    u2, i2 = S.generate(U2, I2, 9000, seed=3)
+    keep = (u2 % 17 != 0) & (i2 % 13 != 0)  # users and items without any interaction
+    u2, i2 = u2[keep], i2[keep]
+    cases.append((U2, I2, u2, i2, H.build_norm_adj(U2, I2, u2, i2)))
+    for U, I, users, items, (ip, ix, dv) in cases:
+        order = np.lexsort((items, users))
+        users, items = users[order], items[order]
+        b = sh.partition_users_by_nnz(np.bincount(users, minlength=U), world)
+        for r in range(world):
+            lo, hi = int(b[r]), int(b[r + 1])
+            want = sh.shard_adjacency(ip, ix, dv, U, I, lo, hi)
+            got = sh.shard_adjacency_from_edges(users, items, U, I, lo, hi)
+            for a, c in zip(want, got):
+                for x, y in zip(a, c):
+                    assert x.dtype == y.dtype and np.array_equal(x, y)
+    with pytest.raises(ValueError):
+        sh.shard_adjacency_from_edges(np.array([1, 0]), np.array([0, 0]), 2, 1, 0, 2)
+
+
 @pytest.mark.parametrize("K,include0,d,n_slices", [(3, True, 64, 1), (2, False, 64, 3), (1, True, 64, 2), (3, True, 256, 2)])
 def test_two_ranks_gloo_cpu_match_single_device(K, include0, d, n_slices, tmp_path, golden_small):
     """n_slices > 1: the item-side products run slice by slice, each slice's all-reduce issued as soon as it exists."""
@@ -183,3 +215,20 @@ def test_two_ranks_hip_kernels_match_single_device(K, include0, d, mode, tmp_pat
     np.savez(path, **p)
     outs = _launch(mode, path, 4)
     _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=(mode == "gpu"))
+
+
+def test_generate_shared_is_generate(tmp_path):
+    """The multi-rank bench draws its graph once per machine (rank 0) and the other ranks load it: same arrays as
+    drawing in-process, also when the cache file is unusable."""
+    import idgrec_amd.synth as S
+
+    calls = []
+    want = S.generate(300, 250, 3600, seed=0)
+    first = S.generate_shared(300, 250, 3600, 0, 0, lambda: calls.append(1), cache_dir=str(tmp_path))
+    other = S.generate_shared(300, 250, 3600, 0, 1, lambda: calls.append(1), cache_dir=str(tmp_path))
+    files = os.listdir(tmp_path)
+    assert len(files) == 1 and len(calls) == 4
+    (tmp_path / files[0]).write_bytes(b"not an array")
+    broken = S.generate_shared(300, 250, 3600, 0, 1, lambda: None, cache_dir=str(tmp_path))
+    for got in (first, other, broken):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
