@@ -70,6 +70,9 @@ def parse():
     p.add_argument("--dp-exchange", default="rows", choices=["rows", "grad"],
                    help="what dp replicas exchange: rows = all-gather of the batches' gradient rows before the backward "
                         "propagation (default), grad = all-reduce of the dense [n, d] gradient after it")
+    p.add_argument("--ramp", default="graph", choices=["graph", "gemm"],
+                   help="untimed clock ramp before the warm-up steps: the graph's own product on a scratch panel (default) or a "
+                        "dense GEMM loop (profile runs: keeps the ramp's launches out of the per-kernel statistics)")
     p.add_argument("--force-sharded", action="store_true",
                    help="run a multi-GPU path even at world size 1 (exercises the RCCL code path): the user-row-sharded one, "
                         "or the replicas with --parallel dp")
@@ -275,7 +278,7 @@ def main():
             eng.prefetch(*batch(i + 1))  # one-batch lookahead of the index-only work (as the trainer does)
         eng.train_step(*batch(i), loss_out=losses[i])
 
-    S.ramp_clocks(graph=graph if graph is not None and nnz * d <= 4e9 else None, d=d)
+    S.ramp_clocks(graph=graph if graph is not None and nnz * d <= 4e9 and args.ramp == "graph" else None, d=d)
     if graph is not None and args.model == "LightGCN":
         for k in range(1, K):
             eng.forward_layer(k)  # allocates the two layer buffers of the launch-timing leg BEFORE the timed region (at
