@@ -9,7 +9,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "yelp2018"
 U, I, E = S.SHAPES[wl]
 users, items = S.generate(U, I, E, seed=0)
 pos_ptr = np.zeros(U + 1, dtype=np.int64); pos_ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
-d, k, Bt = 64, 20, int(os.environ.get("EVAL_BT", "1024"))
+d, k, Bt = int(os.environ.get("EVAL_D", "64")), 20, int(os.environ.get("EVAL_BT", "1024"))
 g = torch.Generator(device="cuda").manual_seed(0)
 Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
 Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
