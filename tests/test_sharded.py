@@ -63,9 +63,10 @@ def _check(p, outs, steps, rtol, atol, sparse=False):
         np.testing.assert_allclose(o["P"][: hi - lo], W[lo:hi], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["P"][hi - lo:], W[U:], rtol=rtol, atol=atol)
     # replicated item table: bit-identical across ranks (coherence without an extra exchange)
-    a, b = outs[0], outs[1]
-    assert np.array_equal(a["P"][int(a["hi"]) - int(a["lo"]):], b["P"][int(b["hi"]) - int(b["lo"]):])
-    assert np.array_equal(a["losses"], b["losses"])  # every rank evaluates the whole batch's loss: same bits
+    a = outs[0]
+    for b in outs[1:]:
+        assert np.array_equal(a["P"][int(a["hi"]) - int(a["lo"]):], b["P"][int(b["hi"]) - int(b["lo"]):])
+        assert np.array_equal(a["losses"], b["losses"])  # every rank evaluates the whole batch's loss: same bits
     # sharded evaluation (users by owner, items replicated, metric sums exchanged) == the single-device Test()
     want = _single_device_test(p, W, [5, 10])
     for o in outs:
@@ -200,6 +201,16 @@ def test_two_ranks_gloo_cpu_match_single_device(K, include0, d, n_slices, tmp_pa
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
     outs = _launch("cpu", path, 3)
+    _check(p, outs, 3, rtol=1e-4, atol=2e-7)
+
+
+def test_three_ranks_gloo_cpu_match_single_device(tmp_path, golden_small):
+    """An odd world size: three uneven user blocks (nnz-balanced), ring all-reduces over three ranks, sliced item side."""
+    p = _problem(golden_small, 3, True, B=160, steps=3, d=64, n_slices=2)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("cpu", path, 3, world=3)
+    assert len({(int(o["lo"]), int(o["hi"])) for o in outs}) == 3
     _check(p, outs, 3, rtol=1e-4, atol=2e-7)
 
 
