@@ -491,7 +491,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
         IDG_LD(pb0, vrow, 96);
         IDG_LD(pb1, vrow, 112);
         IDG_WAIT2(pa0, pa1);
-#if !defined(IDG_TOPK_PROBE) || IDG_TOPK_PROBE != 4
+#if !defined(IDG_TOPK_PROBE) || IDG_TOPK_PROBE != 4  // (timing probe 4, wrong results: half the MFMAs; profiles/r02/topk_roles.txt)
         IDG_PIECE(2, pa0, pa1);
 #endif
         IDG_LD(pa0, vnext, 0);  // (past the last slab: a clamped, valid row nobody uses)
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
       s_flag[t & 1][FT_UPW * wave + lane] = 0u;
     }
     const uint32_t cand = (uint32_t)__ballot(fl_ != 0u);
-#if defined(IDG_TOPK_PROBE) && IDG_TOPK_PROBE == 1
+#if defined(IDG_TOPK_PROBE) && IDG_TOPK_PROBE == 1  // (timing probe 1, wrong results: the producers on their own)
     continue;
 #endif
     if (cand == 0) continue;
