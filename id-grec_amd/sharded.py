@@ -106,8 +106,11 @@ class GlobalBatch:
       head_dst   int64 [B]  the same id for the FIRST owned occurrence of a user in the batch, else -1
       nxt        int64 [B]  batch position of the next occurrence of triple t's user, -1 at the end of its chain
       own_users / own_pos / own_neg  int64 [B_g]  the owned triples (local user ids): the rows this rank's restricted
-                 products have to produce / may gather from"""
-    __slots__ = ("B", "pos", "neg", "own_src", "head_dst", "nxt", "own_users", "own_pos", "own_neg", "n_owned", "key")
+                 products have to produce / may gather from
+      items      int64 [n_items <= 2B]  the batch's distinct item ids, ascending: the only item rows of the LAST forward
+                 layer anybody reads (the BPR loss gathers pos / neg rows) — what that layer's exchange carries"""
+    __slots__ = ("B", "pos", "neg", "own_src", "head_dst", "nxt", "own_users", "own_pos", "own_neg", "n_owned", "key",
+                 "items", "n_items")
 
 
 class ShardedEngine:
@@ -120,8 +123,9 @@ class ShardedEngine:
     (x + 0 + ... + 0: exact) hand them to every rank, and every rank evaluates the WHOLE batch's BPR loss — so the
     loss and the item-side gradient g_I are complete and bit-identical on every rank without any [I, d] exchange, and
     the user-side gradient rows flow back from the guest rows to their owners' rows (chained adds in batch order).
-    Per step: K forward + K backward all-reduces of the [I, d] item panel, cut into slices that overlap the products
-    (SURVEY.md §8e), plus the two [B, d] ones."""
+    Per step: K - 1 forward + K backward all-reduces of the [I, d] item panel, cut into slices that overlap the products
+    (SURVEY.md §8e), plus the two [B, d] ones and one of [<= 2B, d]: the LAST forward layer's item rows are read at the
+    batch's positive / negative items only, so its partial sums travel as those rows, not as the panel."""
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
                  reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None):
@@ -148,7 +152,10 @@ class ShardedEngine:
         iu_ptr = np.asarray(iu_ptr, dtype=np.int64)
         if item_cuts is None:
             item_cuts = np.linspace(0, self.I, max(1, min(int(n_slices), self.I)) + 1).astype(np.int64)
-        cuts = np.asarray(item_cuts, dtype=np.int64)
+        cuts = np.asarray(item_cuts, dtype=np.int64).copy()
+        # inner cuts on multiples of 32 rows: a slice's share of an item-row bitmap then starts on a word boundary (the
+        # rounding is a function of the cuts alone, so the ranks still agree on them)
+        cuts[1:-1] = np.minimum((cuts[1:-1] + 16) // 32 * 32, self.I)
         assert cuts[0] == 0 and cuts[-1] == self.I and (np.diff(cuts) >= 0).all(), "item_cuts must tile [0, I]"
         self.G_iu = []
         for r0, r1 in zip(cuts[:-1], cuts[1:]):
@@ -164,6 +171,7 @@ class ShardedEngine:
         self.GF = z((n, dim))   # d loss / d FIN
         self.XU = [z((self.Ug, dim)), z((self.Ug, dim))]
         self.XI = [z((self.I, dim)), z((self.I, dim)), z((self.I, dim))]
+        self.CI, self.CT = z((2 * self.B, dim)), z((2 * self.B, dim))  # the batch's item rows, compact (last forward layer)
         self.loss = z((2,))
         self.upstream = z((2,))
         kernels.fill(self.upstream, 1.0)
@@ -206,6 +214,8 @@ class ShardedEngine:
         gb.n_owned = int(owned.sum())
         gb.own_users = to(local[owned].astype(np.int64))
         gb.own_pos, gb.own_neg = to(np.asarray(pos, dtype=np.int64)[owned]), to(np.asarray(neg, dtype=np.int64)[owned])
+        items = np.unique(np.concatenate([np.asarray(pos, dtype=np.int64), np.asarray(neg, dtype=np.int64)]))
+        gb.items, gb.n_items = to(items), len(items)
         gb.key = id(gb)
         return gb
 
@@ -224,10 +234,14 @@ class ShardedEngine:
             self.comm.wait(w)
 
     # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
-    def propagate(self, prep=None):
+    def propagate(self, prep=None, gb=None):
         """Layer k: P_I(k) = R^T X_U(k-1) (local partial) -> all-reduce -> X_I(k);  X_U(k) = R X_I(k-1).
         P_I(k+1) needs only X_U(k), not X_I(k): it is launched BEFORE waiting for all-reduce k, so the
-        collectives queue back to back on the communicator while the SpMMs keep the GPU busy."""
+        collectives queue back to back on the communicator while the SpMMs keep the GPU busy.
+        gb (a training step's batch): X_I(K) feeds nothing but FIN's item rows, which the step reads at the batch's
+        items only — the last layer's partials are exchanged as those <= 2B rows (gathered into a compact buffer, one
+        small all-reduce, folded into FIN at those rows) instead of the [I, d] panel; FIN's other item rows are then
+        stale, like its user rows outside the batch.  Evaluation calls propagate() without a batch: every row."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
         fin_u, fin_i = self._u(self.FIN), self._i(self.FIN)
         xu_prev, xi_prev = self._u(self.P), self._i(self.P)
@@ -244,13 +258,31 @@ class ShardedEngine:
                 base = self._i(self.P) if c0 else None
             else:
                 base = fin_i if (c0 or layer > 2) else xi_before
+            if xi_new is None:  # the last layer of a training step: the batch's item rows only (self.CI)
+                n_t = gb.n_items
+                if base is not None:
+                    k.gather_rows(self.CT[:n_t], base, gb.items)
+                k.lincomb(self.CT[:n_t], self.CI[:n_t], scale, self.CT[:n_t] if base is not None else None, scale)
+                k.scatter_rows(fin_i, gb.items, self.CT[:n_t])
+                return
             k.lincomb(fin_i, xi_new, scale, base, scale)
 
         for layer in range(1, K + 1):
             last = layer == K
             xi_new = self.XI[layer % 3]
-            # item-side partial of this layer; X_I(layer-1) (the previous collective) is folded in under its first slice
-            works = self._item_side(xu_prev, xi_new, after_first=finish)
+            if last and gb is not None:
+                # item-side partial of the last layer: produced (all rows, or the batch's with a prepared item bitmap),
+                # the batch's rows gathered, ONE small all-reduce
+                item_bits = getattr(prep, "item_bitmap", None) if prep is not None else None
+                for j, (g, r0, r1) in enumerate(self.G_iu):
+                    k.spmm(g, xu_prev, Y=xi_new[r0:r1], out_rows=None if item_bits is None else item_bits[r0 // 32:])
+                    if j == 0:
+                        finish()
+                k.gather_rows(self.CI[:gb.n_items], xi_new, gb.items)
+                works, xi_fold = [self.comm.all_reduce_async(self.CI[:gb.n_items])], None
+            else:
+                # item-side partial of this layer; X_I(layer-1) (the previous collective) is folded in under its first slice
+                works, xi_fold = self._item_side(xu_prev, xi_new, after_first=finish), xi_new
             if layer == 1:
                 sum_in = self._u(self.P) if c0 else None
             else:
@@ -258,7 +290,7 @@ class ShardedEngine:
             xu_new = None if last else self.XU[layer & 1]
             k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0,
                    out_rows=prep.bitmap if (last and prep is not None) else None)  # BPR reads the batch's users only
-            pending[0] = (works, xi_new, layer, xi_prev)
+            pending[0] = (works, xi_fold, layer, xi_prev)
             xu_prev, xi_prev = xu_new, xi_new
         finish()
         return self.FIN
@@ -313,7 +345,7 @@ class ShardedEngine:
                 prep = k.prepare(self, gb)  # None for kernels without one
             if prep is not None:
                 k.wait_rows(prep)
-        self.propagate(prep)
+        self.propagate(prep, gb)
         # the batch's user rows (final and ego) travel through the guest rows: owners fill, everybody else adds zeros
         fin_g, ego_g = self._guest(self.FIN, Bc), self._guest(self.P, Bc)
         k.gather_rows(fin_g, self._u(self.FIN), gb.own_src)
@@ -424,6 +456,10 @@ class HipKernels:
     def gather_rows(self, dst, src, idx):
         self.ops.rows_gather_raw(dst, src, idx)
 
+    def scatter_rows(self, dst, idx, src):
+        """dst[idx[j]] = src[j] (idx distinct)."""
+        dst.index_copy_(0, idx, src)
+
     def chain_add_rows(self, dst, src, idx, nxt):
         self.ops.rows_chain_add_raw(dst, src, idx, nxt)
 
@@ -437,7 +473,7 @@ class HipKernels:
         return idx.cpu().numpy()
 
     class _Prepared:
-        __slots__ = ("bitmap", "ws", "rows_done", "done", "free", "B", "busy")
+        __slots__ = ("bitmap", "item_bitmap", "ws", "rows_done", "done", "free", "B", "busy")
 
     def prepare(self, eng, gb):
         """Index-only work of a global batch on a side stream: bitmap of the LOCAL user rows this rank owns in it (the
@@ -452,6 +488,9 @@ class HipKernels:
         if prep is None:
             prep = self._Prepared()
             prep.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=self.device)
+            # ... and of the batch's item rows (ALL triples' positives and negatives: every rank evaluates the whole
+            # batch), by global item id: the last forward layer's item-side product produces these rows only
+            prep.item_bitmap = torch.zeros((eng.I + 31) // 32 + 1, dtype=torch.int32, device=self.device)
             prep.ws, prep.B = ops.bpr_workspace(cap, d, self.device), cap
             prep.rows_done, prep.done, prep.free = ops.LocalEvent(), ops.LocalEvent(), None  # device-local events
             self._pool.append(prep)
@@ -464,6 +503,7 @@ class HipKernels:
                                    clear_bits=n)
         else:
             ops.bitmap_clear_raw(prep.bitmap, n, stream=self._side_raw)
+        ops.bpr_touch_rows_raw(gb.pos, gb.pos, gb.neg, 0, prep.item_bitmap, stream=self._side_raw, clear_bits=eng.I)
         prep.rows_done.record(self._side_raw)
         ops.bpr_plan_raw(eng.guest_ids[:gb.B], gb.pos, gb.neg, n_users, n, d, ws=prep.ws, stream=self._side_raw)
         prep.done.record(self._side_raw)
@@ -840,8 +880,10 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                                    "edges, nnz(A)=%d; LightGCN K=%d d=%d, ONE global batch of B=%d triples per Adam step (as "
                                    "the reference, trainer.py:36); item table replicated; per step %d all-reduces of the "
                                    "[%d,%d] fp32 item panel in %d slices that overlap the products + 2 of [%d,%d] (the "
-                                   "batch's user rows) over %s"
-                                   % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, 2 * K, I, d, len(eng.G_iu), B, d,
+                                   "batch's user rows) + 1 of [<=%d,%d] (the last forward layer's item rows, read at the "
+                                   "batch's items only) over %s"
+                                   % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, 2 * K - 1, I, d, len(eng.G_iu), B, d,
+                                      2 * B, d,
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
                        "batch": B, "dim": d, "layers": K, "parallelism": "user-row shard x%d" % world,
                        "comm": comm_name, "item_panel_slices": len(eng.G_iu)},
@@ -856,10 +898,10 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                 "us_user_side": t_ui * 1e6, "us_item_side": t_iu * 1e6, "bytes_gather_user_side": bytes_ui,
                 "bytes_gather_item_side": bytes_iu, "rank0_users": Ug, "rank0_nnz": nnz_ui,
                 "cache_resident": bool(4 * max(I, Ug) * d < (256 << 20)),
-                "exchange_bytes_per_step_per_rank": 2 * K * 4 * I * d + 2 * 4 * B * d,
+                "exchange_bytes_per_step_per_rank": (2 * K - 1) * 4 * I * d + 4 * 4 * B * d,
             },
-            "single_gpu_reference": "the same workload on ONE MI355X, unsharded: profiles/r01/k_c5_single_gpu_bench.json "
-                                    "(builder-run, round 1; not measured in this run)" if args.workload == "synth-10M" else None,
+            "single_gpu_reference": "the same workload on ONE MI355X, unsharded: profiles/r02/bench_c5_single_gpu.json "
+                                    "(builder-run; not measured in this run)" if args.workload == "synth-10M" else None,
         }
     del eng, batches
     torch.cuda.empty_cache()

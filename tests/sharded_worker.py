@@ -38,6 +38,9 @@ class OracleKernels:
     def gather_rows(self, dst, src, idx):
         dst[...] = np.where((idx >= 0)[:, None], src[np.maximum(idx, 0)], np.float32(0))
 
+    def scatter_rows(self, dst, idx, src):
+        dst[idx] = src
+
     def chain_add_rows(self, dst, src, idx, nxt):
         for t in np.nonzero(idx >= 0)[0]:
             acc, j = dst[idx[t]].copy(), t
@@ -134,7 +137,11 @@ def run(rank, world, port, mode, path, steps):
         a = to_np(a)
         return np.concatenate([a[:Ug], a[Ug + B:]])
 
-    out = dict(P=strip(eng.P), FIN=strip(eng.FIN), G=strip(eng.G), losses=np.stack(losses), lo=lo, hi=hi, fin_rows=touched)
+    # item rows of FIN that the LAST step produced: the batch's positive / negative items (the last forward layer's
+    # exchange carries those rows only)
+    fin_items = np.unique(np.concatenate([cur[1][:, 1], cur[1][:, 2]]))
+    out = dict(P=strip(eng.P), FIN=strip(eng.FIN), G=strip(eng.G), losses=np.stack(losses), lo=lo, hi=hi, fin_rows=touched,
+               fin_items=fin_items)
     if "test_users" in z.files:  # sharded evaluation: this rank's test users, its train rows as the exclusion lists
         tu, tptr, titems = z["test_users"], z["test_ptr"], z["test_items"]
         own = [(int(u), titems[tptr[j]:tptr[j + 1]].tolist()) for j, u in enumerate(tu) if lo <= u < hi]

@@ -57,7 +57,8 @@ def _check(p, outs, steps, rtol, atol, sparse=False):
         np.testing.assert_allclose(o["losses"], losses, rtol=rtol)                  # identical on every rank
         rows = o["fin_rows"] if sparse else np.arange(hi - lo)   # batch sparsity: only the batch's users are produced
         np.testing.assert_allclose(o["FIN"][: hi - lo][rows], fin[lo:hi][rows], rtol=rtol, atol=atol)
-        np.testing.assert_allclose(o["FIN"][hi - lo:], fin[U:], rtol=rtol, atol=atol)
+        it = o["fin_items"]  # a training step's forward produces the item rows its loss reads, no others
+        np.testing.assert_allclose(o["FIN"][hi - lo:][it], fin[U:][it], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["G"][: hi - lo], grad[lo:hi], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["G"][hi - lo:], grad[U:], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["P"][: hi - lo], W[lo:hi], rtol=rtol, atol=atol)
