@@ -57,6 +57,7 @@ PROTOTYPES = {
     "idg_lincomb_f32": (C.c_int, [c_vp, c_vp, C.c_float, c_vp, C.c_float, C.c_int64, c_vp]),
     "idg_rows_gather_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
     "idg_rows_chain_add_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
+    "idg_rows_nonzero_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_spmm_noise_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64,
                                      c_vp, c_vp]),
     "idg_perturb_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, C.c_float, C.c_uint64, C.c_uint64, c_vp]),
@@ -134,7 +135,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 114  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 115  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

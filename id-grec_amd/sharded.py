@@ -123,12 +123,15 @@ class ShardedEngine:
     (x + 0 + ... + 0: exact) hand them to every rank, and every rank evaluates the WHOLE batch's BPR loss — so the
     loss and the item-side gradient g_I are complete and bit-identical on every rank without any [I, d] exchange, and
     the user-side gradient rows flow back from the guest rows to their owners' rows (chained adds in batch order).
-    Per step: K - 1 forward + K backward all-reduces of the [I, d] item panel, cut into slices that overlap the products
-    (SURVEY.md §8e), plus the two [B, d] ones and one of [<= 2B, d]: the LAST forward layer's item rows are read at the
-    batch's positive / negative items only, so its partial sums travel as those rows, not as the panel."""
+    Per step: K - 1 forward + K - 1 backward all-reduces of the [I, d] item panel, cut into slices that overlap the
+    products, plus the two [B, d] ones, one of [<= 2B, d] — the LAST forward layer's item rows are read at
+    the batch's positive / negative items only, so its partial sums travel as those rows, not as the panel — and, for
+    the FIRST backward product (input non-zero at the batch's users only), an [I] vector of row flags and the rows
+    somebody has (_exchange_live_rows)."""
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
-                 reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None):
+                 reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None,
+                 live_rows_cap=None, live_rows_min_bytes=64 << 20):
         """batch_sparsity: use what a prepared batch (kernels.prepare) knows — the user side of the last forward
         layer is produced for the batch's owned users only, the first backward product gathers its live rows only,
         the gradient scatter follows a plan sorted ahead of time.  Exact; FIN's user rows outside the batch are then
@@ -136,7 +139,9 @@ class ShardedEngine:
         user_lo: global id of this rank's first user.  n_slices: row slices of R_g^T whose all-reduces overlap the
         following slices' products (default: 4 once the item panel reaches 256 MB, else 1); item_cuts: the slices' row
         bounds — they MUST be the same on every rank (the slices are what the ranks all-reduce); default: equal row
-        counts (callers that know the global item degrees pass entry-balanced cuts)."""
+        counts (callers that know the global item degrees pass entry-balanced cuts).  live_rows_cap: rows of the compact
+        buffer of the first backward step's exchange (default 64 per triple; the same on every rank);
+        live_rows_min_bytes: item panels smaller than this are all-reduced whole in that step (tests pass 0)."""
         self.k, self.comm = kernels, comm
         self.batch_sparsity = bool(batch_sparsity)
         self._prepared = {}
@@ -172,6 +177,10 @@ class ShardedEngine:
         self.XU = [z((self.Ug, dim)), z((self.Ug, dim))]
         self.XI = [z((self.I, dim)), z((self.I, dim)), z((self.I, dim))]
         self.CI, self.CT = z((2 * self.B, dim)), z((2 * self.B, dim))  # the batch's item rows, compact (last forward layer)
+        # first backward step: flags of the item rows some rank's partial has, and those rows, compact (up to 64 per triple)
+        self.FL = z((self.I,))
+        self.live_rows_min_bytes = int(live_rows_min_bytes)
+        self.CS = z((max(1, min(self.I, 64 * self.B if live_rows_cap is None else int(live_rows_cap))), dim))
         self.loss = z((2,))
         self.upstream = z((2,))
         kernels.fill(self.upstream, 1.0)
@@ -232,6 +241,33 @@ class ShardedEngine:
     def _wait_all(self, works):
         for w in works:
             self.comm.wait(w)
+
+    def _exchange_live_rows(self, panel):
+        """Sum over the ranks of an item panel that is zero almost everywhere on every rank (the first backward
+        product: its input is non-zero at the batch's users only, so a rank's partial lives on the items those users
+        interacted with).  Instead of the [I, d] all-reduce: every rank flags its non-zero rows (a row that happens to
+        be all zero adds nothing to any sum: leaving it out is exact), the flags are summed ([I] floats), the rows
+        somebody has — the same ascending list on every rank — are gathered, all-reduced as a compact buffer and put
+        back.  More live rows than the buffer holds (a batch full of hub users): the plain sliced all-reduce.
+        Returns the collectives still in flight."""
+        k = self.k
+        if getattr(self.comm, "world", 2) == 1:
+            return []  # nothing to sum
+        if self.I * self.d * 4 < self.live_rows_min_bytes:
+            # a small panel: its all-reduce costs less than the flag exchange and the host synchronisation that sizes
+            # the compact one (measured at world size 1 on the 9.7 MB panel of the yelp2018 shape: +48 us per step)
+            return [self.comm.all_reduce_async(panel[r0:r1]) for _, r0, r1 in self.G_iu]
+        k.rows_nonzero(panel, self.FL)
+        self.comm.wait(self.comm.all_reduce_async(self.FL))
+        ids, n = k.nonzero_ids(self.FL)  # (the one host synchronisation of the step: the collective's size)
+        if n == 0:
+            return []
+        if n > self.CS.shape[0]:
+            return [self.comm.all_reduce_async(panel[r0:r1]) for _, r0, r1 in self.G_iu]
+        k.gather_rows(self.CS[:n], panel, ids)
+        self.comm.wait(self.comm.all_reduce_async(self.CS[:n]))
+        k.scatter_rows(panel, ids, self.CS[:n])
+        return []
 
     # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
     def propagate(self, prep=None, gb=None):
@@ -297,7 +333,7 @@ class ShardedEngine:
 
     # ---- backward of the above given GF = d loss / d FIN (g_I complete on every rank, g_U at the owners' rows),
     #      accumulated onto G (which already holds the regulariser gradient: item rows complete, user rows owned)
-    def propagate_backward(self, prep=None):
+    def propagate_backward(self, prep=None, gb=None):
         """Horner steps h <- A.h + g, k = K..2, then gE0 = (A.h + c0.g)/cnt.  In block form
         (A.h)_U = R_g h_I (local), (A.h)_I = all-reduce(R_g^T h_U).  As in the forward pass the item-side
         partial of a step needs only the LOCAL h_U, so it is launched before waiting for the previous
@@ -318,7 +354,16 @@ class ShardedEngine:
         live = prep.bitmap if prep is not None else None      # h_U = g_U has the batch's owned users as its only live rows
         for layer in range(K, 1, -1):
             t_i = self.XI[layer % 3]
-            works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)   # partial of (A h)_I: needs h_U only
+            if layer == K and gb is not None:
+                # the first step of a training batch: h_U = g_U is non-zero at the batch's users only — the partial is
+                # exchanged as its live rows (_exchange_live_rows), not as the panel
+                for j, (g, r0, r1) in enumerate(self.G_iu):
+                    k.spmm(g, h_u, Y=t_i[r0:r1], x_rows=live)
+                    if j == 0:
+                        finish()
+                works = self._exchange_live_rows(t_i)
+            else:
+                works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)   # partial of (A h)_I: needs h_U only
             live = None
             t_u = self.XU[layer & 1]
             k.spmm(self.G_ui, h_i[0], Y=t_u, addend=g_u)      # (A h)_U + g_U
@@ -361,7 +406,7 @@ class ShardedEngine:
         # gradients of the guest rows go home: every owned user's occurrences are added in batch order
         k.chain_add_rows(self._u(self.GF), self._guest(self.GF, Bc), gb.head_dst, gb.nxt)
         k.chain_add_rows(self._u(self.G), self._guest(self.G, Bc), gb.head_dst, gb.nxt)
-        self.propagate_backward(prep)
+        self.propagate_backward(prep, gb)
         if prep is not None:
             k.release(prep)
         self.step_count += 1
@@ -460,6 +505,14 @@ class HipKernels:
         """dst[idx[j]] = src[j] (idx distinct)."""
         dst.index_copy_(0, idx, src)
 
+    def rows_nonzero(self, panel, flags):
+        self.ops.rows_nonzero_raw(panel, flags)
+
+    def nonzero_ids(self, flags):
+        """Ascending ids of the non-zero flags and their number (a host synchronisation: the caller sizes a collective)."""
+        ids = self.torch.nonzero(flags).reshape(-1)
+        return ids, int(ids.numel())
+
     def chain_add_rows(self, dst, src, idx, nxt):
         self.ops.rows_chain_add_raw(dst, src, idx, nxt)
 
@@ -528,6 +581,7 @@ class TorchComm:
     def __init__(self, dist):
         self.dist = dist
         self.backend = dist.get_backend()
+        self.world = dist.get_world_size()
         # The sharded step issues 8 collectives; dist.all_reduce() spends ~25 us of host time per call in argument
         # checks before it reaches the process group.  Call the group object directly when this torch exposes it.
         self._pg = self._opts = self._opts_avg = None
@@ -598,6 +652,7 @@ class NativeComm:
         from . import native
 
         self.torch, self.lib, self.check = torch, native.lib, native.check
+        self.world = dist.get_world_size()
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the copy this process already runs
         self.check(self.lib.idg_comm_load(path.encode() if os.path.exists(path) else None), "idg_comm_load")
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -761,6 +816,7 @@ class NoComm:
     """world_size 1."""
 
     averages = True
+    world = 1
 
     def all_reduce_async(self, t, average=False):
         return None
@@ -881,9 +937,10 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                                    "the reference, trainer.py:36); item table replicated; per step %d all-reduces of the "
                                    "[%d,%d] fp32 item panel in %d slices that overlap the products + 2 of [%d,%d] (the "
                                    "batch's user rows) + 1 of [<=%d,%d] (the last forward layer's item rows, read at the "
-                                   "batch's items only) over %s"
-                                   % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, 2 * K - 1, I, d, len(eng.G_iu), B, d,
-                                      2 * B, d,
+                                   "batch's items only) + the first backward product's live item rows (an [%d] flag vector "
+                                   "and the rows some rank has) over %s"
+                                   % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, max(2 * K - 2, 1), I, d, len(eng.G_iu),
+                                      B, d, 2 * B, d, I,
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
                        "batch": B, "dim": d, "layers": K, "parallelism": "user-row shard x%d" % world,
                        "comm": comm_name, "item_panel_slices": len(eng.G_iu)},
@@ -898,7 +955,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                 "us_user_side": t_ui * 1e6, "us_item_side": t_iu * 1e6, "bytes_gather_user_side": bytes_ui,
                 "bytes_gather_item_side": bytes_iu, "rank0_users": Ug, "rank0_nnz": nnz_ui,
                 "cache_resident": bool(4 * max(I, Ug) * d < (256 << 20)),
-                "exchange_bytes_per_step_per_rank": (2 * K - 1) * 4 * I * d + 4 * 4 * B * d,
+                "exchange_bytes_per_step_per_rank": max(2 * K - 2, 1) * 4 * I * d + 4 * 4 * B * d + 4 * I,  # + the live rows
             },
             "single_gpu_reference": "the same workload on ONE MI355X, unsharded: profiles/r02/bench_c5_single_gpu.json "
                                     "(builder-run; not measured in this run)" if args.workload == "synth-10M" else None,

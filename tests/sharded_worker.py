@@ -41,6 +41,13 @@ class OracleKernels:
     def scatter_rows(self, dst, idx, src):
         dst[idx] = src
 
+    def rows_nonzero(self, panel, flags):
+        flags[...] = (panel != 0).any(axis=1).astype(np.float32)
+
+    def nonzero_ids(self, flags):
+        ids = np.nonzero(flags)[0].astype(np.int64)
+        return ids, len(ids)
+
     def chain_add_rows(self, dst, src, idx, nxt):
         for t in np.nonzero(idx >= 0)[0]:
             acc, j = dst[idx[t]].copy(), t
@@ -109,7 +116,8 @@ def run(rank, world, port, mode, path, steps):
         to_np = lambda a: a.cpu().numpy()  # noqa: E731
     n_slices = int(z["n_slices"]) if "n_slices" in z.files else 1
     eng = sh.ShardedEngine(kern, sh.TorchComm(dist), ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
-                           batch_sparsity=(mode != "gpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices)
+                           batch_sparsity=(mode != "gpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
+                           live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None, live_rows_min_bytes=0)
     Ug = hi - lo
     if mode == "cpu":
         eng.P[:Ug] = W0[lo:hi]

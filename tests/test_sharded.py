@@ -205,6 +205,16 @@ def test_two_ranks_gloo_cpu_match_single_device(K, include0, d, n_slices, tmp_pa
     _check(p, outs, 3, rtol=1e-4, atol=2e-7)
 
 
+def test_first_backward_exchange_falls_back_to_the_panel(tmp_path, golden_small):
+    """More live item rows in the first backward step than the compact buffer holds (here: a buffer of 4 rows): the
+    step exchanges the sliced panel instead, same result."""
+    p = _problem(golden_small, 3, True, B=160, steps=2, d=64, n_slices=2)
+    p["live_cap"] = 4
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    _check(p, _launch("cpu", path, 2), 2, rtol=1e-4, atol=2e-7)
+
+
 def test_three_ranks_gloo_cpu_match_single_device(tmp_path, golden_small):
     """An odd world size: three uneven user blocks (nnz-balanced), ring all-reduces over three ranks, sliced item side."""
     p = _problem(golden_small, 3, True, B=160, steps=3, d=64, n_slices=2)
