@@ -1210,6 +1210,23 @@ __global__ __launch_bounds__(BLOCK) void fixup_generic_kernel(const LongRow* __r
   }
 }
 
+// out |= columns of the stored entries of every row flagged in `in` (one thread per virtual row: a row's pieces are its
+// vrows).  The receptive field of a batch, one hop at a time (idg_graph_expand_rows).
+__global__ __launch_bounds__(BLOCK) void expand_rows_kernel(int64_t n_vrows, const int64_t* __restrict__ vptr,
+                                                            const int32_t* __restrict__ vrow_row,
+                                                            const ColVal* __restrict__ cv, const uint32_t* __restrict__ in,
+                                                            uint32_t* __restrict__ out) {
+  const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (v >= n_vrows) return;
+  const int32_t r = vrow_row[v];
+  if (!((in[r >> 5] >> (r & 31)) & 1u)) return;
+  for (int64_t j = vptr[v]; j < vptr[v + 1]; ++j) {
+    const int32_t c = cv[j].col;
+    const uint32_t bit = 1u << (c & 31);
+    if (!(out[c >> 5] & bit)) atomicOr(&out[c >> 5], bit);
+  }
+}
+
 template <int LPR, int NB>
 int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials, int64_t d,
                 const Epilogue& ep, const uint32_t* x_mask, const uint32_t* out_mask, hipStream_t st) {
@@ -2011,7 +2028,7 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
                             void* ws, hipStream_t st, bool backward, int accumulate,
                             const uint32_t* in_mask = nullptr, float noise_eps = 0.f, uint64_t noise_seed = 0,
                             uint64_t noise_stream = 0, const uint32_t* out_rows = nullptr,
-                            const Epilogue* adam = nullptr) {
+                            const Epilogue* adam = nullptr, const uint32_t* const* fields = nullptr) {
   IDG_REQUIRE(g && in && out && ws, "idg_propagate: NULL argument");
   IDG_REQUIRE(g->n_rows == g->n_cols, "idg_propagate: graph must be square");
   IDG_REQUIRE(K >= 1, "idg_propagate: K must be >= 1 (got %d)", K);
@@ -2081,8 +2098,12 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
         }
       }
     }
-    int rc = spmm_dispatch(g, X, d, d, partials, ep, st, (backward && k == 1) ? in_mask : nullptr,
-                           (!backward && last) ? out_rows : nullptr);
+    // fields (idg_propagate_mean*_fields_f32): forward, the rows layer k has to produce; backward, the live rows of
+    // step k's input (step 1: those of g) — the batch's receptive field, hop by hop
+    const uint32_t* x_mask = backward ? (fields ? fields[k - 1] : (k == 1 ? in_mask : nullptr)) : nullptr;
+    if (backward && last && adam) x_mask = nullptr;  // (the Adam epilogue lives in the dense kernel)
+    const uint32_t* o_mask = backward ? nullptr : (fields ? fields[k - 1] : (last ? out_rows : nullptr));
+    int rc = spmm_dispatch(g, X, d, d, partials, ep, st, x_mask, o_mask);
     if (rc != IDG_OK) return rc;
     X = P[(k - 1) & 1];
   }
@@ -2213,10 +2234,53 @@ int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint
   return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate, gout_mask);
 }
 
+static int bwd_adam_impl(const idg_graph* g, const float* gout, const uint32_t* gout_mask, float* gE0, int K,
+                         int include_layer0, int64_t d, int accumulate, float* param, float* exp_avg, float* exp_avg_sq,
+                         double lr, double beta1, double beta2, double eps, int64_t step, void* ws, void* stream,
+                         const uint32_t* const* fields);
+
 int idg_propagate_mean_bwd_adam_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask, float* gE0, int K,
                                     int include_layer0, int64_t d, int accumulate, float* param, float* exp_avg,
                                     float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int64_t step,
                                     void* ws, void* stream) {
+  return bwd_adam_impl(g, gout, gout_mask, gE0, K, include_layer0, d, accumulate, param, exp_avg, exp_avg_sq, lr, beta1, beta2,
+                       eps, step, ws, stream, nullptr);
+}
+
+int idg_propagate_mean_fields_f32(const idg_graph* g, const float* E0, float* out, const uint32_t* const* layer_rows, int K,
+                                  int include_layer0, int64_t d, void* ws, void* stream) {
+  IDG_REQUIRE(layer_rows, "idg_propagate_mean_fields_f32: NULL layer_rows");
+  IDG_REQUIRE(K <= 3, "idg_propagate_mean_fields_f32: up to three layers (the layer mean is formed by the last product)");
+  return propagate_common(g, E0, out, K, include_layer0, d, ws, (hipStream_t)stream, false, 0, nullptr, 0.f, 0, 0,
+                          layer_rows[K - 1], nullptr, layer_rows);
+}
+
+int idg_propagate_mean_bwd_adam_fields_f32(const idg_graph* g, const float* gout, const uint32_t* const* step_rows, float* gE0,
+                                           int K, int include_layer0, int64_t d, int accumulate, float* param,
+                                           float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                                           double eps, int64_t step, void* ws, void* stream) {
+  IDG_REQUIRE(step_rows && step_rows[0], "idg_propagate_mean_bwd_adam_fields_f32: NULL step_rows");
+  return bwd_adam_impl(g, gout, step_rows[0], gE0, K, include_layer0, d, accumulate, param, exp_avg, exp_avg_sq, lr, beta1,
+                       beta2, eps, step, ws, stream, step_rows);
+}
+
+int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t* out_rows, void* stream) {
+  IDG_REQUIRE(g && in_rows && out_rows && in_rows != out_rows, "idg_graph_expand_rows: bad argument");
+  IDG_REQUIRE(g->n_rows == g->n_cols, "idg_graph_expand_rows: graph must be square");
+  IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_expand_rows: handle without a vrow -> row table");
+  hipStream_t st = (hipStream_t)stream;
+  IDG_HIP(hipMemcpyAsync(out_rows, in_rows, (size_t)((g->n_rows + 31) / 32) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  if (g->n_vrows > 0)
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((g->n_vrows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, g->n_vrows,
+                       g->d_vptr, g->d_vrow_row, g->d_cv, in_rows, out_rows);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+static int bwd_adam_impl(const idg_graph* g, const float* gout, const uint32_t* gout_mask, float* gE0, int K,
+                         int include_layer0, int64_t d, int accumulate, float* param, float* exp_avg, float* exp_avg_sq,
+                         double lr, double beta1, double beta2, double eps, int64_t step, void* ws, void* stream,
+                         const uint32_t* const* fields) {
   IDG_REQUIRE(g, "idg_propagate_mean_bwd_adam_f32: NULL graph");
   IDG_REQUIRE(g->flags & IDG_GRAPH_SYMMETRIC, "idg_propagate_mean_bwd_adam_f32: graph not flagged IDG_GRAPH_SYMMETRIC");
   IDG_REQUIRE(param && exp_avg && exp_avg_sq && gE0, "idg_propagate_mean_bwd_adam_f32: NULL argument");
@@ -2239,7 +2303,7 @@ int idg_propagate_mean_bwd_adam_f32(const idg_graph* g, const float* gout, const
   adam.adam_w1 = (float)(1.0 - beta1), adam.adam_beta2 = (float)beta2, adam.adam_w2 = (float)(1.0 - beta2);
   adam.adam_step_size = (float)(lr / bc1), adam.adam_bc2_sqrt = (float)std::sqrt(bc2), adam.adam_eps = (float)eps;
   return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate, gout_mask, 0.f, 0, 0,
-                          nullptr, &adam);
+                          nullptr, &adam, fields);
 }
 
 }  // extern "C"

@@ -258,6 +258,48 @@ class Graph:
               "idg_propagate_mean_bwd_f32")
         return out
 
+    # ---- the batch's receptive field (idg_graph_expand_rows, idg_propagate_mean*_fields_f32)
+    def expand_rows(self, in_rows, out_rows, stream=None):
+        """out_rows = in_rows | neighbours of the rows flagged in in_rows (int32 bitmap tensors of n_rows bits)."""
+        _require_device(in_rows, out_rows)
+        check(lib.idg_graph_expand_rows(self._h, _ptr(in_rows), _ptr(out_rows), _stream() if stream is None else stream),
+              "idg_graph_expand_rows")
+
+    @staticmethod
+    def _bitmap_array(bitmaps):
+        arr = (C.c_void_p * len(bitmaps))(*[None if b is None else b.data_ptr() for b in bitmaps])
+        return arr
+
+    def propagate_mean_fields_raw(self, E0, K, include_layer0, out, layer_rows):
+        """idg_propagate_mean_fields_f32: layer k produces the rows of layer_rows[k-1] only (K bitmaps, the last = the
+        batch's rows)."""
+        _require_device(E0, out, *layer_rows)
+        E0 = _f32c(E0, "E0")
+        d = E0.shape[1]
+        if len(layer_rows) != K:
+            raise ValueError("layer_rows needs K bitmaps")
+        ws = self._workspace("prop", d)
+        check(lib.idg_propagate_mean_fields_f32(self._h, _ptr(E0), _ptr(out), self._bitmap_array(layer_rows), int(K),
+                                                int(bool(include_layer0)), d, _ptr(ws), _stream()),
+              "idg_propagate_mean_fields_f32")
+        return out
+
+    def propagate_mean_bwd_adam_fields_raw(self, gout, K, include_layer0, out, accumulate, step_rows, param, exp_avg,
+                                           exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+        """idg_propagate_mean_bwd_adam_fields_f32: step k's input is zero outside step_rows[k-1] (None = dense)."""
+        _require_device(gout, out, param, exp_avg, exp_avg_sq, *[b for b in step_rows if b is not None])
+        gout = _f32c(gout, "gout")
+        d = gout.shape[1]
+        if len(step_rows) != K or step_rows[0] is None:
+            raise ValueError("step_rows needs K entries, the first a bitmap")
+        ws = self._workspace("prop", d)
+        check(lib.idg_propagate_mean_bwd_adam_fields_f32(self._h, _ptr(gout), self._bitmap_array(step_rows), _ptr(out), int(K),
+                                                         int(bool(include_layer0)), d, int(bool(accumulate)), _ptr(param),
+                                                         _ptr(exp_avg), _ptr(exp_avg_sq), float(lr), float(beta1),
+                                                         float(beta2), float(eps), int(step), _ptr(ws), _stream()),
+              "idg_propagate_mean_bwd_adam_fields_f32")
+        return out
+
     def propagate_mean_bwd_adam_raw(self, gout, K, include_layer0, out, accumulate, mask, param, exp_avg, exp_avg_sq, lr,
                                     step, beta1=0.9, beta2=0.999, eps=1e-8):
         """idg_propagate_mean_bwd_adam_f32: the backward above with the dense Adam step on `param` applied in the

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 115 /* 0.1.13: + idg_rows_nonzero_f32 (sparse exchange of the sharded step) */
+#define IDG_VERSION 116 /* 0.1.14: + receptive-field propagation (idg_graph_expand_rows, idg_propagate_mean*_fields_f32) */
 
 /* error classes */
 #define IDG_OK 0
@@ -168,6 +168,26 @@ size_t idg_graph_live_units_bytes(const idg_graph* g, int64_t max_rows);
 int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream);
 int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows);
 int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap);
+
+/* The batch's receptive field (no reference counterpart: the reference propagates the whole graph every step,
+ * models/LightGCN.py:36-52, although the loss reads the final layer at the batch's rows only).  Layer K is needed at the
+ * batch's rows S, layer K - 1 at S and their neighbours, and so on; the gradient flows back through the same sets.  On a
+ * graph much larger than the batch's K-hop neighbourhood most of every product is work nobody reads.
+ * idg_graph_expand_rows: out_rows = in_rows | {columns of the stored entries of the rows flagged in in_rows} (bitmaps of
+ *   n_rows bits, distinct buffers) — one hop.
+ * idg_propagate_mean_fields_f32: idg_propagate_mean_f32 with layer k producing the rows of layer_rows[k-1] only (host
+ *   array of K device bitmaps; layer_rows[K-1] = the batch's rows; each set must contain the neighbours of the next).
+ *   Rows outside the sets keep whatever the buffers held.  Same bits on the produced rows as the full propagation.
+ * idg_propagate_mean_bwd_adam_fields_f32: idg_propagate_mean_bwd_adam_f32 where step k's input is known to be zero
+ *   outside step_rows[k-1] (step_rows[0] = live rows of gout; NULL = dense; the last step is always dense: it carries
+ *   the Adam update of every row).  Same bits as the unrestricted call. */
+int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t* out_rows, void* stream);
+int idg_propagate_mean_fields_f32(const idg_graph* g, const float* E0, float* out, const uint32_t* const* layer_rows, int K,
+                                  int include_layer0, int64_t d, void* ws, void* stream);
+int idg_propagate_mean_bwd_adam_fields_f32(const idg_graph* g, const float* gout, const uint32_t* const* step_rows, float* gE0,
+                                           int K, int include_layer0, int64_t d, int accumulate, float* param,
+                                           float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                                           double eps, int64_t step, void* ws, void* stream);
 
 /* A copy of `g` with NEW VALUES on the same structure and schedule, taken from a DEVICE CSR (indptr int64 [n_rows+1],
  * indices int32 ascending per row, values fp32) that holds every entry of g (it may hold more): entry (r, c) takes the

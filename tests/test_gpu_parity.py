@@ -920,6 +920,63 @@ def test_live_unit_list_equals_tile_form(ops, d, exact):
     assert torch.equal(unit_out.index_select(0, rows_d), full.index_select(0, rows_d))
 
 
+@pytest.mark.parametrize("d,K", [(64, 3), (32, 2), (256, 3)])
+def test_receptive_field_propagation(ops, d, K):
+    """idg_graph_expand_rows + idg_propagate_mean_fields_f32 + idg_propagate_mean_bwd_adam_fields_f32 on a graph much
+    larger than a batch's K-hop neighbourhood: hop sets equal to the CSR's, the restricted forward bit-equal to the full
+    one on the batch's rows, the restricted backward + Adam bit-equal to the unrestricted call on EVERY row."""
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    U, I, E = 90000, 60000, 380000
+    users, items = S.generate(U, I, E, seed=11)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n = U + I
+    G = ops.Graph(ip, ix, dv, n, n)
+    rng = np.random.default_rng(d)
+    e = rng.integers(0, len(users), 24)
+    batch = np.unique(np.concatenate([users[e], U + items[e], U + rng.integers(0, I, 24)]))
+    words = (n + 31) // 32
+
+    def to_bitmap(rows):
+        b = np.zeros(words, dtype=np.uint32)
+        np.bitwise_or.at(b, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
+        return dev(b.view(np.int32))
+
+    def from_bitmap(t):
+        bits = np.unpackbits(t.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+        return np.nonzero(bits)[0]
+
+    hops, sets = [to_bitmap(batch)], [batch]
+    for _ in range(K - 1):
+        nxt = torch.zeros(words, dtype=torch.int32, device="cuda")
+        G.expand_rows(hops[-1], nxt)
+        want = np.unique(np.concatenate([sets[-1]] + [ix[ip[r]:ip[r + 1]] for r in sets[-1]]))
+        assert np.array_equal(from_bitmap(nxt), want)
+        hops.append(nxt)
+        sets.append(want)
+    assert len(sets[-1]) < 0.8 * n  # the point of the exercise: the field is not the graph
+    E0 = torch.randn(n, d, device="cuda") * 0.1
+    full = G.propagate_mean_raw(E0, K, True)
+    fin = torch.full((n, d), float("nan"), device="cuda")
+    G.propagate_mean_fields_raw(E0, K, True, fin, hops[::-1])  # layer 1 produces the widest set, layer K the batch
+    rows_d = dev(batch)
+    assert torch.equal(fin.index_select(0, rows_d), full.index_select(0, rows_d))
+    # backward: gout non-zero on the batch's rows only
+    gout = torch.zeros(n, d, device="cuda")
+    gout[rows_d] = torch.randn(len(batch), d, device="cuda")
+    state = lambda: (E0.clone(), torch.zeros(n, d, device="cuda"), torch.rand(n, d, device="cuda") * 1e-3,  # noqa: E731
+                     torch.rand(n, d, device="cuda") * 1e-6)
+    torch.manual_seed(5)
+    p1, g1, m1, v1 = state()
+    torch.manual_seed(5)
+    p2, g2, m2, v2 = state()
+    G.propagate_mean_bwd_adam_raw(gout, K, True, g1, True, hops[0], p1, m1, v1, 1e-3, 3)
+    G.propagate_mean_bwd_adam_fields_raw(gout, K, True, g2, True, hops[:K - 1] + [None], p2, m2, v2, 1e-3, 3)
+    for a, b in ((p1, p2), (g1, g2), (m1, m2), (v1, v2)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("keep_prob", [0.9, 0.3])
 def test_node_dropout_masked_copy(ops, golden_small, keep_prob):
     """NGCF.node_dropout (models/NGCF.py:56-65) as a masked copy of the handle: an entry survives where
