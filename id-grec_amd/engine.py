@@ -10,6 +10,8 @@ operators in ops.py execute (tests compare the two), so models may use either.
 Embedding layout: ONE [num_users + num_items, d] panel, users first; the model's two
 nn.Embedding weights are views into it (no torch.cat per step).
 """
+import os
+
 import torch
 
 from . import ops
@@ -46,6 +48,14 @@ class PropagationEngine:
         self._side = ops.side_stream(dev) if self.deterministic else None
         self._side_raw = self._side.cuda_stream if self._side is not None else None  # launches name their stream explicitly
         self._fork = ops.LocalEvent() if self._side is not None else None  # device-local events (ops.LocalEvent) throughout
+        # Receptive-field propagation (plain LightGCN step, K = 2 or 3): layer K is read at the batch's rows, so layer
+        # k is produced on their (K - k)-hop neighbourhood only, and the gradient flows back through the same sets —
+        # exact, and most of every product on a graph much larger than that neighbourhood (configs[4]: 15 M rows, the
+        # two-hop set of a 1024-triple batch ~17 % of them).  On graphs two hops cover (yelp2018, amazon-book) it only
+        # costs the hop bitmaps, hence the row threshold.  IDG_FIELDS=0/1 forces it off / on.
+        want = os.environ.get("IDG_FIELDS", "")
+        self._fields = (self.graph is not None and self.deterministic and self.K in (2, 3)
+                        and (want == "1" or (want != "0" and self.n >= 4_000_000)))
         self._id_storage = None  # storages of the id tensors last ordered against the main stream
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
@@ -91,6 +101,8 @@ class PropagationEngine:
         def __init__(self, words, device):
             self.bitmap = torch.zeros(words, dtype=torch.int32, device=device)
             self.units, self.units_B = None, -1  # live work units of the bitmap (Graph.live_units), rebuilt with it
+            self.hops = None  # [rows of the batch, + 1 hop, + 2 hops ...] (receptive-field propagation)
+            self.use_fields = False
             self.ids = None
             self.ws = None
             self.key = None
@@ -122,6 +134,14 @@ class PropagationEngine:
             slot.units = self.graph.live_units(slot.bitmap, 3 * B, ws=slot.units if slot.units_B == B else None,
                                                stream=self._side_raw)
             slot.units_B = B
+            # (... and much larger than THIS batch's neighbourhood: with ~256 distinct two-hop rows per batch row the
+            #  field of a 2^20-triple batch is the graph, and the restricted kernels only cost: 355 vs 342 ms measured)
+            slot.use_fields = self._fields and 3 * B * 256 <= self.n
+            if slot.use_fields:
+                if slot.hops is None:
+                    slot.hops = [slot.bitmap] + [torch.zeros_like(slot.bitmap) for _ in range(self.K - 1)]
+                for j in range(1, self.K):
+                    self.graph.expand_rows(slot.hops[j - 1], slot.hops[j], stream=self._side_raw)
             slot.rows_done.record(self._side_raw)  # needed by the last forward layer
         ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
         slot.plan_done.record(self._side_raw)  # needed by the gradient scatter
@@ -221,6 +241,11 @@ class PropagationEngine:
                                                 out_rows=slot.bitmap)
             seed1, sid1 = ops.layer_noise_stream(stream, 1)  # layer 1 again, on its own, for the rows of the batch
             ops.spmm_noise_raw(self.graph, self.params, eps, seed1, sid1, out=self._views[0], out_rows=slot.bitmap)
+        elif slot.use_fields and self.sgl is None and self.exchange is None:
+            # layer 1 on the widest hop set ... layer K on the batch's rows.  (The widest set holds the popular items
+            # and the active users — most stored entries point into it although it is a minority of the rows — and the
+            # row-restricted kernel is no faster there than the dense one: leaving layer 1 dense measured 216 vs 212 ms.)
+            self.graph.propagate_mean_fields_raw(self.params, self.K, self.inc, self.final, slot.hops[::-1])
         else:
             self.graph.propagate_mean_raw(self.params, self.K, self.inc, out=self.final, out_rows=slot.bitmap)
         if self.sgl is not None:
@@ -289,7 +314,13 @@ class PropagationEngine:
         mask = slot.bitmap
         if self.exchange is not None:
             mask = self.touched = self.exchange(slot, loss)
-        if _adam_step > 0:
+        if _adam_step > 0 and slot.use_fields and not three and self.exchange is None:
+            # g_final is non-zero on the batch's rows; step k's input lives on their (k - 1)-hop set
+            self.graph.propagate_mean_bwd_adam_fields_raw(self.g_final, self.K, self.inc, self.grad, True,
+                                                          slot.hops[: self.K - 1] + [None], self.params, self.exp_avg,
+                                                          self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
+                                                          self.betas[1], self.eps)
+        elif _adam_step > 0:
             self.graph.propagate_mean_bwd_adam_raw(self.g_final, self.K, self.inc, self.grad, True, mask, self.params,
                                                    self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
                                                    self.betas[1], self.eps)

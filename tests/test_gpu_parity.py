@@ -977,6 +977,43 @@ def test_receptive_field_propagation(ops, d, K):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("K", [3, 2])
+def test_engine_receptive_field_steps_are_the_plain_steps(ops, K, monkeypatch):
+    """The fused LightGCN step with receptive-field propagation (IDG_FIELDS=1; automatic from 4 M rows on) against the
+    same steps without it: identical losses and identical tables, bit for bit, after every step — with and without the
+    one-batch lookahead."""
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+
+    U, I, E = 90000, 60000, 380000
+    users, items = S.generate(U, I, E, seed=11)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n, d, B, steps = U + I, 64, 32, 5
+    W0 = S.xavier_uniform_panel(U, I, d, 7)
+    tri = dev(S.draw_triples(7, users, items, U, I, steps * B)[0][: steps * B])
+    tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
+    G = ops.Graph(ip, ix, dv, n, n)
+
+    def run(fields):
+        monkeypatch.setenv("IDG_FIELDS", fields)
+        eng = PropagationEngine(G, U, I, d, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3, params=W0.cuda())
+        assert eng._fields == (fields == "1")
+        losses = torch.zeros(steps, 2, device="cuda")
+        for i in range(steps):
+            sl = slice(i * B, (i + 1) * B)
+            if i % 2 == 0 and i + 1 < steps:
+                nx = slice((i + 1) * B, (i + 2) * B)
+                eng.prefetch(tu[nx], tp[nx], tn[nx])
+            eng.train_step(tu[sl], tp[sl], tn[sl], loss_out=losses[i])
+        torch.cuda.synchronize()
+        return losses.clone(), eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()
+
+    plain, field = run("0"), run("1")
+    for a, b in zip(plain, field):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("keep_prob", [0.9, 0.3])
 def test_node_dropout_masked_copy(ops, golden_small, keep_prob):
     """NGCF.node_dropout (models/NGCF.py:56-65) as a masked copy of the handle: an entry survives where
