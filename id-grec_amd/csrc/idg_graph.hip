@@ -1227,6 +1227,18 @@ __global__ __launch_bounds__(BLOCK) void expand_rows_kernel(int64_t n_vrows, con
   }
 }
 
+// col_flags[c] = 1.0f for every column c of a stored entry of a row flagged in `in` (any graph shape; the flags are
+// floats because the ranks of a sharded step SUM them: idg_graph_flag_cols).
+__global__ __launch_bounds__(BLOCK) void flag_cols_kernel(int64_t n_vrows, const int64_t* __restrict__ vptr,
+                                                          const int32_t* __restrict__ vrow_row, const ColVal* __restrict__ cv,
+                                                          const uint32_t* __restrict__ in, float* __restrict__ col_flags) {
+  const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (v >= n_vrows) return;
+  const int32_t r = vrow_row[v];
+  if (!((in[r >> 5] >> (r & 31)) & 1u)) return;
+  for (int64_t j = vptr[v]; j < vptr[v + 1]; ++j) col_flags[cv[j].col] = 1.0f;  // (same value from every writer)
+}
+
 template <int LPR, int NB>
 int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials, int64_t d,
                 const Epilogue& ep, const uint32_t* x_mask, const uint32_t* out_mask, hipStream_t st) {
@@ -2273,6 +2285,16 @@ int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t*
   if (g->n_vrows > 0)
     hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((g->n_vrows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, g->n_vrows,
                        g->d_vptr, g->d_vrow_row, g->d_cv, in_rows, out_rows);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_graph_flag_cols(const idg_graph* g, const uint32_t* in_rows, float* col_flags, void* stream) {
+  IDG_REQUIRE(g && in_rows && col_flags, "idg_graph_flag_cols: bad argument");
+  IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_flag_cols: handle without a vrow -> row table");
+  if (g->n_vrows > 0)
+    hipLaunchKernelGGL(flag_cols_kernel, dim3((unsigned)((g->n_vrows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       g->n_vrows, g->d_vptr, g->d_vrow_row, g->d_cv, in_rows, col_flags);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }

@@ -265,6 +265,13 @@ class Graph:
         check(lib.idg_graph_expand_rows(self._h, _ptr(in_rows), _ptr(out_rows), _stream() if stream is None else stream),
               "idg_graph_expand_rows")
 
+    def flag_cols(self, in_rows, col_flags, stream=None):
+        """col_flags[c] = 1.0 for the columns of the stored entries of the rows flagged in in_rows (float32 [n_cols],
+        zeroed by the caller): idg_graph_flag_cols."""
+        _require_device(in_rows, col_flags)
+        check(lib.idg_graph_flag_cols(self._h, _ptr(in_rows), _ptr(col_flags), _stream() if stream is None else stream),
+              "idg_graph_flag_cols")
+
     @staticmethod
     def _bitmap_array(bitmaps):
         arr = (C.c_void_p * len(bitmaps))(*[None if b is None else b.data_ptr() for b in bitmaps])

@@ -123,11 +123,11 @@ class ShardedEngine:
     (x + 0 + ... + 0: exact) hand them to every rank, and every rank evaluates the WHOLE batch's BPR loss — so the
     loss and the item-side gradient g_I are complete and bit-identical on every rank without any [I, d] exchange, and
     the user-side gradient rows flow back from the guest rows to their owners' rows (chained adds in batch order).
-    Per step: K - 1 forward + K - 1 backward all-reduces of the [I, d] item panel, cut into slices that overlap the
-    products, plus the two [B, d] ones, one of [<= 2B, d] — the LAST forward layer's item rows are read at
-    the batch's positive / negative items only, so its partial sums travel as those rows, not as the panel — and, for
-    the FIRST backward product (input non-zero at the batch's users only), an [I] vector of row flags and the rows
-    somebody has (_exchange_live_rows)."""
+    Per step: K - 2 forward + K - 1 backward all-reduces of the [I, d] item panel (3 at K = 3; round 1: 7), cut into
+    slices that overlap the products, plus the two [B, d] ones, one of [<= 2B, d] — the LAST forward
+    layer's item rows are read at the batch's positive / negative items only — and the item rows the batch's users touch
+    for forward layer K - 1 and the first backward product, after an [I] vector of flags to agree on them
+    (_agree_touched_items)."""
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
                  reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None,
@@ -242,32 +242,32 @@ class ShardedEngine:
         for w in works:
             self.comm.wait(w)
 
-    def _exchange_live_rows(self, panel):
-        """Sum over the ranks of an item panel that is zero almost everywhere on every rank (the first backward
-        product: its input is non-zero at the batch's users only, so a rank's partial lives on the items those users
-        interacted with).  Instead of the [I, d] all-reduce: every rank flags its non-zero rows (a row that happens to
-        be all zero adds nothing to any sum: leaving it out is exact), the flags are summed ([I] floats), the rows
-        somebody has — the same ascending list on every rank — are gathered, all-reduced as a compact buffer and put
-        back.  More live rows than the buffer holds (a batch full of hub users): the plain sliced all-reduce.
-        Returns the collectives still in flight."""
+    def _agree_touched_items(self, prep, gb):
+        """The item rows a training batch touches beyond its own positives / negatives: the items its USERS interacted
+        with.  Every rank flags those of the batch users it owns (idg_graph_flag_cols over its block of R), adds the
+        batch's items, the flags are summed over the ranks ([I] floats: 20 MB at configs[4]) and every rank reads off
+        the same ascending id list — the one host synchronisation of the step.  Two exchanges then carry these rows
+        instead of the [I, d] panel: layer K - 1 of the forward pass (the last user-side product, restricted to the
+        batch's users, gathers X_I(K-1) at exactly these rows, and FIN needs it at the batch's items) and the first
+        backward product (whose partials are zero elsewhere).  Returns (ids, n) or None: world size 1, a panel too
+        small to be worth it, kernels without the index work, or more rows than the compact buffer holds."""
+        if gb is None or getattr(self.comm, "world", 2) == 1 or self.I * self.d * 4 < self.live_rows_min_bytes:
+            return None
         k = self.k
-        if getattr(self.comm, "world", 2) == 1:
-            return []  # nothing to sum
-        if self.I * self.d * 4 < self.live_rows_min_bytes:
-            # a small panel: its all-reduce costs less than the flag exchange and the host synchronisation that sizes
-            # the compact one (measured at world size 1 on the 9.7 MB panel of the yelp2018 shape: +48 us per step)
-            return [self.comm.all_reduce_async(panel[r0:r1]) for _, r0, r1 in self.G_iu]
-        k.rows_nonzero(panel, self.FL)
+        if not k.flag_touched_items(self, prep, gb, self.FL):
+            return None
         self.comm.wait(self.comm.all_reduce_async(self.FL))
-        ids, n = k.nonzero_ids(self.FL)  # (the one host synchronisation of the step: the collective's size)
-        if n == 0:
-            return []
-        if n > self.CS.shape[0]:
-            return [self.comm.all_reduce_async(panel[r0:r1]) for _, r0, r1 in self.G_iu]
-        k.gather_rows(self.CS[:n], panel, ids)
+        ids, n = k.nonzero_ids(self.FL)
+        if n == 0 or n > self.CS.shape[0]:
+            return None
+        return ids, n
+
+    def _sum_rows(self, panel, rows):
+        """all-reduce of the panel's rows `rows` = (ids, n) through the compact buffer (synchronous: small)."""
+        ids, n = rows
+        self.k.gather_rows(self.CS[:n], panel, ids)
         self.comm.wait(self.comm.all_reduce_async(self.CS[:n]))
-        k.scatter_rows(panel, ids, self.CS[:n])
-        return []
+        self.k.scatter_rows(panel, ids, self.CS[:n])
 
     # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
     def propagate(self, prep=None, gb=None):
@@ -282,6 +282,7 @@ class ShardedEngine:
         fin_u, fin_i = self._u(self.FIN), self._i(self.FIN)
         xu_prev, xi_prev = self._u(self.P), self._i(self.P)
         pending = [None]  # (works, xi_new, layer, xi_before) of the all-reduce whose result has not been folded in yet
+        self.touched_items = self._agree_touched_items(prep, gb) if K >= 2 else None
 
         def finish():
             if pending[0] is None:
@@ -294,8 +295,13 @@ class ShardedEngine:
                 base = self._i(self.P) if c0 else None
             else:
                 base = fin_i if (c0 or layer > 2) else xi_before
-            if xi_new is None:  # the last layer of a training step: the batch's item rows only (self.CI)
+            if xi_new is None or isinstance(xi_new, tuple):
+                # a layer of a training step whose item rows exist at the batch's items only (the last one: self.CI) or
+                # at the touched items (layer K - 1: rows of its panel): FIN is updated at the batch's items, the only
+                # item rows of FIN the step reads
                 n_t = gb.n_items
+                if xi_new is not None:
+                    k.gather_rows(self.CI[:n_t], xi_new[0], gb.items)
                 if base is not None:
                     k.gather_rows(self.CT[:n_t], base, gb.items)
                 k.lincomb(self.CT[:n_t], self.CI[:n_t], scale, self.CT[:n_t] if base is not None else None, scale)
@@ -316,6 +322,16 @@ class ShardedEngine:
                         finish()
                 k.gather_rows(self.CI[:gb.n_items], xi_new, gb.items)
                 works, xi_fold = [self.comm.all_reduce_async(self.CI[:gb.n_items])], None
+            elif layer == K - 1 and self.touched_items is not None:
+                # layer K - 1 of a training step is read at the touched items only (by the last user-side product, and
+                # by FIN at the batch's items): its partials travel as those rows
+                bits = k.item_rows_bitmap(self, prep, self.touched_items)
+                for j, (g, r0, r1) in enumerate(self.G_iu):
+                    k.spmm(g, xu_prev, Y=xi_new[r0:r1], out_rows=None if bits is None else bits[r0 // 32:])
+                    if j == 0:
+                        finish()
+                self._sum_rows(xi_new, self.touched_items)
+                works, xi_fold = [], (xi_new,)
             else:
                 # item-side partial of this layer; X_I(layer-1) (the previous collective) is folded in under its first slice
                 works, xi_fold = self._item_side(xu_prev, xi_new, after_first=finish), xi_new
@@ -356,12 +372,16 @@ class ShardedEngine:
             t_i = self.XI[layer % 3]
             if layer == K and gb is not None:
                 # the first step of a training batch: h_U = g_U is non-zero at the batch's users only — the partial is
-                # exchanged as its live rows (_exchange_live_rows), not as the panel
+                # zero outside the items those users interacted with and travels as those rows (_agree_touched_items)
                 for j, (g, r0, r1) in enumerate(self.G_iu):
                     k.spmm(g, h_u, Y=t_i[r0:r1], x_rows=live)
                     if j == 0:
                         finish()
-                works = self._exchange_live_rows(t_i)
+                if self.touched_items is not None:
+                    self._sum_rows(t_i, self.touched_items)  # (its non-zero rows lie inside the touched items)
+                    works = []
+                else:
+                    works = [self.comm.all_reduce_async(t_i[r0:r1]) for _, r0, r1 in self.G_iu]
             else:
                 works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)   # partial of (A h)_I: needs h_U only
             live = None
@@ -508,6 +528,23 @@ class HipKernels:
     def rows_nonzero(self, panel, flags):
         self.ops.rows_nonzero_raw(panel, flags)
 
+    def flag_touched_items(self, eng, prep, gb, flags):
+        """flags[i] = 1 for the items the batch's OWNED users interacted with, and for the batch's own items."""
+        if prep is None:
+            return False
+        flags.zero_()
+        eng.G_ui.flag_cols(prep.bitmap, flags)  # (prep.bitmap's first U_g bits are this rank's batch users)
+        flags.index_fill_(0, gb.items, 1.0)
+        return True
+
+    def item_rows_bitmap(self, eng, prep, rows):
+        """Bitmap over the item rows `rows` = (ids, n), for the row-restricted item-side product."""
+        if prep is None:
+            return None
+        ids, n = rows
+        self.ops.bpr_touch_rows_raw(ids, ids, ids, 0, prep.field_bitmap, clear_bits=eng.I)
+        return prep.field_bitmap
+
     def nonzero_ids(self, flags):
         """Ascending ids of the non-zero flags and their number (a host synchronisation: the caller sizes a collective)."""
         ids = self.torch.nonzero(flags).reshape(-1)
@@ -526,7 +563,7 @@ class HipKernels:
         return idx.cpu().numpy()
 
     class _Prepared:
-        __slots__ = ("bitmap", "item_bitmap", "ws", "rows_done", "done", "free", "B", "busy")
+        __slots__ = ("bitmap", "item_bitmap", "field_bitmap", "ws", "rows_done", "done", "free", "B", "busy")
 
     def prepare(self, eng, gb):
         """Index-only work of a global batch on a side stream: bitmap of the LOCAL user rows this rank owns in it (the
@@ -544,6 +581,7 @@ class HipKernels:
             # ... and of the batch's item rows (ALL triples' positives and negatives: every rank evaluates the whole
             # batch), by global item id: the last forward layer's item-side product produces these rows only
             prep.item_bitmap = torch.zeros((eng.I + 31) // 32 + 1, dtype=torch.int32, device=self.device)
+            prep.field_bitmap = torch.zeros((eng.I + 31) // 32 + 1, dtype=torch.int32, device=self.device)
             prep.ws, prep.B = ops.bpr_workspace(cap, d, self.device), cap
             prep.rows_done, prep.done, prep.free = ops.LocalEvent(), ops.LocalEvent(), None  # device-local events
             self._pool.append(prep)
@@ -922,6 +960,8 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
             kern.spmm(gph, eng._u(eng.P), Y=eng.XI[0][r0:r1])
 
     t_iu = timed(item_side)
+    rows_form = world > 1 and I * d * 4 >= eng.live_rows_min_bytes  # forward layer K-1 / first backward product as rows
+    n_panel = (max(K - 2, 0) + (K - 1 if K >= 2 else 1)) if rows_form else (K - 1) + K
     bytes_ui = 4 * (Ug + 1) + 8 * nnz_ui + 4 * nnz_ui * d + 4 * Ug * d
     bytes_iu = 4 * (I + 1) + 8 * nnz_iu + 4 * nnz_iu * d + 4 * I * d
     out = None
@@ -937,9 +977,9 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                                    "the reference, trainer.py:36); item table replicated; per step %d all-reduces of the "
                                    "[%d,%d] fp32 item panel in %d slices that overlap the products + 2 of [%d,%d] (the "
                                    "batch's user rows) + 1 of [<=%d,%d] (the last forward layer's item rows, read at the "
-                                   "batch's items only) + the first backward product's live item rows (an [%d] flag vector "
-                                   "and the rows some rank has) over %s"
-                                   % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, max(2 * K - 2, 1), I, d, len(eng.G_iu),
+                                   "batch's items only) + the item rows the batch's users touch, for forward layer K-1 and the "
+                                   "first backward product (an [%d] flag vector to agree on them, then those rows) over %s"
+                                   % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, n_panel, I, d, len(eng.G_iu),
                                       B, d, 2 * B, d, I,
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
                        "batch": B, "dim": d, "layers": K, "parallelism": "user-row shard x%d" % world,
@@ -955,7 +995,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                 "us_user_side": t_ui * 1e6, "us_item_side": t_iu * 1e6, "bytes_gather_user_side": bytes_ui,
                 "bytes_gather_item_side": bytes_iu, "rank0_users": Ug, "rank0_nnz": nnz_ui,
                 "cache_resident": bool(4 * max(I, Ug) * d < (256 << 20)),
-                "exchange_bytes_per_step_per_rank": max(2 * K - 2, 1) * 4 * I * d + 4 * 4 * B * d + 4 * I,  # + the live rows
+                "exchange_bytes_per_step_per_rank": n_panel * 4 * I * d + 4 * 4 * B * d + 4 * I,  # + the touched rows
             },
             "single_gpu_reference": "the same workload on ONE MI355X, unsharded: profiles/r02/bench_c5_single_gpu.json "
                                     "(builder-run; not measured in this run)" if args.workload == "synth-10M" else None,

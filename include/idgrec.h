@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 116 /* 0.1.14: + receptive-field propagation (idg_graph_expand_rows, idg_propagate_mean*_fields_f32) */
+#define IDG_VERSION 117 /* 0.1.15: + receptive-field propagation (idg_graph_expand_rows / _flag_cols, idg_propagate_mean*_fields_f32) */
 
 /* error classes */
 #define IDG_OK 0
@@ -182,6 +182,10 @@ int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap);
  *   outside step_rows[k-1] (step_rows[0] = live rows of gout; NULL = dense; the last step is always dense: it carries
  *   the Adam update of every row).  Same bits as the unrestricted call. */
 int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t* out_rows, void* stream);
+/* The same hop on a graph of any shape, as float flags over the COLUMNS (caller-zeroed, n_cols floats): col_flags[c] =
+ * 1.0f for every column of a stored entry of a row flagged in in_rows (n_rows bits).  The ranks of the sharded step sum
+ * these to agree on the item rows a batch's users touch. */
+int idg_graph_flag_cols(const idg_graph* g, const uint32_t* in_rows, float* col_flags, void* stream);
 int idg_propagate_mean_fields_f32(const idg_graph* g, const float* E0, float* out, const uint32_t* const* layer_rows, int K,
                                   int include_layer0, int64_t d, void* ws, void* stream);
 int idg_propagate_mean_bwd_adam_fields_f32(const idg_graph* g, const float* gout, const uint32_t* const* step_rows, float* gE0,

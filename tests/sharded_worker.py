@@ -44,6 +44,17 @@ class OracleKernels:
     def rows_nonzero(self, panel, flags):
         flags[...] = (panel != 0).any(axis=1).astype(np.float32)
 
+    def flag_touched_items(self, eng, prep, gb, flags):
+        ptr, idx = eng.G_ui[0], eng.G_ui[1]
+        flags[...] = 0
+        for u in np.unique(gb.own_users):
+            flags[idx[ptr[u]:ptr[u + 1]]] = 1
+        flags[gb.items] = 1
+        return True
+
+    def item_rows_bitmap(self, eng, prep, rows):
+        return None  # (the checker-backed stub produces every row)
+
     def nonzero_ids(self, flags):
         ids = np.nonzero(flags)[0].astype(np.int64)
         return ids, len(ids)

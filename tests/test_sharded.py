@@ -55,7 +55,9 @@ def _check(p, outs, steps, rtol, atol, sparse=False):
     for o in outs:
         lo, hi = int(o["lo"]), int(o["hi"])
         np.testing.assert_allclose(o["losses"], losses, rtol=rtol)                  # identical on every rank
-        rows = o["fin_rows"] if sparse else np.arange(hi - lo)   # batch sparsity: only the batch's users are produced
+        # a training step's forward is exact where its loss reads it: the batch's users (layer K - 1 reaches them through
+        # the item rows the batch touches only; with prepared batches the last user-side product produces nothing else)
+        rows = o["fin_rows"]
         np.testing.assert_allclose(o["FIN"][: hi - lo][rows], fin[lo:hi][rows], rtol=rtol, atol=atol)
         it = o["fin_items"]  # a training step's forward produces the item rows its loss reads, no others
         np.testing.assert_allclose(o["FIN"][hi - lo:][it], fin[U:][it], rtol=rtol, atol=atol)
