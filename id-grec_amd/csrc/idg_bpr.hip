@@ -414,17 +414,6 @@ __global__ __launch_bounds__(BLOCK) void rows_gather_kernel(float* __restrict__ 
   for (int64_t f = threadIdx.x % 64; f < d; f += 64) dst[t * d + f] = r >= 0 ? src[r * d + f] : 0.f;
 }
 
-// flags[r] = 1 if row r of the panel has a non-zero element, else 0   (one wave per row)
-__global__ __launch_bounds__(BLOCK) void rows_nonzero_kernel(const float* __restrict__ panel, int64_t n_rows, int64_t d,
-                                                             float* __restrict__ flags) {
-  const int64_t r = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
-  if (r >= n_rows) return;
-  bool any = false;
-  for (int64_t f = threadIdx.x % 64; f < d; f += 64) any = any || panel[r * d + f] != 0.f;
-  const bool row = __ballot(any) != 0ull;
-  if (threadIdx.x % 64 == 0) flags[r] = row ? 1.f : 0.f;
-}
-
 // For every t with idx[t] >= 0 (the head of a chain): dst[idx[t]] += src[t] + src[next[t]] + src[next[next[t]]] + ...
 // added in chain order (the caller links the occurrences of one destination in list order), one wave per chain: no
 // atomics, run-to-run identical bits.
@@ -849,15 +838,6 @@ int idg_rows_gather_f32(float* dst, const float* src, const int64_t* idx, int64_
   if (count == 0) return IDG_OK;
   hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)((count + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
                      (hipStream_t)stream, dst, src, idx, count, d);
-  IDG_HIP(hipGetLastError());
-  return IDG_OK;
-}
-
-int idg_rows_nonzero_f32(const float* panel, int64_t n_rows, int64_t d, float* flags, void* stream) {
-  IDG_REQUIRE(panel && flags && n_rows >= 0 && d > 0, "idg_rows_nonzero_f32: bad argument");
-  if (n_rows == 0) return IDG_OK;
-  hipLaunchKernelGGL(rows_nonzero_kernel, dim3((unsigned)((n_rows + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
-                     (hipStream_t)stream, panel, n_rows, d, flags);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }

@@ -57,7 +57,6 @@ PROTOTYPES = {
     "idg_lincomb_f32": (C.c_int, [c_vp, c_vp, C.c_float, c_vp, C.c_float, C.c_int64, c_vp]),
     "idg_rows_gather_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
     "idg_rows_chain_add_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
-    "idg_rows_nonzero_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_spmm_noise_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, C.c_float, C.c_uint64, C.c_uint64,
                                      c_vp, c_vp]),
     "idg_perturb_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, C.c_float, C.c_uint64, C.c_uint64, c_vp]),

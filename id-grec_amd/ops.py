@@ -361,14 +361,6 @@ def rows_gather_raw(dst, src, idx):
     check(lib.idg_rows_gather_f32(_ptr(dst), _ptr(src), _ptr(idx), idx.shape[0], src.shape[1], _stream()), "idg_rows_gather_f32")
 
 
-def rows_nonzero_raw(panel, flags):
-    """idg_rows_nonzero_f32: flags[r] = 1.0 where row r of the [n, d] panel has a non-zero element, else 0.0."""
-    _require_device(panel, flags)
-    if panel.dtype != torch.float32 or not panel.is_contiguous() or flags.dtype != torch.float32 or flags.numel() < panel.shape[0]:
-        raise TypeError("rows_nonzero_raw: contiguous float32 panel, float32 flags [n]")
-    check(lib.idg_rows_nonzero_f32(_ptr(panel), panel.shape[0], panel.shape[1], _ptr(flags), _stream()), "idg_rows_nonzero_f32")
-
-
 def rows_chain_add_raw(dst, src, idx, nxt):
     """idg_rows_chain_add_f32: dst[idx[t]] += src[t] + src[nxt[t]] + ... for every chain head t (idx[t] >= 0)."""
     _require_device(dst, src, idx, nxt)

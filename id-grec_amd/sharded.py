@@ -525,9 +525,6 @@ class HipKernels:
         """dst[idx[j]] = src[j] (idx distinct)."""
         dst.index_copy_(0, idx, src)
 
-    def rows_nonzero(self, panel, flags):
-        self.ops.rows_nonzero_raw(panel, flags)
-
     def flag_touched_items(self, eng, prep, gb, flags):
         """flags[i] = 1 for the items the batch's OWNED users interacted with, and for the batch's own items."""
         if prep is None:

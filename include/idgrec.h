@@ -473,10 +473,6 @@ int idg_lincomb_f32(float* out, const float* x, float a, const float* y, float b
 int idg_rows_gather_f32(float* dst, const float* src, const int64_t* idx, int64_t count, int64_t d, void* stream);
 int idg_rows_chain_add_f32(float* dst, const float* src, const int64_t* idx, const int64_t* next, int64_t count,
                            int64_t d, void* stream);
-/* flags[r] = 1.0f if row r of panel [n_rows, d] has a non-zero element, else 0.0f.  The first backward product of the
- * sharded step (its input is non-zero at the batch's users only) leaves a mostly-zero item panel on every rank: the
- * ranks sum these flags, and only the rows somebody has are exchanged (no reference counterpart). */
-int idg_rows_nonzero_f32(const float* panel, int64_t n_rows, int64_t d, float* flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: full-rank scoring, train-positive masking, top-K

@@ -41,9 +41,6 @@ class OracleKernels:
     def scatter_rows(self, dst, idx, src):
         dst[idx] = src
 
-    def rows_nonzero(self, panel, flags):
-        flags[...] = (panel != 0).any(axis=1).astype(np.float32)
-
     def flag_touched_items(self, eng, prep, gb, flags):
         ptr, idx = eng.G_ui[0], eng.G_ui[1]
         flags[...] = 0
