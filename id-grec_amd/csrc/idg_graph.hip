@@ -2289,6 +2289,16 @@ int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t*
   return IDG_OK;
 }
 
+int idg_graph_mark_cols(const idg_graph* g, const uint32_t* in_rows, uint32_t* col_bits, void* stream) {
+  IDG_REQUIRE(g && in_rows && col_bits, "idg_graph_mark_cols: bad argument");
+  IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_mark_cols: handle without a vrow -> row table");
+  if (g->n_vrows > 0)
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((g->n_vrows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                       g->n_vrows, g->d_vptr, g->d_vrow_row, g->d_cv, in_rows, col_bits);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
 int idg_graph_flag_cols(const idg_graph* g, const uint32_t* in_rows, float* col_flags, void* stream) {
   IDG_REQUIRE(g && in_rows && col_flags, "idg_graph_flag_cols: bad argument");
   IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_flag_cols: handle without a vrow -> row table");

@@ -78,6 +78,7 @@ PROTOTYPES = {
     "idg_propagate_mean_fields_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int64, c_vp, c_vp]),
     "idg_graph_expand_rows": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "idg_graph_flag_cols": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "idg_graph_mark_cols": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "idg_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "idg_linear_wgrad_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_int, c_vp,
                                        c_vp]),
@@ -140,7 +141,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 117  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 118  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

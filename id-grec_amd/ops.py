@@ -272,6 +272,13 @@ class Graph:
         check(lib.idg_graph_flag_cols(self._h, _ptr(in_rows), _ptr(col_flags), _stream() if stream is None else stream),
               "idg_graph_flag_cols")
 
+    def mark_cols(self, in_rows, col_bits, stream=None):
+        """col_bits |= the columns of the stored entries of the rows flagged in in_rows (int32 bitmap of n_cols bits, not
+        cleared here): idg_graph_mark_cols."""
+        _require_device(in_rows, col_bits)
+        check(lib.idg_graph_mark_cols(self._h, _ptr(in_rows), _ptr(col_bits), _stream() if stream is None else stream),
+              "idg_graph_mark_cols")
+
     @staticmethod
     def _bitmap_array(bitmaps):
         arr = (C.c_void_p * len(bitmaps))(*[None if b is None else b.data_ptr() for b in bitmaps])

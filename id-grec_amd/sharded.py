@@ -123,15 +123,17 @@ class ShardedEngine:
     (x + 0 + ... + 0: exact) hand them to every rank, and every rank evaluates the WHOLE batch's BPR loss — so the
     loss and the item-side gradient g_I are complete and bit-identical on every rank without any [I, d] exchange, and
     the user-side gradient rows flow back from the guest rows to their owners' rows (chained adds in batch order).
-    Per step: K - 2 forward + K - 1 backward all-reduces of the [I, d] item panel (3 at K = 3; round 1: 7), cut into
-    slices that overlap the products, plus the two [B, d] ones, one of [<= 2B, d] — the LAST forward
-    layer's item rows are read at the batch's positive / negative items only — and the item rows the batch's users touch
-    for forward layer K - 1 and the first backward product, after an [I] vector of flags to agree on them
-    (_agree_touched_items)."""
+    Per training step: K - 3 forward + K - 2 backward all-reduces of the [I, d] item panel (ONE at K = 3 — the last
+    backward product, whose partials reach the batch's three-hop items; round 1: 7), cut into slices that overlap the
+    products; the two [B, d] guest-row ones; one of [<= 2B, d] — the LAST forward layer's item rows are
+    read at the batch's positive / negative items only —; the item rows the batch's users touch for forward layer K - 1
+    and the first backward product (_agree_touched_items); and the two-hop item rows for forward layer K - 2 and the
+    second backward product (_agree_two_hop_items); each set agreed through an [I] vector of flags.  A set that does not
+    fit its compact buffer, and evaluation, use the sliced panel all-reduce."""
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
                  reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None,
-                 live_rows_cap=None, live_rows_min_bytes=64 << 20):
+                 live_rows_cap=None, live_rows_min_bytes=64 << 20, two_hop_cap=None):
         """batch_sparsity: use what a prepared batch (kernels.prepare) knows — the user side of the last forward
         layer is produced for the batch's owned users only, the first backward product gathers its live rows only,
         the gradient scatter follows a plan sorted ahead of time.  Exact; FIN's user rows outside the batch are then
@@ -141,7 +143,8 @@ class ShardedEngine:
         bounds — they MUST be the same on every rank (the slices are what the ranks all-reduce); default: equal row
         counts (callers that know the global item degrees pass entry-balanced cuts).  live_rows_cap: rows of the compact
         buffer of the first backward step's exchange (default 64 per triple; the same on every rank);
-        live_rows_min_bytes: item panels smaller than this are all-reduced whole in that step (tests pass 0)."""
+        live_rows_min_bytes: item panels smaller than this are all-reduced whole in that step (tests pass 0).
+        two_hop_cap: rows of the compact buffer of the two-hop exchanges (default I / 2; 0 = off)."""
         self.k, self.comm = kernels, comm
         self.batch_sparsity = bool(batch_sparsity)
         self._prepared = {}
@@ -181,6 +184,10 @@ class ShardedEngine:
         self.FL = z((self.I,))
         self.live_rows_min_bytes = int(live_rows_min_bytes)
         self.CS = z((max(1, min(self.I, 64 * self.B if live_rows_cap is None else int(live_rows_cap))), dim))
+        # ... and of the TWO-hop item rows (forward layer K - 2, second backward product): up to half the panel
+        two_cap = self.I // 2 if two_hop_cap is None else int(two_hop_cap)
+        self.CS2 = z((two_cap, dim)) if (two_cap > 0 and self.K >= 3 and getattr(comm, "world", 2) > 1) else None
+        self._two_hop_misses, self.two_hop_seen = 0, 0
         self.loss = z((2,))
         self.upstream = z((2,))
         kernels.fill(self.upstream, 1.0)
@@ -240,7 +247,12 @@ class ShardedEngine:
 
     def _wait_all(self, works):
         for w in works:
-            self.comm.wait(w)
+            if isinstance(w, tuple):  # an exchange of rows (_sum_rows_async): the sums go back into their panel
+                work, panel, ids, buf = w
+                self.comm.wait(work)
+                self.k.scatter_rows(panel, ids, buf)
+            else:
+                self.comm.wait(w)
 
     def _agree_touched_items(self, prep, gb):
         """The item rows a training batch touches beyond its own positives / negatives: the items its USERS interacted
@@ -269,6 +281,51 @@ class ShardedEngine:
         self.comm.wait(self.comm.all_reduce_async(self.CS[:n]))
         self.k.scatter_rows(panel, ids, self.CS[:n])
 
+    def _sum_rows_async(self, panel, rows, buf):
+        """The same through `buf`, the products that follow overlapping the collective; _wait_all scatters."""
+        ids, n = rows
+        self.k.gather_rows(buf[:n], panel, ids)
+        return (self.comm.all_reduce_async(buf[:n]), panel, ids, buf[:n])
+
+    def _agree_two_hop_items(self, prep, gb):
+        """One hop further, by what each layer's consumers read (K = 3; S_U / S_I = the batch's users / items):
+          near users  U' = S_U + the owned users that interacted with an item of S_I — where layer K - 1's user rows are
+                           read (by the last item-side product, restricted to S_I, and by FIN at S_U) and where the
+                           second backward product's input h_U lives;
+          two-hop items T = S_I + the items U' interacted with — where forward layer K - 2 is read (by the user-side
+                           product of layer K - 1, restricted to U') and outside which the second backward partial is 0:
+                           both travel as those rows (the sets are nested: T contains the touched items);
+          far users   U'' = S_U + the owned users that interacted with a TOUCHED item — where layer K - 2's user rows are
+                           read (by layer K - 1's item-side product, restricted to the touched items) and where the last
+                           backward product's input lives (a local fact: no exchange; that product's partial reaches
+                           the three-hop items, most of the table, and is all-reduced as the panel).
+        A second [I] flag exchange and host synchronisation.  Used while the two-hop items fit the compact buffer (half
+        the table by default) — then the near / far users are few as well and the products around these exchanges run
+        row-restricted / in sparse-input form; on graphs whose popular items reach most users within a hop (every
+        power-law shape of synth.SHAPES at B = 1024: scripts/hop_sets.py) the set is the whole table, and after three
+        steps in a row that did not fit the engine stops asking (every rank sees the same counts: same decision).  Sets
+        self.two_hop = (ids, n), self.two_hop_bits, self.near_bits / self.far_bits (bitmaps; None with kernels that
+        produce every row) and self.hops."""
+        self.two_hop = self.two_hop_bits = self.near_bits = self.far_bits = None
+        self.hops = False
+        if self.touched_items is None or self.K < 3 or self.CS2 is None or self._two_hop_misses >= 3:
+            return
+        k = self.k
+        if not k.flag_two_hop_items(self, prep, gb, self.FL):
+            return
+        self.comm.wait(self.comm.all_reduce_async(self.FL))
+        ids, n = k.nonzero_ids(self.FL)
+        self.two_hop_seen = n
+        if n == 0 or n > self.CS2.shape[0]:
+            self._two_hop_misses += 1
+            if self._two_hop_misses >= 3:
+                self.CS2 = None  # (its memory goes back: half an item panel)
+            return
+        self._two_hop_misses = 0
+        self.two_hop, self.hops = (ids, n), True
+        self.two_hop_bits = k.item_rows_bitmap(self, prep, self.two_hop, which=1)
+        self.near_bits, self.far_bits = k.user_rows_bitmaps(self, prep, gb, self.touched_bits)
+
     # ---- forward: FIN = mean_k A^k P  (users: local rows, items: replicated)
     def propagate(self, prep=None, gb=None):
         """Layer k: P_I(k) = R^T X_U(k-1) (local partial) -> all-reduce -> X_I(k);  X_U(k) = R X_I(k-1).
@@ -283,6 +340,8 @@ class ShardedEngine:
         xu_prev, xi_prev = self._u(self.P), self._i(self.P)
         pending = [None]  # (works, xi_new, layer, xi_before) of the all-reduce whose result has not been folded in yet
         self.touched_items = self._agree_touched_items(prep, gb) if K >= 2 else None
+        self.touched_bits = k.item_rows_bitmap(self, prep, self.touched_items) if self.touched_items is not None else None
+        self._agree_two_hop_items(prep, gb)
 
         def finish():
             if pending[0] is None:
@@ -325,13 +384,22 @@ class ShardedEngine:
             elif layer == K - 1 and self.touched_items is not None:
                 # layer K - 1 of a training step is read at the touched items only (by the last user-side product, and
                 # by FIN at the batch's items): its partials travel as those rows
-                bits = k.item_rows_bitmap(self, prep, self.touched_items)
+                bits = self.touched_bits
                 for j, (g, r0, r1) in enumerate(self.G_iu):
                     k.spmm(g, xu_prev, Y=xi_new[r0:r1], out_rows=None if bits is None else bits[r0 // 32:])
                     if j == 0:
                         finish()
                 self._sum_rows(xi_new, self.touched_items)
                 works, xi_fold = [], (xi_new,)
+            elif layer == K - 2 and self.two_hop is not None:
+                # ... and layer K - 2 at the two-hop items (_agree_two_hop_items); the user-side product below overlaps
+                # the collective
+                bits = self.two_hop_bits
+                for j, (g, r0, r1) in enumerate(self.G_iu):
+                    k.spmm(g, xu_prev, Y=xi_new[r0:r1], out_rows=None if bits is None else bits[r0 // 32:])
+                    if j == 0:
+                        finish()
+                works, xi_fold = [self._sum_rows_async(xi_new, self.two_hop, self.CS2)], (xi_new,)
             else:
                 # item-side partial of this layer; X_I(layer-1) (the previous collective) is folded in under its first slice
                 works, xi_fold = self._item_side(xu_prev, xi_new, after_first=finish), xi_new
@@ -340,8 +408,13 @@ class ShardedEngine:
             else:
                 sum_in = fin_u if (c0 or layer > 2) else xu_prev
             xu_new = None if last else self.XU[layer & 1]
-            k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0,
-                   out_rows=prep.bitmap if (last and prep is not None) else None)  # BPR reads the batch's users only
+            if last:
+                u_rows = prep.bitmap if prep is not None else None  # BPR reads the batch's users only
+            elif self.hops and layer >= K - 2:  # layer K - 1 is read at the near users, layer K - 2 at the far ones
+                u_rows = self.near_bits if layer == K - 1 else self.far_bits
+            else:
+                u_rows = None
+            k.spmm(self.G_ui, xi_prev, Y=xu_new, sum_in=sum_in, sum_out=fin_u, div=cnt if last else 1.0, out_rows=u_rows)
             pending[0] = (works, xi_fold, layer, xi_prev)
             xu_prev, xi_prev = xu_new, xi_new
         finish()
@@ -382,16 +455,28 @@ class ShardedEngine:
                     works = []
                 else:
                     works = [self.comm.all_reduce_async(t_i[r0:r1]) for _, r0, r1 in self.G_iu]
+                x_items = getattr(prep, "item_bitmap", None) if prep is not None else None  # h_I = g_I: the batch's items
+            elif layer == K - 1 and gb is not None and self.hops:
+                # the second step: h_U is zero outside the near users, the partial outside the two-hop items
+                for j, (g, r0, r1) in enumerate(self.G_iu):
+                    k.spmm(g, h_u, Y=t_i[r0:r1], x_rows=self.near_bits)
+                    if j == 0:
+                        finish()
+                works = [self._sum_rows_async(t_i, self.two_hop, self.CS2)]
+                x_items = self.touched_bits                    # h_I = (first product, zero outside the touched items) + g_I
             else:
                 works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)   # partial of (A h)_I: needs h_U only
+                x_items = None
             live = None
             t_u = self.XU[layer & 1]
-            k.spmm(self.G_ui, h_i[0], Y=t_u, addend=g_u)      # (A h)_U + g_U
+            k.spmm(self.G_ui, h_i[0], Y=t_u, addend=g_u, x_rows=x_items)  # (A h)_U + g_U
             pending[0] = ("t", works, t_i)
             h_u = t_u
         # last Horner step, scaled by 1/cnt
         t_i = self.XI[1]  # 3-buffer rotation: never the buffer of the all-reduce still in flight (layer 2 -> XI[2])
-        works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)       # (live only when K == 1: h_U is still g_U)
+        if K == 3 and gb is not None and self.hops:
+            live = self.far_bits  # h_U(1) = R h_I(2) + g_U is zero outside the far users (h_I(2) lives on the touched items)
+        works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)       # (K == 1: h_U is still g_U)
         k.spmm(self.G_ui, h_i[0], sum_in=g_u if c0 else None, sum_out=self._u(self.G), div=cnt, accumulate=True)
         if c0:
             k.lincomb(self._i(self.G), self._i(self.G), 1.0, g_i, 1.0 / cnt)     # reg_I + g_I/cnt, under the collective
@@ -534,13 +619,38 @@ class HipKernels:
         flags.index_fill_(0, gb.items, 1.0)
         return True
 
-    def item_rows_bitmap(self, eng, prep, rows):
-        """Bitmap over the item rows `rows` = (ids, n), for the row-restricted item-side product."""
+    def item_rows_bitmap(self, eng, prep, rows, which=0):
+        """Bitmap over the item rows `rows` = (ids, n), for the row-restricted item-side products (which: 0 = the touched
+        items, 1 = the two-hop items; two buffers of the prepared batch)."""
         if prep is None:
             return None
         ids, n = rows
-        self.ops.bpr_touch_rows_raw(ids, ids, ids, 0, prep.field_bitmap, clear_bits=eng.I)
-        return prep.field_bitmap
+        bits = prep.field2_bitmap if which else prep.field_bitmap
+        self.ops.bpr_touch_rows_raw(ids, ids, ids, 0, bits, clear_bits=eng.I)
+        return bits
+
+    def flag_two_hop_items(self, eng, prep, gb, flags):
+        """prep.user_near = the owned users that interacted with one of the batch's items, plus the batch's own; flags[i]
+        = 1 for the items those users interacted with, and for the batch's items."""
+        if prep is None:
+            return False
+        self._mark_users(eng, gb, prep.user_near, prep.item_bitmap)
+        flags.zero_()
+        eng.G_ui.flag_cols(prep.user_near, flags)
+        flags.index_fill_(0, gb.items, 1.0)
+        return True
+
+    def _mark_users(self, eng, gb, bits, item_bits):
+        self.ops.bitmap_clear_raw(bits, eng.Ug)
+        for g, r0, r1 in eng.G_iu:
+            g.mark_cols(item_bits[r0 // 32:], bits)
+        if gb.n_owned > 0:
+            self.ops.bpr_touch_rows_raw(gb.own_users, gb.own_users, gb.own_users, 0, bits)
+
+    def user_rows_bitmaps(self, eng, prep, gb, touched_bits):
+        """(near, far): the far users interacted with a TOUCHED item (a local fact, marked here)."""
+        self._mark_users(eng, gb, prep.user_far, touched_bits)
+        return prep.user_near, prep.user_far
 
     def nonzero_ids(self, flags):
         """Ascending ids of the non-zero flags and their number (a host synchronisation: the caller sizes a collective)."""
@@ -560,7 +670,8 @@ class HipKernels:
         return idx.cpu().numpy()
 
     class _Prepared:
-        __slots__ = ("bitmap", "item_bitmap", "field_bitmap", "ws", "rows_done", "done", "free", "B", "busy")
+        __slots__ = ("bitmap", "item_bitmap", "field_bitmap", "field2_bitmap", "user_near", "user_far", "ws", "rows_done", "done", "free",
+                     "B", "busy")
 
     def prepare(self, eng, gb):
         """Index-only work of a global batch on a side stream: bitmap of the LOCAL user rows this rank owns in it (the
@@ -579,6 +690,9 @@ class HipKernels:
             # batch), by global item id: the last forward layer's item-side product produces these rows only
             prep.item_bitmap = torch.zeros((eng.I + 31) // 32 + 1, dtype=torch.int32, device=self.device)
             prep.field_bitmap = torch.zeros((eng.I + 31) // 32 + 1, dtype=torch.int32, device=self.device)
+            prep.field2_bitmap = torch.zeros((eng.I + 31) // 32 + 1, dtype=torch.int32, device=self.device)
+            prep.user_near = torch.zeros((eng.Ug + 31) // 32 + 1, dtype=torch.int32, device=self.device)
+            prep.user_far = torch.zeros((eng.Ug + 31) // 32 + 1, dtype=torch.int32, device=self.device)
             prep.ws, prep.B = ops.bpr_workspace(cap, d, self.device), cap
             prep.rows_done, prep.done, prep.free = ops.LocalEvent(), ops.LocalEvent(), None  # device-local events
             self._pool.append(prep)
@@ -895,7 +1009,8 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
     del users, items
     kern = HipKernels(deterministic=not args.atomic)
     eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
-                        n_slices=n_slices, item_cuts=cuts)
+                        n_slices=n_slices, item_cuts=cuts,
+                        two_hop_cap=0 if os.environ.get("IDG_TWO_HOP", "1") == "0" else None)  # (0: A/B of the two-hop form)
     nnz_ui, nnz_iu = len(ui[1]), len(iu[1])
     del ui, iu
     Ug = hi - lo
@@ -957,10 +1072,16 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
             kern.spmm(gph, eng._u(eng.P), Y=eng.XI[0][r0:r1])
 
     t_iu = timed(item_side)
-    rows_form = world > 1 and I * d * 4 >= eng.live_rows_min_bytes  # forward layer K-1 / first backward product as rows
-    n_panel = (max(K - 2, 0) + (K - 1 if K >= 2 else 1)) if rows_form else (K - 1) + K
+    # what the LAST step exchanged as rows: forward layer K-1 / first backward product (the touched items), forward layer
+    # K-2 / second backward product (the two-hop items)
+    n_touched = eng.touched_items[1] if getattr(eng, "touched_items", None) is not None else 0
+    n_two_hop = eng.two_hop[1] if getattr(eng, "two_hop", None) is not None else 0
+    rows_form = n_touched > 0
+    n_panel = (K - 1) + K - (2 if rows_form else 0) - (2 if n_two_hop else 0) if K >= 2 else 1
     bytes_ui = 4 * (Ug + 1) + 8 * nnz_ui + 4 * nnz_ui * d + 4 * Ug * d
     bytes_iu = 4 * (I + 1) + 8 * nnz_iu + 4 * nnz_iu * d + 4 * I * d
+    # every array of the two products read or written once (the gathered panel once, not once per stored entry)
+    bytes_min = 4 * (Ug + I + 2) + 8 * (nnz_ui + nnz_iu) + 2 * 4 * (Ug + I) * d
     out = None
     if rank == 0:
         n = U + I
@@ -974,10 +1095,14 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                                    "the reference, trainer.py:36); item table replicated; per step %d all-reduces of the "
                                    "[%d,%d] fp32 item panel in %d slices that overlap the products + 2 of [%d,%d] (the "
                                    "batch's user rows) + 1 of [<=%d,%d] (the last forward layer's item rows, read at the "
-                                   "batch's items only) + the item rows the batch's users touch, for forward layer K-1 and the "
-                                   "first backward product (an [%d] flag vector to agree on them, then those rows) over %s"
+                                   "batch's items only)%s over %s"
                                    % (args.workload, world, U, I, n_edges, nnz_global, K, d, B, n_panel, I, d, len(eng.G_iu),
-                                      B, d, 2 * B, d, I,
+                                      B, d, 2 * B, d,
+                                      (" + the %d item rows the batch's users touch, for forward layer K-1 and the first "
+                                       "backward product (an [%d] flag vector to agree on them, then those rows)"
+                                       % (n_touched, I)) * rows_form +
+                                      (" + the %d two-hop item rows, for forward layer K-2 and the second backward product "
+                                       "(a second flag vector)" % n_two_hop) * bool(n_two_hop),
                                       "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal, host-staged)"),
                        "batch": B, "dim": d, "layers": K, "parallelism": "user-row shard x%d" % world,
                        "comm": comm_name, "item_panel_slices": len(eng.G_iu)},
@@ -990,9 +1115,15 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name):
                 "achieved": (bytes_ui + bytes_iu) / (t_ui + t_iu) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": (bytes_ui + bytes_iu) / (t_ui + t_iu) / 1e9 / 8000.0, "traffic": None,
                 "us_user_side": t_ui * 1e6, "us_item_side": t_iu * 1e6, "bytes_gather_user_side": bytes_ui,
-                "bytes_gather_item_side": bytes_iu, "rank0_users": Ug, "rank0_nnz": nnz_ui,
+                "bytes_gather_item_side": bytes_iu, "bytes_min": bytes_min,
+                "frac_bytes_min": bytes_min / (t_ui + t_iu) / 1e9 / 8000.0, "rank0_users": Ug, "rank0_nnz": nnz_ui,
                 "cache_resident": bool(4 * max(I, Ug) * d < (256 << 20)),
-                "exchange_bytes_per_step_per_rank": n_panel * 4 * I * d + 4 * 4 * B * d + 4 * I,  # + the touched rows
+                "exchange_bytes_per_step_per_rank": n_panel * 4 * I * d + 4 * 4 * B * d
+                                                    + (2 * 4 * n_touched * d + 4 * I) * rows_form
+                                                    + (2 * 4 * n_two_hop * d + 4 * I) * bool(n_two_hop),
+                "exchange_rows": {"touched_items": n_touched, "two_hop_items": n_two_hop, "items": I,
+                                  "two_hop_items_counted": int(getattr(eng, "two_hop_seen", 0)),
+                                  "two_hop_buffer_rows": 0 if eng.CS2 is None else int(eng.CS2.shape[0])},
             },
             "single_gpu_reference": "the same workload on ONE MI355X, unsharded: profiles/r02/bench_c5_single_gpu.json "
                                     "(builder-run; not measured in this run)" if args.workload == "synth-10M" else None,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 117 /* 0.1.15: + receptive-field propagation (idg_graph_expand_rows / _flag_cols, idg_propagate_mean*_fields_f32) */
+#define IDG_VERSION 118 /* 0.1.16: + idg_graph_mark_cols (the hop of idg_graph_flag_cols as a bitmap over the columns) */
 
 /* error classes */
 #define IDG_OK 0
@@ -186,6 +186,9 @@ int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t*
  * 1.0f for every column of a stored entry of a row flagged in in_rows (n_rows bits).  The ranks of the sharded step sum
  * these to agree on the item rows a batch's users touch. */
 int idg_graph_flag_cols(const idg_graph* g, const uint32_t* in_rows, float* col_flags, void* stream);
+/* ... and as a bitmap over the columns (n_cols bits, NOT cleared here: col_bits |= the hop, so the row slices of one
+ * matrix can mark into one bitmap).  The sharded step marks the users that reach the touched items this way. */
+int idg_graph_mark_cols(const idg_graph* g, const uint32_t* in_rows, uint32_t* col_bits, void* stream);
 int idg_propagate_mean_fields_f32(const idg_graph* g, const float* E0, float* out, const uint32_t* const* layer_rows, int K,
                                   int include_layer0, int64_t d, void* ws, void* stream);
 int idg_propagate_mean_bwd_adam_fields_f32(const idg_graph* g, const float* gout, const uint32_t* const* step_rows, float* gE0,

@@ -49,8 +49,24 @@ class OracleKernels:
         flags[gb.items] = 1
         return True
 
-    def item_rows_bitmap(self, eng, prep, rows):
+    def item_rows_bitmap(self, eng, prep, rows, which=0):
         return None  # (the checker-backed stub produces every row)
+
+    def flag_two_hop_items(self, eng, prep, gb, flags):
+        users = set(np.unique(gb.own_users).tolist())  # near users: the batch's, and those of the batch's items
+        for g, r0, r1 in eng.G_iu:
+            ptr, idx = g[0], g[1]
+            for i in gb.items[(gb.items >= r0) & (gb.items < r1)] - r0:
+                users.update(idx[ptr[i]:ptr[i + 1]].tolist())
+        ptr, idx = eng.G_ui[0], eng.G_ui[1]
+        flags[...] = 0
+        for u in users:
+            flags[idx[ptr[u]:ptr[u + 1]]] = 1
+        flags[gb.items] = 1
+        return True
+
+    def user_rows_bitmaps(self, eng, prep, gb, touched_bits):
+        return None, None
 
     def nonzero_ids(self, flags):
         ids = np.nonzero(flags)[0].astype(np.int64)
@@ -125,7 +141,8 @@ def run(rank, world, port, mode, path, steps):
     n_slices = int(z["n_slices"]) if "n_slices" in z.files else 1
     eng = sh.ShardedEngine(kern, sh.TorchComm(dist), ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
                            batch_sparsity=(mode != "gpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
-                           live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None, live_rows_min_bytes=0)
+                           live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None, live_rows_min_bytes=0,
+                           two_hop_cap=int(z["two_cap"]) if "two_cap" in z.files else None)
     Ug = hi - lo
     if mode == "cpu":
         eng.P[:Ug] = W0[lo:hi]
@@ -157,7 +174,10 @@ def run(rank, world, port, mode, path, steps):
     # exchange carries those rows only)
     fin_items = np.unique(np.concatenate([cur[1][:, 1], cur[1][:, 2]]))
     out = dict(P=strip(eng.P), FIN=strip(eng.FIN), G=strip(eng.G), losses=np.stack(losses), lo=lo, hi=hi, fin_rows=touched,
-               fin_items=fin_items)
+               fin_items=fin_items,
+               touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1],
+               two_hop_n=-1 if getattr(eng, "two_hop", None) is None else eng.two_hop[1],
+               two_hop_misses=eng._two_hop_misses)
     if "test_users" in z.files:  # sharded evaluation: this rank's test users, its train rows as the exclusion lists
         tu, tptr, titems = z["test_users"], z["test_ptr"], z["test_items"]
         own = [(int(u), titems[tptr[j]:tptr[j + 1]].tolist()) for j, u in enumerate(tu) if lo <= u < hi]

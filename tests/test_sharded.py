@@ -28,6 +28,24 @@ def _problem(g, K, include0, B, steps, seed=0, d=64, n_slices=1):
                 test_items=np.concatenate(t_items).astype(np.int64), train_ptr=g["pos_indptr"], train_items=g["pos_indices"])
 
 
+def _sparse_problem(K, include0, B, steps, d=64, n_slices=2, U=600, I=800, E=1500, seed=5):
+    """A graph thin enough that a small batch's two-hop neighbourhood is a strict subset of the items (the golden graph
+    is too dense for that), users and items without interactions included; triples drawn from its edges."""
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    users, items = S.generate(U, I, E, seed=seed)
+    keep = (users % 11 != 0) & (items % 7 != 0)
+    users, items = users[keep], items[keep]
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    rng = np.random.default_rng(seed)
+    W0 = np.concatenate([(rng.random((m, d)) * 2 - 1) * np.sqrt(6.0 / (m + d)) for m in (U, I)]).astype(np.float32)
+    pick = rng.permutation(len(users))[: B * steps]
+    tri = np.stack([users[pick], items[pick], rng.integers(0, I, len(pick))], axis=1).astype(np.int64)
+    return dict(indptr=ip, indices=ix, values=dv, W0=W0, triples=tri, U=U, I=I, K=K, B=B, include0=include0,
+                n_slices=n_slices, two_cap=I)
+
+
 def _single_device_reference(p, steps):
     """The same steps on one device, by the oracle."""
     W = p["W0"].copy()
@@ -70,6 +88,8 @@ def _check(p, outs, steps, rtol, atol, sparse=False):
     for b in outs[1:]:
         assert np.array_equal(a["P"][int(a["hi"]) - int(a["lo"]):], b["P"][int(b["hi"]) - int(b["lo"]):])
         assert np.array_equal(a["losses"], b["losses"])  # every rank evaluates the whole batch's loss: same bits
+    if "test_users" not in p:
+        return
     # sharded evaluation (users by owner, items replicated, metric sums exchanged) == the single-device Test()
     want = _single_device_test(p, W, [5, 10])
     for o in outs:
@@ -217,6 +237,31 @@ def test_first_backward_exchange_falls_back_to_the_panel(tmp_path, golden_small)
     _check(p, _launch("cpu", path, 2), 2, rtol=1e-4, atol=2e-7)
 
 
+@pytest.mark.parametrize("include0,world", [(True, 2), (False, 3)])
+def test_two_hop_exchanges_match_single_device(include0, world, tmp_path):
+    """K = 3 on a thin graph: forward layer 1 and the second backward product travel as the batch's two-hop item rows
+    (a strict subset of the items here — asserted — so a product reading an un-exchanged row would show)."""
+    p = _sparse_problem(3, include0, B=6, steps=3)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("cpu", path, 3, world=world)
+    for o in outs:
+        assert 0 < int(o["touched_n"]) < int(o["two_hop_n"]) < p["I"] // 2
+    _check(p, outs, 3, rtol=1e-4, atol=2e-7)
+
+
+def test_two_hop_exchange_falls_back_to_the_panel(tmp_path):
+    """More two-hop rows than the compact buffer holds: those two exchanges go back to the sliced panel, and after three
+    such steps in a row the engine stops asking (five steps, three misses counted)."""
+    p = _sparse_problem(3, True, B=6, steps=5)
+    p["two_cap"] = 8
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("cpu", path, 5)
+    assert all(int(o["two_hop_n"]) == -1 and int(o["touched_n"]) > 0 and int(o["two_hop_misses"]) == 3 for o in outs)
+    _check(p, outs, 5, rtol=1e-4, atol=2e-7)
+
+
 def test_three_ranks_gloo_cpu_match_single_device(tmp_path, golden_small):
     """An odd world size: three uneven user blocks (nnz-balanced), ring all-reduces over three ranks, sliced item side."""
     p = _problem(golden_small, 3, True, B=160, steps=3, d=64, n_slices=2)
@@ -239,6 +284,20 @@ def test_two_ranks_hip_kernels_match_single_device(K, include0, d, mode, tmp_pat
     np.savez(path, **p)
     outs = _launch(mode, path, 4)
     _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=(mode == "gpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("include0,d", [(True, 64), (False, 256)])
+def test_two_hop_exchanges_hip_kernels(include0, d, tmp_path):
+    """The same on the HIP kernels (two ranks on cuda:0): row-restricted item- and user-side products of layers 1 and 2,
+    sparse-input products of the backward steps, the compact two-hop exchanges."""
+    p = _sparse_problem(3, include0, B=6, steps=4, d=d)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("gpu", path, 4)
+    for o in outs:
+        assert 0 < int(o["touched_n"]) < int(o["two_hop_n"]) < p["I"] // 2
+    _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=True)
 
 
 def test_generate_shared_is_generate(tmp_path):
