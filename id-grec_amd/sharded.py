@@ -340,7 +340,16 @@ class ShardedEngine:
         xu_prev, xi_prev = self._u(self.P), self._i(self.P)
         pending = [None]  # (works, xi_new, layer, xi_before) of the all-reduce whose result has not been folded in yet
         self.touched_items = self._agree_touched_items(prep, gb) if K >= 2 else None
-        self.touched_bits = k.item_rows_bitmap(self, prep, self.touched_items) if self.touched_items is not None else None
+        if self.touched_items is not None:
+            self.touched_bits = k.item_rows_bitmap(self, prep, self.touched_items)
+        elif (gb is not None and K >= 2 and getattr(self.comm, "world", 2) == 1
+              and self.I * self.d * 4 >= self.live_rows_min_bytes):
+            # a single rank has nothing to agree on or exchange: the bitmap alone (no host synchronisation) restricts the
+            # products exactly as on the ranks of a larger job (same size rule: on a small graph the touched items are
+            # most of the table — yelp2018 shape: 70 % — and the restricted forms cost more than they save)
+            self.touched_bits = k.touched_bitmap_local(self, prep, gb)
+        else:
+            self.touched_bits = None
         self._agree_two_hop_items(prep, gb)
 
         def finish():
@@ -381,15 +390,16 @@ class ShardedEngine:
                         finish()
                 k.gather_rows(self.CI[:gb.n_items], xi_new, gb.items)
                 works, xi_fold = [self.comm.all_reduce_async(self.CI[:gb.n_items])], None
-            elif layer == K - 1 and self.touched_items is not None:
+            elif layer == K - 1 and (self.touched_items is not None or self.touched_bits is not None):
                 # layer K - 1 of a training step is read at the touched items only (by the last user-side product, and
-                # by FIN at the batch's items): its partials travel as those rows
+                # by FIN at the batch's items): its partials travel as those rows (one rank: nothing travels)
                 bits = self.touched_bits
                 for j, (g, r0, r1) in enumerate(self.G_iu):
                     k.spmm(g, xu_prev, Y=xi_new[r0:r1], out_rows=None if bits is None else bits[r0 // 32:])
                     if j == 0:
                         finish()
-                self._sum_rows(xi_new, self.touched_items)
+                if self.touched_items is not None:
+                    self._sum_rows(xi_new, self.touched_items)
                 works, xi_fold = [], (xi_new,)
             elif layer == K - 2 and self.two_hop is not None:
                 # ... and layer K - 2 at the two-hop items (_agree_two_hop_items); the user-side product below overlaps
@@ -628,6 +638,14 @@ class HipKernels:
         bits = prep.field2_bitmap if which else prep.field_bitmap
         self.ops.bpr_touch_rows_raw(ids, ids, ids, 0, bits, clear_bits=eng.I)
         return bits
+
+    def touched_bitmap_local(self, eng, prep, gb):
+        """Bitmap of the touched items from this rank's rows alone (complete when it is the only rank)."""
+        if prep is None:
+            return None
+        prep.field_bitmap.copy_(prep.item_bitmap)
+        eng.G_ui.mark_cols(prep.bitmap, prep.field_bitmap)
+        return prep.field_bitmap
 
     def flag_two_hop_items(self, eng, prep, gb, flags):
         """prep.user_near = the owned users that interacted with one of the batch's items, plus the batch's own; flags[i]

@@ -52,6 +52,9 @@ class OracleKernels:
     def item_rows_bitmap(self, eng, prep, rows, which=0):
         return None  # (the checker-backed stub produces every row)
 
+    def touched_bitmap_local(self, eng, prep, gb):
+        return None
+
     def flag_two_hop_items(self, eng, prep, gb, flags):
         users = set(np.unique(gb.own_users).tolist())  # near users: the batch's, and those of the batch's items
         for g, r0, r1 in eng.G_iu:

@@ -300,6 +300,21 @@ def test_two_hop_exchanges_hip_kernels(include0, d, tmp_path):
     _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,include0,d", [(3, True, 64), (2, False, 64), (3, False, 256)])
+def test_one_rank_hip_kernels_match_single_device(K, include0, d, tmp_path):
+    """World size 1 (what `bench.py --force-sharded` runs): nothing is agreed or exchanged as rows, but the touched-item
+    bitmap — marked locally, no host synchronisation — restricts layer K - 1's item-side product and feeds the second
+    backward step's sparse-input product, as on the ranks of a larger job.  Thin graph: the touched items are a strict
+    subset, so a product reading an unproduced row would show."""
+    p = _sparse_problem(K, include0, B=6, steps=4, d=d)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("gpu", path, 4, world=1)
+    assert int(outs[0]["touched_n"]) == -1
+    _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=True)
+
+
 def test_generate_shared_is_generate(tmp_path):
     """The multi-rank bench draws its graph once per machine (rank 0) and the other ranks load it: same arrays as
     drawing in-process, also when the cache file is unusable."""
