@@ -123,13 +123,14 @@ class ShardedEngine:
     (x + 0 + ... + 0: exact) hand them to every rank, and every rank evaluates the WHOLE batch's BPR loss — so the
     loss and the item-side gradient g_I are complete and bit-identical on every rank without any [I, d] exchange, and
     the user-side gradient rows flow back from the guest rows to their owners' rows (chained adds in batch order).
-    Per training step: K - 3 forward + K - 2 backward all-reduces of the [I, d] item panel (ONE at K = 3 — the last
-    backward product, whose partials reach the batch's three-hop items; round 1: 7), cut into slices that overlap the
-    products; the two [B, d] guest-row ones; one of [<= 2B, d] — the LAST forward layer's item rows are
-    read at the batch's positive / negative items only —; the item rows the batch's users touch for forward layer K - 1
-    and the first backward product (_agree_touched_items); and the two-hop item rows for forward layer K - 2 and the
-    second backward product (_agree_two_hop_items); each set agreed through an [I] vector of flags.  A set that does not
-    fit its compact buffer, and evaluation, use the sliced panel all-reduce."""
+    Per training step: K - 2 forward + K - 1 backward all-reduces of the [I, d] item panel (3 at K = 3; round 1: 7), cut
+    into slices that overlap the products; the two [B, d] guest-row ones; one of [<= 2B, d] — the LAST
+    forward layer's item rows are read at the batch's positive / negative items only —; and the item rows the batch's
+    users touch for forward layer K - 1 and the first backward product (_agree_touched_items), agreed through an [I]
+    vector of flags.  Where the batch's two-hop item rows are under half the table, forward layer K - 2 and the second
+    backward product travel as those rows as well (_agree_two_hop_items: one panel all-reduce left at K = 3, the last
+    backward product, whose partials reach three hops).  A set that does not fit its compact buffer, and evaluation,
+    use the sliced panel all-reduce."""
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
                  reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None,
@@ -491,7 +492,8 @@ class ShardedEngine:
                 x_items = self.touched_bits                    # h_I = (first product, zero outside the touched items) + g_I
             else:
                 works = self._item_side(h_u, t_i, x_rows=live, after_first=finish)   # partial of (A h)_I: needs h_U only
-                x_items = None
+                # the second step's h_I = (first product: zero outside the touched items) + g_I, however it was exchanged
+                x_items = self.touched_bits if (layer == K - 1 and gb is not None) else None
             live = None
             t_u = self.XU[layer & 1]
             k.spmm(self.G_ui, h_i[0], Y=t_u, addend=g_u, x_rows=x_items)  # (A h)_U + g_U
