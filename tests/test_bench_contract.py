@@ -1,0 +1,61 @@
+"""bench.py's output contract on a small graph: ONE JSON line on stdout with the fields the driver reads, the `roofline`
+and `cpu_baseline` objects, for one GPU and for the multi-rank launch (two ranks sharing the GPU over gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline")
+
+
+def _one_line(out):
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must hold ONE line, got %d:\n%s" % (len(lines), out[-2000:])
+    return json.loads(lines[0])
+
+
+def _env():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.gpu
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "medium", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1",
+                        "--hbm-leg", "off", "--epoch-leg", "off"], cwd=ROOT, env=_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    for k in KEYS + ("cpu_baseline",):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["higher_is_better"] is True
+    assert d["unit"] == "triples/s" and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["batch"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["us_per_launch"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+
+
+@pytest.mark.gpu
+def test_two_rank_line():
+    """The launch the driver uses for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks on
+    one GPU over gloo: the user-row-sharded step, exchanged row counts reported, item table coherent across ranks."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29633", "bench.py", "--gpus", "2", "--backend", "gloo", "--parallel", "shard",
+                        "--workload", "medium", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, env=_env(),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "strong" and d["item_table_coherent"] is True
+    assert abs(d["value"] - d["config"]["batch"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert d["roofline"]["exchange_rows"]["items"] == 3000 and d["config"]["parallelism"] == "user-row shard x2"
