@@ -445,11 +445,14 @@ class ShardedEngine:
 
     # ---- backward of the above given GF = d loss / d FIN (g_I complete on every rank, g_U at the owners' rows),
     #      accumulated onto G (which already holds the regulariser gradient: item rows complete, user rows owned)
-    def propagate_backward(self, prep=None, gb=None):
+    def propagate_backward(self, prep=None, gb=None, adam_step=None):
         """Horner steps h <- A.h + g, k = K..2, then gE0 = (A.h + c0.g)/cnt.  In block form
         (A.h)_U = R_g h_I (local), (A.h)_I = all-reduce(R_g^T h_U).  As in the forward pass the item-side
         partial of a step needs only the LOCAL h_U, so it is launched before waiting for the previous
-        all-reduce; the user-side product is what waits for it."""
+        all-reduce; the user-side product is what waits for it.  adam_step (train_step passes its step number): the
+        replicated item rows are completed AND Adam-updated slice by slice as each slice's last all-reduce lands, under
+        the following slices' collectives — every rank carries this tail for all I rows, after the step's last exchange,
+        so it is on the critical path of every step at any N."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
         g_u, g_i = self._u(self.GF), self._i(self.GF)
         h_u = g_u
@@ -510,8 +513,16 @@ class ShardedEngine:
                 self._rows_lincomb(self._i(self.G), 1.0, g_i, 1.0 / cnt, gb)
             else:
                 k.lincomb(self._i(self.G), self._i(self.G), 1.0, g_i, 1.0 / cnt)
-        self._wait_all(works)
-        k.lincomb(self._i(self.G), t_i, 1.0 / cnt, self._i(self.G), 1.0)         # + (sum of the ranks' partials)/cnt
+        G_i, P_i, M_i, V_i = self._i(self.G), self._i(self.P), self._i(self.M), self._i(self.V)
+        if os.environ.get("IDG_SHARD_TAIL", "1") == "0":                         # (A/B knob: the tail after ALL slices)
+            self._wait_all(works)
+            works = [None] * len(works)
+        for w, (_, r0, r1) in zip(works, self.G_iu):                             # (one collective per slice, in order)
+            if w is not None:
+                self._wait_all([w])
+            k.lincomb(G_i[r0:r1], t_i[r0:r1], 1.0 / cnt, G_i[r0:r1], 1.0)        # + (sum of the ranks' partials)/cnt
+            if adam_step is not None:
+                k.adam(P_i[r0:r1], G_i[r0:r1], M_i[r0:r1], V_i[r0:r1], self.lr, adam_step)
         return self.G
 
     def train_step(self, gb):
@@ -541,12 +552,12 @@ class ShardedEngine:
         # gradients of the guest rows go home: every owned user's occurrences are added in batch order
         k.chain_add_rows(self._u(self.GF), self._guest(self.GF, Bc), gb.head_dst, gb.nxt)
         k.chain_add_rows(self._u(self.G), self._guest(self.G, Bc), gb.head_dst, gb.nxt)
-        self.propagate_backward(prep, gb)
+        self.step_count += 1
+        self.propagate_backward(prep, gb, adam_step=self.step_count)  # (updates the item rows, slice by slice)
         if prep is not None:
             k.release(prep)
-        self.step_count += 1
-        for sl in (slice(0, self.Ug), slice(self.Ug + self.B, None)):  # (the guest rows are not parameters)
-            k.adam(self.P[sl], self.G[sl], self.M[sl], self.V[sl], self.lr, self.step_count)
+        sl = slice(0, self.Ug)  # the owned user rows (the guest rows are not parameters)
+        k.adam(self.P[sl], self.G[sl], self.M[sl], self.V[sl], self.lr, self.step_count)
         return self.loss
 
     def prefetch(self, gb):
