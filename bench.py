@@ -73,6 +73,10 @@ def parse():
     p.add_argument("--ramp", default="graph", choices=["graph", "gemm"],
                    help="untimed clock ramp before the warm-up steps: the graph's own product on a scratch panel (default) or a "
                         "dense GEMM loop (profile runs: keeps the ramp's launches out of the per-kernel statistics)")
+    p.add_argument("--scale-point", default="auto", choices=["auto", "on", "off"],
+                   help="the multi-GPU lines' workload (synth-10M, d=256: BASELINE configs[4]) measured unsharded on ONE GPU in "
+                        "this run: as `scale_point` of the default 1-GPU line (auto: only there) and as `single_gpu_reference` "
+                        "/ `speedup_vs_1gpu` of a sharded line (auto: when the shape fits one GPU)")
     p.add_argument("--force-sharded", action="store_true",
                    help="run a multi-GPU path even at world size 1 (exercises the RCCL code path): the user-row-sharded one, "
                         "or the replicas with --parallel dp")
@@ -170,8 +174,78 @@ def cpu_baseline_scaled(args):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (torch.distributed.run,
+    one per GPU) before this process has touched the GPU, relay rank 0's JSON line, leave with the launcher's exit code.
+    (Never an exec: a process that has initialised HIP must not be replaced — and this one has not, but a child is the
+    form that is always safe.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(proc.returncode if proc.returncode or lines else 1)
+
+
+def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2):
+    """The multi-GPU lines' workload on ONE GPU, unsharded, through the fused single-GPU engine (PropagationEngine): the
+    1-GPU point the N-GPU speed-ups are quoted against, measured in the same run.  ~140 GB resident at synth-10M d=256."""
+    import idgrec_amd.host as H
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+
+    t_all = time.perf_counter()
+    U, I, E = S.SHAPES[workload]
+    K, B = args.layers, args.batch
+    users, items = S.generate(U, I, E, seed=0)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n, nnz, n_edges = U + I, len(ix), len(users)
+    tri = torch.from_numpy(S.draw_triples(args.seed, users, items, U, I, (steps + warmup) * B)[0]).cuda()
+    del users, items
+    graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
+    del ip, ix, dv
+    eng = PropagationEngine(graph, U, I, dim, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
+                            params=S.xavier_uniform_panel(U, I, dim, args.seed).cuda())
+    tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
+
+    def step(i):
+        s = slice(i * B, (i + 1) * B)
+        if i + 1 < steps + warmup:
+            s2 = slice((i + 1) * B, (i + 2) * B)
+            eng.prefetch(tu[s2], tp[s2], tn[s2])
+        eng.train_step(tu[s], tp[s], tn[s])
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "%s: %d users x %d items, %d train edges, nnz(A)=%d; LightGCN K=%d d=%d B=%d, ONE GPU, unsharded "
+                       "(fused single-GPU engine)" % (workload, U, I, n_edges, nnz, K, dim, B),
+           "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "triples/s", "steps": steps, "warmup": warmup,
+           "loss_last": float(eng.loss.sum().item())}
+    del eng, graph, tri, tu, tp, tn
+    torch.cuda.empty_cache()
+    out["seconds_including_graph_build"] = time.perf_counter() - t_all
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(args)
     # stdout carries ONE line, the JSON.  Libraries print there too (RCCL announces its version on fd 1 when a
     # communicator comes up): hand fd 1 to stderr for the run and keep the real stdout for the result alone.
     sys.stdout.flush()
@@ -228,7 +302,14 @@ def main():
         if form == "dp":
             out = run_replicated_bench(args, rank, world, dist, comm, comm_name)
         else:
-            out = run_sharded_bench(args, rank, world, dist, comm, comm_name)
+            # the same workload on ONE GPU, measured in this run (rank 0, after the timed region): what speedup_vs_1gpu
+            # divides by.  auto: when the unsharded step fits one GPU (9 panels + the graph)
+            U_, I_, E_ = S.SHAPES[args.workload]
+            fits = 9 * 4 * (U_ + I_) * args.dim + 24 * E_ < 250e9
+            ref = None
+            if args.scale_point == "on" or (args.scale_point == "auto" and world > 1 and fits):
+                ref = lambda a: single_gpu_point(a, a.workload, a.dim)  # noqa: E731
+            out = run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_reference=ref)
             if args.parallel == "auto" and world > 1:
                 rep = run_replicated_bench(args, rank, world, dist, comm, comm_name, workload="yelp2018", dim=64)
                 if rank == 0:
@@ -343,6 +424,16 @@ def main():
         out["epoch"] = epoch_leg(args)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl, W0.numpy())
+    if args.scale_point == "on" or (args.scale_point == "auto" and args.workload == "yelp2018" and d == 64
+                                    and args.model == "LightGCN"):
+        # the 1-GPU point of the multi-GPU curve: `bench.py --gpus N` (N > 1) measures BASELINE configs[4], not this
+        # line's workload — the same step on ONE GPU, so that a 1 -> N ratio compares like with like
+        del eng, graph, tri, tu, tp, tn, losses
+        torch.cuda.empty_cache()
+        try:
+            out["scale_point"] = single_gpu_point(args)
+        except Exception as exc:  # noqa: BLE001 - the headline stands without it
+            out["scale_point"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     args.emit(out)
 
 

@@ -705,6 +705,7 @@ int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* 
                        uint32_t* bitmap, void* stream) {
   IDG_REQUIRE(users && pos && neg && bitmap, "idg_bpr_touch_rows: NULL argument");
   IDG_REQUIRE(B > 0 && num_users >= 0, "idg_bpr_touch_rows: bad sizes");
+  idg::rows_changed(bitmap);
   hipLaunchKernelGGL(bpr_touch_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, users,
                      pos, neg, B, num_users, bitmap);
   IDG_HIP(hipGetLastError());
@@ -713,6 +714,7 @@ int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* 
 
 int idg_bitmap_clear(uint32_t* bitmap, int64_t n_bits, void* stream) {
   IDG_REQUIRE(bitmap && n_bits >= 0, "idg_bitmap_clear: bad argument");
+  idg::rows_changed(bitmap);
   IDG_HIP(hipMemsetAsync(bitmap, 0, (size_t)((n_bits + 31) / 32) * sizeof(uint32_t), (hipStream_t)stream));
   return IDG_OK;
 }
@@ -741,6 +743,7 @@ static int bpr_backward_impl(const float* final_panel, const float* ego_panel, i
   a.g_ego = g_ego;
   a.upstream = upstream;
   a.touched = touched;
+  idg::rows_changed(touched);  // (the scatter sets bits in it)
   char* base = reinterpret_cast<char*>(ws);
   if (!deterministic) {
     const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
@@ -791,6 +794,7 @@ int idg_bpr_pack_rows_f32(const void* ws, int64_t B, int64_t d, const float* g_f
   IDG_REQUIRE(ws && g_final && loss && message, "idg_bpr_pack_rows_f32: NULL argument");
   IDG_REQUIRE(clear_bits >= 0 && (clear_bitmap || clear_bits == 0), "idg_bpr_pack_rows_f32: bad bitmap to clear");
   IDG_REQUIRE(B > 0 && d > 0 && 3 * B < ((int64_t)1 << 31), "idg_bpr_pack_rows_f32: bad sizes");
+  idg::rows_changed(clear_bitmap);
   const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
   const MsgLayout m = msg_layout(B, d);
   const int32_t* skeys = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ws) + w.skeys);
@@ -809,6 +813,7 @@ int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t
   IDG_REQUIRE(world > 0 && world <= MSG_MAX_WORLD, "idg_bpr_unpack_rows_f32: world size %d outside [1, %d]", world, MSG_MAX_WORLD);
   IDG_REQUIRE(B > 0 && d > 0 && n > 0 && g_final != g_ego, "idg_bpr_unpack_rows_f32: bad sizes / aliased panels");
   hipStream_t st = (hipStream_t)stream;
+  idg::rows_changed(touched);
   const MsgLayout m = msg_layout(B, d);
   const int64_t n3 = 3 * B;
   const int64_t nb = (n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE);

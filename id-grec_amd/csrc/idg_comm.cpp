@@ -22,6 +22,7 @@ struct Rccl {
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
   decltype(&ncclAllReduce) all_reduce = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclReduceScatter) reduce_scatter = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
   decltype(&ncclGetVersion) get_version = nullptr;
 };
@@ -62,7 +63,8 @@ int idg_comm_load(const char* librccl_path) {
   r.handle = h;
   const bool ok = bind(h, "ncclGetUniqueId", r.get_unique_id) && bind(h, "ncclCommInitRank", r.comm_init_rank) &&
                   bind(h, "ncclCommDestroy", r.comm_destroy) && bind(h, "ncclAllReduce", r.all_reduce) &&
-                  bind(h, "ncclAllGather", r.all_gather) && bind(h, "ncclGetErrorString", r.error_string) &&
+                  bind(h, "ncclAllGather", r.all_gather) && bind(h, "ncclReduceScatter", r.reduce_scatter) &&
+                  bind(h, "ncclGetErrorString", r.error_string) &&
                   bind(h, "ncclGetVersion", r.get_version);
   if (!ok) {
     dlclose(h);
@@ -131,6 +133,14 @@ int idg_allgather_f32(idg_comm* c, const float* in, float* out, int64_t count, v
   IDG_REQUIRE(in && out && count >= 0, "idg_allgather_f32: NULL buffer / negative count");
   if (count == 0) return IDG_OK;
   IDG_RCCL(g_rccl.all_gather(in, out, (size_t)count, ncclFloat32, c->comm, (hipStream_t)stream));
+  return IDG_OK;
+}
+
+int idg_reduce_scatter_f32(idg_comm* c, const float* in, float* out, int64_t count, void* stream) {
+  IDG_REQUIRE(c && c->comm, "idg_reduce_scatter_f32: NULL communicator");
+  IDG_REQUIRE(in && out && count >= 0, "idg_reduce_scatter_f32: NULL buffer / negative count");
+  if (count == 0) return IDG_OK;
+  IDG_RCCL(g_rccl.reduce_scatter(in, out, (size_t)count, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream));
   return IDG_OK;
 }
 

@@ -23,6 +23,10 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// A row bitmap is about to be rewritten by a library call: live-unit lists registered for it (idg_graph_live_units)
+// describe its old contents and are dropped (idg_graph.hip).
+void rows_changed(const void* bitmap);
+
 }  // namespace idg
 
 #define IDG_REQUIRE(cond, ...)                                   \

@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -60,6 +61,7 @@ constexpr int DEFAULT_TILE_CAP = 512;  // entries per tile: small tiles even out
 constexpr int64_t BAND_PANEL_BYTES = (int64_t)128 << 20;  // use XCD band placement up to this gathered-panel size
 constexpr int FIX_WAYS = 4;            // lane groups that share one split row in the fix-up pass
 constexpr int32_t UNIT_LONG = INT32_MIN;  // row_unit code of a chunked row: UNIT_LONG + its LongRow index
+constexpr int UNITS_HEADER = 2;           // words in front of a live-unit list: [count, overflow flag]
 
 struct __attribute__((aligned(16))) Tile {
   int64_t nnz_begin;
@@ -156,16 +158,68 @@ struct idg_graph {
   // the chunk's global partial slot)
   int32_t* d_row_unit = nullptr;
   int32_t* d_slot_unit = nullptr;
-  // bitmaps whose live-unit lists are known (idg_graph_live_units): a restricted launch naming one of them walks the
-  // listed units, one wave each, instead of visiting every tile
-  static constexpr int MAX_BOUND = 8;
-  mutable const uint32_t* bound_bitmap[MAX_BOUND] = {};
-  mutable const int32_t* bound_units[MAX_BOUND] = {};
-  mutable int64_t bound_cap[MAX_BOUND] = {};
-  mutable int bound_next = 0;
   // host copies for the checker
   std::vector<int64_t> h_long_rows, h_seg_len, h_chunk_len;
 };
+
+// ---- registry of live-unit lists (idg_graph_live_units) ---------------------------------------------------------
+// (schedule, row bitmap) -> the bitmap's list of work units.  Process-wide and keyed by the SCHEDULE a handle runs on
+// (its vrow pointer table, which masked / revalued copies share with their base), so a copy finds its base's lists
+// without a second registration, and nothing is copied with a handle.  Every library entry point that WRITES a row
+// bitmap (idg_bpr_touch_rows, idg_bitmap_clear, the `touched` argument of the BPR backward, idg_graph_expand_rows,
+// idg_graph_mark_cols, pack / unpack of gradient rows) drops the lists of that bitmap first (idg::rows_changed): a
+// restricted launch that finds no list visits the tiles, which is always correct.  A buffer freed and handed out again
+// by the caller's allocator is therefore harmless as soon as its new owner fills it through the library; callers that
+// write a registered bitmap by other means must call idg_graph_forget_live_units (include/idgrec.h).
+namespace {
+struct UnitList {
+  const void* sched = nullptr;
+  const uint32_t* bitmap = nullptr;
+  const int32_t* units = nullptr;
+  int64_t cap = 0;
+};
+constexpr int MAX_UNIT_LISTS = 64;
+UnitList g_unit_lists[MAX_UNIT_LISTS];
+int g_unit_next = 0;
+std::mutex g_unit_mutex;
+
+void units_register(const void* sched, const uint32_t* bitmap, const int32_t* units, int64_t cap) {
+  std::lock_guard<std::mutex> lock(g_unit_mutex);
+  int at = -1;
+  for (int i = 0; i < MAX_UNIT_LISTS; ++i)
+    if (g_unit_lists[i].sched == sched && g_unit_lists[i].bitmap == bitmap) at = i;
+  if (at < 0)
+    for (int i = 0; i < MAX_UNIT_LISTS && at < 0; ++i)
+      if (g_unit_lists[i].bitmap == nullptr) at = i;
+  if (at < 0) at = g_unit_next, g_unit_next = (g_unit_next + 1) % MAX_UNIT_LISTS;  // full: the oldest slot is replaced
+  g_unit_lists[at] = UnitList{sched, bitmap, units, cap};
+}
+
+bool units_find(const void* sched, const uint32_t* bitmap, const int32_t** units, int64_t* cap) {
+  std::lock_guard<std::mutex> lock(g_unit_mutex);
+  for (int i = 0; i < MAX_UNIT_LISTS; ++i)
+    if (g_unit_lists[i].sched == sched && g_unit_lists[i].bitmap == bitmap && bitmap != nullptr) {
+      if (units) *units = g_unit_lists[i].units;
+      if (cap) *cap = g_unit_lists[i].cap;
+      return true;
+    }
+  return false;
+}
+
+// sched == nullptr: every schedule; bitmap == nullptr: every bitmap
+void units_forget(const void* sched, const void* bitmap) {
+  std::lock_guard<std::mutex> lock(g_unit_mutex);
+  for (int i = 0; i < MAX_UNIT_LISTS; ++i)
+    if ((sched == nullptr || g_unit_lists[i].sched == sched) && (bitmap == nullptr || g_unit_lists[i].bitmap == bitmap))
+      g_unit_lists[i] = UnitList{};
+}
+}  // namespace
+
+namespace idg {
+void rows_changed(const void* bitmap) {
+  if (bitmap) units_forget(nullptr, bitmap);
+}
+}  // namespace idg
 
 namespace {
 
@@ -456,16 +510,17 @@ __device__ __forceinline__ int group_leader() {
   return lane & ~(LPR - 1);
 }
 
-template <int LPR, int NB, int UNROLL, int EPI, bool FUSED>
+template <int LPR, int NB, int UNROLL, int EPI, bool FUSED, bool XM = false>
 __device__ __forceinline__ void do_vrow(const ColVal* s_cv, int s, int e, int tgt, int l, const float* __restrict__ X,
                                         int64_t ldx, float* __restrict__ partials, int64_t d, const Epilogue& ep,
-                                        const FixCtx& fx, float4* s_part) {
+                                        const FixCtx& fx, float4* s_part, const uint32_t* __restrict__ xm = nullptr) {
   float nscale = 0.f;
   if (EPI == EPI_NOISE && tgt >= 0) nscale = noise_row_scale<LPR, NB>(ep, tgt, l);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc = walk<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, acc);
+    if (XM) acc = walk_masked<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, xm, acc);  // (XM: rows of X outside xm are zero and not read)
+    else acc = walk<UNROLL>(s_cv, s, e, X + (b * LPR + l) * 4, ldx, acc);
     // the store addresses are rebuilt from the lane id once per vrow: hoisting them out of the vrow loop as
     // 64-bit per-lane pairs costs the registers that keep the kernel at 64 VGPRs (8 waves/SIMD)
     int lo = l;
@@ -678,7 +733,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
 // of a training step feeds nothing but the layer mean at the <= 3B rows of the batch).  A tile
 // without a flagged row exits before staging its entries; otherwise the flagged vrows run the
 // ordinary walk, so the produced rows are bit-identical to the full product.
-template <int LPR, int NB, bool FUSED, int EPI = EPI_PLAIN>
+template <int LPR, int NB, bool FUSED, int EPI = EPI_PLAIN, bool XM = false>
 __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __restrict__ tiles,
                                                                const int64_t* __restrict__ vptr,
                                                                const int32_t* __restrict__ vtgt,
@@ -687,7 +742,8 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
                                                                const float* __restrict__ X, int64_t ldx,
                                                                float* __restrict__ partials, int64_t d, Epilogue ep,
                                                                FixCtx fx, const uint32_t* __restrict__ out_mask,
-                                                               const LocalRow* __restrict__ locals) {
+                                                               const LocalRow* __restrict__ locals,
+                                                               const uint32_t* __restrict__ x_mask) {
   __shared__ ColVal s_cv[TILE_NNZ];
   __shared__ float4 s_part[LSLOTS * NB * LPR];
   __shared__ int s_ptr[TILE_VROWS + 1];
@@ -745,7 +801,8 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_rows_kernel(const Tile* __res
   int q = g;
   while (q < nlive) {
     const int v = s_live[q];
-    do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
+    do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI, FUSED, XM>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part,
+                                                      x_mask);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
     q = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
@@ -880,7 +937,9 @@ __global__ __launch_bounds__(BLOCK) void live_units_kernel(const uint32_t* __res
                                                            const LongRow* __restrict__ longs,
                                                            const int32_t* __restrict__ slot_unit, int32_t* __restrict__ out,
                                                            int64_t cap) {
-  // out[0] = number of units, out[1..] = the units (order irrelevant)
+  // out[0] = number of units, out[1] = 1 when more units were found than the list holds (the caller's bound on the set
+  // bits was wrong: the consumer poisons its output and idg_graph_live_units_check reports it), out[2..] = the units
+  // (order irrelevant)
   const int64_t w = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (w * 32 >= n_rows) return;
   uint32_t m = bitmap[w];
@@ -892,23 +951,26 @@ __global__ __launch_bounds__(BLOCK) void live_units_kernel(const uint32_t* __res
     const int32_t u = row_unit[r];
     if (u > UNIT_LONG / 2) {  // a vrow (>= 0) or ~LocalRow
       const int pos = atomicAdd(out, 1);
-      if (pos < cap) out[1 + pos] = u;
+      if (pos < cap) out[UNITS_HEADER + pos] = u;
+      else out[1] = 1;
     } else {
       const LongRow lr = longs[u - UNIT_LONG];
       const int pos = atomicAdd(out, lr.n_seg);
       for (int k = 0; k < lr.n_seg; ++k)
-        if (pos + k < cap) out[1 + pos + k] = slot_unit[lr.slot_begin + k];
+        if (pos + k < cap) out[UNITS_HEADER + pos + k] = slot_unit[lr.slot_begin + k];
+        else out[1] = 1;
     }
   }
 }
 
-template <int LPR, int NB, int EPI>
+template <int LPR, int NB, int EPI, bool XM = false>
 __global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32_t* __restrict__ units, int64_t cap,
                                                            const int64_t* __restrict__ vptr,
                                                            const int32_t* __restrict__ vtgt,
                                                            const ColVal* __restrict__ cv, const float* __restrict__ X,
                                                            int64_t ldx, float* __restrict__ partials, int64_t d, Epilogue ep,
-                                                           FixCtx fx, const LocalRow* __restrict__ locals) {
+                                                           FixCtx fx, const LocalRow* __restrict__ locals,
+                                                           const uint32_t* __restrict__ x_mask) {
   constexpr int GPW = 64 / LPR;  // lane groups per wave
   constexpr int W = NB * LPR;
   __shared__ float4 s_part[IDG_UNITS_BLOCK / 64][LSLOTS * W];
@@ -917,7 +979,10 @@ __global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32
   int64_t count = units[0];
   if (count > cap) count = cap;
   if (u_idx >= count) return;  // whole waves leave together
-  const int32_t unit = units[1 + u_idx];
+  const int32_t unit = units[UNITS_HEADER + u_idx];
+  // the list overflowed when it was built (more set bits than the caller's bound): rows are missing from it, so what
+  // this launch can produce is incomplete — every row it does produce is poisoned instead of passing for a result
+  const bool poison = units[1] != 0;
   const int g = lane / LPR, l = lane % LPR;
   if (unit >= 0) {  // a plain vrow: one lane group.  Its target is a row, or (a short last chunk) a global partial slot
     if (g != 0) return;
@@ -931,8 +996,10 @@ __global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int64_t c = s; c < e; c += (1 << 20)) {
         const int len = (int)((e - c) < (1 << 20) ? (e - c) : (1 << 20));
-        acc = walk<IDG_UNITS_UNROLL>(cv + c, 0, len, X + off, ldx, acc);
+        acc = XM ? walk_masked<IDG_UNITS_UNROLL>(cv + c, 0, len, X + off, ldx, x_mask, acc)
+                 : walk<IDG_UNITS_UNROLL>(cv + c, 0, len, X + off, ldx, acc);
       }
+      if (poison) acc = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
       if (tgt >= 0) {
         if (EPI == EPI_NOISE) acc = perturb(ep, tgt, b * LPR + l, nscale, acc);
         epilogue_store<EPI>(ep, tgt, off, acc);
@@ -953,7 +1020,8 @@ __global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = walk<IDG_UNITS_UNROLL>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, acc);
+      acc = XM ? walk_masked<IDG_UNITS_UNROLL>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, x_mask, acc)
+               : walk<IDG_UNITS_UNROLL>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, acc);
       part[q * W + b * LPR + l] = acc;
     }
   }
@@ -977,6 +1045,7 @@ __global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32
 #pragma unroll
     for (int q = 1; q < FIX_WAYS; ++q)
       if (q < lr.n_seg) row = add4(row, sq[q]);
+    if (poison) row = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
     if (lr.tgt >= 0) {
       if (EPI == EPI_NOISE) row = perturb(ep, lr.tgt, b * LPR + l, nscale, row);
       epilogue_store<EPI>(ep, lr.tgt, off, row);
@@ -1265,35 +1334,43 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
   } while (0)
     const int32_t* units = nullptr;
     int64_t ucap = 0;
-    if (out_mask)
-      for (int i = 0; i < idg_graph::MAX_BOUND; ++i)
-        if (g->bound_bitmap[i] == out_mask) units = g->bound_units[i], ucap = g->bound_cap[i];
+    if (out_mask && !g->no_units) units_find(g->d_vptr, out_mask, &units, &ucap);
     if (units && ucap > 0 && (g->n_long == 0 || fused_fix) && !g->no_units) {
       // the bitmap's live work units are listed: one wave per unit, no tile is visited (spmm_units_kernel)
       const dim3 ugrid((unsigned)((ucap + IDG_UNITS_BLOCK / 64 - 1) / (IDG_UNITS_BLOCK / 64))), ublock(IDG_UNITS_BLOCK);
       if (ep.noise_eps != 0.f)
         hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_NOISE>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
-                           X, ldx, partials, d, ep, fx, g->d_local);
+                           X, ldx, partials, d, ep, fx, g->d_local, nullptr);
+      else if (x_mask)  // ... of a panel whose live rows are flagged too (a backward product between two small row sets)
+        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_PLAIN, true>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt,
+                           g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, x_mask);
       else
         hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_PLAIN>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
-                           X, ldx, partials, d, ep, fx, g->d_local);
+                           X, ldx, partials, d, ep, fx, g->d_local, nullptr);
       IDG_HIP(hipGetLastError());
       return IDG_OK;
     }
     if (out_mask && ep.noise_eps != 0.f) {  // flagged rows of a perturbed layer (the noise of a row depends on that row only)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true, EPI_NOISE>), grid, block, 0, st, tile_order, g->d_vptr,
-                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
       else
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false, EPI_NOISE>), grid, block, 0, st, tile_order, g->d_vptr,
-                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
+    } else if (out_mask && x_mask) {  // flagged output rows of a panel with flagged live rows
+      if (fused_fix)
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true, EPI_PLAIN, true>), grid, block, 0, st, tile_order, g->d_vptr,
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, x_mask);
+      else
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false, EPI_PLAIN, true>), grid, block, 0, st, tile_order, g->d_vptr,
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, x_mask);
     } else if (out_mask) {  // only flagged output rows (last forward layer of a training step)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
+                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
       else
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
-                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local);
+                           g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
     } else if (x_mask) {  // sparse-input form (first backward layer)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
@@ -1718,6 +1795,7 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
 
 int idg_graph_destroy(idg_graph* g) {
   if (!g) return IDG_OK;
+  if (!g->borrowed && g->d_vptr) units_forget(g->d_vptr, nullptr);  // the schedule goes away: so do its unit lists
   if (g->device >= 0 && idg_device_count() > g->device) {
     DeviceGuard guard;
     if (guard.enter(g->device) == IDG_OK) {
@@ -1892,25 +1970,18 @@ int idg_graph_masked_copy(const idg_graph* g, float add, float divisor, uint64_t
 
 size_t idg_graph_live_units_bytes(const idg_graph* g, int64_t max_rows) {
   if (!g || max_rows < 0) return 0;
-  return sizeof(int32_t) * (size_t)(1 + max_rows + g->n_slots);
+  return sizeof(int32_t) * (size_t)(UNITS_HEADER + max_rows + g->n_slots);
 }
 
 int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows) {
   IDG_REQUIRE(g && bitmap && units_ws && max_rows >= 0, "idg_graph_bind_live_units: bad argument");
-  int at = -1;
-  for (int i = 0; i < idg_graph::MAX_BOUND; ++i)
-    if (g->bound_bitmap[i] == bitmap) at = i;
-  if (at < 0) at = g->bound_next, g->bound_next = (g->bound_next + 1) % idg_graph::MAX_BOUND;
-  g->bound_bitmap[at] = bitmap;
-  g->bound_units[at] = reinterpret_cast<const int32_t*>(units_ws);
-  g->bound_cap[at] = max_rows + g->n_slots;
+  units_register(g->d_vptr, bitmap, reinterpret_cast<const int32_t*>(units_ws), max_rows + g->n_slots);
   return IDG_OK;
 }
 
 int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap) {
   IDG_REQUIRE(g, "idg_graph_forget_live_units: NULL handle");
-  for (int i = 0; i < idg_graph::MAX_BOUND; ++i)
-    if (g->bound_bitmap[i] == bitmap || bitmap == nullptr) g->bound_bitmap[i] = nullptr, g->bound_units[i] = nullptr;
+  units_forget(g->d_vptr, bitmap);
   return IDG_OK;
 }
 
@@ -1918,13 +1989,24 @@ int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units
   IDG_REQUIRE(g && bitmap && units_ws && max_rows >= 0, "idg_graph_live_units: bad argument");
   IDG_REQUIRE(g->d_row_unit || g->n_rows == 0, "idg_graph_live_units: handle without a row -> unit table");
   hipStream_t st = (hipStream_t)stream;
-  IDG_HIP(hipMemsetAsync(units_ws, 0, sizeof(int32_t), st));
+  IDG_HIP(hipMemsetAsync(units_ws, 0, UNITS_HEADER * sizeof(int32_t), st));
   const int64_t words = (g->n_rows + 31) / 32;
   if (words > 0)
     hipLaunchKernelGGL(live_units_kernel, dim3((unsigned)((words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, bitmap, g->n_rows,
                        g->d_row_unit, g->d_long, g->d_slot_unit, reinterpret_cast<int32_t*>(units_ws), max_rows + g->n_slots);
   IDG_HIP(hipGetLastError());
   return idg_graph_bind_live_units(g, bitmap, units_ws, max_rows);
+}
+
+int idg_graph_live_units_check(const void* units_ws, void* stream) {
+  IDG_REQUIRE(units_ws, "idg_graph_live_units_check: NULL list");
+  int32_t head[UNITS_HEADER] = {0, 0};
+  IDG_HIP(hipMemcpyAsync(head, units_ws, sizeof head, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  IDG_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (head[1] != 0)
+    return idg::fail(IDG_E_INVALID, "idg_graph_live_units: the bitmap holds more rows than max_rows allows (%d work units "
+                     "found): the list is incomplete and launches that use it poison their output", (int)head[0]);
+  return IDG_OK;
 }
 
 int idg_graph_info(const idg_graph* g, int64_t info[8]) {
@@ -1972,7 +2054,6 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
                     const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
                     const uint32_t* out_rows, const uint32_t* x_rows, int64_t d, void* ws, void* stream) {
   IDG_REQUIRE(g && X && (Y || sum_out), "idg_spmm_ex_f32: NULL argument");
-  IDG_REQUIRE(!(out_rows && x_rows), "idg_spmm_ex_f32: out_rows and x_rows cannot be combined");
   IDG_REQUIRE(d > 0 && ldx >= d && ldy >= d, "idg_spmm_ex_f32: bad d/ldx/ldy (%lld,%lld,%lld)", (long long)d,
               (long long)ldx, (long long)ldy);
   IDG_REQUIRE(div != 0.0f, "idg_spmm_ex_f32: div must be non-zero");
@@ -1984,6 +2065,44 @@ int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, c
   ep.ldy = ldy;
   ep.div = div;
   ep.accumulate = accumulate;
+  return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, x_rows, out_rows);
+}
+
+static void adam_constants(Epilogue& ep, float* p, float* m, float* v, double lr, double beta1, double beta2, double eps,
+                           int64_t step) {
+  // scalars in double on the host, exactly as idg_adam_step_f32 (and torch/optim/adam.py) forms them
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  ep.adam_p = p, ep.adam_m = m, ep.adam_v = v;
+  ep.adam_w1 = (float)(1.0 - beta1), ep.adam_beta2 = (float)beta2, ep.adam_w2 = (float)(1.0 - beta2);
+  ep.adam_step_size = (float)(lr / bc1), ep.adam_bc2_sqrt = (float)std::sqrt(bc2), ep.adam_eps = (float)eps;
+}
+
+int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d, const idg_epilogue* e,
+                     const uint32_t* out_rows, const uint32_t* x_rows, void* ws, void* stream) {
+  IDG_REQUIRE(g && X && e && (e->Y || e->sum_out), "idg_spmm_epi_f32: NULL argument");
+  IDG_REQUIRE(d > 0 && ldx >= d && e->ldy >= d, "idg_spmm_epi_f32: bad d/ldx/ldy (%lld,%lld,%lld)", (long long)d,
+              (long long)ldx, (long long)e->ldy);
+  IDG_REQUIRE(e->div != 0.0f, "idg_spmm_epi_f32: div must be non-zero");
+  IDG_REQUIRE(e->sum_in || (!e->sum_in2 && !e->sum_in3), "idg_spmm_epi_f32: sum_in2 / sum_in3 need sum_in");
+  Epilogue ep{};
+  ep.Y = e->Y;
+  ep.addend = e->addend;
+  ep.sum_in = e->sum_in, ep.sum_in2 = e->sum_in2, ep.sum_in3 = e->sum_in3;
+  ep.sum_out = e->sum_out;
+  ep.ldy = e->ldy;
+  ep.div = e->div;
+  ep.accumulate = e->accumulate;
+  ep.mask = e->mask;
+  if (e->adam_param) {
+    IDG_REQUIRE(e->sum_out && e->adam_exp_avg && e->adam_exp_avg_sq && e->adam_step >= 1,
+                "idg_spmm_epi_f32: the Adam epilogue needs sum_out (the gradient), both moments and a 1-based step");
+    IDG_REQUIRE(!out_rows && !x_rows, "idg_spmm_epi_f32: the Adam epilogue lives in the dense launch (no out_rows / x_rows)");
+    IDG_REQUIRE(((uintptr_t)e->adam_param | (uintptr_t)e->adam_exp_avg | (uintptr_t)e->adam_exp_avg_sq) % 16 == 0,
+                "idg_spmm_epi_f32: Adam panels must be 16-byte aligned");
+    adam_constants(ep, e->adam_param, e->adam_exp_avg, e->adam_exp_avg_sq, e->adam_lr, e->adam_beta1, e->adam_beta2,
+                   e->adam_eps, e->adam_step);
+  }
   return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, x_rows, out_rows);
 }
 
@@ -2171,8 +2290,7 @@ int idg_propagate_views_f32(const idg_graph* g, const float* E0, int K, int64_t 
   }
   // layers 2..K: mean(X1..XK) = propagate_mean(X1, K - 1, include_layer0 = 1), per pass
   bool listed = false;  // a live-unit list for this bitmap: the per-panel launches take the one-wave-per-unit form
-  if (out_rows && !g->no_units)
-    for (int i = 0; i < idg_graph::MAX_BOUND; ++i) listed = listed || g->bound_bitmap[i] == out_rows;
+  if (out_rows && !g->no_units) listed = units_find(g->d_vptr, out_rows, nullptr, nullptr);
   const bool multi_ok = out_rows && !listed && g->n_tiles > 0 && g->n_xl == 0 && !g->no_fused_fix &&
                         (g->n_slots * d * (int64_t)sizeof(float)) < ((int64_t)1 << 31);
   for (int k = 2; k <= K; ++k) {
@@ -2280,6 +2398,7 @@ int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t*
   IDG_REQUIRE(g && in_rows && out_rows && in_rows != out_rows, "idg_graph_expand_rows: bad argument");
   IDG_REQUIRE(g->n_rows == g->n_cols, "idg_graph_expand_rows: graph must be square");
   IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_expand_rows: handle without a vrow -> row table");
+  idg::rows_changed(out_rows);
   hipStream_t st = (hipStream_t)stream;
   IDG_HIP(hipMemcpyAsync(out_rows, in_rows, (size_t)((g->n_rows + 31) / 32) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   if (g->n_vrows > 0)
@@ -2292,6 +2411,7 @@ int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t*
 int idg_graph_mark_cols(const idg_graph* g, const uint32_t* in_rows, uint32_t* col_bits, void* stream) {
   IDG_REQUIRE(g && in_rows && col_bits, "idg_graph_mark_cols: bad argument");
   IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_mark_cols: handle without a vrow -> row table");
+  idg::rows_changed(col_bits);
   if (g->n_vrows > 0)
     hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((g->n_vrows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                        g->n_vrows, g->d_vptr, g->d_vrow_row, g->d_cv, in_rows, col_bits);
@@ -2328,12 +2448,7 @@ static int bwd_adam_impl(const idg_graph* g, const float* gout, const uint32_t* 
     return idg_adam_step_f32(param, gE0, exp_avg, exp_avg_sq, g->n_rows * d, lr, beta1, beta2, eps, step, stream);
   }
   Epilogue adam{};
-  adam.adam_p = param, adam.adam_m = exp_avg, adam.adam_v = exp_avg_sq;
-  // scalars in double on the host, exactly as idg_adam_step_f32 (and torch/optim/adam.py) forms them
-  const double bc1 = 1.0 - std::pow(beta1, (double)step);
-  const double bc2 = 1.0 - std::pow(beta2, (double)step);
-  adam.adam_w1 = (float)(1.0 - beta1), adam.adam_beta2 = (float)beta2, adam.adam_w2 = (float)(1.0 - beta2);
-  adam.adam_step_size = (float)(lr / bc1), adam.adam_bc2_sqrt = (float)std::sqrt(bc2), adam.adam_eps = (float)eps;
+  adam_constants(adam, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step);
   return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate, gout_mask, 0.f, 0, 0,
                           nullptr, &adam, fields);
 }

@@ -1,0 +1,220 @@
+// Row movers and the item-row tail of the user-row-sharded training step (id-grec_amd/sharded.py).
+// The reference trains on one device (utility/utility_train/trainer.py:36-56); these kernels are what sits between its
+// step's products when the user rows are cut across GPUs: the batch's user rows travel through "guest" rows, the item
+// rows a batch touches travel as compact row sets, and each rank finishes the gradient and applies Adam for the 1/N of
+// the item rows it owns.  All of them are HBM / latency bound row copies: one wave per row, 16-byte lanes, no atomics.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "idg_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ bool bit_at(const uint32_t* __restrict__ bits, int64_t r) { return (bits[r >> 5] >> (r & 31)) & 1u; }
+
+// dstP[t] = idx[t] >= 0 ? srcP[idx[t]] : 0 for up to two (dst, src) panel pairs sharing one index list
+__global__ __launch_bounds__(BLOCK) void rows_gather2_kernel(float* __restrict__ dst0, const float* __restrict__ src0,
+                                                             float* __restrict__ dst1, const float* __restrict__ src1,
+                                                             const int64_t* __restrict__ idx, int64_t count, int64_t d) {
+  const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int64_t t = w >> 1;
+  if (t >= count) return;
+  float* dst = (w & 1) ? dst1 : dst0;
+  const float* src = (w & 1) ? src1 : src0;
+  if (!dst) return;
+  const int64_t r = idx[t];
+  for (int64_t f = (threadIdx.x % WAVE) * 4; f < d; f += WAVE * 4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= 0) v = *reinterpret_cast<const float4*>(src + r * d + f);
+    *reinterpret_cast<float4*>(dst + t * d + f) = v;
+  }
+}
+
+// dst[idx[j]] = src[j]  (idx distinct, >= 0)
+__global__ __launch_bounds__(BLOCK) void rows_scatter_kernel(float* __restrict__ dst, const int64_t* __restrict__ idx,
+                                                             const float* __restrict__ src, int64_t count, int64_t d) {
+  const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  if (j >= count) return;
+  const int64_t r = idx[j];
+  for (int64_t f = (threadIdx.x % WAVE) * 4; f < d; f += WAVE * 4)
+    *reinterpret_cast<float4*>(dst + r * d + f) = *reinterpret_cast<const float4*>(src + j * d + f);
+}
+
+// For every head t (idx[t] >= 0): dstP[idx[t]] = srcP[t] + srcP[next[t]] + ... in chain order — STORED, so the
+// destination panel needs no zero-fill (its other rows are never read: the consumers go by the row bitmap).
+__global__ __launch_bounds__(BLOCK) void rows_chain_store2_kernel(float* __restrict__ dst0, const float* __restrict__ src0,
+                                                                  float* __restrict__ dst1, const float* __restrict__ src1,
+                                                                  const int64_t* __restrict__ idx,
+                                                                  const int64_t* __restrict__ next, int64_t count, int64_t d) {
+  const int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int64_t t = w >> 1;
+  if (t >= count) return;
+  float* dst = (w & 1) ? dst1 : dst0;
+  const float* src = (w & 1) ? src1 : src0;
+  if (!dst) return;
+  const int64_t r = idx[t];
+  if (r < 0) return;
+  for (int64_t f = (threadIdx.x % WAVE) * 4; f < d; f += WAVE * 4) {
+    float4 acc = *reinterpret_cast<const float4*>(src + t * d + f);
+    for (int64_t j = next[t]; j >= 0; j = next[j]) {
+      const float4 x = *reinterpret_cast<const float4*>(src + j * d + f);
+      acc.x += x.x, acc.y += x.y, acc.z += x.z, acc.w += x.w;
+    }
+    *reinterpret_cast<float4*>(dst + r * d + f) = acc;
+  }
+}
+
+// out[ids[j]] = (((a[ids[j]] + b[ids[j]]) + c[ids[j]]) + last[j]) / div — the layer mean (models/LightGCN.py:47-48, in
+// torch.mean(torch.stack(...))'s left-to-right order) at the few item rows a training step reads; absent terms skipped
+__global__ __launch_bounds__(BLOCK) void rows_layer_mean_kernel(float* __restrict__ out, const int64_t* __restrict__ ids,
+                                                                int64_t count, const float* __restrict__ a,
+                                                                const float* __restrict__ b, const float* __restrict__ c,
+                                                                const float* __restrict__ last, float div, int64_t d) {
+  const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  if (j >= count) return;
+  const int64_t r = ids[j];
+  for (int64_t f = (threadIdx.x % WAVE) * 4; f < d; f += WAVE * 4) {
+    float4 s = *reinterpret_cast<const float4*>(last + j * d + f);
+    const float* terms[3] = {a, b, c};
+    bool have = false;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (terms[k]) {
+        const float4 x = *reinterpret_cast<const float4*>(terms[k] + r * d + f);
+        if (have) t.x += x.x, t.y += x.y, t.z += x.z, t.w += x.w;
+        else t = x, have = true;
+      }
+    if (have) s.x = t.x + s.x, s.y = t.y + s.y, s.z = t.z + s.z, s.w = t.w + s.w;
+    if (div != 1.0f) s.x = s.x / div, s.y = s.y / div, s.z = s.z / div, s.w = s.w / div;
+    *reinterpret_cast<float4*>(out + r * d + f) = s;
+  }
+}
+
+// The item-row tail of a sharded step, for a block of rows this rank owns: finish the gradient from the reduced
+// partial sums t of the last backward product and apply Adam —
+//   s = (c0 && live ? g + t : t) / cnt;  s = live ? G + s : s;  [G = s];  Adam(p, m, v; s)
+// live = the row is one of the batch's items (bit row0 + r of `bits`): only there do g (d loss / d final) and G (the
+// regulariser's gradient) hold anything.  Operation for operation what the last backward epilogue of the single-device
+// step computes (idg_graph.hip: sum_in + acc, / div, sum_out + s, then EPI_ADAM).
+__global__ __launch_bounds__(BLOCK) void grad_tail_adam_kernel(const float* __restrict__ t, const float* __restrict__ g,
+                                                               float* __restrict__ G, const uint32_t* __restrict__ bits,
+                                                               int64_t row0, int64_t rows, int64_t d, int c0, float cnt,
+                                                               int store_grad, float* __restrict__ p, float* __restrict__ m,
+                                                               float* __restrict__ v, float w1, float beta2, float w2,
+                                                               float step_size, float bc2_sqrt, float eps) {
+  const int64_t d4 = d / 4;
+  const int64_t n4 = rows * d4;
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
+    const int64_t r = i / d4;
+    const bool live = bits != nullptr && bit_at(bits, row0 + r);
+    float4 s = reinterpret_cast<const float4*>(t)[i];
+    if (c0 && live) {
+      const float4 x = reinterpret_cast<const float4*>(g)[i];
+      s.x = x.x + s.x, s.y = x.y + s.y, s.z = x.z + s.z, s.w = x.w + s.w;
+    }
+    s.x = s.x / cnt, s.y = s.y / cnt, s.z = s.z / cnt, s.w = s.w / cnt;
+    if (live) {
+      const float4 x = reinterpret_cast<const float4*>(G)[i];
+      s.x = x.x + s.x, s.y = x.y + s.y, s.z = x.z + s.z, s.w = x.w + s.w;
+    }
+    if (store_grad) reinterpret_cast<float4*>(G)[i] = s;
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+#define IDG_ADAM1(c)                                                 \
+  M.c = __builtin_fmaf(w1, s.c - M.c, M.c);                          \
+  V.c = __builtin_fmaf(w2 * s.c, s.c, V.c * beta2);                  \
+  P.c = P.c - step_size * (M.c / (sqrtf(V.c) / bc2_sqrt + eps));
+    IDG_ADAM1(x) IDG_ADAM1(y) IDG_ADAM1(z) IDG_ADAM1(w)
+#undef IDG_ADAM1
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int idg_rows_gather2_f32(float* dst0, const float* src0, float* dst1, const float* src1, const int64_t* idx, int64_t count,
+                         int64_t d, void* stream) {
+  IDG_REQUIRE(dst0 && src0 && idx && count >= 0 && d > 0 && d % 4 == 0, "idg_rows_gather2_f32: bad argument");
+  IDG_REQUIRE((dst1 == nullptr) == (src1 == nullptr), "idg_rows_gather2_f32: the second pair is both or neither");
+  IDG_REQUIRE(((uintptr_t)dst0 | (uintptr_t)src0 | (uintptr_t)dst1 | (uintptr_t)src1) % 16 == 0,
+              "idg_rows_gather2_f32: panels must be 16-byte aligned");
+  if (count == 0) return IDG_OK;
+  const int64_t waves = 2 * count;
+  hipLaunchKernelGGL(rows_gather2_kernel, dim3((unsigned)((waves + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, dst0, src0, dst1, src1, idx, count, d);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_rows_scatter_f32(float* dst, const int64_t* idx, const float* src, int64_t count, int64_t d, void* stream) {
+  IDG_REQUIRE(dst && src && idx && count >= 0 && d > 0 && d % 4 == 0, "idg_rows_scatter_f32: bad argument");
+  IDG_REQUIRE(((uintptr_t)dst | (uintptr_t)src) % 16 == 0, "idg_rows_scatter_f32: panels must be 16-byte aligned");
+  if (count == 0) return IDG_OK;
+  hipLaunchKernelGGL(rows_scatter_kernel, dim3((unsigned)((count + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, dst, idx, src, count, d);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_rows_chain_store2_f32(float* dst0, const float* src0, float* dst1, const float* src1, const int64_t* idx,
+                              const int64_t* next, int64_t count, int64_t d, void* stream) {
+  IDG_REQUIRE(dst0 && src0 && idx && next && count >= 0 && d > 0 && d % 4 == 0, "idg_rows_chain_store2_f32: bad argument");
+  IDG_REQUIRE((dst1 == nullptr) == (src1 == nullptr), "idg_rows_chain_store2_f32: the second pair is both or neither");
+  IDG_REQUIRE(((uintptr_t)dst0 | (uintptr_t)src0 | (uintptr_t)dst1 | (uintptr_t)src1) % 16 == 0,
+              "idg_rows_chain_store2_f32: panels must be 16-byte aligned");
+  if (count == 0) return IDG_OK;
+  const int64_t waves = 2 * count;
+  hipLaunchKernelGGL(rows_chain_store2_kernel, dim3((unsigned)((waves + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, dst0, src0, dst1, src1, idx, next, count, d);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_rows_layer_mean_f32(float* out, const int64_t* ids, int64_t count, const float* a, const float* b, const float* c,
+                            const float* last, float div, int64_t d, void* stream) {
+  IDG_REQUIRE(out && ids && last && count >= 0 && d > 0 && d % 4 == 0 && div != 0.f, "idg_rows_layer_mean_f32: bad argument");
+  IDG_REQUIRE(((uintptr_t)out | (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)last) % 16 == 0,
+              "idg_rows_layer_mean_f32: panels must be 16-byte aligned");
+  if (count == 0) return IDG_OK;
+  hipLaunchKernelGGL(rows_layer_mean_kernel, dim3((unsigned)((count + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, out, ids, count, a, b, c, last, div, d);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_grad_tail_adam_f32(const float* t, const float* g, float* G, const uint32_t* live_bits, int64_t row0, int64_t rows,
+                           int64_t d, int include_layer0, float cnt, int store_grad, float* param, float* exp_avg,
+                           float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
+  IDG_REQUIRE(t && param && exp_avg && exp_avg_sq && rows >= 0 && d > 0 && d % 4 == 0 && row0 >= 0,
+              "idg_grad_tail_adam_f32: bad argument");
+  IDG_REQUIRE(cnt != 0.f && step >= 1, "idg_grad_tail_adam_f32: cnt must be non-zero, step 1-based");
+  IDG_REQUIRE(!live_bits || (g && G), "idg_grad_tail_adam_f32: live rows need the g and G panels");
+  IDG_REQUIRE(!store_grad || G, "idg_grad_tail_adam_f32: store_grad needs G");
+  IDG_REQUIRE(((uintptr_t)t | (uintptr_t)g | (uintptr_t)G | (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+              "idg_grad_tail_adam_f32: panels must be 16-byte aligned");
+  if (rows == 0) return IDG_OK;
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  const int64_t n4 = rows * (d / 4);
+  int64_t nb = (n4 + BLOCK - 1) / BLOCK;
+  nb = nb < 1 ? 1 : (nb > 256 * 8 ? 256 * 8 : nb);
+  hipLaunchKernelGGL(grad_tail_adam_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, t, g, G, live_bits, row0,
+                     rows, d, include_layer0 ? 1 : 0, cnt, store_grad ? 1 : 0, param, exp_avg, exp_avg_sq, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1), (float)std::sqrt(bc2), (float)eps);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+}  // extern "C"

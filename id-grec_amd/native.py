@@ -44,6 +44,7 @@ PROTOTYPES = {
     "idg_graph_live_units": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "idg_graph_bind_live_units": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64]),
     "idg_graph_forget_live_units": (C.c_int, [c_vp, c_vp]),
+    "idg_graph_live_units_check": (C.c_int, [c_vp, c_vp]),
     "idg_graph_revalued_copy": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(c_vp)]),
     "idg_subgraph_values_f32": (C.c_int, [C.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "idg_graph_remask": (C.c_int, [c_vp, c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp]),
@@ -54,6 +55,13 @@ PROTOTYPES = {
     "idg_spmm_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, c_vp]),
     "idg_spmm_ex_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_float, C.c_int,
                                   c_vp, c_vp, C.c_int64, c_vp, c_vp]),
+    "idg_spmm_epi_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "idg_rows_gather2_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
+    "idg_rows_scatter_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
+    "idg_rows_chain_store2_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
+    "idg_rows_layer_mean_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_float, C.c_int64, c_vp]),
+    "idg_grad_tail_adam_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int,
+                                         c_vp, c_vp, c_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, c_vp]),
     "idg_lincomb_f32": (C.c_int, [c_vp, c_vp, C.c_float, c_vp, C.c_float, C.c_int64, c_vp]),
     "idg_rows_gather_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
     "idg_rows_chain_add_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
@@ -108,6 +116,7 @@ PROTOTYPES = {
     "idg_comm_destroy": (C.c_int, [c_vp]),
     "idg_allreduce_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, c_vp]),
     "idg_allgather_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
+    "idg_reduce_scatter_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "idg_bpr_rows_message_floats": (C.c_size_t, [C.c_int64, C.c_int64]),
     "idg_bpr_pack_rows_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "idg_bpr_unpack_rows_f32": (C.c_int, [c_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_float, c_vp, c_vp,
@@ -128,6 +137,15 @@ PROTOTYPES = {
 IDG_GRAPH_SYMMETRIC = 1
 IDG_GRAPH_EXACT_ORDER = 2
 
+
+class Epilogue(C.Structure):
+    """idg_epilogue (include/idgrec.h): every epilogue option of idg_spmm_epi_f32."""
+    _fields_ = [("Y", c_vp), ("addend", c_vp), ("sum_in", c_vp), ("sum_in2", c_vp), ("sum_in3", c_vp), ("sum_out", c_vp),
+                ("ldy", C.c_int64), ("div", C.c_float), ("accumulate", C.c_int), ("mask", c_vp),
+                ("adam_param", c_vp), ("adam_exp_avg", c_vp), ("adam_exp_avg_sq", c_vp),
+                ("adam_lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("adam_step", C.c_int64)]
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "libidgrec.so is not built (%s). Run `python id-grec_amd/build.py` (needs hipcc); "
@@ -141,7 +159,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 118  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 130  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -10,6 +10,7 @@ reg_lambda*get_reg_loss of `forward()` (models/LightGCN.py:57-68); `score_topk` 
 get_rating_for_test + mask + torch.topk (utility/utility_train/batch_test.py:59-68).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -52,6 +53,12 @@ def _i64c(t, name):
 
 def _ptr(t):
     return t.data_ptr() if t is not None else None  # ctypes converts int / None for void* parameters
+
+
+def _forget_units_of(graph_ref, bitmap_ptr):
+    g = graph_ref()
+    if g is not None and getattr(g, "_h", None) and lib is not None:
+        lib.idg_graph_forget_live_units(g._h, bitmap_ptr)
 
 
 class Graph:
@@ -122,7 +129,18 @@ class Graph:
                              device=self.device)
         check(lib.idg_graph_live_units(self._h, _ptr(bitmap), _ptr(ws), int(max_rows), _stream() if stream is None else stream),
               "idg_graph_live_units")
+        # the registration names two caller-owned buffers: it must not outlive either (the allocator may hand the same
+        # address to something else).  One finalizer per tensor object, however often the list is rebuilt.
+        for t in (bitmap, ws):
+            if not getattr(t, "_idg_units_finalizer", False):
+                weakref.finalize(t, _forget_units_of, weakref.ref(self), bitmap.data_ptr())
+                t._idg_units_finalizer = True
         return ws
+
+    @staticmethod
+    def live_units_check(ws, stream=None):
+        """Raises if the list in `ws` could not hold every row of its bitmap (idg_graph_live_units_check; synchronises)."""
+        check(lib.idg_graph_live_units_check(_ptr(ws), _stream() if stream is None else stream), "idg_graph_live_units_check")
 
     def bind_live_units(self, bitmap, ws, max_rows):
         """Register an existing list (built on a handle with the same schedule: the base of a masked / revalued copy)."""
@@ -344,6 +362,70 @@ def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.
     ws = graph._workspace("spmm", d)
     check(lib.idg_spmm_ex_f32(graph._h, _ptr(X), d, _ptr(Y), _ptr(addend), _ptr(sum_in), _ptr(sum_out), d, float(div),
                               int(bool(accumulate)), _ptr(out_rows), _ptr(x_rows), d, _ptr(ws), _stream()), "idg_spmm_ex_f32")
+
+
+def spmm_epi_raw(graph, X, Y=None, addend=None, sum_in=None, sum_in2=None, sum_in3=None, sum_out=None, div=1.0,
+                 accumulate=False, mask=None, adam=None, out_rows=None, x_rows=None):
+    """idg_spmm_epi_f32: the product with every epilogue option (include/idgrec.h, idg_epilogue).  mask: bitmap of the
+    live rows of addend / sum_in* / the accumulate target; adam = (param, exp_avg, exp_avg_sq, lr, step[, beta1, beta2,
+    eps]): the Adam update of the rows of `param` with gradient sum_out in the same launch.  out_rows and x_rows may be
+    combined."""
+    _require_device(X, Y, addend, sum_in, sum_in2, sum_in3, sum_out, mask, out_rows, x_rows)
+    d = X.shape[1]
+    for t in (X, Y, addend, sum_in, sum_in2, sum_in3, sum_out):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != d):
+            raise TypeError("spmm_epi_raw needs contiguous float32 [*, %d] panels" % d)
+    e = native.Epilogue(_ptr(Y), _ptr(addend), _ptr(sum_in), _ptr(sum_in2), _ptr(sum_in3), _ptr(sum_out), d, float(div),
+                        int(bool(accumulate)), _ptr(mask))
+    if adam is not None:
+        p, m, v, lr, step = adam[:5]
+        b1, b2, eps = (tuple(adam[5:8]) + (0.9, 0.999, 1e-8)[len(adam) - 5:])[:3] if len(adam) > 5 else (0.9, 0.999, 1e-8)
+        _require_device(p, m, v)
+        e.adam_param, e.adam_exp_avg, e.adam_exp_avg_sq = _ptr(p), _ptr(m), _ptr(v)
+        e.adam_lr, e.adam_beta1, e.adam_beta2, e.adam_eps, e.adam_step = float(lr), float(b1), float(b2), float(eps), int(step)
+    ws = graph._workspace("spmm", d)
+    check(lib.idg_spmm_epi_f32(graph._h, _ptr(X), d, d, C.byref(e), _ptr(out_rows), _ptr(x_rows), _ptr(ws), _stream()),
+          "idg_spmm_epi_f32")
+
+
+def rows_gather2_raw(dst0, src0, dst1, src1, idx):
+    """dstP[t] = srcP[idx[t]] (zeros where idx[t] < 0) for two panel pairs in one launch (idg_rows_gather2_f32)."""
+    _require_device(dst0, src0, dst1, src1, idx)
+    check(lib.idg_rows_gather2_f32(_ptr(dst0), _ptr(src0), _ptr(dst1), _ptr(src1), _ptr(idx), int(idx.shape[0]),
+                                   int(dst0.shape[1]), _stream()), "idg_rows_gather2_f32")
+
+
+def rows_scatter_raw(dst, idx, src):
+    """dst[idx[j]] = src[j] (idg_rows_scatter_f32)."""
+    _require_device(dst, idx, src)
+    check(lib.idg_rows_scatter_f32(_ptr(dst), _ptr(idx), _ptr(src), int(src.shape[0]), int(dst.shape[1]), _stream()),
+          "idg_rows_scatter_f32")
+
+
+def rows_chain_store2_raw(dst0, src0, dst1, src1, idx, nxt):
+    """dstP[idx[t]] = srcP[t] + srcP[nxt[t]] + ... for every head t, stored (idg_rows_chain_store2_f32)."""
+    _require_device(dst0, src0, dst1, src1, idx, nxt)
+    check(lib.idg_rows_chain_store2_f32(_ptr(dst0), _ptr(src0), _ptr(dst1), _ptr(src1), _ptr(idx), _ptr(nxt),
+                                        int(idx.shape[0]), int(dst0.shape[1]), _stream()), "idg_rows_chain_store2_f32")
+
+
+def rows_layer_mean_raw(out, ids, terms, last, div):
+    """out[ids[j]] = (((a + b) + c)[ids[j]] + last[j]) / div, terms = up to three panels (idg_rows_layer_mean_f32)."""
+    terms = [t for t in terms if t is not None]
+    _require_device(out, ids, last, *terms)
+    a, b, c = (terms + [None, None, None])[:3]
+    check(lib.idg_rows_layer_mean_f32(_ptr(out), _ptr(ids), int(ids.shape[0]), _ptr(a), _ptr(b), _ptr(c), _ptr(last),
+                                      float(div), int(out.shape[1]), _stream()), "idg_rows_layer_mean_f32")
+
+
+def grad_tail_adam_raw(t, g, G, live_bits, row0, include_layer0, cnt, store_grad, param, exp_avg, exp_avg_sq, lr, step,
+                       beta1=0.9, beta2=0.999, eps=1e-8):
+    """idg_grad_tail_adam_f32 on a block of rows: every tensor is the block's [rows, d] slice of its panel."""
+    _require_device(t, g, G, live_bits, param, exp_avg, exp_avg_sq)
+    check(lib.idg_grad_tail_adam_f32(_ptr(t), _ptr(g), _ptr(G), _ptr(live_bits), int(row0), int(t.shape[0]), int(t.shape[1]),
+                                     int(bool(include_layer0)), float(cnt), int(bool(store_grad)), _ptr(param),
+                                     _ptr(exp_avg), _ptr(exp_avg_sq), float(lr), float(beta1), float(beta2), float(eps),
+                                     int(step), _stream()), "idg_grad_tail_adam_f32")
 
 
 def lincomb_raw(out, x, a, y=None, b=0.0):

@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 118 /* 0.1.16: + idg_graph_mark_cols (the hop of idg_graph_flag_cols as a bitmap over the columns) */
+#define IDG_VERSION 130 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
+                           epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
+                           _chain_store2 / _layer_mean, idg_grad_tail_adam_f32, idg_reduce_scatter_f32 */
 
 /* error classes */
 #define IDG_OK 0
@@ -156,18 +158,27 @@ int idg_graph_remask(const idg_graph* g, idg_graph* copy, float add, float divis
 /* Live work units of a row bitmap (optional accelerator of the row-restricted launches; round 2).  A launch given
  * `out_rows` normally visits every tile to find the few rows wanted.  idg_graph_live_units turns the bitmap into the list
  * of work units behind its rows — on `stream`: meant for the side stream that prepares a batch's index-only work — and
- * registers (bitmap pointer -> list) on the handle; from then on every restricted launch on this handle that names THIS
- * bitmap pointer runs one wave per listed unit and visits no tile.  Results are bit-identical to the tile form.  The
- * list is valid for the bitmap's contents at the time of the call: call again after changing the bitmap (same units_ws:
- * the registration is replaced), or idg_graph_forget_live_units (bitmap = NULL: all).  max_rows: upper bound on the set
- * bits (3 x batch size); more set bits than that is the caller's error (the surplus rows would not be produced).
+ * registers (schedule, bitmap pointer -> list); from then on every restricted launch on this handle, or on a masked /
+ * revalued copy of it (copies share the schedule: no second registration), that names THIS bitmap pointer runs one wave
+ * per listed unit and visits no tile.  Results are bit-identical to the tile form.
+ * Validity.  A list describes the bitmap's contents at the time of the call.  Every library entry point that writes a row
+ * bitmap (idg_bpr_touch_rows, idg_bitmap_clear, the `touched` argument of idg_bpr_backward_f32 / idg_bpr_fused_f32,
+ * idg_graph_expand_rows / idg_graph_mark_cols outputs, idg_bpr_pack_rows_f32 / idg_bpr_unpack_rows_f32) drops the lists
+ * registered for that pointer before it writes, and launches then fall back to the tile form (always correct) until
+ * idg_graph_live_units is called again — so a buffer that was freed and handed out again is harmless once its new owner
+ * fills it through the library.  A caller that rewrites a registered bitmap by other means calls
+ * idg_graph_forget_live_units first (bitmap = NULL: every list of this handle's schedule); destroying the handle forgets
+ * its lists.  The registry is process-wide, holds 64 lists (oldest replaced) and is thread-safe.
+ * max_rows: upper bound on the set bits (3 x batch size).  More set bits than that cannot be listed: the list is marked
+ * incomplete on the device, launches that use it write NaN into every row they produce, and idg_graph_live_units_check
+ * (synchronises `stream`; for tests and debugging) returns IDG_E_INVALID.
  * units_ws: idg_graph_live_units_bytes(g, max_rows) bytes of device memory owned by the caller, alive while registered.
- * Copies of a handle (masked / revalued) share its schedule: idg_graph_bind_live_units registers an existing list on them.
- * At most 8 bitmaps are registered per handle (oldest replaced). */
+ * idg_graph_bind_live_units registers an existing list under another bitmap pointer / handle of the same schedule. */
 size_t idg_graph_live_units_bytes(const idg_graph* g, int64_t max_rows);
 int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream);
 int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows);
 int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap);
+int idg_graph_live_units_check(const void* units_ws, void* stream);
 
 /* The batch's receptive field (no reference counterpart: the reference propagates the whole graph every step,
  * models/LightGCN.py:36-52, although the loss reads the final layer at the batch's rows only).  Layer K is needed at the
@@ -239,11 +250,43 @@ int idg_spmm_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int6
  * loop themselves (the user-row-sharded multi-GPU path, where an all-reduce sits between the
  * layers):  t = A.X (+ addend);  Y = t (if Y);  s = (sum_in ? sum_in + t : t) / div;
  * sum_out (+)= s (if sum_out; += when accumulate).  All panels share ldy.  out_rows (nullable):
- * bitmap of the output rows to produce; the others are left untouched. */
+ * bitmap of the output rows to produce; the others are left untouched.  x_rows (nullable): bitmap of the live rows of
+ * X; the others are zero by agreement and are not read. */
 int idg_spmm_ex_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, const float* addend,
                     const float* sum_in, float* sum_out, int64_t ldy, float div, int accumulate,
                     const uint32_t* out_rows, const uint32_t* x_rows, int64_t d, void* ws,
                     void* stream);
+
+/* The same product with EVERY epilogue option as a struct (idg_spmm_ex_f32 is the subset without sum_in2 / sum_in3, mask
+ * and Adam).  In order, for each produced row r:
+ *   t = (A.X)[r]  (+ addend[r] if live(r));  Y[r] = t (if Y);
+ *   s = live(r) && sum_in ? ((sum_in[r] + sum_in2[r]) + sum_in3[r]) + t : t   (absent terms skipped; this is the layer
+ *       mean's left-to-right order, models/LightGCN.py:47-48);  s = s / div;
+ *   sum_out[r] = accumulate && live(r) ? sum_out[r] + s : s (if sum_out);
+ *   adam_param != NULL: the Adam update of row r of (param, exp_avg, exp_avg_sq) with gradient sum_out[r]
+ *       (trainer.py:54-56; same arithmetic as idg_adam_step_f32; dense launches only).
+ * live(r) = mask == NULL or bit r of mask: rows of addend / sum_in* / the accumulate target whose bit is clear are zero
+ * by agreement and are NOT read (they may hold anything).  out_rows: produce only these rows; x_rows: rows of X outside
+ * are zero and not read; the two may be combined (a backward product between two small row sets). */
+typedef struct idg_epilogue {
+  float* Y;
+  const float* addend;
+  const float* sum_in;
+  const float* sum_in2;
+  const float* sum_in3;
+  float* sum_out;
+  int64_t ldy;
+  float div;
+  int accumulate;
+  const uint32_t* mask;
+  float* adam_param;
+  float* adam_exp_avg;
+  float* adam_exp_avg_sq;
+  double adam_lr, adam_beta1, adam_beta2, adam_eps;
+  int64_t adam_step;
+} idg_epilogue;
+int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d, const idg_epilogue* epilogue,
+                     const uint32_t* out_rows, const uint32_t* x_rows, void* ws, void* stream);
 
 /* One perturbed layer (models/XSimGCL.py:51-54): Y = A.X;  Y += sign(Y) * normalize(u, dim=-1) * eps,
  * u ~ U[0,1)^d from Philox4x32-10(seed; stream_id, row, feature block).  d in {32,...,512}.
@@ -477,6 +520,34 @@ int idg_rows_gather_f32(float* dst, const float* src, const int64_t* idx, int64_
 int idg_rows_chain_add_f32(float* dst, const float* src, const int64_t* idx, const int64_t* next, int64_t count,
                            int64_t d, void* stream);
 
+/* The same movers in the forms the round-3 step uses (16-byte lanes; d % 4 == 0, panels 16-byte aligned):
+ * idg_rows_gather2_f32: idg_rows_gather_f32 for two (dst, src) panel pairs sharing one index list in ONE launch (the
+ *   batch users' final and ego rows go to the guest rows together); the second pair may be NULL.
+ * idg_rows_scatter_f32: dst[idx[j], :] = src[j, :] (idx distinct, >= 0) — puts an exchanged compact row set back.
+ * idg_rows_chain_store2_f32: idg_rows_chain_add_f32 that STORES the chain's sum (dst[idx[t]] = src[t] + src[next[t]] + ...)
+ *   for two panel pairs: the destination panels are never zero-filled, their live rows are known by bitmap.
+ * idg_rows_layer_mean_f32: out[ids[j], :] = (((a[ids[j]] + b[ids[j]]) + c[ids[j]]) + last[j]) / div with a, b, c nullable
+ *   [*, d] panels and `last` a compact [count, d] buffer — LightGCN's layer mean (models/LightGCN.py:47-48, torch.mean of
+ *   the stacked layers: left-to-right sum, true division) at the batch's item rows, whose last layer arrives as a
+ *   compact exchanged row set.
+ * idg_grad_tail_adam_f32: the item-row tail of a sharded step for a block of `rows` rows one rank owns, starting at
+ *   global item row row0: s = (include_layer0 && live ? g + t : t) / cnt; s = live ? G + s : s; [G = s if store_grad];
+ *   Adam(param, exp_avg, exp_avg_sq; s) — t = the reduced partial sums of the last backward product, g = d loss / d final
+ *   and G = the regulariser's gradient, both meaningful only at live rows (bit row0 + r of live_bits; NULL = no live
+ *   row).  Pointers address the block's first row.  Same operations in the same order as the last backward epilogue of
+ *   the single-device step (autograd of models/LightGCN.py:43-48 + trainer.py:54-56). */
+int idg_rows_gather2_f32(float* dst0, const float* src0, float* dst1, const float* src1, const int64_t* idx,
+                         int64_t count, int64_t d, void* stream);
+int idg_rows_scatter_f32(float* dst, const int64_t* idx, const float* src, int64_t count, int64_t d, void* stream);
+int idg_rows_chain_store2_f32(float* dst0, const float* src0, float* dst1, const float* src1, const int64_t* idx,
+                              const int64_t* next, int64_t count, int64_t d, void* stream);
+int idg_rows_layer_mean_f32(float* out, const int64_t* ids, int64_t count, const float* a, const float* b,
+                            const float* c, const float* last, float div, int64_t d, void* stream);
+int idg_grad_tail_adam_f32(const float* t, const float* g, float* G, const uint32_t* live_bits, int64_t row0,
+                           int64_t rows, int64_t d, int include_layer0, float cnt, int store_grad, float* param,
+                           float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                           int64_t step, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * DEVICE: full-rank scoring, train-positive masking, top-K
  * (get_rating_for_test models/LightGCN.py:74-80, MFBPR.py:44-49; batch_test.Test
@@ -537,8 +608,13 @@ int idg_comm_create(int rank, int world, const void* unique_id, int device, idg_
 int idg_comm_destroy(idg_comm* comm);
 /* buf[0..count) <- sum over ranks (average != 0: mean over ranks), in place. */
 int idg_allreduce_f32(idg_comm* comm, float* buf, int64_t count, int average, void* stream);
-/* out[r * count .. (r + 1) * count) <- rank r's in[0..count). */
+/* out[r * count .. (r + 1) * count) <- rank r's in[0..count).  In place when in == out + rank * count. */
 int idg_allgather_f32(idg_comm* comm, const float* in, float* out, int64_t count, void* stream);
+/* out[0..count) <- sum over ranks of their in[rank * count .. (rank + 1) * count): every rank hands in world * count
+ * floats and keeps the reduced block it owns (ncclReduceScatter).  In place when out == in + rank * count.  The sharded
+ * step ends its last backward exchange with this: each rank finishes the gradient and applies Adam for the item rows it
+ * owns, and the updated rows go round by idg_allgather_f32. */
+int idg_reduce_scatter_f32(idg_comm* comm, const float* in, float* out, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,10 @@ if ROOT not in sys.path:
 
 
 class OracleKernels:
-    """`kernels` interface of ShardedEngine on numpy + oracle/ (tests only)."""
+    """`kernels` interface of ShardedEngine on numpy + oracle/ (tests only).  Row bitmaps are numpy bool arrays.  Every
+    restricted form is honoured AND made unforgiving: a product restricted to some output rows writes NaN into the rows it
+    does not produce, the gradient scatter leaves NaN in every row it does not store, and rows of an input panel outside
+    its live set are never read — so a consumer that reads a row nobody produced turns the loss and the tables into NaN."""
 
     def __init__(self):
         from oracle import oracle
@@ -29,8 +32,29 @@ class OracleKernels:
     def make_graph(self, indptr, indices, values, n_rows, n_cols):
         return (np.asarray(indptr), np.asarray(indices), np.asarray(values), n_rows, n_cols)
 
+    class _Prep:
+        pass
+
     def prepare(self, eng, gb):
-        return None  # no batch lookahead in the checker-backed stub: every product is the dense one
+        prep = self._Prep()
+        prep.own_users = np.zeros(eng.Ug, dtype=bool)
+        prep.own_users[gb.own_users] = True
+        prep.items = np.zeros(eng.Ip, dtype=bool)
+        prep.items[gb.items] = True
+        prep.touched = prep.near = None
+        return prep
+
+    def wait_rows(self, prep):
+        pass
+
+    def release(self, prep):
+        pass
+
+    def bits_from(self, bits, row0):
+        return bits[row0:]
+
+    def ones_bits(self, n_bits):
+        return np.ones(n_bits, dtype=bool)
 
     def to_device(self, a):
         return np.ascontiguousarray(a)
@@ -38,85 +62,207 @@ class OracleKernels:
     def gather_rows(self, dst, src, idx):
         dst[...] = np.where((idx >= 0)[:, None], src[np.maximum(idx, 0)], np.float32(0))
 
+    def gather_rows2(self, dst0, src0, dst1, src1, idx):
+        self.gather_rows(dst0, src0, idx)
+        self.gather_rows(dst1, src1, idx)
+
     def scatter_rows(self, dst, idx, src):
         dst[idx] = src
 
-    def flag_touched_items(self, eng, prep, gb, flags):
+    def _adjacent_items(self, eng, user_bits):
         ptr, idx = eng.G_ui[0], eng.G_ui[1]
-        flags[...] = 0
-        for u in np.unique(gb.own_users):
-            flags[idx[ptr[u]:ptr[u + 1]]] = 1
-        flags[gb.items] = 1
-        return True
+        out = np.zeros(eng.Ip, dtype=bool)
+        for u in np.nonzero(user_bits)[0]:
+            out[idx[ptr[u]:ptr[u + 1]]] = True
+        return out
 
-    def item_rows_bitmap(self, eng, prep, rows, which=0):
-        return None  # (the checker-backed stub produces every row)
-
-    def touched_bitmap_local(self, eng, prep, gb):
-        return None
-
-    def flag_two_hop_items(self, eng, prep, gb, flags):
-        users = set(np.unique(gb.own_users).tolist())  # near users: the batch's, and those of the batch's items
-        for g, r0, r1 in eng.G_iu:
+    def _near(self, eng, prep):
+        near = prep.own_users.copy()
+        for g, r0, r1, r1p in eng.slices:
             ptr, idx = g[0], g[1]
-            for i in gb.items[(gb.items >= r0) & (gb.items < r1)] - r0:
-                users.update(idx[ptr[i]:ptr[i + 1]].tolist())
-        ptr, idx = eng.G_ui[0], eng.G_ui[1]
-        flags[...] = 0
-        for u in users:
-            flags[idx[ptr[u]:ptr[u + 1]]] = 1
-        flags[gb.items] = 1
-        return True
+            for i in np.nonzero(prep.items[r0:r1])[0]:
+                near[idx[ptr[i]:ptr[i + 1]]] = True
+        prep.near = near
 
-    def user_rows_bitmaps(self, eng, prep, gb, touched_bits):
-        return None, None
+    def touched_local(self, eng, prep, gb):
+        prep.touched = prep.items | self._adjacent_items(eng, prep.own_users)
+        self._near(eng, prep)
+
+    def flag_touched_items(self, eng, prep, gb, flags):
+        flags[...] = (prep.items | self._adjacent_items(eng, prep.own_users))[: eng.I]
 
     def nonzero_ids(self, flags):
         ids = np.nonzero(flags)[0].astype(np.int64)
         return ids, len(ids)
 
-    def chain_add_rows(self, dst, src, idx, nxt):
-        for t in np.nonzero(idx >= 0)[0]:
-            acc, j = dst[idx[t]].copy(), t
-            while j >= 0:
-                acc = acc + src[j]
-                j = nxt[j]
-            dst[idx[t]] = acc
+    def touched_from_ids(self, eng, prep, ids, n):
+        prep.touched = np.zeros(eng.Ip, dtype=bool)
+        prep.touched[ids[:n]] = True
+        self._near(eng, prep)
+
+    def chain_rows2(self, dst0, src0, dst1, src1, idx, nxt, store):
+        for dst, src in ((dst0, src0), (dst1, src1)):
+            for t in np.nonzero(idx >= 0)[0]:
+                acc, j = (src[t].copy(), nxt[t]) if store else (dst[idx[t]].copy(), t)
+                while j >= 0:
+                    acc = acc + src[j]
+                    j = nxt[j]
+                dst[idx[t]] = acc
+
+    def layer_mean(self, out, ids, terms, last, div):
+        s = last
+        if terms:
+            acc = terms[0][ids]
+            for x in terms[1:]:
+                acc = acc + x[ids]
+            s = acc + last
+        out[ids] = s / np.float32(div)
 
     def topk(self, user_panel, item_panel, users, k, excl_indptr, excl_items):
-        R = self.o.score(user_panel, item_panel, np.asarray(users))
+        R = self.o.score(user_panel, np.ascontiguousarray(item_panel), np.asarray(users))
         for b, u in enumerate(users):
             R[b, excl_items[excl_indptr[u]:excl_indptr[u + 1]]] = -1
         return self.o.topk_reference(R, k)
 
-    def spmm(self, graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.0, accumulate=False, out_rows=None,
-             x_rows=None):
-        assert out_rows is None and x_rows is None
-        t = self.o.spmm(graph[0], graph[1], graph[2], X)
-        if addend is not None:
-            t = t + addend
-        if Y is not None:
-            Y[...] = t
-        if sum_out is not None:
-            s = t if sum_in is None else sum_in + t
-            if div != 1.0:
-                s = s / np.float32(div)
-            sum_out[...] = sum_out + s if accumulate else s
+    def spmm(self, graph, X, Y=None, addend=None, sums=(), sum_out=None, div=1.0, accumulate=False, mask=None, adam=None,
+             out_rows=None, x_rows=None):
+        ptr, idx, val, n_rows, n_cols = graph
+        Xe = np.ascontiguousarray(X[:n_cols])
+        if x_rows is not None:  # rows outside the live set are zero by agreement and must not be read
+            Xe = np.where(x_rows[:n_cols, None], Xe, np.float32(0))
+        t = self.o.spmm(ptr, idx, val, np.ascontiguousarray(Xe))
+        live = np.ones(n_rows, dtype=bool) if mask is None else mask[:n_rows]
+        rows = np.ones(n_rows, dtype=bool) if out_rows is None else out_rows[:n_rows]
+        with np.errstate(invalid="ignore"):
+            if addend is not None:
+                t = np.where(live[:, None], t + addend[:n_rows], t)
+            if Y is not None:
+                Y[:n_rows][rows] = t[rows]
+                Y[:n_rows][~rows] = np.nan
+            if sum_out is not None:
+                s = t
+                if len(sums):
+                    acc = sums[0][:n_rows]
+                    for x in sums[1:]:
+                        acc = acc + x[:n_rows]
+                    s = np.where(live[:, None], acc + t, t)
+                if div != 1.0:
+                    s = s / np.float32(div)
+                if accumulate:
+                    s = np.where(live[:, None], sum_out[:n_rows] + s, s)
+                sum_out[:n_rows][rows] = s[rows]
+                sum_out[:n_rows][~rows] = np.nan
+                if adam is not None:
+                    assert out_rows is None and x_rows is None
+                    p, m, v, lr, step = adam
+                    self.o.adam(p, np.ascontiguousarray(s), m, v, lr, step)
 
-    def lincomb(self, out, x, a, y, b):
-        r = np.float32(a) * x
-        if y is not None:
-            r = r + np.float32(b) * y
-        out[...] = r
-
-    def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, upstream, g_final, g_ego, loss, prep=None):
-        l, gf, ge = self.o.bpr(fin, ego, n_users, users, pos, neg, reg_lambda)
+    def bpr(self, fin, ego, n_users, users, pos, neg, reg_lambda, g_final, g_ego, loss, prep=None):
+        reached = np.unique(np.concatenate([users, n_users + pos, n_users + neg]))
+        f, e = np.zeros_like(fin), np.zeros_like(ego)  # (the rows the loss does not read may hold anything)
+        f[reached], e[reached] = fin[reached], ego[reached]
+        l, gf, ge = self.o.bpr(f, e, n_users, users, pos, neg, reg_lambda)
         loss[...] = l
-        g_final += upstream[0] * gf
-        g_ego += upstream[1] * ge
+        if prep is None:
+            g_final += gf
+            g_ego += ge
+        else:  # the reached rows are STORED; nothing else is defined
+            g_final[...] = np.nan
+            g_ego[...] = np.nan
+            g_final[reached] = gf[reached]
+            g_ego[reached] = ge[reached]
+
+    def item_tail(self, t, g, G, live_bits, row0, c0, cnt, store_grad, p, m, v, lr, step):
+        rows = t.shape[0]
+        live = live_bits[row0:row0 + rows][:, None]
+        with np.errstate(invalid="ignore"):
+            s = np.where(live, g + t, t) if c0 else t
+            s = s / np.float32(cnt)
+            s = np.where(live, G + s, s)
+        if store_grad:
+            G[...] = s
+        self.o.adam(p, np.ascontiguousarray(s), m, v, lr, step)
 
     def adam(self, p, g, m, v, lr, step):
         self.o.adam(p, np.ascontiguousarray(g), m, v, lr, step)
+
+
+class DeferredComm:
+    """TorchComm whose asynchronous collectives do NOTHING until wait(): the engine sees un-reduced partials if it reads a
+    buffer before waiting for its collective, and the wrong operands are reduced if it rewrites a buffer that is still
+    in flight — either shows against the single-device oracle.  (gloo itself completes every collective inside the call,
+    which hides exactly those mistakes.)  Collectives still run in the same order on every rank: waits happen in program
+    order."""
+
+    def __init__(self, inner):
+        self.inner, self.world, self.rank = inner, inner.world, inner.rank
+        self.averages = inner.averages
+
+    def all_reduce_async(self, t, average=False):
+        return ("ar", t, average)
+
+    def all_gather_async(self, out, t):
+        return ("ag", out, t)
+
+    def reduce_scatter_async(self, t):
+        return ("rs", t)
+
+    def wait(self, work):
+        if work is None:
+            return
+        kind = work[0]
+        if kind == "ar":
+            self.inner.wait(self.inner.all_reduce_async(work[1], work[2]))
+        elif kind == "ag":
+            self.inner.wait(self.inner.all_gather_async(work[1], work[2]))
+        else:
+            self.inner.wait(self.inner.reduce_scatter_async(work[1]))
+
+
+class SideStreamComm:
+    """Device tensors over gloo with the reduction done on a SIDE stream that is ordered after the step's stream when the
+    collective is issued and that the step's stream only joins in wait() — the ordering contract of NativeComm's
+    second-stream route and of c10d work objects, on one GPU shared by the ranks.  A missing wait() lets the products that
+    follow race with the copy back."""
+
+    def __init__(self, dist):
+        import torch
+
+        self.dist, self.torch = dist, torch
+        self.world, self.rank, self.averages = dist.get_world_size(), dist.get_rank(), False
+        self.side = torch.cuda.Stream()
+
+    def _run(self, fn, *tensors):
+        torch = self.torch
+        issued = torch.cuda.Event()
+        issued.record()
+        self.side.wait_event(issued)
+        with torch.cuda.stream(self.side):
+            fn()
+            done = torch.cuda.Event()
+            done.record()
+        return done
+
+    def all_reduce_async(self, t, average=False):
+        def fn():
+            host = t.cpu()
+            self.dist.all_reduce(host)
+            t.copy_(host, non_blocking=False)
+        return self._run(fn)
+
+    def all_gather_async(self, out, t):
+        def fn():
+            host = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, t.cpu().contiguous())
+            out.copy_(host)
+        return self._run(fn)
+
+    def reduce_scatter_async(self, t):
+        return self.all_reduce_async(t)
+
+    def wait(self, work):
+        if work is not None:
+            self.torch.cuda.current_stream().wait_event(work)
 
 
 def run(rank, world, port, mode, path, steps):
@@ -134,7 +280,7 @@ def run(rank, world, port, mode, path, steps):
     bounds = sh.partition_users_by_nnz(deg, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     ui, iu = sh.shard_adjacency(ip, ix, dv, U, I, lo, hi)
-    if mode == "cpu":
+    if mode.startswith("cpu"):
         kern, to_dev, to_np = OracleKernels(), (lambda a: np.ascontiguousarray(a)), (lambda a: a)
     else:
         torch.cuda.set_device(0)
@@ -142,17 +288,22 @@ def run(rank, world, port, mode, path, steps):
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         to_np = lambda a: a.cpu().numpy()  # noqa: E731
     n_slices = int(z["n_slices"]) if "n_slices" in z.files else 1
-    eng = sh.ShardedEngine(kern, sh.TorchComm(dist), ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
-                           batch_sparsity=(mode != "gpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
-                           live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None, live_rows_min_bytes=0,
-                           two_hop_cap=int(z["two_cap"]) if "two_cap" in z.files else None)
+    comm = sh.TorchComm(dist) if world > 1 or mode.startswith("cpu") else sh.NoComm()
+    if mode == "cpu-deferred":
+        comm = DeferredComm(comm)
+    if mode == "gpu-async":
+        comm = SideStreamComm(dist)
+    eng = sh.ShardedEngine(kern, comm, ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
+                           batch_sparsity=mode not in ("gpu-dense", "cpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
+                           live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None,
+                           live_rows_min_bytes=int(z["min_bytes"]) if "min_bytes" in z.files else 0)
     Ug = hi - lo
-    if mode == "cpu":
+    if mode.startswith("cpu"):
         eng.P[:Ug] = W0[lo:hi]
-        eng.P[Ug + B:] = W0[U:]
+        eng.item_rows(eng.P)[...] = W0[U:]
     else:
         eng.P[:Ug].copy_(to_dev(W0[lo:hi]))
-        eng.P[Ug + B:].copy_(to_dev(W0[U:]))
+        eng.item_rows(eng.P).copy_(to_dev(W0[U:]))
     losses = []
 
     def batch(s):
@@ -169,18 +320,20 @@ def run(rank, world, port, mode, path, steps):
     mine = cur[1][(cur[1][:, 0] >= lo) & (cur[1][:, 0] < hi)]
     touched = np.unique(mine[:, 0] - lo)  # local user rows of the LAST batch: the only FIN user rows guaranteed fresh
 
-    def strip(a):  # (drop the guest rows: users, then items)
+    eng._wait_item_table()  # the last step's all-gathers of the updated item rows
+
+    def strip(a):  # (drop the guest rows and the padding: users, then items)
         a = to_np(a)
-        return np.concatenate([a[:Ug], a[Ug + B:]])
+        return np.concatenate([a[:Ug], a[Ug + B: Ug + B + I]])
+
+    own_items = np.concatenate([np.arange(o0, min(o0 + c, I)) for o0, c, _ in eng.own]).astype(np.int64)
 
     # item rows of FIN that the LAST step produced: the batch's positive / negative items (the last forward layer's
     # exchange carries those rows only)
     fin_items = np.unique(np.concatenate([cur[1][:, 1], cur[1][:, 2]]))
     out = dict(P=strip(eng.P), FIN=strip(eng.FIN), G=strip(eng.G), losses=np.stack(losses), lo=lo, hi=hi, fin_rows=touched,
-               fin_items=fin_items,
-               touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1],
-               two_hop_n=-1 if getattr(eng, "two_hop", None) is None else eng.two_hop[1],
-               two_hop_misses=eng._two_hop_misses)
+               fin_items=fin_items, own_items=own_items,
+               touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1])
     if "test_users" in z.files:  # sharded evaluation: this rank's test users, its train rows as the exclusion lists
         tu, tptr, titems = z["test_users"], z["test_ptr"], z["test_items"]
         own = [(int(u), titems[tptr[j]:tptr[j + 1]].tolist()) for j, u in enumerate(tu) if lo <= u < hi]

@@ -920,6 +920,202 @@ def test_live_unit_list_equals_tile_form(ops, d, exact):
     assert torch.equal(unit_out.index_select(0, rows_d), full.index_select(0, rows_d))
 
 
+def _row_bitmap(n, rows):
+    bitmap = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
+    np.bitwise_or.at(bitmap, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
+    return dev(bitmap.view(np.int32))
+
+
+def test_live_unit_lists_follow_their_bitmap(ops):
+    """a unit list must never outlive the bitmap contents it was built from.  (1) Rewriting a registered bitmap
+    through the library (idg_bpr_touch_rows / idg_bitmap_clear) drops the list: the next restricted launch visits the
+    tiles and produces the NEW rows.  (2) A masked copy of the handle finds its base's list (shared schedule) and a copy
+    made BEFORE a list existed does too.  (3) More set bits than max_rows: the list is marked incomplete, the launch
+    poisons what it writes and idg_graph_live_units_check raises."""
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    U, I, E = 3000, 2000, 90000
+    users, items = S.generate(U, I, E, seed=9)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n, d = U + I, 64
+    G = ops.Graph(ip, ix, dv, n, n)
+    sub = G.dropout_copy(0.5, stream=(5, 1))  # a copy made before any list exists
+    X = torch.randn(n, d, device="cuda") * 0.1
+    full, full_sub = G.spmm_raw(X), sub.spmm_raw(X)
+    rng = np.random.default_rng(0)
+    rows_a = np.unique(rng.integers(0, n, 300))
+    rows_b = np.unique(rng.integers(0, n, 300))
+    bm = _row_bitmap(n, rows_a)
+
+    def restricted(graph):
+        out = torch.full((n, d), float("nan"), device="cuda")
+        ops.spmm_ex_raw(graph, X, Y=out, out_rows=bm)
+        return out
+
+    ws = G.live_units(bm, len(rows_a))
+    ra, rb = dev(rows_a), dev(rows_b)
+    out = restricted(G)
+    assert torch.equal(out[ra], full[ra]) and int(torch.isfinite(out).all(dim=1).sum()) == len(rows_a)
+    out = restricted(sub)  # (2) the copy runs on the base's schedule: same list, its own values
+    assert torch.equal(out[ra], full_sub[ra]) and int(torch.isfinite(out).all(dim=1).sum()) == len(rows_a)
+    # (1) the bitmap is rewritten through the library: rows_b now
+    ids = dev(rows_b)
+    ops.bpr_touch_rows_raw(ids, ids, ids, 0, bm, clear_bits=n)
+    out = restricted(G)
+    assert torch.equal(out[rb], full[rb]) and int(torch.isfinite(out).all(dim=1).sum()) == len(rows_b)
+    # ... and listed again
+    G.live_units(bm, len(rows_b), ws=ws)
+    out = restricted(G)
+    assert torch.equal(out[rb], full[rb]) and int(torch.isfinite(out).all(dim=1).sum()) == len(rows_b)
+    ops.Graph.live_units_check(ws)
+    # (3) a bound that is too small
+    small = G.live_units(bm, 10)
+    with pytest.raises(RuntimeError, match="more rows than max_rows"):
+        ops.Graph.live_units_check(small)
+    out = restricted(G)
+    produced = ~torch.isnan(out).all(dim=1)
+    assert int(produced.sum()) == 0  # whatever the incomplete list covers is poisoned, nothing passes for a result
+    G.forget_live_units(bm)
+    out = restricted(G)
+    assert torch.equal(out[rb], full[rb])
+
+
+@pytest.mark.parametrize("d", [64, 256])
+def test_product_between_two_row_sets(ops, d):
+    """out_rows and x_rows in ONE launch (round 3: the first backward products of the sharded step run between the
+    batch's rows and the rows one hop away), tile form and live-unit form: the produced rows equal the dense product of
+    the masked panel bit for bit, dead rows of X are never read (NaN poison), nothing else is written."""
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    U, I, E = 6000, 2500, 260000
+    users, items = S.generate(U, I, E, seed=5)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n = U + I
+    G = ops.Graph(ip, ix, dv, n, n)
+    rng = np.random.default_rng(d)
+    deg = np.diff(ip)
+    live = np.unique(np.concatenate([rng.integers(0, n, 900), np.argsort(deg)[-20:]]))
+    want_rows = np.unique(np.concatenate([rng.integers(0, n, 700), np.argsort(deg)[-40:], [0, n - 1]]))
+    xb, ob = _row_bitmap(n, live), _row_bitmap(n, want_rows)
+    X = torch.randn(n, d, device="cuda") * 0.1
+    Xz = torch.zeros_like(X)
+    Xz[dev(live)] = X[dev(live)]
+    Xp = torch.full_like(X, float("nan"))
+    Xp[dev(live)] = X[dev(live)]
+    addend = torch.randn(n, d, device="cuda")
+    ref = G.spmm_raw(Xz, addend=addend)
+    wd = dev(want_rows)
+    others = torch.ones(n, dtype=torch.bool, device="cuda")
+    others[wd] = False
+    for listed in (False, True):
+        if listed:
+            G.live_units(ob, len(want_rows))
+        out = torch.full((n, d), float("nan"), device="cuda")
+        ops.spmm_epi_raw(G, Xp, Y=out, addend=addend, out_rows=ob, x_rows=xb)
+        assert torch.equal(out[wd], ref[wd]) and bool(torch.isnan(out[others]).all())
+    G.forget_live_units(ob)
+
+
+def test_epilogue_struct_forms(ops, golden_small):
+    """idg_spmm_epi_f32: three earlier terms summed left to right before the product (the layer mean formed by the last
+    layer, as idg_propagate_mean_f32 does internally) equals propagate_mean bit for bit; a row mask on addend / sum_in /
+    accumulate reads no dead row; the Adam group equals idg_adam_step_f32 on the stored gradient."""
+    g = golden_small
+    U, I = int(g["num_users"]), int(g["num_items"])
+    n, d, K = U + I, 64, 3
+    G = ops.Graph(g["adj_indptr"], g["adj_indices"], g["adj_data"], n, n)
+    E0 = dev(np.concatenate([g["d64_init_user"], g["d64_init_item"]]))
+    X1, X2 = G.spmm_raw(E0), None
+    X2 = G.spmm_raw(X1)
+    out = torch.empty_like(E0)
+    ops.spmm_epi_raw(G, X2, sum_in=E0, sum_in2=X1, sum_in3=X2, sum_out=out, div=4.0)
+    assert torch.equal(out, G.propagate_mean_raw(E0, K, True))
+    # masked addend / accumulate: dead rows hold NaN and are not read
+    rows = np.unique(np.random.default_rng(1).integers(0, n, 200))
+    bm, rd = _row_bitmap(n, rows), dev(rows)
+    add = torch.full((n, d), float("nan"), device="cuda")
+    add[rd] = torch.randn(len(rows), d, device="cuda")
+    acc = torch.full((n, d), float("nan"), device="cuda")
+    acc[rd] = torch.randn(len(rows), d, device="cuda")
+    want = G.spmm_raw(E0)
+    want[rd] = want[rd] + add[rd]
+    want_acc = want / 3.0
+    want_acc[rd] = acc[rd] + want_acc[rd]
+    Y = torch.empty_like(E0)
+    ops.spmm_epi_raw(G, E0, Y=Y, addend=add, sum_out=acc, div=3.0, accumulate=True, mask=bm)
+    assert torch.equal(Y, want) and torch.equal(acc, want_acc)
+    # Adam in the epilogue == the separate kernel
+    p1, m1, v1 = torch.randn(n, d, device="cuda"), torch.rand(n, d, device="cuda") * 0.1, torch.rand(n, d, device="cuda") * 0.01
+    p2, m2, v2 = p1.clone(), m1.clone(), v1.clone()
+    grad = torch.empty_like(E0)
+    ops.spmm_epi_raw(G, E0, sum_out=grad, div=4.0, adam=(p1, m1, v1, 1e-3, 7))
+    ops.adam_step_raw(p2, grad, m2, v2, 1e-3, 7)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
+@pytest.mark.parametrize("d", [64, 256])
+def test_sharded_row_movers_and_item_tail(ops, d):
+    """The round-3 movers of the sharded step against their numpy statements, and idg_grad_tail_adam_f32 against the
+    operations of the single-device step's last epilogue (same order: (g + t) / cnt, + G, Adam)."""
+    rng = np.random.default_rng(d)
+    n, B = 500, 64
+    src0, src1 = rng.standard_normal((n, d)).astype(np.float32), rng.standard_normal((n, d)).astype(np.float32)
+    idx = rng.integers(-1, n, B).astype(np.int64)
+    d0, d1 = torch.full((B, d), float("nan"), device="cuda"), torch.full((B, d), float("nan"), device="cuda")
+    ops.rows_gather2_raw(d0, dev(src0), d1, dev(src1), dev(idx))
+    for got, src in ((d0, src0), (d1, src1)):
+        assert np.array_equal(got.cpu().numpy(), np.where((idx >= 0)[:, None], src[np.maximum(idx, 0)], np.float32(0)))
+    ids = np.sort(rng.choice(n, 40, replace=False)).astype(np.int64)
+    compact = rng.standard_normal((40, d)).astype(np.float32)
+    panel = torch.full((n, d), float("nan"), device="cuda")
+    ops.rows_scatter_raw(panel, dev(ids), dev(compact))
+    assert np.array_equal(panel.cpu().numpy()[ids], compact) and int(torch.isnan(panel).all(dim=1).sum()) == n - 40
+    # chains: heads 3 -> 9 -> 20, 5 (alone), 7 -> 8
+    nxt = np.full(B, -1, dtype=np.int64)
+    nxt[3], nxt[9], nxt[7] = 9, 20, 8
+    head = np.full(B, -1, dtype=np.int64)
+    head[3], head[5], head[7] = 11, 2, 30
+    s0, s1 = rng.standard_normal((B, d)).astype(np.float32), rng.standard_normal((B, d)).astype(np.float32)
+    t0, t1 = torch.full((n, d), float("nan"), device="cuda"), torch.full((n, d), float("nan"), device="cuda")
+    ops.rows_chain_store2_raw(t0, dev(s0), t1, dev(s1), dev(head), dev(nxt))
+    for got, s in ((t0, s0), (t1, s1)):
+        got = got.cpu().numpy()
+        assert np.array_equal(got[11], (s[3] + s[9]) + s[20]) and np.array_equal(got[2], s[5]) and np.array_equal(got[30], s[7] + s[8])
+        assert np.isnan(got).all(axis=1).sum() == n - 3
+    # layer mean at rows
+    a, b, c = (rng.standard_normal((n, d)).astype(np.float32) for _ in range(3))
+    out = torch.full((n, d), float("nan"), device="cuda")
+    ops.rows_layer_mean_raw(out, dev(ids), [dev(a), dev(b), dev(c)], dev(compact), 4.0)
+    assert np.array_equal(out.cpu().numpy()[ids], (((a[ids] + b[ids]) + c[ids]) + compact) / np.float32(4.0))
+    ops.rows_layer_mean_raw(out, dev(ids), [dev(b)], dev(compact), 2.0)
+    assert np.array_equal(out.cpu().numpy()[ids], (b[ids] + compact) / np.float32(2.0))
+    ops.rows_layer_mean_raw(out, dev(ids), [], dev(compact), 1.0)
+    assert np.array_equal(out.cpu().numpy()[ids], compact)
+    # the item tail on a block of rows [row0, row0 + rows) with live bits taken at GLOBAL row ids
+    rows, row0 = 96, 37
+    live_rows = np.sort(rng.choice(rows, 20, replace=False))
+    bits = _row_bitmap(row0 + rows + 64, row0 + live_rows)
+    t = rng.standard_normal((rows, d)).astype(np.float32)
+    gg = np.full((rows, d), np.nan, dtype=np.float32)
+    GG = np.full((rows, d), np.nan, dtype=np.float32)
+    gg[live_rows], GG[live_rows] = rng.standard_normal((20, d)), rng.standard_normal((20, d))
+    live = np.zeros(rows, dtype=bool)
+    live[live_rows] = True
+    with np.errstate(invalid="ignore"):
+        s = np.where(live[:, None], gg + t, t) / np.float32(4.0)
+        s = np.where(live[:, None], GG + s, s)
+    p = torch.randn(rows, d, device="cuda")
+    m, v = torch.rand(rows, d, device="cuda") * 0.1, torch.rand(rows, d, device="cuda") * 0.01
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    Gd = dev(GG)
+    ops.grad_tail_adam_raw(dev(t), dev(gg), Gd, bits, row0, True, 4.0, True, p, m, v, 1e-3, 3)
+    assert np.array_equal(Gd.cpu().numpy(), s)
+    ops.adam_step_raw(p2, dev(s), m2, v2, 1e-3, 3)
+    assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+
+
 @pytest.mark.parametrize("d,K", [(64, 3), (32, 2), (256, 3)])
 def test_receptive_field_propagation(ops, d, K):
     """idg_graph_expand_rows + idg_propagate_mean_fields_f32 + idg_propagate_mean_bwd_adam_fields_f32 on a graph much

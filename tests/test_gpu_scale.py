@@ -322,3 +322,94 @@ def test_training_trajectory_at_yelp_size_vs_cpu_port():
     moved = np.abs(Wr - W0.numpy()) > 1e-4
     np.testing.assert_allclose((Wg - W0.numpy())[moved], (Wr - W0.numpy())[moved], rtol=2e-2, atol=2e-5)
     np.testing.assert_allclose(Wg, Wr, rtol=1e-4, atol=2e-5)
+
+
+def test_sharded_step_at_config5_shape_equals_the_fused_engine():
+    """BASELINE configs[4] at its REAL shape — synth-10M: 10 M users x 5 M items, 199 M edges, d = 256, K = 3, B = 1024 —
+    through the user-row-sharded engine at world size 1 (4 item-panel slices, the touched-item and near-user forms
+    active, gradient rows stored, owner tail, what `bench.py --gpus N` runs on every rank) and through the fused
+    single-GPU engine, from the same tables and the same batches: two training steps each.  Same split schedule, same
+    fmaf chains, same epilogue operations in the same order => the same BITS: both losses, FIN at the batch's rows, the
+    gradient and the post-Adam tables on sampled user and item rows (batch rows, their neighbours, hub rows, slice cuts,
+    random rows).  The fused engine itself is pinned to the oracle's chains on sampled rows of a wider panel above."""
+    import gc
+
+    import idgrec_amd.host as H
+    import idgrec_amd.ops as ops
+    import idgrec_amd.sharded as sh
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+
+    free, total = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~150 GB of free HBM (MI355X: 288 GB)")
+    U, I, E = S.SHAPES["synth-10M"]
+    d, K, B, steps = 256, 3, 1024, 2
+    users, items = S.generate(U, I, E, seed=0)
+    tri = S.draw_triples(2024, users, items, U, I, steps * B)[0]
+    g = torch.Generator().manual_seed(7)
+    W_u = (torch.rand(U, d, generator=g) * 2 - 1) * (6.0 / (U + d)) ** 0.5
+    W_i = (torch.rand(I, d, generator=g) * 2 - 1) * (6.0 / (I + d)) ** 0.5
+    rng = np.random.default_rng(1)
+    deg_u, deg_i = np.bincount(users, minlength=U), np.bincount(items, minlength=I)
+    b_last = tri[(steps - 1) * B: steps * B]
+    # sampled rows: the last batch's, neighbours of its users / items, the hubs, rows at the slice cuts, random ones
+    s_users = np.unique(np.concatenate([b_last[:, 0], users[np.isin(items, b_last[:64, 1])][:500], np.argsort(deg_u)[-8:],
+                                        [0, U - 1], rng.integers(0, U, 1500)]))
+    cuts = sh.partition_users_by_nnz(deg_i, 4)
+    s_items = np.unique(np.concatenate([b_last[:, 1], b_last[:, 2], items[np.isin(users, b_last[:64, 0])][:500],
+                                        np.argsort(deg_i)[-8:], [0, I - 1], rng.integers(0, I, 1500),
+                                        np.clip(np.concatenate([cuts[1:-1] + k for k in (-33, -1, 0, 1, 32)]), 0, I - 1)]))
+    su_d, si_d = dev(s_users), dev(s_items)
+
+    # ---- the sharded engine at world size 1
+    ui, iu = sh.shard_adjacency_from_edges(users, items, U, I, 0, U)
+    eng = sh.ShardedEngine(sh.HipKernels(), sh.NoComm(), ui, iu, U, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=0,
+                           n_slices=4, item_cuts=cuts)
+    del ui, iu
+    assert len(eng.slices) == 4
+    eng.P[:U].copy_(W_u)
+    eng.item_rows(eng.P).copy_(W_i)
+    batches = [eng.make_batch(tri[s * B:(s + 1) * B, 0], tri[s * B:(s + 1) * B, 1], tri[s * B:(s + 1) * B, 2]) for s in range(steps)]
+    sh_loss = []
+    for s in range(steps):
+        if s + 1 < steps:
+            eng.prefetch(batches[s + 1])
+        sh_loss.append(eng.train_step(batches[s]).cpu().numpy().copy())
+    eng._wait_item_table()
+    torch.cuda.synchronize()
+    bu, bi = dev(np.unique(b_last[:, 0])), dev(np.unique(np.concatenate([b_last[:, 1], b_last[:, 2]])))
+    got = dict(P_u=eng.P[:U].index_select(0, su_d).cpu(), P_i=eng.item_rows(eng.P).index_select(0, si_d).cpu(),
+               G_u=eng.G[:U].index_select(0, su_d).cpu(), G_i=eng.item_rows(eng.G).index_select(0, si_d).cpu(),
+               M_u=eng.MU.index_select(0, su_d).cpu(), V_i=eng.VI[:I].index_select(0, si_d).cpu(),
+               F_u=eng.FIN[:U].index_select(0, bu).cpu(), F_i=eng.item_rows(eng.FIN).index_select(0, bi).cpu())
+    # (world size 1 owns every item row: the compact moment arrays are the table's, block by block in slice order)
+    assert [o for o, _, _ in eng.own] == [r0 for _, r0, _, _ in eng.slices]
+    del eng, batches
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    # ---- the fused single-GPU engine on the global adjacency
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    del users, items
+    n = U + I
+    G = ops.Graph(ip, ix, dv, n, n)
+    del ip, ix, dv
+    params = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    params[:U].copy_(W_u)
+    params[U:].copy_(W_i)
+    del W_u, W_i
+    fe = PropagationEngine(G, U, I, d, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3, params=params)
+    t = dev(tri)
+    fu_loss = []
+    for s in range(steps):
+        sl = slice(s * B, (s + 1) * B)
+        fu_loss.append(fe.train_step(t[sl, 0].contiguous(), t[sl, 1].contiguous(), t[sl, 2].contiguous()).cpu().numpy().copy())
+    torch.cuda.synchronize()
+    assert np.array_equal(np.stack(sh_loss), np.stack(fu_loss)), (sh_loss, fu_loss)
+    want = dict(P_u=fe.params[:U].index_select(0, su_d).cpu(), P_i=fe.params[U:].index_select(0, si_d).cpu(),
+                G_u=fe.grad[:U].index_select(0, su_d).cpu(), G_i=fe.grad[U:].index_select(0, si_d).cpu(),
+                M_u=fe.exp_avg[:U].index_select(0, su_d).cpu(), V_i=fe.exp_avg_sq[U:].index_select(0, si_d).cpu(),
+                F_u=fe.final[:U].index_select(0, bu).cpu(), F_i=fe.final[U:].index_select(0, bi).cpu())
+    for key in want:
+        assert torch.equal(got[key], want[key]), "%s differs between the sharded and the fused step" % key

@@ -29,8 +29,9 @@ def _problem(g, K, include0, B, steps, seed=0, d=64, n_slices=1):
 
 
 def _sparse_problem(K, include0, B, steps, d=64, n_slices=2, U=600, I=800, E=1500, seed=5):
-    """A graph thin enough that a small batch's two-hop neighbourhood is a strict subset of the items (the golden graph
-    is too dense for that), users and items without interactions included; triples drawn from its edges."""
+    """A graph thin enough that the items a small batch's users touch, and the users near its items, are strict subsets
+    (the golden graph is too dense for that), users and items without interactions included; triples drawn from its
+    edges."""
     import idgrec_amd.host as H
     import idgrec_amd.synth as S
 
@@ -43,7 +44,7 @@ def _sparse_problem(K, include0, B, steps, d=64, n_slices=2, U=600, I=800, E=150
     pick = rng.permutation(len(users))[: B * steps]
     tri = np.stack([users[pick], items[pick], rng.integers(0, I, len(pick))], axis=1).astype(np.int64)
     return dict(indptr=ip, indices=ix, values=dv, W0=W0, triples=tri, U=U, I=I, K=K, B=B, include0=include0,
-                n_slices=n_slices, two_cap=I)
+                n_slices=n_slices)
 
 
 def _single_device_reference(p, steps):
@@ -80,10 +81,13 @@ def _check(p, outs, steps, rtol, atol, sparse=False):
         it = o["fin_items"]  # a training step's forward produces the item rows its loss reads, no others
         np.testing.assert_allclose(o["FIN"][hi - lo:][it], fin[U:][it], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["G"][: hi - lo], grad[lo:hi], rtol=rtol, atol=atol)
-        np.testing.assert_allclose(o["G"][hi - lo:], grad[U:], rtol=rtol, atol=atol)
+        own = o["own_items"]  # a rank finishes the gradient of the item rows it OWNS (1/N of each slice), no others
+        np.testing.assert_allclose(o["G"][hi - lo:][own], grad[U:][own], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["P"][: hi - lo], W[lo:hi], rtol=rtol, atol=atol)
         np.testing.assert_allclose(o["P"][hi - lo:], W[U:], rtol=rtol, atol=atol)
-    # replicated item table: bit-identical across ranks (coherence without an extra exchange)
+    # the owned blocks tile the item rows, and the item table — updated by its owners, all-gathered — is bit-identical
+    # on every rank
+    assert sorted(np.concatenate([o["own_items"] for o in outs]).tolist()) == list(range(p["I"]))
     a = outs[0]
     for b in outs[1:]:
         assert np.array_equal(a["P"][int(a["hi"]) - int(a["lo"]):], b["P"][int(b["hi"]) - int(b["lo"]):])
@@ -151,7 +155,8 @@ def test_global_batch_chains_and_guest_row_movers():
     assert np.array_equal(guest[[0, 2, 5]], np.tile(src[2], (3, 1))) and np.all(guest[[1, 6]] == 0)
     g_guest = np.random.default_rng(0).standard_normal((8, 3)).astype(np.float32)
     dst = np.zeros((5, 3), dtype=np.float32)
-    k.chain_add_rows(dst, g_guest, gb.head_dst, gb.nxt)
+    dst2 = np.full((5, 3), np.nan, dtype=np.float32)
+    k.chain_rows2(dst, g_guest, dst2, 2 * g_guest, gb.head_dst, gb.nxt, store=False)
     want = np.zeros_like(dst)
     for t in (0, 2, 5):
         want[2] = want[2] + g_guest[t]
@@ -159,6 +164,9 @@ def test_global_batch_chains_and_guest_row_movers():
         want[4] = want[4] + g_guest[t]
     want[0] = g_guest[4]
     assert np.array_equal(dst, want)
+    # the storing form: the same sums land in rows that held anything (here NaN); rows without a chain keep it
+    k.chain_rows2(dst2, g_guest, dst2.copy(), g_guest, gb.head_dst, gb.nxt, store=True)
+    assert np.array_equal(dst2[[0, 2, 4]], want[[0, 2, 4]]) and np.isnan(dst2[[1, 3]]).all()
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -237,29 +245,51 @@ def test_first_backward_exchange_falls_back_to_the_panel(tmp_path, golden_small)
     _check(p, _launch("cpu", path, 2), 2, rtol=1e-4, atol=2e-7)
 
 
-@pytest.mark.parametrize("include0,world", [(True, 2), (False, 3)])
-def test_two_hop_exchanges_match_single_device(include0, world, tmp_path):
-    """K = 3 on a thin graph: forward layer 1 and the second backward product travel as the batch's two-hop item rows
-    (a strict subset of the items here — asserted — so a product reading an un-exchanged row would show)."""
-    p = _sparse_problem(3, include0, B=6, steps=3)
+@pytest.mark.parametrize("K,include0,world", [(3, True, 2), (3, False, 3), (2, True, 2), (2, False, 1), (3, True, 1)])
+def test_restricted_forms_on_a_thin_graph(K, include0, world, tmp_path):
+    """A thin graph, where the row sets of a step are strict subsets (asserted for the touched items): layer K - 1 on
+    the touched items / the near users, the first backward product between the batch's rows and those sets, gradient rows
+    stored instead of accumulated.  The checker-backed stub poisons every row a restricted product does not produce and
+    every gradient row the scatter does not store, so a consumer reading outside its set would turn everything into NaN.
+    World size 1 marks the sets locally; 2 and 3 agree on the touched items through the flag vector."""
+    p = _sparse_problem(K, include0, B=6, steps=3)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
     outs = _launch("cpu", path, 3, world=world)
     for o in outs:
-        assert 0 < int(o["touched_n"]) < int(o["two_hop_n"]) < p["I"] // 2
+        assert (0 < int(o["touched_n"]) < p["I"] // 2) if world > 1 else int(o["touched_n"]) == -1
     _check(p, outs, 3, rtol=1e-4, atol=2e-7)
 
 
-def test_two_hop_exchange_falls_back_to_the_panel(tmp_path):
-    """More two-hop rows than the compact buffer holds: those two exchanges go back to the sliced panel, and after three
-    such steps in a row the engine stops asking (five steps, three misses counted)."""
-    p = _sparse_problem(3, True, B=6, steps=5)
-    p["two_cap"] = 8
+@pytest.mark.parametrize("K,include0,world,thin", [(3, True, 2, False), (3, False, 3, True), (2, True, 2, True)])
+def test_collectives_are_waited_for(K, include0, world, thin, tmp_path, golden_small):
+    """The same steps with a communicator whose asynchronous collectives take effect only in wait() (sliced all-reduces,
+    the reduce-scatter / owner tail / all-gather chain that ends a step and is waited for in the NEXT step, compact row
+    exchanges): reading a buffer before its collective was waited for, or rewriting one still in flight, would show."""
+    p = _sparse_problem(K, include0, B=6, steps=4) if thin else _problem(golden_small, K, include0, B=160, steps=4, n_slices=3)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
-    outs = _launch("cpu", path, 5)
-    assert all(int(o["two_hop_n"]) == -1 and int(o["touched_n"]) > 0 and int(o["two_hop_misses"]) == 3 for o in outs)
-    _check(p, outs, 5, rtol=1e-4, atol=2e-7)
+    _check(p, _launch("cpu-deferred", path, 4, world=world), 4, rtol=1e-4, atol=2e-7)
+
+
+@pytest.mark.parametrize("K,include0", [(3, True), (1, False)])
+def test_dense_form_matches_single_device(K, include0, tmp_path, golden_small):
+    """batch_sparsity=False: every product dense over zero-filled gradient panels — the plain form of the same step."""
+    p = _problem(golden_small, K, include0, B=160, steps=2, d=64, n_slices=2)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    _check(p, _launch("cpu-dense", path, 2), 2, rtol=1e-4, atol=2e-7)
+
+
+def test_small_panels_skip_the_touched_item_forms(tmp_path, golden_small):
+    """Below live_rows_min_bytes nothing is agreed: the panel all-reduces carry layer K - 1 and the first backward product."""
+    p = _problem(golden_small, 3, True, B=160, steps=2, d=64, n_slices=1)
+    p["min_bytes"] = 1 << 40
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("cpu", path, 2)
+    assert all(int(o["touched_n"]) == -1 for o in outs)
+    _check(p, outs, 2, rtol=1e-4, atol=2e-7)
 
 
 def test_three_ranks_gloo_cpu_match_single_device(tmp_path, golden_small):
@@ -287,26 +317,39 @@ def test_two_ranks_hip_kernels_match_single_device(K, include0, d, mode, tmp_pat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("include0,d", [(True, 64), (False, 256)])
-def test_two_hop_exchanges_hip_kernels(include0, d, tmp_path):
-    """The same on the HIP kernels (two ranks on cuda:0): row-restricted item- and user-side products of layers 1 and 2,
-    sparse-input products of the backward steps, the compact two-hop exchanges."""
-    p = _sparse_problem(3, include0, B=6, steps=4, d=d)
+@pytest.mark.parametrize("K,include0,d", [(3, True, 64), (3, False, 256), (2, True, 64)])
+def test_restricted_forms_hip_kernels(K, include0, d, tmp_path):
+    """The thin-graph case on the HIP kernels (two ranks on cuda:0): row-restricted item- and user-side products of layer
+    K - 1, the first backward products between two row sets (out_rows + x_rows in one launch), the compact exchanges of
+    the touched item rows, stored gradient rows, the owner tail + all-gather."""
+    p = _sparse_problem(K, include0, B=6, steps=4, d=d)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
     outs = _launch("gpu", path, 4)
     for o in outs:
-        assert 0 < int(o["touched_n"]) < int(o["two_hop_n"]) < p["I"] // 2
+        assert 0 < int(o["touched_n"]) < p["I"] // 2
     _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,include0,d,thin", [(3, True, 64, False), (3, True, 256, True), (2, False, 64, True)])
+def test_two_ranks_hip_kernels_with_side_stream_collectives(K, include0, d, thin, tmp_path, golden_small):
+    """The HIP kernels under a communicator that reduces on a side stream and is joined only by wait() (the ordering
+    contract of NativeComm's second-stream route and of c10d work objects): six steps, every other one through the
+    lookahead, against the single-device oracle."""
+    p = _sparse_problem(K, include0, B=6, steps=6, d=d) if thin else _problem(golden_small, K, include0, B=160, steps=6, d=d, n_slices=3)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    _check(p, _launch("gpu-async", path, 6), 6, rtol=1e-4, atol=2e-7, sparse=True)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,include0,d", [(3, True, 64), (2, False, 64), (3, False, 256)])
 def test_one_rank_hip_kernels_match_single_device(K, include0, d, tmp_path):
     """World size 1 (what `bench.py --force-sharded` runs): nothing is agreed or exchanged as rows, but the touched-item
-    bitmap — marked locally, no host synchronisation — restricts layer K - 1's item-side product and feeds the second
-    backward step's sparse-input product, as on the ranks of a larger job.  Thin graph: the touched items are a strict
-    subset, so a product reading an unproduced row would show."""
+    and near-user bitmaps — marked locally, no host synchronisation — restrict layer K - 1's products and the first
+    backward step's, as on the ranks of a larger job.  Thin graph: the sets are strict subsets, so a product reading an
+    unproduced row would show."""
     p = _sparse_problem(K, include0, B=6, steps=4, d=d)
     path = str(tmp_path / "prob.npz")
     np.savez(path, **p)
