@@ -82,37 +82,86 @@ def generate(num_users, num_items, num_edges, seed=0, zipf_a=0.8, match_edges=Tr
 GENERATOR_VERSION = 2  # part of generate_shared's cache file name: bump when generate()'s output changes
 
 
+def _edges_fingerprint(users, items):
+    """(E, wrapping int64 sums of the two id arrays and of users*31 + items): cheap (one pass), and any truncated,
+    permuted-between-columns or foreign file changes it."""
+    with np.errstate(over="ignore"):
+        return [int(len(users)), int(users.sum(dtype=np.int64)), int(items.sum(dtype=np.int64)),
+                int((users * np.int64(31) + items).sum(dtype=np.int64))]
+
+
+def _valid_edges(users, items, num_users, num_items):
+    """What shard_adjacency_from_edges needs: ids in range, sorted by (user, item), no duplicate pair."""
+    if users.ndim != 1 or users.shape != items.shape or users.dtype != np.int64 or items.dtype != np.int64 or len(users) == 0:
+        return False
+    if users[0] < 0 or users[-1] >= num_users or items.min() < 0 or items.max() >= num_items:
+        return False
+    du = np.diff(users)
+    return not ((du < 0).any() or ((du == 0) & (np.diff(items) <= 0)).any())
+
+
 def generate_shared(num_users, num_items, num_edges, seed, rank, barrier, cache_dir=None):
     """generate() for the ranks of one multi-process run on one host: rank 0 draws the graph (or finds it already drawn
-    by an earlier run on this machine) and leaves it in a cache file under the temporary directory, the others load
-    it — the 2e8-edge shape costs ~45 s and 10 GB of host memory to draw, per process.  `barrier` is the process
-    group's barrier (called twice by every rank).  Any trouble with the file (no space, unreadable, wrong length)
-    falls back to drawing in this process: the result is the same arrays either way."""
+    by an earlier run of THIS user on this machine) and leaves it in a cache file, the others load it — the 2e8-edge
+    shape costs ~45 s and 10 GB of host memory to draw, per process.  `barrier` is the process group's barrier (called
+    twice by every rank).  The cache lives in a directory of the calling user's own (mode 0700) and carries a header
+    (generator version, shape, edge count, fingerprint of the id arrays); a file is used only if the header matches what
+    was asked for AND the arrays match the header AND they are what shard_adjacency_from_edges needs (ids in range,
+    sorted by (user, item), no duplicates).  Anything else — no space, unreadable, stale, foreign, truncated — falls
+    back to drawing in this process: generate() is deterministic, so every rank ends with the same arrays whichever way
+    it got them, and no rank is left behind at the next collective."""
+    import json
     import tempfile
 
-    d = cache_dir or os.environ.get("IDG_SYNTH_CACHE") or tempfile.gettempdir()
-    path = os.path.join(d, "idgrec_synth_v%d_%d_%d_%d_%d.npy" % (GENERATOR_VERSION, num_users, num_items, num_edges, seed))
-    drawn = None
-    barrier()
-    if rank == 0 and not os.path.exists(path):
-        drawn = generate(num_users, num_items, num_edges, seed=seed)
-        try:
-            tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "wb") as f:
-                np.save(f, np.stack(drawn))
-            os.replace(tmp, path)
-        except OSError:
-            pass
-    barrier()
-    if drawn is not None:
-        return drawn
+    d = cache_dir or os.environ.get("IDG_SYNTH_CACHE")
+    if d is None:
+        d = os.path.join(tempfile.gettempdir(), "idgrec_synth_%d" % os.getuid())
     try:
-        both = np.load(path)
-        if both.ndim == 2 and both.shape[0] == 2 and both.dtype == np.int64:
-            return both[0], both[1]
-    except (OSError, ValueError):
+        os.makedirs(d, mode=0o700, exist_ok=True)
+    except OSError:
         pass
-    return generate(num_users, num_items, num_edges, seed=seed)
+    path = os.path.join(d, "idgrec_synth_v%d_%d_%d_%d_%d.npy" % (GENERATOR_VERSION, num_users, num_items, num_edges, seed))
+    want = {"version": GENERATOR_VERSION, "num_users": int(num_users), "num_items": int(num_items),
+            "num_edges": int(num_edges), "seed": int(seed)}
+
+    def load():
+        try:
+            with open(path + ".json") as f:
+                head = json.load(f)
+            if any(head.get(k) != v for k, v in want.items()):
+                return None
+            both = np.load(path)
+            if both.ndim != 2 or both.shape[0] != 2 or both.dtype != np.int64:
+                return None
+            users, items = both[0], both[1]
+            if _edges_fingerprint(users, items) != head.get("fingerprint") or not _valid_edges(users, items, num_users, num_items):
+                return None
+            return users, items
+        except (OSError, ValueError, KeyError, TypeError):
+            return None
+
+    got = None
+    barrier()
+    if rank == 0:
+        got = load()
+        if got is None:
+            got = generate(num_users, num_items, num_edges, seed=seed)
+            try:
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "wb") as f:
+                    np.save(f, np.stack(got))
+                with open(tmp + ".json", "w") as f:
+                    json.dump(dict(want, fingerprint=_edges_fingerprint(*got)), f)
+                os.replace(tmp, path)
+                os.replace(tmp + ".json", path + ".json")
+            except OSError:
+                pass
+    barrier()
+    if got is None:
+        got = load()
+    if got is None:
+        got = generate(num_users, num_items, num_edges, seed=seed)
+    return got
 
 
 def split_test(users, items, num_users, n_test=1, seed=1):

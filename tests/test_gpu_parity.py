@@ -1039,13 +1039,13 @@ def test_epilogue_struct_forms(ops, golden_small):
     add[rd] = torch.randn(len(rows), d, device="cuda")
     acc = torch.full((n, d), float("nan"), device="cuda")
     acc[rd] = torch.randn(len(rows), d, device="cuda")
-    want = G.spmm_raw(E0)
-    want[rd] = want[rd] + add[rd]
-    want_acc = want / 3.0
-    want_acc[rd] = acc[rd] + want_acc[rd]
+    want = G.spmm_raw(E0).cpu().numpy()
+    want[rows] = want[rows] + add[rd].cpu().numpy()
+    want_acc = want / np.float32(3.0)  # (a true division, as the kernel's: torch's device op multiplies by 1/3)
+    want_acc[rows] = acc[rd].cpu().numpy() + want_acc[rows]
     Y = torch.empty_like(E0)
     ops.spmm_epi_raw(G, E0, Y=Y, addend=add, sum_out=acc, div=3.0, accumulate=True, mask=bm)
-    assert torch.equal(Y, want) and torch.equal(acc, want_acc)
+    assert np.array_equal(Y.cpu().numpy(), want) and np.array_equal(acc.cpu().numpy(), want_acc)
     # Adam in the epilogue == the separate kernel
     p1, m1, v1 = torch.randn(n, d, device="cuda"), torch.rand(n, d, device="cuda") * 0.1, torch.rand(n, d, device="cuda") * 0.01
     p2, m2, v2 = p1.clone(), m1.clone(), v1.clone()

@@ -360,16 +360,40 @@ def test_one_rank_hip_kernels_match_single_device(K, include0, d, tmp_path):
 
 def test_generate_shared_is_generate(tmp_path):
     """The multi-rank bench draws its graph once per machine (rank 0) and the other ranks load it: same arrays as
-    drawing in-process, also when the cache file is unusable."""
+    drawing in-process — also when the cache file is unusable, stale or foreign: a garbage file, a file whose
+    arrays do not match its header, a well-formed file of ANOTHER graph under this graph's name, unsorted edges."""
+    import json
+
     import idgrec_amd.synth as S
 
     calls = []
     want = S.generate(300, 250, 3600, seed=0)
     first = S.generate_shared(300, 250, 3600, 0, 0, lambda: calls.append(1), cache_dir=str(tmp_path))
     other = S.generate_shared(300, 250, 3600, 0, 1, lambda: calls.append(1), cache_dir=str(tmp_path))
-    files = os.listdir(tmp_path)
-    assert len(files) == 1 and len(calls) == 4
-    (tmp_path / files[0]).write_bytes(b"not an array")
-    broken = S.generate_shared(300, 250, 3600, 0, 1, lambda: None, cache_dir=str(tmp_path))
-    for got in (first, other, broken):
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 2 and files[1] == files[0] + ".json" and len(calls) == 4
+    npy, head = tmp_path / files[0], tmp_path / files[1]
+    good_npy, good_head = npy.read_bytes(), head.read_text()
+
+    def check(rank=1):
+        got = S.generate_shared(300, 250, 3600, 0, rank, lambda: None, cache_dir=str(tmp_path))
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+    for got in (first, other):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    npy.write_bytes(b"not an array")
+    check()
+    # a well-formed file of another graph (same shape of array, other edges) under this name: the fingerprint differs
+    foreign = S.generate(300, 250, 3600, seed=1)
+    np.save(open(npy, "wb"), np.stack([foreign[0][: len(want[0])], foreign[1][: len(want[0])]]))
+    check()
+    # ... and with a header that matches the foreign arrays but not the request (another seed)
+    head.write_text(json.dumps(dict(json.loads(good_head), seed=1, fingerprint=S._edges_fingerprint(*foreign))))
+    check()
+    # unsorted edges behind a consistent header
+    perm = np.random.default_rng(0).permutation(len(want[0]))
+    np.save(open(npy, "wb"), np.stack([want[0][perm], want[1][perm]]))
+    head.write_text(json.dumps(dict(json.loads(good_head), fingerprint=S._edges_fingerprint(want[0][perm], want[1][perm]))))
+    check()
+    check(rank=0)  # rank 0 finds the bad file, draws, and replaces it
+    assert npy.read_bytes() == good_npy and json.loads(head.read_text()) == json.loads(good_head)
