@@ -8,7 +8,6 @@
 // 3B (row, slot) pairs are sorted and one lane group per distinct row adds its
 // contributions in batch order.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 
@@ -160,13 +159,18 @@ __device__ __forceinline__ unsigned long long shfl_xor_key<unsigned long long>(u
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Workgroup b sorts the keys [b * 1024 E, (b + 1) * 1024 E) of the list (one workgroup: the whole list).  packed_out != NULL:
+// the sorted PACKED keys go there (a run for merge_runs_kernel) instead of being unpacked into keys_out / slots_out.
 template <typename KeyT, int E>
 __global__ __launch_bounds__(1024) void lds_sort_kernel(const int32_t* __restrict__ keys,
                                                         const int32_t* __restrict__ slots, int n, int p2,
                                                         int slot_bits, int32_t* __restrict__ keys_out,
-                                                        int32_t* __restrict__ slots_out) {
+                                                        int32_t* __restrict__ slots_out, KeyT* __restrict__ packed_out) {
   __shared__ KeyT s_k[1024 * E];
   const int tid = threadIdx.x;
+  const int base = blockIdx.x * (1024 * E);
+  keys += base, slots += base;
+  n = n - base < 1024 * E ? n - base : 1024 * E;
   KeyT v[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -218,8 +222,56 @@ __global__ __launch_bounds__(1024) void lds_sort_kernel(const int32_t* __restric
   for (int e = 0; e < E; ++e) {
     const int i = e * 1024 + tid;
     if (i < n) {
-      keys_out[i] = (int32_t)(v[e] >> slot_bits);
-      slots_out[i] = (int32_t)(v[e] & slot_mask);
+      if (packed_out) {
+        packed_out[base + i] = v[e];
+      } else {
+        keys_out[base + i] = (int32_t)(v[e] >> slot_bits);
+        slots_out[base + i] = (int32_t)(v[e] & slot_mask);
+      }
+    }
+  }
+}
+
+// One merge pass over sorted runs of `run` packed keys (the last run may be shorter): runs 2p and 2p + 1 become one run of
+// 2 * run keys.  Every thread produces MERGE_ITEMS consecutive outputs: a merge-path search (binary search along the
+// output diagonal; the keys are unique, so the split is unique) finds where its outputs start in the two runs, then it
+// merges sequentially.  With keys_out != NULL (the last pass) the keys are unpacked on the way out.  Batches beyond the
+// LDS sort's 8192 pairs (B > 2730; the throughput-oriented batch of BASELINE configs[4] is B = 2^20) sort this way:
+// LDS-sorted runs of 8192 + ceil(log2(runs)) passes over 8 B per pair — bandwidth-trivial, on the side stream.
+constexpr int MERGE_ITEMS = 8;
+__global__ __launch_bounds__(BLOCK) void merge_runs_kernel(const unsigned long long* __restrict__ in,
+                                                           unsigned long long* __restrict__ out, int64_t n, int64_t run,
+                                                           int slot_bits, int32_t* __restrict__ keys_out,
+                                                           int32_t* __restrict__ slots_out) {
+  const int64_t o0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * MERGE_ITEMS;
+  if (o0 >= n) return;
+  const int64_t a0 = o0 / (2 * run) * (2 * run);
+  const int64_t a_len = n - a0 < run ? n - a0 : run;
+  const int64_t b0 = a0 + a_len;
+  const int64_t b_len = n - b0 < run ? (n - b0 > 0 ? n - b0 : 0) : run;
+  const unsigned long long* A = in + a0;
+  const unsigned long long* Bv = in + b0;
+  const int64_t diag = o0 - a0;  // outputs of this pair that precede this thread's
+  int64_t lo = diag > b_len ? diag - b_len : 0, hi = diag < a_len ? diag : a_len;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (A[mid] < Bv[diag - 1 - mid]) lo = mid + 1;
+    else hi = mid;
+  }
+  int64_t i = lo, j = diag - lo;
+  const unsigned long long slot_mask = ((unsigned long long)1 << slot_bits) - 1;
+#pragma unroll
+  for (int t = 0; t < MERGE_ITEMS; ++t) {
+    if (o0 + t >= n || (i >= a_len && j >= b_len)) break;
+    const bool take_a = j >= b_len || (i < a_len && A[i] < Bv[j]);
+    const unsigned long long v = take_a ? A[i] : Bv[j];
+    i += take_a ? 1 : 0;
+    j += take_a ? 0 : 1;
+    if (keys_out) {
+      keys_out[o0 + t] = (int32_t)(v >> slot_bits);
+      slots_out[o0 + t] = (int32_t)(v & slot_mask);
+    } else {
+      out[o0 + t] = v;
     }
   }
 }
@@ -228,11 +280,30 @@ template <typename KeyT>
 static void launch_lds_sort(const int32_t* keys, const int32_t* slots, int n3, int p2, int slot_bits, int32_t* skeys,
                             int32_t* sslots, hipStream_t st) {
   const int E = p2 <= 1024 ? 1 : p2 / 1024;
+  KeyT* none = nullptr;
   switch (E) {
-    case 1: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 1>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2 < 64 ? 64 : p2, slot_bits, skeys, sslots); break;
-    case 2: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 2>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots); break;
-    case 4: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 4>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots); break;
-    default: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 8>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots); break;
+    case 1: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 1>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2 < 64 ? 64 : p2, slot_bits, skeys, sslots, none); break;
+    case 2: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 2>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots, none); break;
+    case 4: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 4>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots, none); break;
+    default: hipLaunchKernelGGL((lds_sort_kernel<KeyT, 8>), dim3(1), dim3(1024), 0, st, keys, slots, n3, p2, slot_bits, skeys, sslots, none); break;
+  }
+}
+
+// n3 > LDS_SORT_MAX pairs: runs of LDS_SORT_MAX sorted in LDS (one workgroup each), then merge passes between the two
+// halves of `temp` (2 x n3 packed 64-bit keys); the last pass unpacks into skeys / sslots.
+static void launch_merge_sort(const int32_t* keys, const int32_t* slots, int64_t n3, int slot_bits, int32_t* skeys,
+                              int32_t* sslots, void* temp, hipStream_t st) {
+  unsigned long long* buf[2] = {reinterpret_cast<unsigned long long*>(temp), reinterpret_cast<unsigned long long*>(temp) + n3};
+  const unsigned runs = (unsigned)((n3 + LDS_SORT_MAX - 1) / LDS_SORT_MAX);
+  hipLaunchKernelGGL((lds_sort_kernel<unsigned long long, LDS_SORT_MAX / 1024>), dim3(runs), dim3(1024), 0, st, keys, slots,
+                     (int)n3, LDS_SORT_MAX, slot_bits, skeys, sslots, buf[0]);
+  const unsigned nb = (unsigned)((n3 + (int64_t)BLOCK * MERGE_ITEMS - 1) / ((int64_t)BLOCK * MERGE_ITEMS));
+  int cur = 0;
+  for (int64_t run = LDS_SORT_MAX; run < n3; run *= 2) {
+    const bool last = run * 2 >= n3;
+    hipLaunchKernelGGL(merge_runs_kernel, dim3(nb), dim3(BLOCK), 0, st, buf[cur], buf[cur ^ 1], n3, run, slot_bits,
+                       last ? skeys : nullptr, last ? sslots : nullptr);
+    cur ^= 1;
   }
 }
 
@@ -573,7 +644,7 @@ struct BprWs {
   size_t coef, loss_i, sq, keys, slots, skeys, sslots, temp, total;
 };
 
-BprWs bpr_layout(int64_t B, size_t cub_temp) {
+BprWs bpr_layout(int64_t B, size_t sort_temp) {
   BprWs w;
   size_t o = 0;
   w.coef = o;
@@ -591,16 +662,15 @@ BprWs bpr_layout(int64_t B, size_t cub_temp) {
   w.sslots = o;
   o += align256((size_t)B * 12);
   w.temp = o;
-  o += align256(cub_temp);
+  o += align256(sort_temp);
   w.total = o;
   return w;
 }
 
-// Upper bound of rocPRIM's radix-sort scratch for n (int32,int32) pairs; checked against the
-// real request at call time.
-size_t cub_temp_bound(int64_t n3) {
+// Scratch of the merge sort of n3 > LDS_SORT_MAX (row, slot) pairs: two buffers of n3 packed 64-bit keys.
+size_t sort_temp_bytes(int64_t n3) {
   if (n3 <= LDS_SORT_MAX) return 0;
-  return (size_t)n3 * 16 + ((size_t)8 << 20);
+  return (size_t)n3 * 16;
 }
 
 }  // namespace
@@ -610,7 +680,7 @@ extern "C" {
 size_t idg_bpr_workspace_bytes(int64_t B, int64_t d) {
   (void)d;
   if (B <= 0) return 0;
-  return bpr_layout(B, cub_temp_bound(3 * B)).total;
+  return bpr_layout(B, sort_temp_bytes(3 * B)).total;
 }
 
 static int bpr_args(BprArgs& a, const BprWs& w, const float* final_panel, const float* ego_panel,
@@ -644,7 +714,7 @@ static int bpr_forward_impl(const float* final_panel, const float* ego_panel, in
                             float reg_lambda, float* loss, void* ws, void* stream, bool reduce_now) {
   IDG_REQUIRE(loss, "idg_bpr_forward_f32: loss is NULL");
   hipStream_t st = (hipStream_t)stream;
-  const BprWs w = bpr_layout(B > 0 ? B : 1, cub_temp_bound(3 * B));
+  const BprWs w = bpr_layout(B > 0 ? B : 1, sort_temp_bytes(3 * B));
   BprArgs a{};
   int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
                     "idg_bpr_forward_f32");
@@ -667,7 +737,7 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
   if (!(users && pos && neg && ws)) return idg::fail(IDG_E_INVALID, "%s: NULL argument", who);
   if (!(B > 0 && num_users >= 0 && n >= num_users)) return idg::fail(IDG_E_INVALID, "%s: bad sizes", who);
   if (n >= ((int64_t)1 << 31) || 3 * B >= ((int64_t)1 << 31)) return idg::fail(IDG_E_INVALID, "%s: sizes exceed int32 keys", who);
-  const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
+  const BprWs w = bpr_layout(B, sort_temp_bytes(3 * B));
   char* base = reinterpret_cast<char*>(ws);
   int32_t* keys = reinterpret_cast<int32_t*>(base + w.keys);
   int32_t* slots = reinterpret_cast<int32_t*>(base + w.slots);
@@ -687,15 +757,9 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
     else
       launch_lds_sort<unsigned long long>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);
   } else {
-    int end_bit = 1;
-    while (((int64_t)1 << end_bit) < n) ++end_bit;
-    size_t need = 0;
-    IDG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, skeys, slots, sslots, (int)n3, 0, end_bit, st));
-    const size_t have = cub_temp_bound(n3);
-    if (need > have)
-      return idg::fail(IDG_E_UNSUPPORTED, "%s: radix sort wants %zu scratch bytes, layout reserves %zu", who, need, have);
-    size_t tb = have;
-    IDG_HIP(hipcub::DeviceRadixSort::SortPairs(base + w.temp, tb, keys, skeys, slots, sslots, (int)n3, 0, end_bit, st));
+    int slot_bits = 1;
+    while (((int64_t)1 << slot_bits) < n3) ++slot_bits;
+    launch_merge_sort(keys, slots, n3, slot_bits, skeys, sslots, base + w.temp, st);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
@@ -714,7 +778,7 @@ int idg_bpr_touch_rows(const int64_t* users, const int64_t* pos, const int64_t* 
 
 int idg_bitmap_clear(uint32_t* bitmap, int64_t n_bits, void* stream) {
   IDG_REQUIRE(bitmap && n_bits >= 0, "idg_bitmap_clear: bad argument");
-  idg::rows_changed(bitmap);
+  idg::rows_changed(bitmap, (size_t)((n_bits + 31) / 32) * sizeof(uint32_t));
   IDG_HIP(hipMemsetAsync(bitmap, 0, (size_t)((n_bits + 31) / 32) * sizeof(uint32_t), (hipStream_t)stream));
   return IDG_OK;
 }
@@ -733,7 +797,7 @@ static int bpr_backward_impl(const float* final_panel, const float* ego_panel, i
   hipStream_t st = (hipStream_t)stream;
   IDG_REQUIRE(!touched || (deterministic && g_final != g_ego),
               "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter and g_final distinct from g_ego");
-  const BprWs w = bpr_layout(B > 0 ? B : 1, cub_temp_bound(3 * B));
+  const BprWs w = bpr_layout(B > 0 ? B : 1, sort_temp_bytes(3 * B));
   BprArgs a{};
   int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
                     "idg_bpr_backward_f32");
@@ -743,7 +807,7 @@ static int bpr_backward_impl(const float* final_panel, const float* ego_panel, i
   a.g_ego = g_ego;
   a.upstream = upstream;
   a.touched = touched;
-  idg::rows_changed(touched);  // (the scatter sets bits in it)
+  idg::rows_changed(touched, (size_t)((n + 31) / 32) * sizeof(uint32_t));  // (the scatter sets bits in it)
   char* base = reinterpret_cast<char*>(ws);
   if (!deterministic) {
     const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
@@ -794,8 +858,8 @@ int idg_bpr_pack_rows_f32(const void* ws, int64_t B, int64_t d, const float* g_f
   IDG_REQUIRE(ws && g_final && loss && message, "idg_bpr_pack_rows_f32: NULL argument");
   IDG_REQUIRE(clear_bits >= 0 && (clear_bitmap || clear_bits == 0), "idg_bpr_pack_rows_f32: bad bitmap to clear");
   IDG_REQUIRE(B > 0 && d > 0 && 3 * B < ((int64_t)1 << 31), "idg_bpr_pack_rows_f32: bad sizes");
-  idg::rows_changed(clear_bitmap);
-  const BprWs w = bpr_layout(B, cub_temp_bound(3 * B));
+  idg::rows_changed(clear_bitmap, (size_t)((clear_bits + 31) / 32) * sizeof(uint32_t));
+  const BprWs w = bpr_layout(B, sort_temp_bytes(3 * B));
   const MsgLayout m = msg_layout(B, d);
   const int32_t* skeys = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ws) + w.skeys);
   const int64_t n3 = 3 * B;
@@ -813,7 +877,7 @@ int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t
   IDG_REQUIRE(world > 0 && world <= MSG_MAX_WORLD, "idg_bpr_unpack_rows_f32: world size %d outside [1, %d]", world, MSG_MAX_WORLD);
   IDG_REQUIRE(B > 0 && d > 0 && n > 0 && g_final != g_ego, "idg_bpr_unpack_rows_f32: bad sizes / aliased panels");
   hipStream_t st = (hipStream_t)stream;
-  idg::rows_changed(touched);
+  idg::rows_changed(touched, (size_t)((n + 31) / 32) * sizeof(uint32_t));
   const MsgLayout m = msg_layout(B, d);
   const int64_t n3 = 3 * B;
   const int64_t nb = (n3 + (BLOCK / WAVE) - 1) / (BLOCK / WAVE);

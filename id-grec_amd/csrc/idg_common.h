@@ -1,6 +1,7 @@
 // Shared internals of libidgrec.so: error reporting and HIP call checking.
 #pragma once
 #include <cstdarg>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 
@@ -24,8 +25,9 @@ inline int fail(int code, const char* fmt, ...) {
 }
 
 // A row bitmap is about to be rewritten by a library call: live-unit lists registered for it (idg_graph_live_units)
-// describe its old contents and are dropped (idg_graph.hip).
-void rows_changed(const void* bitmap);
+// describe its old contents and are dropped (idg_graph.hip).  bytes: extent of the write when the caller knows it (lists
+// registered for a sub-range starting inside it go too); 0 = lists registered at `bitmap` itself.
+void rows_changed(const void* bitmap, size_t bytes = 0);
 
 }  // namespace idg
 

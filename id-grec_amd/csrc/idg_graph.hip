@@ -118,6 +118,7 @@ struct Epilogue {
   float* adam_m;
   float* adam_v;
   float adam_w1, adam_beta2, adam_w2, adam_step_size, adam_bc2_sqrt, adam_eps;
+  int adam_discard;     // the finished gradient feeds the update and is NOT written to sum_out (4 B / element less)
 };
 
 }  // namespace
@@ -206,18 +207,24 @@ bool units_find(const void* sched, const uint32_t* bitmap, const int32_t** units
   return false;
 }
 
-// sched == nullptr: every schedule; bitmap == nullptr: every bitmap
-void units_forget(const void* sched, const void* bitmap) {
+// sched == nullptr: every schedule; bitmap == nullptr: every bitmap, else the lists whose bitmap STARTS inside
+// [bitmap, bitmap + bytes) (bytes = 0: at `bitmap` itself) — a list may be registered for a sub-range of a larger bitmap
+// (a row slice of the sharded step's item bitmap)
+void units_forget(const void* sched, const void* bitmap, size_t bytes = 0) {
   std::lock_guard<std::mutex> lock(g_unit_mutex);
-  for (int i = 0; i < MAX_UNIT_LISTS; ++i)
-    if ((sched == nullptr || g_unit_lists[i].sched == sched) && (bitmap == nullptr || g_unit_lists[i].bitmap == bitmap))
+  const char* lo = reinterpret_cast<const char*>(bitmap);
+  const char* hi = lo + (bytes > 0 ? bytes : 1);
+  for (int i = 0; i < MAX_UNIT_LISTS; ++i) {
+    const char* b = reinterpret_cast<const char*>(g_unit_lists[i].bitmap);
+    if ((sched == nullptr || g_unit_lists[i].sched == sched) && b != nullptr && (bitmap == nullptr || (b >= lo && b < hi)))
       g_unit_lists[i] = UnitList{};
+  }
 }
 }  // namespace
 
 namespace idg {
-void rows_changed(const void* bitmap) {
-  if (bitmap) units_forget(nullptr, bitmap);
+void rows_changed(const void* bitmap, size_t bytes) {
+  if (bitmap) units_forget(nullptr, bitmap, bytes);
 }
 }  // namespace idg
 
@@ -313,7 +320,7 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, in
       s.w = s.w / ep.div;
     }
     if (ep.accumulate && live) s = add4(*reinterpret_cast<const float4*>(ep.sum_out + o), s);
-    *reinterpret_cast<float4*>(ep.sum_out + o) = s;
+    if (EPI != EPI_ADAM || !ep.adam_discard) *reinterpret_cast<float4*>(ep.sum_out + o) = s;
     if (EPI == EPI_ADAM) {  // same arithmetic, operation for operation, as adam_kernel (idg_bpr.hip)
       float4 P = *reinterpret_cast<const float4*>(ep.adam_p + o);
       float4 M = *reinterpret_cast<const float4*>(ep.adam_m + o);
@@ -2102,6 +2109,7 @@ int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d,
                 "idg_spmm_epi_f32: Adam panels must be 16-byte aligned");
     adam_constants(ep, e->adam_param, e->adam_exp_avg, e->adam_exp_avg_sq, e->adam_lr, e->adam_beta1, e->adam_beta2,
                    e->adam_eps, e->adam_step);
+    ep.adam_discard = e->adam_discard_grad != 0;
   }
   return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, x_rows, out_rows);
 }
@@ -2398,7 +2406,7 @@ int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t*
   IDG_REQUIRE(g && in_rows && out_rows && in_rows != out_rows, "idg_graph_expand_rows: bad argument");
   IDG_REQUIRE(g->n_rows == g->n_cols, "idg_graph_expand_rows: graph must be square");
   IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_expand_rows: handle without a vrow -> row table");
-  idg::rows_changed(out_rows);
+  idg::rows_changed(out_rows, (size_t)((g->n_rows + 31) / 32) * sizeof(uint32_t));
   hipStream_t st = (hipStream_t)stream;
   IDG_HIP(hipMemcpyAsync(out_rows, in_rows, (size_t)((g->n_rows + 31) / 32) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   if (g->n_vrows > 0)
@@ -2411,7 +2419,7 @@ int idg_graph_expand_rows(const idg_graph* g, const uint32_t* in_rows, uint32_t*
 int idg_graph_mark_cols(const idg_graph* g, const uint32_t* in_rows, uint32_t* col_bits, void* stream) {
   IDG_REQUIRE(g && in_rows && col_bits, "idg_graph_mark_cols: bad argument");
   IDG_REQUIRE(g->d_vrow_row || g->nnz == 0, "idg_graph_mark_cols: handle without a vrow -> row table");
-  idg::rows_changed(col_bits);
+  idg::rows_changed(col_bits, (size_t)((g->n_cols + 31) / 32) * sizeof(uint32_t));
   if (g->n_vrows > 0)
     hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((g->n_vrows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                        g->n_vrows, g->d_vptr, g->d_vrow_row, g->d_cv, in_rows, col_bits);

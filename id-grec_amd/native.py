@@ -144,7 +144,7 @@ class Epilogue(C.Structure):
                 ("ldy", C.c_int64), ("div", C.c_float), ("accumulate", C.c_int), ("mask", c_vp),
                 ("adam_param", c_vp), ("adam_exp_avg", c_vp), ("adam_exp_avg_sq", c_vp),
                 ("adam_lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("adam_step", C.c_int64)]
+                ("adam_step", C.c_int64), ("adam_discard_grad", C.c_int)]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -159,7 +159,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 130  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 131  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

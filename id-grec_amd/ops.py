@@ -365,11 +365,11 @@ def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.
 
 
 def spmm_epi_raw(graph, X, Y=None, addend=None, sum_in=None, sum_in2=None, sum_in3=None, sum_out=None, div=1.0,
-                 accumulate=False, mask=None, adam=None, out_rows=None, x_rows=None):
+                 accumulate=False, mask=None, adam=None, out_rows=None, x_rows=None, adam_discard_grad=False):
     """idg_spmm_epi_f32: the product with every epilogue option (include/idgrec.h, idg_epilogue).  mask: bitmap of the
     live rows of addend / sum_in* / the accumulate target; adam = (param, exp_avg, exp_avg_sq, lr, step[, beta1, beta2,
-    eps]): the Adam update of the rows of `param` with gradient sum_out in the same launch.  out_rows and x_rows may be
-    combined."""
+    eps]): the Adam update of the rows of `param` with gradient sum_out in the same launch (adam_discard_grad: without
+    writing that gradient).  out_rows and x_rows may be combined."""
     _require_device(X, Y, addend, sum_in, sum_in2, sum_in3, sum_out, mask, out_rows, x_rows)
     d = X.shape[1]
     for t in (X, Y, addend, sum_in, sum_in2, sum_in3, sum_out):
@@ -383,6 +383,7 @@ def spmm_epi_raw(graph, X, Y=None, addend=None, sum_in=None, sum_in2=None, sum_i
         _require_device(p, m, v)
         e.adam_param, e.adam_exp_avg, e.adam_exp_avg_sq = _ptr(p), _ptr(m), _ptr(v)
         e.adam_lr, e.adam_beta1, e.adam_beta2, e.adam_eps, e.adam_step = float(lr), float(b1), float(b2), float(eps), int(step)
+        e.adam_discard_grad = int(bool(adam_discard_grad))
     ws = graph._workspace("spmm", d)
     check(lib.idg_spmm_epi_f32(graph._h, _ptr(X), d, d, C.byref(e), _ptr(out_rows), _ptr(x_rows), _ptr(ws), _stream()),
           "idg_spmm_epi_f32")

@@ -213,6 +213,12 @@ class ShardedEngine:
         self.CS = z((max(1, min(self.I, 64 * self.B if live_rows_cap is None else int(live_rows_cap))), dim))
         self.loss = z((2,))
         self.guest_ids = kernels.to_device(np.arange(self.Ug, self.Ug + self.B, dtype=np.int64))
+        # views handed to the kernels every step, made once (slicing a tensor costs the host ~1.5 us)
+        self.P_u, self.P_i = self._u(self.P), self._i(self.P)
+        self.FIN_u, self.FIN_i = self._u(self.FIN), self._i(self.FIN)
+        self.GF_u, self.GF_i = self._u(self.GF), self._i(self.GF)
+        self.G_u, self.G_i = self._u(self.G), self._i(self.G)
+        self._views = {}
         self._all_item_ids = None
         self._all_items_bits = None
         self._ag = []          # all-gathers of the updated item rows still in flight (waited before P_I is read again)
@@ -227,6 +233,15 @@ class ShardedEngine:
 
     def _i(self, a):
         return a[self.Ug + self.B:]
+
+    def _slice_rows(self, panel_i, j, padded=False):
+        """Rows of slice j of an item-row panel ([I_p, d]); padded: up to the slice's share of the padding."""
+        key = (id(panel_i), j, padded)
+        v = self._views.get(key)
+        if v is None:
+            _, r0, r1, r1p = self.slices[j]
+            v = self._views[key] = (panel_i, panel_i[r0:(r1p if padded else r1)])  # (keeps the panel alive: id() stays its)
+        return v[1]
 
     def item_rows(self, a):
         """The real item rows of a local panel (without the padding)."""
@@ -281,14 +296,15 @@ class ShardedEngine:
         (this rank keeps its own block of the slice), None = no exchange (the caller moves rows).  Returns the works."""
         k, works = self.k, []
         add = addend if self.rank == 0 else None
-        for g, r0, r1, r1p in self.slices:
-            k.spmm(g, X_u, Y=Y_i[r0:r1], addend=None if add is None else add[r0:r1],
+        for j, (g, r0, r1, r1p) in enumerate(self.slices):
+            y = self._slice_rows(Y_i, j)
+            k.spmm(g, X_u, Y=y, addend=None if add is None else self._slice_rows(add, j),
                    mask=None if (add is None or mask is None) else k.bits_from(mask, r0),
                    out_rows=None if out_bits is None else k.bits_from(out_bits, r0), x_rows=x_rows)
             if reduce == "all":
-                works.append(self.comm.all_reduce_async(Y_i[r0:r1]))
+                works.append(self.comm.all_reduce_async(y))
             elif reduce == "scatter":
-                works.append(self.comm.reduce_scatter_async(Y_i[r0:r1p]))
+                works.append(self.comm.reduce_scatter_async(self._slice_rows(Y_i, j, padded=True)))
         return works
 
     def _sum_rows(self, panel, rows):
@@ -333,8 +349,7 @@ class ShardedEngine:
         is formed once, by the last product's epilogue (users) and by one rows kernel (the batch's items), in
         torch.mean(torch.stack(...))'s left-to-right order.  Evaluation calls propagate() without a batch: every row."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
-        P_u, P_i = self._u(self.P), self._i(self.P)
-        fin_u, fin_i = self._u(self.FIN), self._i(self.FIN)
+        P_u, P_i, fin_u, fin_i = self.P_u, self.P_i, self.FIN_u, self.FIN_i
         train = gb is not None
         self.touched_items = None
         touched = near = None
@@ -395,8 +410,7 @@ class ShardedEngine:
         slice's collective lands, and sends the updated rows round (all-gathers left in flight: _wait_item_table); its
         user side applies Adam to the owned user rows in the product's epilogue."""
         k, K, c0, cnt = self.k, self.K, self.c0, self.cnt
-        g_u, g_i = self._u(self.GF), self._i(self.GF)
-        G_u, G_i, P_i = self._u(self.G), self._i(self.G), self._i(self.P)
+        g_u, g_i, G_u, G_i, P_i = self.GF_u, self.GF_i, self.G_u, self.G_i, self.P_i
         sparse = prep is not None
         users_bits = prep.own_users if sparse else None      # live rows of g_U / reg_U (the owned batch users)
         items_bits = prep.items if sparse else self._ones_items()  # live rows of g_I / reg_I (the batch's items)
@@ -425,22 +439,34 @@ class ShardedEngine:
         t_i = self.XI[K - 1]
         works = self._item_side(h_u, t_i, x_rows=live_u, reduce="scatter")
         self._wait(pending)
-        adam = (self._u(self.P), self.MU, self.VU, self.lr, adam_step)
+        adam = (self.P_u, self.MU, self.VU, self.lr, adam_step)
         if live_i is None:   # a dense launch: the owned users' Adam update rides in its epilogue
-            k.spmm(self.G_ui, h_i, sums=[g_u] if c0 else [], sum_out=G_u, div=cnt, accumulate=True, mask=users_bits, adam=adam)
+            k.spmm(self.G_ui, h_i, sums=[g_u] if c0 else [], sum_out=G_u, div=cnt, accumulate=True, mask=users_bits, adam=adam,
+                   discard_grad=not self.store_item_grad)
         else:                # (K <= 2 with restricted inputs: the epilogue form needs the dense kernel)
             k.spmm(self.G_ui, h_i, sums=[g_u] if c0 else [], sum_out=G_u, div=cnt, accumulate=True, mask=users_bits,
                    x_rows=live_i)
-            k.adam(self._u(self.P), G_u, self.MU, self.VU, self.lr, adam_step)
+            k.adam(self.P_u, G_u, self.MU, self.VU, self.lr, adam_step)
         # the owned item rows: finish the gradient, Adam, and send the updated rows round
-        for w, (_, r0, r1, r1p), (o0, c, off) in zip(works, self.slices, self.own):
+        for j, (w, (o0, c, off)) in enumerate(zip(works, self.own)):
             self.comm.wait(w)
+            blocks = self._own_blocks(j, t_i)
             if c > 0:
-                blk = slice(o0, o0 + c)
-                k.item_tail(t_i[blk], g_i[blk], G_i[blk], items_bits, o0, c0, cnt, self.store_item_grad, P_i[blk],
-                            self.MI[off:off + c], self.VI[off:off + c], self.lr, adam_step)
-            self._ag.append(self.comm.all_gather_async(P_i[r0:r1p], P_i[o0:o0 + c]))
+                k.item_tail(blocks[0], blocks[1], blocks[2], items_bits, o0, c0, cnt, self.store_item_grad, blocks[3],
+                            blocks[4], blocks[5], self.lr, adam_step)
+            self._ag.append(self.comm.all_gather_async(self._slice_rows(P_i, j, padded=True), blocks[3]))
         return self.G
+
+    def _own_blocks(self, j, t_i):
+        """The rows of slice j this rank owns, in (t, g, G, P, M, V)."""
+        key = ("own", id(t_i), j)
+        v = self._views.get(key)
+        if v is None:
+            o0, c, off = self.own[j]
+            blk = slice(o0, o0 + c)
+            v = self._views[key] = (t_i[blk], self.GF_i[blk], self.G_i[blk], self.P_i[blk], self.MI[off:off + c],
+                                    self.VI[off:off + c], t_i)
+        return v
 
     def _ones_items(self):
         if self._all_items_bits is None:
@@ -459,8 +485,12 @@ class ShardedEngine:
             k.wait_rows(prep)
         self.propagate(prep, gb)
         # the batch's user rows (final and ego) travel through the guest rows: owners fill, everybody else adds zeros
-        fin_g, ego_g = self._guest(self.FIN, Bc), self._guest(self.P, Bc)
-        k.gather_rows2(fin_g, self._u(self.FIN), ego_g, self._u(self.P), gb.own_src)
+        guests = self._views.get(("guest", Bc))
+        if guests is None:
+            guests = self._views[("guest", Bc)] = tuple(self._guest(a, Bc) for a in (self.FIN, self.P, self.GF, self.G)) \
+                                                   + (self.guest_ids[:Bc],)
+        fin_g, ego_g = guests[0], guests[1]
+        k.gather_rows2(fin_g, self.FIN_u, ego_g, self.P_u, gb.own_src)
         w1 = self.comm.all_reduce_async(fin_g)
         w2 = self.comm.all_reduce_async(ego_g)
         if prep is None:
@@ -468,11 +498,10 @@ class ShardedEngine:
             k.fill(self.GF, 0.0)
         self.comm.wait(w1)
         self.comm.wait(w2)
-        k.bpr(self.FIN, self.P, self.Ug + self.B, self.guest_ids[:Bc], gb.pos, gb.neg, self.reg_lambda, self.GF, self.G,
+        k.bpr(self.FIN, self.P, self.Ug + self.B, guests[4], gb.pos, gb.neg, self.reg_lambda, self.GF, self.G,
               self.loss, prep)
         # gradients of the guest rows go home: every owned user's occurrences are added in batch order
-        k.chain_rows2(self._u(self.GF), self._guest(self.GF, Bc), self._u(self.G), self._guest(self.G, Bc), gb.head_dst,
-                      gb.nxt, store=prep is not None)
+        k.chain_rows2(self.GF_u, guests[2], self.G_u, guests[3], gb.head_dst, gb.nxt, store=prep is not None)
         self.step_count += 1
         self.propagate_backward(prep, gb, self.step_count)
         if prep is not None:
@@ -522,16 +551,23 @@ class ShardedEngine:
 
 # --------------------------------------------------------------------------- product bindings
 class HipKernels:
-    """`kernels` bound to libidgrec.so on the current HIP device."""
+    """`kernels` bound to libidgrec.so on the current HIP device.  The step issues ~40 library calls; what is marshalled
+    here is kept minimal (the engine hands over the same preallocated buffers every step: pointers and views are cached,
+    arguments are not re-validated — ops.py's wrappers do that for everybody else)."""
 
     def __init__(self, device=None):
+        import ctypes as C
+
         import torch
 
-        from . import ops
+        from . import native, ops
 
-        self.torch, self.ops = torch, ops
+        self.torch, self.ops, self.C = torch, ops, C
+        self.lib, self.check, self.Epilogue = native.lib, native.check, native.Epilogue
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._pool = []
+        self._bits = {}
+        self._ws = {}
         # side stream of the batch preparation, claimed at construction (ops.side_stream: hardware-queue placement)
         self._side = ops.side_stream(self.device)
         self._side_raw = self._side.cuda_stream
@@ -549,13 +585,37 @@ class HipKernels:
                               build_transpose=False)
 
     def spmm(self, graph, X, Y=None, addend=None, sums=(), sum_out=None, div=1.0, accumulate=False, mask=None, adam=None,
-             out_rows=None, x_rows=None):
-        s = list(sums) + [None, None, None]
-        self.ops.spmm_epi_raw(graph, X, Y, addend, s[0], s[1], s[2], sum_out, div, accumulate, mask, adam, out_rows, x_rows)
+             out_rows=None, x_rows=None, discard_grad=False):
+        """idg_spmm_epi_f32 (include/idgrec.h): the product with the whole epilogue."""
+        d = X.shape[1]
+        n_s = len(sums)
+        e = self.Epilogue(None if Y is None else Y.data_ptr(), None if addend is None else addend.data_ptr(),
+                          sums[0].data_ptr() if n_s > 0 else None, sums[1].data_ptr() if n_s > 1 else None,
+                          sums[2].data_ptr() if n_s > 2 else None, None if sum_out is None else sum_out.data_ptr(), d, div,
+                          1 if accumulate else 0, None if mask is None else mask.data_ptr())
+        if adam is not None:
+            p, m, v, lr, step = adam
+            e.adam_param, e.adam_exp_avg, e.adam_exp_avg_sq = p.data_ptr(), m.data_ptr(), v.data_ptr()
+            e.adam_lr, e.adam_beta1, e.adam_beta2, e.adam_eps, e.adam_step = lr, 0.9, 0.999, 1e-8, step
+            e.adam_discard_grad = 1 if discard_grad else 0
+        key = (id(graph), d)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = (graph, graph._workspace("spmm", d).data_ptr())
+        rc = self.lib.idg_spmm_epi_f32(graph._h, X.data_ptr(), d, d, self.C.byref(e), None if out_rows is None else out_rows.data_ptr(),
+                                       None if x_rows is None else x_rows.data_ptr(), ws[1], self.ops._stream())
+        if rc:
+            self.check(rc, "idg_spmm_epi_f32")
 
     def bits_from(self, bits, row0):
         """The bitmap of rows row0, row0 + 1, ... (row0 a multiple of 32)."""
-        return bits if row0 == 0 else bits[row0 // 32:]
+        if row0 == 0:
+            return bits
+        key = (bits.data_ptr(), row0)
+        v = self._bits.get(key)
+        if v is None:
+            v = self._bits[key] = (bits, bits[row0 // 32:])  # (holds the base: the key's address stays its)
+        return v[1]
 
     def ones_bits(self, n_bits):
         return self.torch.full(((n_bits + 31) // 32 + 1,), -1, dtype=self.torch.int32, device=self.device)
@@ -572,10 +632,16 @@ class HipKernels:
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
     def gather_rows(self, dst, src, idx):
-        self.ops.rows_gather_raw(dst, src, idx)
+        rc = self.lib.idg_rows_gather_f32(dst.data_ptr(), src.data_ptr(), idx.data_ptr(), idx.shape[0], dst.shape[1],
+                                          self.ops._stream())
+        if rc:
+            self.check(rc, "idg_rows_gather_f32")
 
     def gather_rows2(self, dst0, src0, dst1, src1, idx):
-        self.ops.rows_gather2_raw(dst0, src0, dst1, src1, idx)
+        rc = self.lib.idg_rows_gather2_f32(dst0.data_ptr(), src0.data_ptr(), dst1.data_ptr(), src1.data_ptr(), idx.data_ptr(),
+                                           idx.shape[0], dst0.shape[1], self.ops._stream())
+        if rc:
+            self.check(rc, "idg_rows_gather2_f32")
 
     def scatter_rows(self, dst, idx, src):
         """dst[idx[j]] = src[j] (idx distinct)."""
@@ -583,7 +649,11 @@ class HipKernels:
 
     def chain_rows2(self, dst0, src0, dst1, src1, idx, nxt, store):
         if store:
-            self.ops.rows_chain_store2_raw(dst0, src0, dst1, src1, idx, nxt)
+            rc = self.lib.idg_rows_chain_store2_f32(dst0.data_ptr(), src0.data_ptr(), dst1.data_ptr(), src1.data_ptr(),
+                                                    idx.data_ptr(), nxt.data_ptr(), idx.shape[0], dst0.shape[1],
+                                                    self.ops._stream())
+            if rc:
+                self.check(rc, "idg_rows_chain_store2_f32")
         else:
             self.ops.rows_chain_add_raw(dst0, src0, idx, nxt)
             self.ops.rows_chain_add_raw(dst1, src1, idx, nxt)
@@ -592,7 +662,11 @@ class HipKernels:
         self.ops.rows_layer_mean_raw(out, ids, terms, last, div)
 
     def item_tail(self, t, g, G, live_bits, row0, c0, cnt, store_grad, p, m, v, lr, step):
-        self.ops.grad_tail_adam_raw(t, g, G, live_bits, row0, c0, cnt, store_grad, p, m, v, lr, step)
+        rc = self.lib.idg_grad_tail_adam_f32(t.data_ptr(), g.data_ptr(), G.data_ptr(), live_bits.data_ptr(), row0, t.shape[0],
+                                             t.shape[1], c0, cnt, 1 if store_grad else 0, p.data_ptr(), m.data_ptr(),
+                                             v.data_ptr(), lr, 0.9, 0.999, 1e-8, step, self.ops._stream())
+        if rc:
+            self.check(rc, "idg_grad_tail_adam_f32")
 
     def adam(self, p, g, m, v, lr, step):
         self.ops.adam_step_raw(p, g, m, v, lr, step)
@@ -619,6 +693,13 @@ class HipKernels:
     def touched_from_ids(self, eng, prep, ids, n):
         self.ops.bpr_touch_rows_raw(ids, ids, ids, 0, prep.touched_buf, clear_bits=eng.Ip)
         prep.touched = prep.touched_buf
+        # n is known here (and bounded by the compact buffer): the products restricted to the touched items — layer K - 1's
+        # item side, the first backward product — run one wave per live work unit instead of visiting every tile
+        st = self.ops._stream()
+        for j, (g, r0, r1, r1p) in enumerate(eng.slices):
+            ws = self._units(prep, ("t", j), g, eng.CS.shape[0])
+            self.check(self.lib.idg_graph_live_units(g._h, self.bits_from(prep.touched_buf, r0).data_ptr(), ws.data_ptr(),
+                                                     eng.CS.shape[0], st), "idg_graph_live_units")
         self._near_users(eng, prep, None)
 
     def _near_users(self, eng, prep, gb):
@@ -629,6 +710,13 @@ class HipKernels:
         for g, r0, r1, r1p in eng.slices:
             g.mark_cols(self.bits_from(prep.items, r0), prep.near_buf)
         prep.near = prep.near_buf
+
+    def _units(self, prep, key, graph, max_rows):
+        ws = prep.units.get(key)
+        if ws is None:
+            nbytes = int(self.lib.idg_graph_live_units_bytes(graph._h, int(max_rows)))
+            ws = prep.units[key] = self.torch.empty(nbytes // 4, dtype=self.torch.int32, device=self.device)
+        return ws
 
     def topk(self, user_panel, item_panel, users, k, excl_indptr, excl_items):
         """Top-k item ids [len(users), k] (numpy) for local user ids `users`, train items excluded."""
@@ -641,14 +729,15 @@ class HipKernels:
 
     class _Prepared:
         __slots__ = ("own_users", "items", "touched_buf", "near_buf", "touched", "near", "bpr_bits", "ws", "rows_done", "done",
-                     "B", "busy")
+                     "B", "busy", "units", "graphs")
 
     def prepare(self, eng, gb):
         """Index-only work of a global batch on a side stream: the bitmap of the LOCAL user rows this rank owns in it,
         the bitmap of the batch's item rows (ALL triples' positives and negatives: every rank evaluates the whole batch),
-        a cleared bitmap for the gradient scatter to flag its stored rows in, and the sorted scatter plan of the whole
-        batch over the guest rows.  Host cost matters here: raw stream handles and events allocated once."""
-        torch, ops = self.torch, self.ops
+        their lists of live work units (the last forward layer runs one wave per unit: idg_graph_live_units), a cleared
+        bitmap for the gradient scatter to flag its stored rows in, and the sorted scatter plan of the whole batch over
+        the guest rows.  Host cost matters here: raw stream handles and events allocated once."""
+        torch, ops, lib = self.torch, self.ops, self.lib
         cap, n_users, n, d = eng.B, eng.Ug + eng.B, eng.Ug + eng.B + eng.Ip, eng.d
         prep = next((p for p in self._pool if p.B == cap and not p.busy), None)
         if prep is None:
@@ -659,22 +748,29 @@ class HipKernels:
             prep.bpr_bits = words(n)
             prep.ws, prep.B = ops.bpr_workspace(cap, d, self.device), cap
             prep.rows_done, prep.done = ops.LocalEvent(), ops.LocalEvent()  # device-local events
+            prep.units = {}
+            prep.graphs = [eng.G_ui] + [sl[0] for sl in eng.slices]  # (their unit lists name this object's bitmaps)
             self._pool.append(prep)
         prep.busy = True
         prep.touched = prep.near = None
-        main = ops._stream()
-        self._fork.record(main)              # the id tensors may have just been produced on the main stream,
-        self._fork.wait(self._side_raw)      # and the step that last used these buffers is ordered before it
+        side = self._side_raw
+        self._fork.record(ops._stream())     # the id tensors may have just been produced on the main stream,
+        self._fork.wait(side)                # and the step that last used these buffers is ordered before it
         if gb.n_owned > 0:
-            ops.bpr_touch_rows_raw(gb.own_users, gb.own_users, gb.own_users, 0, prep.own_users, stream=self._side_raw,
-                                   clear_bits=eng.Ug)
+            ops.bpr_touch_rows_raw(gb.own_users, gb.own_users, gb.own_users, 0, prep.own_users, stream=side, clear_bits=eng.Ug)
         else:
-            ops.bitmap_clear_raw(prep.own_users, eng.Ug, stream=self._side_raw)
-        ops.bpr_touch_rows_raw(gb.pos, gb.pos, gb.neg, 0, prep.items, stream=self._side_raw, clear_bits=eng.Ip)
-        ops.bitmap_clear_raw(prep.bpr_bits, n, stream=self._side_raw)
-        prep.rows_done.record(self._side_raw)
-        ops.bpr_plan_raw(eng.guest_ids[:gb.B], gb.pos, gb.neg, n_users, n, d, ws=prep.ws, stream=self._side_raw)
-        prep.done.record(self._side_raw)
+            ops.bitmap_clear_raw(prep.own_users, eng.Ug, stream=side)
+        ops.bpr_touch_rows_raw(gb.pos, gb.pos, gb.neg, 0, prep.items, stream=side, clear_bits=eng.Ip)
+        ops.bitmap_clear_raw(prep.bpr_bits, n, stream=side)
+        self.check(lib.idg_graph_live_units(eng.G_ui._h, prep.own_users.data_ptr(),
+                                            self._units(prep, "u", eng.G_ui, cap).data_ptr(), cap, side), "idg_graph_live_units")
+        for j, (g, r0, r1, r1p) in enumerate(eng.slices):
+            self.check(lib.idg_graph_live_units(g._h, self.bits_from(prep.items, r0).data_ptr(),
+                                                self._units(prep, ("i", j), g, 2 * cap).data_ptr(), 2 * cap, side),
+                       "idg_graph_live_units")
+        prep.rows_done.record(side)
+        ops.bpr_plan_raw(eng.guest_ids[:gb.B], gb.pos, gb.neg, n_users, n, d, ws=prep.ws, stream=side)
+        prep.done.record(side)
         return prep
 
     def wait_rows(self, prep):
@@ -683,6 +779,15 @@ class HipKernels:
 
     def release(self, prep):
         prep.busy = False  # its buffers go back to the pool; reuse is ordered by the fork event of the next prepare()
+
+    def __del__(self):
+        # the pooled bitmaps and unit lists die with this object: nothing may stay registered under their addresses
+        try:
+            for prep in self._pool:
+                for g in prep.graphs:
+                    g.forget_live_units()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 class TorchComm:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 130 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
+#define IDG_VERSION 131 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
                            _chain_store2 / _layer_mean, idg_grad_tail_adam_f32, idg_reduce_scatter_f32 */
 
@@ -284,6 +284,8 @@ typedef struct idg_epilogue {
   float* adam_exp_avg_sq;
   double adam_lr, adam_beta1, adam_beta2, adam_eps;
   int64_t adam_step;
+  int adam_discard_grad; /* != 0: the finished gradient feeds the update and is not written to sum_out (which is still
+                            READ at live rows when accumulate is set): one [n, d] write less per step */
 } idg_epilogue;
 int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d, const idg_epilogue* epilogue,
                      const uint32_t* out_rows, const uint32_t* x_rows, void* ws, void* stream);

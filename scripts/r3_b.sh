@@ -1,0 +1,8 @@
+# kernel traces of the sharded step at world size 1 (yelp2018 shape, configs[4] shape)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03_shard1_yelp -o t -- python3 $R/bench.py --gpus 1 --force-sharded --parallel shard --no-cpu-baseline --workload yelp2018 --steps 300 --warmup 30 --ramp gemm > $R/gpurun_out/prof_r03_shard1_yelp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03_shard1_c5 -o t -- python3 $R/bench.py --gpus 1 --force-sharded --parallel shard --no-cpu-baseline --workload synth-10M --dim 256 --steps 6 --warmup 3 --ramp gemm > $R/gpurun_out/prof_r03_shard1_c5.log 2>&1
+cd $R
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "epilogue_struct or row_movers" 2>&1 | tail -5

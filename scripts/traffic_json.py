@@ -15,8 +15,9 @@ dense = [k for k in s if k.startswith("spmm_tile_kernel<%d, 1, 8, true" % (d // 
 # the plain (EPI = 0) instantiation is the dominant kernel; with --separate-adam it is the only dense one
 dense.sort(key=lambda k: -s[k]["FETCH_SIZE"]["n"])
 k = dense[0]
-fetch, write = s[k]["FETCH_SIZE"]["avg"] * 1024 if s[k]["FETCH_SIZE"]["avg"] < 1e7 else s[k]["FETCH_SIZE"]["avg"], None
-write = s[k]["WRITE_SIZE"]["avg"] * 1024 if s[k]["WRITE_SIZE"]["avg"] < 1e7 else s[k]["WRITE_SIZE"]["avg"]
+# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KILOBYTES (round 3: the earlier "x 1024 below 1e7" guess broke on launches
+# that move more than 10 GB)
+fetch, write = s[k]["FETCH_SIZE"]["avg"] * 1024, s[k]["WRITE_SIZE"]["avg"] * 1024
 hit, miss = s[k].get("TCC_HIT_sum", {}).get("avg"), s[k].get("TCC_MISS_sum", {}).get("avg")
 out = {
     "kernel": k, "workload": workload, "d": d,
@@ -26,8 +27,8 @@ out = {
 }
 adam = s.get("adam_kernel")
 if adam and "FETCH_SIZE" in adam:
-    af = adam["FETCH_SIZE"]["avg"] * (1024 if adam["FETCH_SIZE"]["avg"] < 1e7 else 1)
-    aw = adam["WRITE_SIZE"]["avg"] * (1024 if adam["WRITE_SIZE"]["avg"] < 1e7 else 1)
+    af = adam["FETCH_SIZE"]["avg"] * 1024
+    aw = adam["WRITE_SIZE"]["avg"] * 1024
     out["calibration_adam_kernel"] = {"fetch_raw": af, "write": aw,
                                       "note": "known traffic: reads = 4/3 x writes (p,g,m,v in; p,m,v out)",
                                       "reads_over_writes_with_x2": 2 * af / aw}
@@ -35,7 +36,7 @@ out["method"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_H
                  "(scripts/pmc.sh, bench.py --separate-adam), per-dispatch average; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                  "(gfx950 tallies 128-B read requests at 64 B), checked on adam_kernel in the same run. Fabric-side bytes: "
                  "Infinity Cache hits are included, so for a cache-resident panel this is not DRAM traffic.")
-sub = sys.argv[4] if len(sys.argv) > 4 else "r02"  # profiles/<round>/: bench.py reads the newest round's file
+sub = sys.argv[4] if len(sys.argv) > 4 else "r03"  # profiles/<round>/: bench.py reads the newest round's file
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", sub, "traffic_%s_d%d.json" % (workload, d))
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)

@@ -125,7 +125,7 @@ class OracleKernels:
         return self.o.topk_reference(R, k)
 
     def spmm(self, graph, X, Y=None, addend=None, sums=(), sum_out=None, div=1.0, accumulate=False, mask=None, adam=None,
-             out_rows=None, x_rows=None):
+             out_rows=None, x_rows=None, discard_grad=False):
         ptr, idx, val, n_rows, n_cols = graph
         Xe = np.ascontiguousarray(X[:n_cols])
         if x_rows is not None:  # rows outside the live set are zero by agreement and must not be read

@@ -375,6 +375,47 @@ def test_bpr_upstream_scaling_and_determinism(ops, golden_small):
     np.testing.assert_allclose(f.grad.cpu().numpy(), gf2, rtol=RTOL, atol=1e-7)
 
 
+@pytest.mark.parametrize("B", [2731, 5462, 21846, 1 << 20])
+def test_bpr_plan_beyond_the_lds_sort(ops, B):
+    """3B > 8192 (row, slot) pairs: LDS-sorted runs of 8192 + merge-path passes (round 3: the library's own sort; hipCUB is
+    gone).  3B = 8193 (a second run of ONE key), 16386 (three runs: an odd merge), 65538, and 3 x 2^20 — the
+    throughput-oriented batch of BASELINE configs[4].  The plan itself is checked (keys ascending, slots ascending inside a
+    run of equal keys, a permutation of the input), then loss and gradients against the oracle, run-to-run identical."""
+    rng = np.random.default_rng(B)
+    U, I, d = 700, 1300, 64
+    n = U + I
+    users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    ud, pd, nd = dev(users), dev(pos), dev(neg)
+    ws = ops.bpr_workspace(B, d, torch.device("cuda"))
+    ops.bpr_plan_raw(ud, pd, nd, U, n, d, ws=ws)
+    torch.cuda.synchronize()
+    # the plan is the stable sort of (row, slot), slot = 3 t + role: users, positives, negatives of triple t.  Workspace layout
+    # (idg_bpr.hip, bpr_layout): coef [B] | loss terms [B] | squares [3B] | keys [3B] | slots [3B] | SORTED keys [3B] |
+    # SORTED slots [3B] | sort scratch, every region aligned to 256 bytes
+    rows = np.stack([users, U + pos, U + neg], axis=1).reshape(-1)
+    order = np.lexsort((np.arange(3 * B), rows))
+    al = lambda x: (x + 255) // 256 * 256  # noqa: E731
+    off = al(B * 4) * 2 + al(B * 12) * 3
+    raw = ws.cpu().numpy()
+    got_keys = raw[off: off + 12 * B].view(np.int32)
+    got_slots = raw[off + al(B * 12): off + al(B * 12) + 12 * B].view(np.int32)
+    assert np.array_equal(got_keys, rows[order].astype(np.int32)), "sorted row keys differ from the stable sort"
+    assert np.array_equal(got_slots, order.astype(np.int32)), "sorted slots differ from the stable sort"
+    fin = dev(rng.standard_normal((n, d)).astype(np.float32) * 0.3)
+    ego = dev(rng.standard_normal((n, d)).astype(np.float32) * 0.3)
+    outs = []
+    for _ in range(2):
+        gf, ge = torch.zeros_like(fin), torch.zeros_like(ego)
+        loss = ops.bpr_fused_raw(fin, ego, ud, pd, nd, U, 1e-2, gf, ge, deterministic=2, ws=ws)
+        outs.append((loss.clone(), gf, ge))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    l_o, gf_o, ge_o = oracle.bpr(fin.cpu().numpy(), ego.cpu().numpy(), U, users, pos, neg, 1e-2)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), l_o, rtol=1e-4)
+    # (a row of this small table collects up to ~1500 terms at B = 2^20: the oracle adds them in the same batch order)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), gf_o, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), ge_o, rtol=2e-4, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------ Adam
 def test_adam_vs_torch_and_oracle(ops):
     rng = np.random.default_rng(0)
