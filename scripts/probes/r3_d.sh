@@ -7,3 +7,6 @@ import json; d=json.load(open('gpurun_out/r03_shard1_yelp.json')); print('yelp s
 bash scripts/sharded1.sh --workload synth-10M --dim 256 --steps 6 --warmup 3 > gpurun_out/r03_shard1_c5.json 2> gpurun_out/r03_shard1_c5.err; python -c "
 import json; d=json.load(open('gpurun_out/r03_shard1_c5.json')); print('c5 shard1', d['ms_per_step'], d['host_issue_ms_per_step'])"
 tail -3 gpurun_out/r03_shard1_c5.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r03_eval -o t -- python3 $GRAFT_REPO_ROOT/scripts/eval_bench.py yelp2018 > $GRAFT_REPO_ROOT/gpurun_out/prof_r03_eval.log 2>&1
+grep "ms per full" $GRAFT_REPO_ROOT/gpurun_out/prof_r03_eval.log
