@@ -199,9 +199,10 @@ def self_launch(args):
     sys.exit(proc.returncode if proc.returncode or lines else 1)
 
 
-def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2):
+def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None):
     """The multi-GPU lines' workload on ONE GPU, unsharded, through the fused single-GPU engine (PropagationEngine): the
-    1-GPU point the N-GPU speed-ups are quoted against, measured in the same run.  ~140 GB resident at synth-10M d=256."""
+    1-GPU point the N-GPU speed-ups are quoted against, measured in the same run.  ~140 GB resident at synth-10M d=256.
+    edges: the (users, items) arrays when the caller has drawn the graph already."""
     import idgrec_amd.host as H
     import idgrec_amd.ops as ops
     import idgrec_amd.synth as S
@@ -210,7 +211,7 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2):
     t_all = time.perf_counter()
     U, I, E = S.SHAPES[workload]
     K, B = args.layers, args.batch
-    users, items = S.generate(U, I, E, seed=0)
+    users, items = edges if edges is not None else S.generate(U, I, E, seed=0)
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
     n, nnz, n_edges = U + I, len(ix), len(users)
     tri = torch.from_numpy(S.draw_triples(args.seed, users, items, U, I, (steps + warmup) * B)[0]).cuda()
@@ -312,7 +313,7 @@ def main():
             fits = 9 * 4 * (U_ + I_) * args.dim + 24 * E_ < 250e9
             ref = None
             if args.scale_point == "on" or (args.scale_point == "auto" and world > 1 and fits):
-                ref = lambda a: single_gpu_point(a, a.workload, a.dim)  # noqa: E731
+                ref = lambda a, edges=None: single_gpu_point(a, a.workload, a.dim, edges=edges)  # noqa: E731
             out = run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_reference=ref)
             if args.parallel == "auto" and world > 1:
                 rep = run_replicated_bench(args, rank, world, dist, comm, comm_name, workload="yelp2018", dim=64)

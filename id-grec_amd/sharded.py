@@ -854,10 +854,17 @@ class TorchComm:
             return self.all_reduce_async(t)
         flat = t.view(-1)
         c = flat.numel() // self.world
-        return self.dist.reduce_scatter_tensor(flat[self.rank * c:(self.rank + 1) * c], flat, async_op=True)
+        own = flat[self.rank * c:(self.rank + 1) * c]
+        out = torch.empty_like(own)  # (c10d does not promise the in-place form: reduce into a scratch block, then copy)
+        work = self.dist.reduce_scatter_tensor(out, flat, async_op=True)
+        return ("copy_after", work, own, out)
 
     def wait(self, work):
-        if work is not None:
+        if isinstance(work, tuple):  # reduce_scatter_async: the reduced block goes to its place once the collective is done
+            _, inner, own, out = work
+            inner.wait()
+            own.copy_(out)
+        elif work is not None:
             work.wait()
 
 
@@ -1114,6 +1121,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     cuts = partition_users_by_nnz(np.bincount(items, minlength=I), n_slices)  # same cuts on every rank: global item degrees
     need = (args.steps + args.warmup) * B
     tri = S.draw_triples(args.seed, users, items, U, I, need)[0]  # the same global sequence on every rank
+    edges = (users, items) if (rank == 0 and single_gpu_reference is not None) else None  # (rank 0 measures the 1-GPU point later)
     del users, items
     kern = HipKernels()
     eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
@@ -1242,7 +1250,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         ref = None
         if rank == 0:
             try:
-                ref = single_gpu_reference(args)
+                ref = single_gpu_reference(args, edges)
             except Exception as exc:  # noqa: BLE001 - the headline stands without it; the line says why it is missing
                 ref = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
             out["single_gpu_reference"] = ref
