@@ -1117,7 +1117,9 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     ui, iu = shard_adjacency_from_edges(users, items, U, I, lo, hi)  # this rank's rows only: no global CSR
     nnz_global, n_edges = 2 * len(users), len(users)
-    n_slices = 4 if I * d * 4 >= (256 << 20) else 1
+    # slices of the item panel: what a collective moves at a time.  From 4 ranks on the communicator's stream is the
+    # critical path and a collective can start when its first slice exists: finer slices there
+    n_slices = (8 if world >= 4 else 4) if I * d * 4 >= (256 << 20) else 1
     cuts = partition_users_by_nnz(np.bincount(items, minlength=I), n_slices)  # same cuts on every rank: global item degrees
     need = (args.steps + args.warmup) * B
     tri = S.draw_triples(args.seed, users, items, U, I, need)[0]  # the same global sequence on every rank

@@ -22,6 +22,19 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.fixture(autouse=True)
+def _free_device_memory():
+    """Every test here wants most of the device: return what earlier tests left in torch's caching allocator first (the
+    free-memory checks below look at the device, not at the cache — a cached 150 GB would turn a test into a skip)."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    yield
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def _sampled_rows_problem(ip, ix, dv, rows, X_dev):
     """The CSR rows `rows` of (ip, ix, dv) as a small CSR over a compact column space + the gathered panel rows of
     X_dev they need (read back from the device).  Column order inside a row is preserved (the remap is monotone)."""
