@@ -1800,6 +1800,30 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   return IDG_OK;
 }
 
+int idg_graph_create_from_device(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                                 const int32_t* d_indices, const float* d_values, uint32_t flags, int64_t split_threshold,
+                                 void* stream, idg_graph** out) {
+  IDG_REQUIRE(out, "idg_graph_create_from_device: out is NULL");
+  IDG_REQUIRE(n_rows >= 0 && nnz >= 0 && d_indptr && (nnz == 0 || (d_indices && d_values)),
+              "idg_graph_create_from_device: bad argument");
+  // The row-block schedule (virtual rows, tiles, XCD bands, split tables) is built by the host code of idg_graph_create:
+  // the arrays are staged through host memory — ordered after `stream`, where the caller may just have produced them.
+  std::vector<int64_t> ip((size_t)n_rows + 1);
+  std::vector<int32_t> ix((size_t)nnz);
+  std::vector<float> dv((size_t)nnz);
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != IDG_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  IDG_HIP(hipMemcpyAsync(ip.data(), d_indptr, ip.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  if (nnz > 0) {
+    IDG_HIP(hipMemcpyAsync(ix.data(), d_indices, ix.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    IDG_HIP(hipMemcpyAsync(dv.data(), d_values, dv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  IDG_HIP(hipStreamSynchronize(st));
+  return idg_graph_create(device, n_rows, n_cols, nnz, ip.data(), ix.data(), dv.data(), flags, split_threshold, out);
+}
+
 int idg_graph_destroy(idg_graph* g) {
   if (!g) return IDG_OK;
   if (!g->borrowed && g->d_vptr) units_forget(g->d_vptr, nullptr);  // the schedule goes away: so do its unit lists

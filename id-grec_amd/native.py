@@ -39,6 +39,8 @@ PROTOTYPES = {
                                      C.POINTER(C.c_double), c_i64p, c_i64p, c_i32p, c_f32p]),
     "idg_graph_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i32p, c_f32p, C.c_uint32,
                                    C.c_int64, C.POINTER(c_vp)]),
+    "idg_graph_create_from_device": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_uint32,
+                                               C.c_int64, c_vp, C.POINTER(c_vp)]),
     "idg_graph_destroy": (C.c_int, [c_vp]),
     "idg_graph_live_units_bytes": (C.c_size_t, [c_vp, C.c_int64]),
     "idg_graph_live_units": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
@@ -159,7 +161,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 131  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 132  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -103,6 +103,29 @@ class Graph:
                             _transpose_of=self)
 
     @classmethod
+    def from_torch_sparse(cls, t, symmetric=True, exact_order=False, split_threshold=0):
+        """From the reference's own operand: a coalesced sparse COO (or CSR) fp32 tensor that lives on the device
+        (models/LightGCN.py:31-32: convert_sp_mat_to_sp_tensor(...).coalesce().to(device)) — idg_graph_create_from_device.
+        Non-symmetric graphs get no transposed handle here (build it from t.t().coalesce())."""
+        if not t.is_cuda:
+            raise RuntimeError("Graph.from_torch_sparse needs a device tensor; idgrec_amd has no CPU path")
+        csr = t if t.layout == torch.sparse_csr else t.coalesce().to_sparse_csr()
+        crow = csr.crow_indices().to(torch.int64).contiguous()
+        col = csr.col_indices().to(torch.int32).contiguous()
+        val = csr.values().to(torch.float32).contiguous()
+        g = cls.__new__(cls)
+        g.device, (g.n_rows, g.n_cols), g.nnz = t.device, (int(t.shape[0]), int(t.shape[1])), int(col.shape[0])
+        g.symmetric, g._ws, g._T = bool(symmetric), {}, None
+        flags = (native.IDG_GRAPH_SYMMETRIC if symmetric else 0) | (native.IDG_GRAPH_EXACT_ORDER if exact_order else 0)
+        h = C.c_void_p()
+        with torch.cuda.device(t.device):
+            check(lib.idg_graph_create_from_device(t.device.index, g.n_rows, g.n_cols, g.nnz, _ptr(crow), _ptr(col), _ptr(val),
+                                                   flags, int(split_threshold), _stream(), C.byref(h)),
+                  "idg_graph_create_from_device")
+        g._h = h
+        return g
+
+    @classmethod
     def from_scipy(cls, mat, **kw):
         m = mat.tocsr()
         m.sort_indices()

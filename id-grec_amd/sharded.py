@@ -932,7 +932,7 @@ class NativeComm:
         self.handle = handle
         self.overlap_bytes = int(overlap_bytes)
         self._own = self._own_raw = None   # the collectives' own stream, made on first use
-        self._ring, self._next = [], 0     # (issued, done) event pairs, reused round-robin (a layer's slices + the previous layer's: <= 8 collectives in flight)
+        self._ring, self._next = [], 0     # (issued, done) event pairs, reused round-robin (a step issues up to 4 x slices collectives here; a handle is waited for within the next step)
 
     def _fork(self):
         """Order the communicator's stream after the current one; returns (raw stream handle, event to record when done)."""
@@ -940,7 +940,7 @@ class NativeComm:
         if self._own is None:
             self._own = torch.cuda.Stream()
             self._own_raw = self._own.cuda_stream
-            self._ring = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(32)]
+            self._ring = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(128)]  # > 3 steps' worth of collectives
         issued, done = self._ring[self._next]
         self._next = (self._next + 1) % len(self._ring)
         issued.record()

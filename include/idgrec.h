@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 131 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
+#define IDG_VERSION 132 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
                            _chain_store2 / _layer_mean, idg_grad_tail_adam_f32, idg_reduce_scatter_f32 */
 
@@ -138,6 +138,13 @@ typedef struct idg_graph idg_graph;
 int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
                      const int32_t* indices, const float* values, uint32_t flags,
                      int64_t split_threshold, idg_graph** out);
+/* The same from DEVICE CSR arrays (SURVEY.md 8b's signature: the reference's graph is a coalesced sparse tensor that
+ * already lives on the device, models/LightGCN.py:31-32).  The schedule is still built by host code: the arrays are copied
+ * to host memory behind `stream` (the one call of this library that synchronises a stream: graph construction is a
+ * one-off).  A device-side schedule build is future work. */
+int idg_graph_create_from_device(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                                 const int32_t* d_indices, const float* d_values, uint32_t flags,
+                                 int64_t split_threshold, void* stream, idg_graph** out);
 int idg_graph_destroy(idg_graph* g);
 
 /* A copy of `g` whose stored entry (r, c) keeps values[k] / divisor when floor(u + add) != 0 and becomes an explicit

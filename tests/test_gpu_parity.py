@@ -961,6 +961,25 @@ def test_live_unit_list_equals_tile_form(ops, d, exact):
     assert torch.equal(unit_out.index_select(0, rows_d), full.index_select(0, rows_d))
 
 
+def test_graph_from_the_references_device_tensor(ops, golden_small):
+    """the operand the reference hands to torch.sparse.mm is a coalesced fp32 COO tensor ON the device
+    (models/LightGCN.py:31-32).  Graph.from_torch_sparse / idg_graph_create_from_device take exactly that; the handle is
+    the one the host-CSR constructor builds: same product bits, same propagation bits."""
+    g = golden_small
+    U, I = int(g["num_users"]), int(g["num_items"])
+    n = U + I
+    ip, ix, dv = g["adj_indptr"], g["adj_indices"], g["adj_data"]
+    rows = np.repeat(np.arange(n), np.diff(ip))
+    coo = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, ix.astype(np.int64)])), torch.from_numpy(dv), (n, n)).coalesce().cuda()
+    G1 = ops.Graph(ip, ix, dv, n, n)
+    G2 = ops.Graph.from_torch_sparse(coo)
+    assert G1.info() == G2.info()
+    X = dev(np.concatenate([g["d64_init_user"], g["d64_init_item"]]))
+    assert torch.equal(G1.spmm_raw(X), G2.spmm_raw(X))
+    assert torch.equal(G1.propagate_mean_raw(X, 3, True), G2.propagate_mean_raw(X, 3, True))
+    assert torch.allclose(G2.spmm_raw(X), torch.sparse.mm(coo, X), rtol=1e-5, atol=1e-7)
+
+
 def _row_bitmap(n, rows):
     bitmap = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
     np.bitwise_or.at(bitmap, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
