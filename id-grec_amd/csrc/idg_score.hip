@@ -166,6 +166,12 @@ constexpr int FT_USERS = 64;
 constexpr int FT_SLAB = 128;
 constexpr int FT_LD = FT_SLAB + 4;
 constexpr int FT_UPW = FT_USERS / (BLOCK / WAVE);  // users per wave
+#ifndef IDG_TOPK_FLOOR_SLABS
+#define IDG_TOPK_FLOOR_SLABS 3
+#endif
+constexpr int FLOOR_SLABS = IDG_TOPK_FLOOR_SLABS;   // slabs of a chunk the floor phase of a many-chunk call looks at (at most
+                                                    // half the chunk; full yelp2018-size evaluation in calls of 1024 users:
+                                                    // 2 / 3 / 4 / 5 slabs -> profiles/r03/topk_floor_slabs.txt)
 constexpr int TOPK_WGS = 1024;                      // workgroups wanted per launch (3 fit a CU; measured best of 512..1536)
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src) {
@@ -400,7 +406,15 @@ __device__ __forceinline__ void flag_candidates(const f32x16& acc0, const f32x16
   }
 }
 
-template <bool SIGMOID, bool D64>
+// Calls with few user tiles cut the catalogue into many short chunks (to fill the chip), and a chunk's list starts
+// empty: while it is young nearly every (user, slab) pair holds a candidate and pays the ~2,800-cycle select — at 1024
+// users per call (the reference's test_batch_size shape, batch_test.py:52-68) that was 190 of a launch's 240 us.  So
+// such calls run in two phases.  MAXONLY: every (tile, chunk) workgroup scores the first few slabs of its chunk and writes
+// each user's maximum (train items masked) to chunk_max[b, chunk]; chunk_floor_kernel takes the k-th largest of a
+// user's chunk maxima — k items score at least that, so it is a lower bound of the final k-th score — and the main
+// launch starts every chunk with that floor (floor0): an item below it is never a candidate, lists start empty, and a
+// (user, slab) pair is looked at only when a score reaches the floor.  Same final lists (ties at the floor are kept).
+template <bool SIGMOID, bool D64, bool MAXONLY = false>
 __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const float* __restrict__ U,
                                                                     const float* __restrict__ V,
                                                                     const int64_t* __restrict__ users, int64_t Bt,
@@ -408,21 +422,27 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
                                                                     const int64_t* __restrict__ excl_indptr,
                                                                     const int32_t* __restrict__ excl_items, int k,
                                                                     unsigned long long* __restrict__ partial,
-                                                                    const unsigned long long* __restrict__ bound) {
+                                                                    const unsigned long long* __restrict__ bound,
+                                                                    float* __restrict__ chunk_max,
+                                                                    const float* __restrict__ floor0) {
   __shared__ float s_buf[2][FT_USERS * FT_LD];
   __shared__ __attribute__((aligned(16))) float s_floor[FT_USERS];  // per user: score of its k-th key (consumers publish)
   __shared__ uint32_t s_flag[2][FT_USERS];                          // per slab buffer and user: a candidate may exist
 
   const int tid = threadIdx.x, lane = tid % WAVE;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid / WAVE);  // scalar: the role branch below is wave-uniform
-  if (tid < FT_USERS) s_floor[tid] = -__builtin_inff(), s_flag[0][tid] = 0u, s_flag[1][tid] = 0u;
+  const int64_t b0 = (int64_t)blockIdx.y * FT_USERS;
+  if (tid < FT_USERS) {
+    s_floor[tid] = (!MAXONLY && floor0 && b0 + tid < Bt) ? floor0[b0 + tid] : -__builtin_inff();
+    s_flag[0][tid] = 0u, s_flag[1][tid] = 0u;
+  }
   __syncthreads();
   const int i = lane & 31, h = lane >> 5;
-  const int64_t b0 = (int64_t)blockIdx.y * FT_USERS;
   const int64_t c_lo = (int64_t)blockIdx.x * chunk_items;
   const int64_t c_hi = c_lo + chunk_items < I ? c_lo + chunk_items : I;
   const int n_chunks = gridDim.x;
-  const int n_slabs = c_hi > c_lo ? (int)((c_hi - c_lo + FT_SLAB - 1) / FT_SLAB) : 0;
+  int n_slabs = c_hi > c_lo ? (int)((c_hi - c_lo + FT_SLAB - 1) / FT_SLAB) : 0;
+  if (MAXONLY && n_slabs > k) n_slabs = k;  // (MAXONLY launches pass the number of slabs to look at where k would be)
 
   if (wave8 < BLOCK / WAVE) {
     // ================= producers: wave p computes items slab + 32p .. slab + 32p + 31 for the block's 64 users
@@ -611,6 +631,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
   for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull;
   unsigned long long my_bound = ~0ull;
   if (bound && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_bound = bound[b0 + FT_UPW * wave + lane];
+  float my_floor = -__builtin_inff();  // lane uu: the floor user uu of this wave starts every chunk with (floor0)
+  if (!MAXONLY && floor0 && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_floor = floor0[b0 + FT_UPW * wave + lane];
   auto key_of = [](float sc, uint32_t not_item) {  // make_key with the item id already complemented
     const uint32_t ub = __float_as_uint(sc);
     const uint32_t hi = ub ^ ((uint32_t)((int32_t)ub >> 31) | 0x80000000u);
@@ -652,7 +674,21 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
     }
     const bool in0 = slab + lane < c_hi, in1 = slab + 64 + lane < c_hi;
     const uint32_t not_item0 = ~(uint32_t)(slab + lane), not_item1 = ~(uint32_t)(slab + 64 + lane);
-    if (t == 0) {
+    if (MAXONLY) {
+      // phase one of a many-chunk call: the best score per user over the chunk's first FLOOR_SLABS slabs, nothing else
+      // (lane uu keeps user uu's running maximum)
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        const int u = FT_UPW * wave + uu;
+        float m = fmaxf(in0 ? s_score[u * FT_LD + lane] : -__builtin_inff(), in1 ? s_score[u * FT_LD + 64 + lane] : -__builtin_inff());
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+        if (lane == uu) my_floor = fmaxf(my_floor, m);
+      }
+      if (t + 1 == n_slabs && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt)
+        chunk_max[(b0 + FT_UPW * wave + lane) * n_chunks + blockIdx.x] = my_floor;
+      continue;
+    }
+    if (t == 0 && !floor0) {
       // first slab of the chunk: one 128-key sorting network per user fills its list
       for (int uu = 0; uu < FT_UPW; ++uu) {
         const int u = FT_UPW * wave + uu;
@@ -698,10 +734,16 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
         c0 = c0 < bd ? c0 : 0ull;
         c1 = c1 < bd ? c1 : 0ull;
       }
+      float fl0 = -__builtin_inff();
+      if (floor0) {  // nothing below the user's starting floor can reach the final list (the chunk's list may stay short)
+        fl0 = __shfl(my_floor, uu, WAVE);
+        c0 = s0 >= fl0 ? c0 : 0ull;
+        c1 = s1 >= fl0 ? c1 : 0ull;
+      }
       unsigned long long tk = shfl_u64(best[uu], k - 1);
       const bool ch0 = offer(best[uu], tk, c0);
       const bool ch1 = offer(best[uu], tk, c1);
-      if ((ch0 || ch1) && lane == 0) s_floor[u] = floor_of(tk);
+      if ((ch0 || ch1) && lane == 0) s_floor[u] = fmaxf(fl0, floor_of(tk));
     }
   }
 #pragma unroll
@@ -724,8 +766,8 @@ __global__ __launch_bounds__(BLOCK) void topk_merge_kernel(const unsigned long l
   unsigned long long best = partial[(b * n_chunks) * 64 + lane];
   unsigned long long tau = readlane_u64(best, k - 1);
   for (int c = 1; c < n_chunks; ++c) {
-    const unsigned long long a = partial[(b * n_chunks + c) * 64 + lane];
-    list_offer(best, tau, lane < k ? a : 0ull, k, lane);
+    const unsigned long long a = lane < k ? partial[(b * n_chunks + c) * 64 + lane] : 0ull;
+    list_offer(best, tau, a, k, lane);
   }
   if (lane < k) {
     out_idx[b * ld_out + col0 + lane] = (int64_t)key_item(best);
@@ -736,6 +778,30 @@ __global__ __launch_bounds__(BLOCK) void topk_merge_kernel(const unsigned long l
     }
   }
   if (bound_out && lane == k - 1) bound_out[b] = best;  // ranks col0 + k ... of the next pass lie strictly below this key
+}
+
+// floor0[b] = the k-th largest of user b's n_chunks chunk maxima (n_chunks >= k): one wave per user, rank by counting
+__global__ __launch_bounds__(BLOCK) void chunk_floor_kernel(const float* __restrict__ chunk_max, int64_t Bt, int n_chunks, int k,
+                                                           float* __restrict__ floor0) {
+  const int lane = threadIdx.x % WAVE;
+  const int64_t b = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  if (b >= Bt) return;
+  const float* m = chunk_max + b * n_chunks;
+  // value v is the k-th largest iff fewer than k values are greater and at least k are greater or equal
+  float found = -__builtin_inff();
+  for (int j0 = 0; j0 < n_chunks; j0 += WAVE) {
+    const int j = j0 + lane;
+    const float v = j < n_chunks ? m[j] : -__builtin_inff();
+    int gt = 0, ge = 0;
+    for (int q = 0; q < n_chunks; ++q) {
+      const float w = m[q];
+      gt += w > v, ge += w >= v;
+    }
+    const bool is_kth = j < n_chunks && gt < k && ge >= k;
+    const unsigned long long hit = __ballot(is_kth);
+    if (hit) found = __shfl(v, __builtin_ctzll(hit), WAVE);
+  }
+  if (lane == 0) floor0[b] = found;
 }
 
 }  // namespace
@@ -771,13 +837,16 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 // from about 16 user tiles on (calls of 1024 users: 7.9 vs 8.4 ms for the 31,668 users; of 4096: 3.9 vs 5.2 ms);
 // below that the two kernels tie at the launch floor (calls of 100 users, the reference's test_batch_size: 66 vs 69 ms
 // for 317 calls) and the alternating kernel, with its ~1024 short workgroups, is kept.
-static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr) {
+static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr, int k = 0) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
   const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 forces a kernel
   const int forced = fv && *fv ? std::atoi(fv) : -1;
   const int form = forced >= 0 ? forced : (user_tiles >= 16 ? 1 : 0);
   if (form_out) *form_out = form;
   int64_t nc = form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
+  // a many-chunk call of the producer / consumer kernel starts its chunks from a floor that needs at least k chunks
+  // (floor_phase): a few more, shorter chunks cost less than doing without it
+  if (form == 1 && nc > 1 && nc < k + 2 && k <= 64) nc = k + 2;
   if (const char* v = std::getenv("IDG_TOPK_WGS"))
     if (*v) nc = (std::atoll(v) + user_tiles - 1) / user_tiles;  // testing knob
   const int64_t max_nc = (I + 1023) / 1024;
@@ -790,14 +859,24 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
   *chunk_items = ci;
 }
 
+// Two-phase form (chunk maxima -> per-user starting floor): the producer / consumer kernel, one pass (k <= 64), at least
+// k chunks (the floor is the k-th largest of the chunk maxima) of at least two slabs.  IDG_TOPK_FLOOR=0 turns it off.
+static inline bool floor_phase(int form, int nc, int64_t ci, int k) {
+  const char* v = std::getenv("IDG_TOPK_FLOOR");
+  if (v && *v && std::atoi(v) == 0) return false;
+  return form == 1 && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
+}
+
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   (void)d;
   if (Bt <= 0 || I <= 0) return 0;
-  int nc;
+  int nc, form;
   int64_t ci;
-  fused_geometry(Bt, I, &nc, &ci);
-  // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes
-  return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0);
+  fused_geometry(Bt, I, &nc, &ci, &form, k);
+  // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes + (two-phase form) one
+  // maximum per (user, chunk) and one starting floor per user
+  return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
+         (floor_phase(form, nc, ci, k) ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
 }
 
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt,
@@ -812,7 +891,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   hipStream_t st = (hipStream_t)stream;
   int nc, form;
   int64_t ci;
-  fused_geometry(Bt, I, &nc, &ci, &form);
+  fused_geometry(Bt, I, &nc, &ci, &form, k);
   unsigned long long* partial = reinterpret_cast<unsigned long long*>(ws);
   const dim3 grid((unsigned)nc, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
   const unsigned nbm = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
@@ -820,6 +899,25 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   // ranks; pass p only admits keys strictly below the last key pass p - 1 emitted (keys are unique per item, so
   // "below the 64p-th best" is exactly "not among the best 64p"), and its winners fill columns [64p, 64p + kk).
   unsigned long long* bound = k > 64 ? partial + (size_t)Bt * (size_t)nc * 64 : nullptr;
+  float* chunk_max = nullptr;
+  float* floor0 = nullptr;
+  if (floor_phase(form, nc, ci, k)) {
+    chunk_max = reinterpret_cast<float*>(partial + (size_t)Bt * (size_t)nc * 64);
+    floor0 = chunk_max + (size_t)Bt * (size_t)nc;
+    const bool d64 = d == 64 && (uintptr_t)user_panel % 16 == 0 && (uintptr_t)item_panel % 16 == 0;
+    const int slabs_per_chunk = (int)(ci / FT_SLAB);
+    const int floor_slabs = slabs_per_chunk / 2 < FLOOR_SLABS ? slabs_per_chunk / 2 : FLOOR_SLABS;
+#define IDG_MAXONLY(SIG, D64)                                                                                              \
+  hipLaunchKernelGGL((score_topk_spec_kernel<SIG, D64, true>), grid, dim3(SP_BLOCK), 0, st, user_panel, item_panel, users, \
+                     Bt, I, d, ci, excl_indptr, excl_items, floor_slabs, partial, (const unsigned long long*)nullptr,     \
+                     chunk_max, (const float*)nullptr)
+    if (apply_sigmoid && d64) IDG_MAXONLY(true, true);
+    else if (apply_sigmoid) IDG_MAXONLY(true, false);
+    else if (d64) IDG_MAXONLY(false, true);
+    else IDG_MAXONLY(false, false);
+#undef IDG_MAXONLY
+    hipLaunchKernelGGL(chunk_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, chunk_max, Bt, nc, k, floor0);
+  }
   for (int done = 0; done < k; done += 64) {
     const int kk = k - done < 64 ? k - done : 64;
     const unsigned long long* bd_in = done > 0 ? bound : nullptr;
@@ -828,7 +926,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
       const bool d64 = d == 64 && (uintptr_t)user_panel % 16 == 0 && (uintptr_t)item_panel % 16 == 0;
 #define IDG_SPEC(SIG, D64)                                                                                           \
   hipLaunchKernelGGL((score_topk_spec_kernel<SIG, D64>), grid, dim3(SP_BLOCK), 0, st, user_panel, item_panel, users, \
-                     Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in)
+                     Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in, (float*)nullptr, (const float*)floor0)
       if (apply_sigmoid && d64) IDG_SPEC(true, true);
       else if (apply_sigmoid) IDG_SPEC(true, false);
       else if (d64) IDG_SPEC(false, true);

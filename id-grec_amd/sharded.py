@@ -140,7 +140,7 @@ class ShardedEngine:
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
                  reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None,
-                 live_rows_cap=None, live_rows_min_bytes=64 << 20, store_item_grad=True):
+                 live_rows_cap=None, live_rows_min_bytes=64 << 20, store_grad=True):
         """batch_sparsity: use the batch's row bitmaps (kernels.prepare) — restricted products, stored gradient rows, no
         fills; False = every product dense over zero-filled gradient panels (the plain form, kept as an A/B check).
         batch_size: capacity of the guest rows (the global batch size).  user_lo: global id of this rank's first user.
@@ -149,7 +149,8 @@ class ShardedEngine:
         row counts (callers that know the global item degrees pass entry-balanced cuts).  live_rows_cap: rows of the
         compact buffer of the touched-item exchanges (default 64 per triple; the same on every rank);
         live_rows_min_bytes: item panels smaller than this skip the touched-item forms (tests pass 0).
-        store_item_grad: keep the finished item gradient of the OWNED rows in G (tests read it; the step does not)."""
+        store_grad: keep the finished gradient in G — the user rows and the OWNED item rows (tests read it; the step
+        does not: without it the last products feed Adam and write no gradient panel)."""
         self.k, self.comm = kernels, comm
         self.world, self.rank = int(getattr(comm, "world", 1)), int(getattr(comm, "rank", 0))
         self.batch_sparsity = bool(batch_sparsity)
@@ -162,7 +163,7 @@ class ShardedEngine:
         self.c0 = 1 if include_layer0 else 0
         self.cnt = float(self.K + self.c0)
         self.reg_lambda, self.lr = float(reg_lambda), float(lr)
-        self.store_item_grad = bool(store_item_grad)
+        self.store_grad = bool(store_grad)
         self.G_ui = kernels.make_graph(*ui_csr, self.Ug, self.I)
         if n_slices is None:
             n_slices = 4 if self.I * self.d * 4 >= (256 << 20) else 1
@@ -442,7 +443,7 @@ class ShardedEngine:
         adam = (self.P_u, self.MU, self.VU, self.lr, adam_step)
         if live_i is None:   # a dense launch: the owned users' Adam update rides in its epilogue
             k.spmm(self.G_ui, h_i, sums=[g_u] if c0 else [], sum_out=G_u, div=cnt, accumulate=True, mask=users_bits, adam=adam,
-                   discard_grad=not self.store_item_grad)
+                   discard_grad=not self.store_grad)
         else:                # (K <= 2 with restricted inputs: the epilogue form needs the dense kernel)
             k.spmm(self.G_ui, h_i, sums=[g_u] if c0 else [], sum_out=G_u, div=cnt, accumulate=True, mask=users_bits,
                    x_rows=live_i)
@@ -452,7 +453,7 @@ class ShardedEngine:
             self.comm.wait(w)
             blocks = self._own_blocks(j, t_i)
             if c > 0:
-                k.item_tail(blocks[0], blocks[1], blocks[2], items_bits, o0, c0, cnt, self.store_item_grad, blocks[3],
+                k.item_tail(blocks[0], blocks[1], blocks[2], items_bits, o0, c0, cnt, self.store_grad, blocks[3],
                             blocks[4], blocks[5], self.lr, adam_step)
             self._ag.append(self.comm.all_gather_async(self._slice_rows(P_i, j, padded=True), blocks[3]))
         return self.G
@@ -1127,7 +1128,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     del users, items
     kern = HipKernels()
     eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
-                        n_slices=n_slices, item_cuts=cuts, store_item_grad=False)
+                        n_slices=n_slices, item_cuts=cuts, store_grad=False)
     nnz_ui, nnz_iu = len(ui[1]), len(iu[1])
     del ui, iu
     Ug = hi - lo

@@ -980,6 +980,47 @@ def test_graph_from_the_references_device_tensor(ops, golden_small):
     assert torch.allclose(G2.spmm_raw(X), torch.sparse.mm(coo, X), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("d,sig", [(64, True), (64, False), (128, True)])
+def test_topk_calls_of_1024_users_start_from_a_floor(ops, d, sig):
+    """Round 3: a call with few user tiles (the reference evaluates 1024 users per call, batch_test.py:52-68) cuts the
+    catalogue into ~30 short chunks; every chunk now starts from a per-user floor — the k-th largest of the user's chunk
+    maxima, found by a first launch over the chunks' first slabs — instead of from an empty list.  The lists must be the
+    ones the plain form gives (IDG_TOPK_FLOOR=0) and the ones ONE call over all users gives, ids and values, for k = 1, 20,
+    30, 31 (the chunk count follows k) and 64, with train items masked."""
+    import os
+
+    import idgrec_amd.synth as S
+
+    U, I = 4096, 38048
+    users, items = S.generate(U, I, 160000, seed=11)
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    ip, ix = dev(ptr), dev(items.astype(np.int32))
+    g = torch.Generator(device="cuda").manual_seed(d)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
+    Ie[::97] = Ie[5]  # duplicate item rows: ties, also across chunk boundaries
+    calls = [torch.arange(s0, s0 + 1024, device="cuda") for s0 in range(0, U, 1024)]
+    every = torch.arange(U, device="cuda")
+    old = os.environ.get("IDG_TOPK_FLOOR")
+    try:
+        for k in (1, 20, 30, 31, 64):
+            os.environ["IDG_TOPK_FLOOR"] = "1"
+            got = [ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True) for b in calls]
+            os.environ["IDG_TOPK_FLOOR"] = "0"
+            plain = [ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True) for b in calls]
+            whole = ops.score_topk(Ue, Ie, every, k, ip, ix, apply_sigmoid=sig, return_values=True)
+            gi, gv = torch.cat([x[0] for x in got]), torch.cat([x[1] for x in got])
+            pi, pv = torch.cat([x[0] for x in plain]), torch.cat([x[1] for x in plain])
+            assert torch.equal(gi, pi) and torch.equal(gv, pv), "k=%d: floor form differs from the plain form" % k
+            assert torch.equal(gi, whole[0]) and torch.equal(gv, whole[1]), "k=%d: calls of 1024 differ from one call" % k
+    finally:
+        if old is None:
+            os.environ.pop("IDG_TOPK_FLOOR", None)
+        else:
+            os.environ["IDG_TOPK_FLOOR"] = old
+
+
 def _row_bitmap(n, rows):
     bitmap = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
     np.bitwise_or.at(bitmap, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
