@@ -217,4 +217,37 @@ int idg_grad_tail_adam_f32(const float* t, const float* g, float* G, const uint3
   return IDG_OK;
 }
 
+int idg_shard_prepare(const idg_shard_prep* p) {
+  IDG_REQUIRE(p, "idg_shard_prepare: NULL argument");
+  IDG_REQUIRE(p->pos && p->neg && p->guest_ids && p->users_bits && p->items_bits && p->scatter_bits && p->plan_ws && p->B > 0,
+              "idg_shard_prepare: NULL bitmap / id array");
+  IDG_REQUIRE(p->n_own == 0 || p->own_users, "idg_shard_prepare: owned users without their id array");
+  IDG_REQUIRE(p->n_slices >= 0 && (p->n_slices == 0 || (p->slice_graphs && p->slice_row0 && p->slice_units)),
+              "idg_shard_prepare: slice tables missing");
+  void* side = p->side_stream;
+  int rc;
+#define IDG_TRY(call) \
+  if ((rc = (call)) != IDG_OK) return rc
+  // the id arrays may just have been produced on the step's stream, and the step that last used these buffers runs there
+  if (p->ev_fork) {
+    IDG_TRY(idg_event_record(p->ev_fork, p->main_stream));
+    IDG_TRY(idg_stream_wait_event(side, p->ev_fork));
+  }
+  IDG_TRY(idg_bitmap_clear(p->users_bits, p->n_local_users, side));
+  if (p->n_own > 0) IDG_TRY(idg_bpr_touch_rows(p->own_users, p->own_users, p->own_users, p->n_own, 0, p->users_bits, side));
+  IDG_TRY(idg_bitmap_clear(p->items_bits, p->n_items_padded, side));
+  IDG_TRY(idg_bpr_touch_rows(p->pos, p->pos, p->neg, p->B, 0, p->items_bits, side));
+  IDG_TRY(idg_bitmap_clear(p->scatter_bits, p->n_panel_rows, side));
+  if (p->user_graph && p->user_units)
+    IDG_TRY(idg_graph_live_units(p->user_graph, p->users_bits, p->user_units, p->B_cap, side));
+  for (int j = 0; j < p->n_slices; ++j)
+    if (p->slice_units[j])
+      IDG_TRY(idg_graph_live_units(p->slice_graphs[j], p->items_bits + p->slice_row0[j] / 32, p->slice_units[j], 2 * p->B_cap, side));
+  if (p->ev_rows) IDG_TRY(idg_event_record(p->ev_rows, side));
+  IDG_TRY(idg_bpr_plan_f32(p->guest_ids, p->pos, p->neg, p->B, p->n_local_users + p->B_cap, p->n_panel_rows, p->plan_ws, side));
+  if (p->ev_plan) IDG_TRY(idg_event_record(p->ev_plan, side));
+#undef IDG_TRY
+  return IDG_OK;
+}
+
 }  // extern "C"

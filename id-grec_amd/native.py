@@ -64,6 +64,7 @@ PROTOTYPES = {
     "idg_rows_layer_mean_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_float, C.c_int64, c_vp]),
     "idg_grad_tail_adam_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int,
                                          c_vp, c_vp, c_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, c_vp]),
+    "idg_shard_prepare": (C.c_int, [c_vp]),
     "idg_lincomb_f32": (C.c_int, [c_vp, c_vp, C.c_float, c_vp, C.c_float, C.c_int64, c_vp]),
     "idg_rows_gather_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
     "idg_rows_chain_add_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
@@ -140,6 +141,16 @@ IDG_GRAPH_SYMMETRIC = 1
 IDG_GRAPH_EXACT_ORDER = 2
 
 
+class ShardPrep(C.Structure):
+    """idg_shard_prep (include/idgrec.h): one global batch's index-only preparation for the sharded step."""
+    _fields_ = [("own_users", c_vp), ("n_own", C.c_int64), ("pos", c_vp), ("neg", c_vp), ("guest_ids", c_vp),
+                ("B", C.c_int64), ("B_cap", C.c_int64), ("users_bits", c_vp), ("n_local_users", C.c_int64),
+                ("items_bits", c_vp), ("n_items_padded", C.c_int64), ("scatter_bits", c_vp), ("n_panel_rows", C.c_int64),
+                ("user_graph", c_vp), ("user_units", c_vp), ("n_slices", C.c_int), ("slice_graphs", C.POINTER(c_vp)),
+                ("slice_row0", C.POINTER(C.c_int64)), ("slice_units", C.POINTER(c_vp)), ("plan_ws", c_vp),
+                ("main_stream", c_vp), ("side_stream", c_vp), ("ev_fork", c_vp), ("ev_rows", c_vp), ("ev_plan", c_vp)]
+
+
 class Epilogue(C.Structure):
     """idg_epilogue (include/idgrec.h): every epilogue option of idg_spmm_epi_f32."""
     _fields_ = [("Y", c_vp), ("addend", c_vp), ("sum_in", c_vp), ("sum_in2", c_vp), ("sum_in3", c_vp), ("sum_out", c_vp),
@@ -161,7 +172,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 132  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 133  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

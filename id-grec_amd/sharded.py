@@ -564,7 +564,7 @@ class HipKernels:
         from . import native, ops
 
         self.torch, self.ops, self.C = torch, ops, C
-        self.lib, self.check, self.Epilogue = native.lib, native.check, native.Epilogue
+        self.lib, self.check, self.Epilogue, self.ShardPrep = native.lib, native.check, native.Epilogue, native.ShardPrep
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._pool = []
         self._bits = {}
@@ -730,7 +730,7 @@ class HipKernels:
 
     class _Prepared:
         __slots__ = ("own_users", "items", "touched_buf", "near_buf", "touched", "near", "bpr_bits", "ws", "rows_done", "done",
-                     "B", "busy", "units", "graphs")
+                     "B", "busy", "units", "graphs", "args", "tables")
 
     def prepare(self, eng, gb):
         """Index-only work of a global batch on a side stream: the bitmap of the LOCAL user rows this rank owns in it,
@@ -751,27 +751,31 @@ class HipKernels:
             prep.rows_done, prep.done = ops.LocalEvent(), ops.LocalEvent()  # device-local events
             prep.units = {}
             prep.graphs = [eng.G_ui] + [sl[0] for sl in eng.slices]  # (their unit lists name this object's bitmaps)
+            C, S = self.C, len(eng.slices)
+            a = prep.args = self.ShardPrep()
+            a.guest_ids, a.B_cap = eng.guest_ids.data_ptr(), cap
+            a.users_bits, a.n_local_users = prep.own_users.data_ptr(), eng.Ug
+            a.items_bits, a.n_items_padded = prep.items.data_ptr(), eng.Ip
+            a.scatter_bits, a.n_panel_rows = prep.bpr_bits.data_ptr(), n
+            a.user_graph, a.user_units = eng.G_ui._h, self._units(prep, "u", eng.G_ui, cap).data_ptr()
+            a.n_slices = S
+            prep.tables = ((C.c_void_p * S)(*[sl[0]._h.value for sl in eng.slices]), (C.c_int64 * S)(*[sl[1] for sl in eng.slices]),
+                           (C.c_void_p * S)(*[self._units(prep, ("i", j), sl[0], 2 * cap).data_ptr() for j, sl in enumerate(eng.slices)]))
+            a.slice_graphs, a.slice_row0, a.slice_units = prep.tables
+            a.plan_ws = prep.ws.data_ptr()
+            a.side_stream = self._side_raw
+            a.ev_fork, a.ev_rows, a.ev_plan = self._fork._h, prep.rows_done._h, prep.done._h
             self._pool.append(prep)
         prep.busy = True
         prep.touched = prep.near = None
-        side = self._side_raw
-        self._fork.record(ops._stream())     # the id tensors may have just been produced on the main stream,
-        self._fork.wait(side)                # and the step that last used these buffers is ordered before it
-        if gb.n_owned > 0:
-            ops.bpr_touch_rows_raw(gb.own_users, gb.own_users, gb.own_users, 0, prep.own_users, stream=side, clear_bits=eng.Ug)
-        else:
-            ops.bitmap_clear_raw(prep.own_users, eng.Ug, stream=side)
-        ops.bpr_touch_rows_raw(gb.pos, gb.pos, gb.neg, 0, prep.items, stream=side, clear_bits=eng.Ip)
-        ops.bitmap_clear_raw(prep.bpr_bits, n, stream=side)
-        self.check(lib.idg_graph_live_units(eng.G_ui._h, prep.own_users.data_ptr(),
-                                            self._units(prep, "u", eng.G_ui, cap).data_ptr(), cap, side), "idg_graph_live_units")
-        for j, (g, r0, r1, r1p) in enumerate(eng.slices):
-            self.check(lib.idg_graph_live_units(g._h, self.bits_from(prep.items, r0).data_ptr(),
-                                                self._units(prep, ("i", j), g, 2 * cap).data_ptr(), 2 * cap, side),
-                       "idg_graph_live_units")
-        prep.rows_done.record(side)
-        ops.bpr_plan_raw(eng.guest_ids[:gb.B], gb.pos, gb.neg, n_users, n, d, ws=prep.ws, stream=side)
-        prep.done.record(side)
+        # one library call for the whole preparation (idg_shard_prepare); only the batch's own arrays change per call
+        a = prep.args
+        a.own_users, a.n_own = (gb.own_users.data_ptr() if gb.n_owned > 0 else None), gb.n_owned
+        a.pos, a.neg, a.B = gb.pos.data_ptr(), gb.neg.data_ptr(), gb.B
+        a.main_stream = ops._stream()
+        rc = lib.idg_shard_prepare(self.C.byref(a))
+        if rc:
+            self.check(rc, "idg_shard_prepare")
         return prep
 
     def wait_rows(self, prep):
@@ -931,6 +935,7 @@ class NativeComm:
         self.check(self.lib.idg_comm_create(self.rank, self.world, uid.data_ptr(), int(device_index), C.byref(handle)),
                    "idg_comm_create")
         self.handle = handle
+        self._force = False  # self_test(): enqueue on RCCL even at world size 1, where a collective is the identity
         self.overlap_bytes = int(overlap_bytes)
         self._own = self._own_raw = None   # the collectives' own stream, made on first use
         self._ring, self._next = [], 0     # (issued, done) event pairs, reused round-robin (a step issues up to 4 x slices collectives here; a handle is waited for within the next step)
@@ -959,6 +964,8 @@ class NativeComm:
         return t.data_ptr()
 
     def all_reduce_async(self, t, average=False):
+        if self.world == 1 and not self._force:  # (the identity: nothing to enqueue; self_test() still runs RCCL itself)
+            return None
         if t.numel() * 4 >= self.overlap_bytes:
             stream, done = self._fork()
             self.check(self.lib.idg_allreduce_f32(self.handle, self._f32(t), t.numel(), int(bool(average)), stream),
@@ -971,6 +978,10 @@ class NativeComm:
 
     def all_gather_async(self, out, t):
         assert out.numel() == t.numel() * self.world
+        if self.world == 1 and not self._force:
+            if out.data_ptr() != t.data_ptr():
+                out.view(-1).copy_(t.view(-1))
+            return None
         if out.numel() * 4 >= self.overlap_bytes:
             stream, done = self._fork()
             self.check(self.lib.idg_allgather_f32(self.handle, self._f32(t), self._f32(out), t.numel(), stream),
@@ -985,6 +996,8 @@ class NativeComm:
         """t = world equal blocks; this rank's block <- the sum over ranks of that block, in place."""
         c = t.numel() // self.world
         assert c * self.world == t.numel(), "reduce-scatter of %d floats over %d ranks" % (t.numel(), self.world)
+        if self.world == 1 and not self._force:
+            return None
         base = self._f32(t)
         own = base + 4 * c * self.rank
         if t.numel() * 4 >= self.overlap_bytes:
@@ -999,8 +1012,28 @@ class NativeComm:
         if work is not None:
             self.torch.cuda.current_stream().wait_event(work)
 
+    def through_rccl(self):
+        """Context manager: at world size 1 a collective is the identity and is normally not enqueued at all; inside this
+        context it goes through RCCL as on a larger world (tests, the self-test)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def forced():
+            old, self._force = self._force, True
+            try:
+                yield self
+            finally:
+                self._force = old
+
+        return forced()
+
     def self_test(self):
-        """One all-reduce and one all-gather with known answers; True when both are right on this rank."""
+        """All-reduce (both stream routes), all-gather and reduce-scatter + in-place all-gather with known answers; True when
+        all are right on this rank.  Runs through RCCL at any world size."""
+        with self.through_rccl():
+            return self._self_test()
+
+    def _self_test(self):
         torch = self.torch
         a = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device="cuda")
         g = torch.zeros(1024 * self.world, dtype=torch.float32, device="cuda")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 132 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
+#define IDG_VERSION 133 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
                            _chain_store2 / _layer_mean, idg_grad_tail_adam_f32, idg_reduce_scatter_f32 */
 
@@ -556,6 +556,29 @@ int idg_grad_tail_adam_f32(const float* t, const float* g, float* G, const uint3
                            int64_t rows, int64_t d, int include_layer0, float cnt, int store_grad, float* param,
                            float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
                            int64_t step, void* stream);
+
+/* The index-only preparation of ONE global batch of the user-row-sharded step as one call (id-grec_amd/sharded.py
+ * HipKernels.prepare did this in twelve: the host cost of a step is its calls).  On `side_stream`, ordered after
+ * `main_stream` through ev_fork:  users_bits = bitmap of own_users[0..n_own) (n_local_users bits); items_bits = bitmap
+ * of pos[0..B) and neg[0..B) (n_items_padded bits); scatter_bits cleared (n_panel_rows bits: the gradient scatter flags
+ * its stored rows there); the live-unit lists of users_bits on user_graph and of each item slice's share of items_bits
+ * (bit offset slice_row0[j], a multiple of 32) on slice_graphs[j]; ev_rows recorded; the sorted scatter plan of
+ * (guest_ids, pos, neg) over a panel of n_panel_rows rows whose items start at row n_local_users + B_cap
+ * (idg_bpr_plan_f32) into plan_ws; ev_plan recorded.  Events are idg_event_create handles (NULL: skipped); unit-list
+ * buffers as idg_graph_live_units_bytes(graph, B_cap) / (graph, 2 B_cap) (NULL: no list for that graph). */
+typedef struct idg_shard_prep {
+  const int64_t* own_users; int64_t n_own;       /* local ids of the owned triples' users */
+  const int64_t* pos; const int64_t* neg; const int64_t* guest_ids; int64_t B, B_cap;
+  uint32_t* users_bits; int64_t n_local_users;
+  uint32_t* items_bits; int64_t n_items_padded;
+  uint32_t* scatter_bits; int64_t n_panel_rows;
+  const idg_graph* user_graph; void* user_units;
+  int n_slices; const idg_graph* const* slice_graphs; const int64_t* slice_row0; void* const* slice_units;
+  void* plan_ws;
+  void* main_stream; void* side_stream;
+  void* ev_fork; void* ev_rows; void* ev_plan;
+} idg_shard_prep;
+int idg_shard_prepare(const idg_shard_prep* prep);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: full-rank scoring, train-positive masking, top-K

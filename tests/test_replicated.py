@@ -134,18 +134,25 @@ def test_native_rccl_communicator_world_1(form, golden_small):
         assert comm.self_test()
         x = torch.arange(4096, dtype=torch.float32, device="cuda")
         y = x.clone()
-        comm.all_reduce_async(y, average=True)
+        assert comm.all_reduce_async(y, average=True) is None  # world size 1: the identity, nothing is enqueued
         out = torch.zeros_like(x)
         comm.all_gather_async(out, x)
         torch.cuda.synchronize()
         assert torch.equal(x, y) and torch.equal(x, out)
-        big = torch.arange(17 << 20, dtype=torch.float32, device="cuda")  # 68 MB: the second-stream form
-        ref = big.clone()
-        work = comm.all_reduce_async(big)
-        assert work is not None
-        comm.wait(work)
-        torch.cuda.synchronize()
-        assert torch.equal(big, ref)
+        with comm.through_rccl():  # ... unless asked to: the same calls as RCCL launches, as on a larger world
+            comm.all_reduce_async(y, average=True)
+            out.zero_()
+            comm.all_gather_async(out, x)
+            big = torch.arange(17 << 20, dtype=torch.float32, device="cuda")  # 68 MB: the second-stream form
+            ref = big.clone()
+            work = comm.all_reduce_async(big)
+            assert work is not None
+            comm.wait(work)
+            rs = torch.arange(4096, dtype=torch.float32, device="cuda")
+            comm.wait(comm.reduce_scatter_async(rs))
+            comm.wait(comm.all_gather_async(rs, rs))
+            torch.cuda.synchronize()
+            assert torch.equal(big, ref) and torch.equal(x, y) and torch.equal(x, out) and torch.equal(rs, x)
         p = _problem(golden_small, 3, True, B=128, steps=3, world=1)
         n = p["U"] + p["I"]
         g = ops.Graph(p["indptr"], p["indices"], p["values"], n, n)
