@@ -52,9 +52,10 @@ def parse():
                    help="Adam as its own kernel instead of the last backward epilogue (PMC calibration runs)")
     p.add_argument("--seed", type=int, default=2024)
     p.add_argument("--hbm-leg", default="auto", choices=["auto", "on", "off"],
-                   help="after the headline, time the dominant dense launch on the HBM-bound synth-1M d=64 graph (gathered "
-                        "panel 384 MB > the 256 MiB Infinity Cache) and report it as roofline.hbm_bound; auto = only "
-                        "for the default headline workload (yelp2018 LightGCN d=64)")
+                   help="after the headline, time the dominant dense launch where it is HBM-bound — synth-10M at d=64, "
+                        "gathered panel 3.84 GB = 15 x the Infinity Cache, on the scale point's graph — as roofline.hbm_bound, "
+                        "and on synth-1M (384 MB panel, mostly Infinity-Cache hits) as the labelled roofline.cache_boundary; "
+                        "auto = only for the default headline workload (yelp2018 LightGCN d=64)")
     p.add_argument("--epoch-leg", default="auto", choices=["auto", "on", "off"],
                    help="after the headline, run epochs through the plugin surface main.py uses (dataset files -> Data -> "
                         "models.<Model>.Trainer.train(), native sampler included) and report E / epoch_time as `epoch`; "
@@ -199,10 +200,12 @@ def self_launch(args):
     sys.exit(proc.returncode if proc.returncode or lines else 1)
 
 
-def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None):
+def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None, before_engine=None):
     """The multi-GPU lines' workload on ONE GPU, unsharded, through the fused single-GPU engine (PropagationEngine): the
     1-GPU point the N-GPU speed-ups are quoted against, measured in the same run.  ~140 GB resident at synth-10M d=256.
-    edges: the (users, items) arrays when the caller has drawn the graph already."""
+    edges: the (users, items) arrays when the caller has drawn the graph already.  before_engine(graph, U, I, n, nnz,
+    n_edges) -> dict: run on the built graph handle before the d=`dim` engine exists (the default line's HBM-bound
+    roofline leg at d=64: same graph, drawn and scheduled once); its result is returned under "before_engine"."""
     import idgrec_amd.host as H
     import idgrec_amd.ops as ops
     import idgrec_amd.synth as S
@@ -218,6 +221,16 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
     del users, items
     graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
     del ip, ix, dv
+    extra = None
+    if before_engine is not None:
+        t_x = time.perf_counter()
+        try:
+            extra = before_engine(graph, U, I, n, nnz, n_edges)
+        except Exception as exc:  # noqa: BLE001 - the scale point stands without it
+            extra = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        graph._ws.clear()  # the d=64 layer buffers
+        torch.cuda.empty_cache()
+        t_all += time.perf_counter() - t_x  # not part of the scale point's own time
     eng = PropagationEngine(graph, U, I, dim, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
                             params=S.xavier_uniform_panel(U, I, dim, args.seed).cuda())
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
@@ -244,6 +257,8 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
     del eng, graph, tri, tu, tp, tn
     torch.cuda.empty_cache()
     out["seconds_including_graph_build"] = time.perf_counter() - t_all
+    if extra is not None:
+        out["before_engine"] = extra
     return out
 
 
@@ -399,13 +414,12 @@ def main():
         "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[-1].sum().item())],
         "host_issue_ms_per_step": t_issue / args.steps * 1e3,
     }
+    hbm_leg = False
     if graph is not None:
         out["roofline"] = roofline(args, eng, graph, n, nnz, d, K, args.workload, in_step_form=(args.model == "LightGCN"),
                                    bitmap=eng.touched)
         hbm_leg = args.hbm_leg == "on" or (args.hbm_leg == "auto" and args.workload == "yelp2018" and d == 64
                                            and args.model == "LightGCN")
-        if hbm_leg:
-            out["roofline"]["hbm_bound"] = hbm_bound_leg(args)
     # beside the headline: the host sampler's own rate, and full-rank evaluation (propagate + fused
     # score/mask/top-20 of every user against the train CSR) on the same tables — both outside the timed region
     out["sampler"] = {"value": wl["sampler_rate"], "unit": "triples/s", "what": "native MT19937 sampler + shuffle permutation, "
@@ -429,16 +443,34 @@ def main():
         out["epoch"] = epoch_leg(args)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, wl, W0.numpy())
-    if args.scale_point == "on" or (args.scale_point == "auto" and args.workload == "yelp2018" and d == 64
-                                    and args.model == "LightGCN"):
-        # the 1-GPU point of the multi-GPU curve: `bench.py --gpus N` (N > 1) measures BASELINE configs[4], not this
-        # line's workload — the same step on ONE GPU, so that a 1 -> N ratio compares like with like
-        del eng, graph, tri, tu, tp, tn, losses
-        torch.cuda.empty_cache()
+    scale_point = args.scale_point == "on" or (args.scale_point == "auto" and args.workload == "yelp2018" and d == 64
+                                               and args.model == "LightGCN")
+    del eng, graph, tri, tu, tp, tn, losses
+    torch.cuda.empty_cache()
+    if hbm_leg:
         try:
-            out["scale_point"] = single_gpu_point(args)
+            out["roofline"]["cache_boundary"] = cache_boundary_leg(args)
+        except Exception as exc:  # noqa: BLE001 - the headline stands without it
+            out["roofline"]["cache_boundary"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    if scale_point:
+        # the 1-GPU point of the multi-GPU curve: `bench.py --gpus N` (N > 1) measures BASELINE configs[4], not this
+        # line's workload — the same step on ONE GPU, so that a 1 -> N ratio compares like with like.  The HBM-bound
+        # roofline leg (d=64) runs on the same graph handle first: synth-10M is drawn and scheduled once.
+        def hook(g, U_, I_, n_, nnz_, ne_):
+            out["roofline"]["hbm_bound"] = hbm_bound_leg(args, graph=g, shape=(U_, I_, n_, nnz_, ne_))
+
+        try:
+            out["scale_point"] = single_gpu_point(args, before_engine=hook if hbm_leg else None)
+            err = out["scale_point"].pop("before_engine", None)
+            if err and "hbm_bound" not in out["roofline"]:
+                out["roofline"]["hbm_bound"] = err
         except Exception as exc:  # noqa: BLE001 - the headline stands without it
             out["scale_point"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    elif hbm_leg:
+        try:
+            out["roofline"]["hbm_bound"] = hbm_bound_leg(args)
+        except Exception as exc:  # noqa: BLE001
+            out["roofline"]["hbm_bound"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     args.emit(out)
 
 
@@ -487,7 +519,8 @@ def roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form, bitmap=None
     achieved = gather / spmm_s / 1e9
     traffic, source, hit = None, None, None
     tname = "traffic_%s_d%d.json" % (workload, d)
-    for sub in ("r03", "r02", ""):
+    rounds = sorted((x for x in os.listdir(os.path.join(ROOT, "profiles")) if x.startswith("r")), reverse=True)
+    for sub in rounds + [""]:  # the newest round's file
         tfile = os.path.join(ROOT, "profiles", sub, tname)
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
@@ -507,10 +540,12 @@ def roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form, bitmap=None
         "kernel": "spmm_tile_kernel<%d,1,8,dyn> (split rows combined in-kernel)" % (d // 4),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         # `frac` is SURVEY.md §8(d)'s figure as specified (gather-equivalent bytes over the HBM peak): with a cache-resident
-        # panel it is not an HBM fraction and may exceed 1.  `ceiling` is what the guide's measured gather rates allow for
-        # the measured L2 hit rate; frac_of_ceiling is the number to read as "how close to the hardware".
-        "ceiling": ceiling, "frac_of_ceiling": achieved / ceiling,
-        "ceiling_basis": "MI355X_MICROARCH.md 'Indexed rows': L2-resident rows %.1f TB/s, %s %.2f TB/s; L2 hit rate %s"
+        # panel it is not an HBM fraction and may exceed 1.  `model_estimate` is a two-level MODEL, not an upper bound
+        # (ADVICE r03): the guide's gather rates mixed by an L2 hit rate taken from an EARLIER profiled run; gathers served
+        # by the CU's own L1 / LDS never reach the L2 the hit rate is counted at, so achieved / model_estimate can exceed 1.
+        "model_estimate": ceiling, "frac_of_model_estimate": achieved / ceiling,
+        "model_estimate_basis": "NOT an upper bound. MI355X_MICROARCH.md 'Indexed rows': L2-resident rows %.1f TB/s, %s %.2f TB/s, "
+                                "harmonic mix by the L2 hit rate %s; L1-served gathers are outside the model"
                          % (GATHER_L2_GBS / 1e3, "Infinity Cache" if resident else "random rows out of HBM", miss_gbs / 1e3,
                             ("%.3f (PMC, same file as `traffic`)" % hit) if hit is not None else "not measured: miss rate assumed for every gather"),
         "traffic": traffic, "traffic_source": source,
@@ -527,30 +562,56 @@ def roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form, bitmap=None
     }
 
 
-def hbm_bound_leg(args, workload="synth-1M", d=64, K=3):
-    """The same dense launch where it IS HBM-bound ("the d=64 >= 60 % of HBM peak target should be
-    demonstrated on a graph with 4nd > 256 MiB"): synth-1M, 1 M users x 0.5 M items, nnz 40 M, gathered panel 384 MB.
-    Built, timed and freed after the headline's timed region; same kernel, same in-step launch form."""
+def dense_launch_leg(args, workload, d=64, K=3, graph=None, shape=None, reps=5):
+    """The dominant dense launch on another graph, after the headline's timed region: same kernel, same in-step launch
+    form, timed by roofline().  graph / shape=(U, I, n, nnz, n_edges): a handle the caller has built already (the scale
+    point's synth-10M graph); otherwise the graph is drawn, scheduled and freed here."""
     import idgrec_amd.host as H
     import idgrec_amd.ops as ops
     import idgrec_amd.synth as S
     from idgrec_amd.engine import PropagationEngine
 
-    U, I, E = S.SHAPES[workload]
-    users, items = S.generate(U, I, E, seed=0)
-    ip, ix, dv = H.build_norm_adj(U, I, users, items)
-    n, nnz = U + I, len(ix)
-    graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
+    own = graph is None
+    if own:
+        U, I, E = S.SHAPES[workload]
+        users, items = S.generate(U, I, E, seed=0)
+        ip, ix, dv = H.build_norm_adj(U, I, users, items)
+        n, nnz, n_edges = U + I, len(ix), len(users)
+        del users, items
+        graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
+        del ip, ix, dv
+    else:
+        U, I, n, nnz, n_edges = shape
     g = torch.Generator(device="cuda").manual_seed(args.seed)
     params = (torch.rand((n, d), device="cuda", generator=g) * 2 - 1) * (6.0 / (U + d)) ** 0.5
     eng = PropagationEngine(graph, U, I, d, K, include_layer0=True, deterministic=False, params=params)
-    r = roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form=True, reps=5)
-    r["workload"] = "%s: %d users x %d items, %d train edges, nnz(A)=%d, d=%d (gathered panel %.0f MB)" \
-                    % (workload, U, I, len(users), nnz, d, 4 * n * d / 1e6)
-    for k in ("kernel", "peak", "unit", "row_restricted_last_layer_us"):
+    r = roofline(args, eng, graph, n, nnz, d, K, workload, in_step_form=True, reps=reps)
+    r["workload"] = "%s: %d users x %d items, %d train edges, nnz(A)=%d, d=%d (gathered panel %.0f MB = %.1f x the %d MiB " \
+                    "Infinity Cache)" % (workload, U, I, n_edges, nnz, d, 4 * n * d / 1e6, 4 * n * d / INFINITY_CACHE_BYTES,
+                                         INFINITY_CACHE_BYTES >> 20)
+    for k in ("peak", "unit", "row_restricted_last_layer_us"):
         r.pop(k, None)
-    del eng, graph, params
+    del eng, params
+    if own:
+        del graph
     torch.cuda.empty_cache()
+    return r
+
+
+def hbm_bound_leg(args, graph=None, shape=None):
+    """"the d=64 >= 60 % of HBM peak target should be demonstrated on a graph with 4nd > 256 MiB".
+    synth-10M at d=64: 15 M rows, nnz 398 M, gathered panel 3.84 GB = 15 x the Infinity Cache — the dense launch is
+    HBM-bound there (L2 hit rate 11 %, profiles/r0N/traffic_synth-10M_d64.json).  In the default run the graph is the
+    scale point's (drawn and scheduled once)."""
+    return dense_launch_leg(args, "synth-10M", d=64, K=3, graph=graph, shape=shape, reps=5)
+
+
+def cache_boundary_leg(args):
+    """synth-1M at d=64 (gathered panel 384 MB = 1.5 x the Infinity Cache): between the cache-resident headline and the
+    HBM-bound leg — most gathers still hit the Infinity Cache, so this is NOT an HBM figure and is labelled
+    so."""
+    r = dense_launch_leg(args, "synth-1M", d=64, K=3, reps=5)
+    r["bound"] = "infinity-cache boundary (panel 1.5 x the Infinity Cache: mostly cache hits, not an HBM figure)"
     return r
 
 

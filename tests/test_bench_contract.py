@@ -42,7 +42,7 @@ def test_single_gpu_line():
     assert rf["bound"] == "l2+infinity-cache gather" and rf["cache_resident"] is True
     assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["us_per_launch"] > 0
-    assert rf["ceiling"] > 0 and abs(rf["frac_of_ceiling"] - rf["achieved"] / rf["ceiling"]) < 1e-9
+    assert rf["model_estimate"] > 0 and abs(rf["frac_of_model_estimate"] - rf["achieved"] / rf["model_estimate"]) < 1e-9
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
 

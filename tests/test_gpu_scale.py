@@ -407,6 +407,7 @@ def test_sharded_step_at_config5_shape_equals_the_fused_engine():
     del users, items
     n = U + I
     G = ops.Graph(ip, ix, dv, n, n)
+    ip_keep, ix_keep, dv_keep = ip, ix, dv  # (3.3 GB of host memory) for the oracle's rows below
     del ip, ix, dv
     params = torch.empty((n, d), dtype=torch.float32, device="cuda")
     params[:U].copy_(W_u)
@@ -426,3 +427,58 @@ def test_sharded_step_at_config5_shape_equals_the_fused_engine():
                 F_u=fe.final[:U].index_select(0, bu).cpu(), F_i=fe.final[U:].index_select(0, bi).cpu())
     for key in want:
         assert torch.equal(got[key], want[key]), "%s differs between the sharded and the fused step" % key
+    del got, want
+
+    # ---- and the fused engine pinned to the ORACLE on THIS graph (not only to itself, and not only on the
+    # 40 M-edge graph above — the hub rows here are ~5x longer): the dense forward layer by layer on sampled rows
+    # against the sequential fmaf chain (models/LightGCN.py:43-48), the backward by its adjoint identity
+    # <mean_k A^k X, g> = <X, mean_k A^k g> (A symmetric: the autograd of the same lines) in float64.
+    sched = G.long_rows()
+    longs, deg = np.asarray(sched[0]), np.diff(ip_keep)
+    b_rows = np.unique(np.concatenate([b_last[:, 0], U + b_last[:, 1], U + b_last[:, 2]]))
+    cut_rows = U + np.clip(np.concatenate([cuts[1:-1] + k for k in (-1, 0, 1)]), 0, I - 1)
+    rows = np.unique(np.concatenate([[0, U - 1, U, n - 1], b_rows[::3], cut_rows, longs[:: max(1, len(longs) // 150)],
+                                     longs[np.argsort(deg[longs])[-2:]], np.argsort(deg[:U])[-2:],
+                                     rng.integers(0, n, 1200)]))
+    assert 1500 <= len(rows) <= 3000
+    rows_d = dev(rows)
+
+    def at(t_):
+        return t_.index_select(0, rows_d).cpu().numpy()
+
+    X = fe.params
+    fin = fe.propagate(force=True)  # the dense forward: layer outputs stay in the handle's two layer buffers
+    ws = G._workspace("prop", d)
+    panel_bytes = (n * d * 4 + 255) // 256 * 256
+    L1 = ws[:n * d * 4].view(torch.float32).view(n, d)
+    L2 = ws[panel_bytes:panel_bytes + n * d * 4].view(torch.float32).view(n, d)
+    y1 = _oracle_rows(ip_keep, ix_keep, dv_keep, rows, X, sched)
+    assert np.array_equal(at(L1), y1), "configs[4] shape: forward layer 1 differs from the fmaf chain"
+    y2 = _oracle_rows(ip_keep, ix_keep, dv_keep, rows, L1, sched)
+    assert np.array_equal(at(L2), y2), "configs[4] shape: forward layer 2 differs"
+    y3 = _oracle_rows(ip_keep, ix_keep, dv_keep, rows, L2, sched)
+    mean = (((at(X) + y1) + y2) + y3) / np.float32(4.0)
+    assert np.array_equal(at(fin), mean), "configs[4] shape: layer mean differs"
+    del y1, y2, y3, mean
+
+    def dot64(a, b_):
+        tot = 0.0
+        for r0 in range(0, n, 1 << 20):
+            tot += float((a[r0:r0 + (1 << 20)].double() * b_[r0:r0 + (1 << 20)].double()).sum())
+        return tot
+
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    g_out = fe.g_final  # a panel the engine owns already (15.4 GB): filled with a dense random cotangent
+    g_out.copy_(torch.rand((n, d), device="cuda", generator=gen).sub_(0.5))
+    back = G.propagate_mean_bwd_raw(g_out, K, True, out=fe.grad)
+    lhs, rhs = dot64(fin, g_out), dot64(X, back)
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1e-30), (lhs, rhs)
+    # the identity is blind to a symmetric error: the backward's own Horner chain on the sampled rows as well —
+    # h1 = A.g + g, h2 = A.h1 + g, grad = (g + A.h2) / 4 — each step against the fmaf chain on the device's previous step
+    g_rows = at(g_out)
+    h1 = _oracle_rows(ip_keep, ix_keep, dv_keep, rows, g_out, sched) + g_rows
+    assert np.array_equal(at(L1), h1), "configs[4] shape: backward step 1 differs"
+    h2 = _oracle_rows(ip_keep, ix_keep, dv_keep, rows, L1, sched) + g_rows
+    assert np.array_equal(at(L2), h2), "configs[4] shape: backward step 2 differs"
+    t3 = _oracle_rows(ip_keep, ix_keep, dv_keep, rows, L2, sched)
+    assert np.array_equal(at(back), (g_rows + t3) / np.float32(4.0)), "configs[4] shape: backward result differs"
