@@ -18,7 +18,10 @@ sys.dont_write_bytecode = True
 REF = os.environ.get("IDG_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import golden_io  # noqa: E402
+
+OUT = golden_io.out_dir()
 sys.path.insert(0, REF)
 
 import numpy as np  # noqa: E402
@@ -53,21 +56,25 @@ def base_config(name, **kw):
     return cfg
 
 
-def make_data(tmp, gname, dup_edge=False, n_test=2):
-    U, I, E = synth.SHAPES[gname]
-    users, items = synth.generate(U, I, E, seed=3)
-    (tu, ti), (su, si) = synth.split_test(users, items, U, n_test=n_test, seed=4)
-    d = os.path.join(tmp, gname)
-    synth.write_ratings(os.path.join(d, "train.txt"), tu, ti)
-    synth.write_ratings(os.path.join(d, "test.txt"), su, si)
-    if dup_edge:
-        # repeat one (user, item) pair inside train.txt: the loader keeps both edges and the
-        # interaction matrix sums them to 2 (data_loader.py:42)
-        lines = open(os.path.join(d, "train.txt")).read().splitlines()
-        parts = lines[3].split(" ")
-        lines[3] = " ".join(parts + [parts[1]])
-        open(os.path.join(d, "train.txt"), "w").write("\n".join(lines) + "\n")
-    return d
+def make_data(tmp, gname, dup_edge=False, n_test=2, frozen=None):
+    """The dataset directory <tmp>/<gname> the reference loads.  Its two text files are FROZEN INPUTS
+    (tests/golden/inputs/<frozen or gname>/, golden_io.frozen_dataset); the generator below runs only when they do not
+    exist yet."""
+    def draw(d):
+        U, I, E = synth.SHAPES[gname]
+        users, items = synth.generate(U, I, E, seed=3)
+        (tu, ti), (su, si) = synth.split_test(users, items, U, n_test=n_test, seed=4)
+        synth.write_ratings(os.path.join(d, "train.txt"), tu, ti)
+        synth.write_ratings(os.path.join(d, "test.txt"), su, si)
+        if dup_edge:
+            # repeat one (user, item) pair inside train.txt: the loader keeps both edges and the
+            # interaction matrix sums them to 2 (data_loader.py:42)
+            lines = open(os.path.join(d, "train.txt")).read().splitlines()
+            parts = lines[3].split(" ")
+            lines[3] = " ".join(parts + [parts[1]])
+            open(os.path.join(d, "train.txt"), "w").write("\n".join(lines) + "\n")
+
+    return golden_io.frozen_dataset(frozen or gname, os.path.join(tmp, gname), draw)
 
 
 def csr_arrays(m):
@@ -272,10 +279,10 @@ def main():
     try:
         for gname, d_list, dup in (("tiny", [64, 256], True), ("small", [64], False)):
             out = golden_for_graph(tmp, gname, d_list, dup)
-            np.savez_compressed(os.path.join(OUT, "graph_%s.npz" % gname), **out)
+            golden_io.save_npz(os.path.join(OUT, "graph_%s.npz" % gname), **out)
             print("wrote graph_%s.npz (%d arrays)" % (gname, len(out)))
         out = golden_misc()
-        np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+        golden_io.save_npz(os.path.join(OUT, "misc.npz"), **out)
         print("wrote misc.npz")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

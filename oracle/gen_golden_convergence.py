@@ -21,6 +21,9 @@ sys.dont_write_bytecode = True
 REF = os.environ.get("IDG_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import golden_io  # noqa: E402
+
 sys.path.insert(0, REF)
 
 import numpy as np  # noqa: E402
@@ -40,14 +43,17 @@ EPOCHS, INTERVAL = 40, 5
 
 
 def main():
-    torch.set_num_threads(8)
+    torch.set_num_threads(1)  # ONE thread: the 8-thread run is reproducible only to ~5e-7 (its log lines are, its weights are not)
     tmp = tempfile.mkdtemp(prefix="idg_conv_")
-    U, I, E = synth.SHAPES["medium"]
-    users, items = synth.generate(U, I, E, seed=11)
-    (tu, ti), (su, si) = synth.split_test(users, items, U, n_test=5, seed=12)
-    d = os.path.join(tmp, "medium")
-    synth.write_ratings(os.path.join(d, "train.txt"), tu, ti)
-    synth.write_ratings(os.path.join(d, "test.txt"), su, si)
+    def draw(d):
+        U, I, E = synth.SHAPES["medium"]
+        users, items = synth.generate(U, I, E, seed=11)
+        (tu, ti), (su, si) = synth.split_test(users, items, U, n_test=5, seed=12)
+        synth.write_ratings(os.path.join(d, "train.txt"), tu, ti)
+        synth.write_ratings(os.path.join(d, "test.txt"), su, si)
+
+    # frozen input (tests/golden/inputs/medium_conv/): the generator runs only if it does not exist yet
+    d = golden_io.frozen_dataset("medium_conv", os.path.join(tmp, "medium"), draw)
     cfg = ref_tools.read_configuration(os.path.join(REF, "configure", "LightGCN.txt"), "LightGCN")
     cfg.update(dataset="medium", dataset_path=tmp + "/", training_epochs=str(EPOCHS), interval=str(INTERVAL),
                early_stopping="1000", top_K="[10, 20]")
@@ -65,13 +71,14 @@ def main():
     out = {
         "train_txt": np.frombuffer(open(os.path.join(d, "train.txt"), "rb").read(), dtype=np.uint8),
         "test_txt": np.frombuffer(open(os.path.join(d, "test.txt"), "rb").read(), dtype=np.uint8),
-        "config_keys": np.array(sorted(cfg)), "config_values": np.array([cfg[k] for k in sorted(cfg)]),
+        # (the scratch directory's name is not part of the fixture)
+        "config_keys": np.array(sorted(cfg)), "config_values": np.array([dict(cfg, dataset_path="<tmp>/")[k] for k in sorted(cfg)]),
         "log": np.array(lines),
         "final_user": model.user_embedding.weight.detach().numpy().copy(),
         "final_item": model.item_embedding.weight.detach().numpy().copy(),
     }
-    path = os.path.join(ROOT, "tests", "golden", "convergence_medium.npz")
-    np.savez_compressed(path, **out)
+    path = os.path.join(golden_io.out_dir(), "convergence_medium.npz")
+    golden_io.save_npz(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
     for ln in lines:
         if "Test recall" in ln or "Best epoch" in ln:

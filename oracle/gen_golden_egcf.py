@@ -24,7 +24,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="idg_golden_egcf_")
     try:
         gname = "small"
-        path = G.make_data(tmp, gname)
+        path = G.make_data(tmp, gname, frozen="small_egcf")
         out = {}
         for mode in ("parallel", "alternating"):
             cfg = G.base_config("EGCF", dataset=gname, dataset_path=tmp + "/", mode=mode)
@@ -55,8 +55,9 @@ def main():
         out["train_txt"] = np.frombuffer(open(os.path.join(path, "train.txt"), "rb").read(), dtype=np.uint8)
         out["test_txt"] = np.frombuffer(open(os.path.join(path, "test.txt"), "rb").read(), dtype=np.uint8)
         cfg_keys = sorted(cfg)
-        out["config_keys"], out["config_values"] = np.array(cfg_keys), np.array([cfg[k] for k in cfg_keys])
-        np.savez_compressed(os.path.join(G.OUT, "egcf_small.npz"), **out)
+        stored = dict(cfg, dataset_path="<tmp>/")  # (the scratch directory's name is not part of the fixture)
+        out["config_keys"], out["config_values"] = np.array(cfg_keys), np.array([stored[k] for k in cfg_keys])
+        G.golden_io.save_npz(os.path.join(G.OUT, "egcf_small.npz"), **out)
         print("wrote egcf_small.npz (%d arrays)" % len(out), {k: out[k] for k in out if k.endswith("_loss")})
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -87,7 +87,7 @@ def main():
         with torch.no_grad():
             xu, xi = x.aggregate(perturbed=False)
         out["xsimgcl_user"], out["xsimgcl_item"] = xu.numpy().copy(), xi.numpy().copy()
-        np.savez_compressed(os.path.join(G.OUT, "next_small.npz"), **out)
+        G.golden_io.save_npz(os.path.join(G.OUT, "next_small.npz"), **out)
         print("wrote next_small.npz (%d arrays)" % len(out))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -139,3 +139,25 @@ def test_metrics(golden_misc):
         got = [oracle.recall_at_k(r, k, test), oracle.precision_at_k(r, k, test), oracle.ndcg_at_k(r, k, test)]
         np.testing.assert_allclose(got, g["metrics_k%d" % k], rtol=1e-12)
     assert np.array_equal(oracle.get_label(test, g["label_pred"]), g["label"])
+
+
+def test_goldens_regenerate_from_the_reference_at_head():
+    """Every fixture under tests/golden/ is what oracle/regen_all.py produces TODAY from the imported reference and the
+    frozen inputs under tests/golden/inputs/ (the pin must be reproducible at HEAD, not only self-contained):
+    regenerate into a temp dir, compare array by array — dtype, shape, values.  Runs only where the reference tree
+    exists (this container; never the GPU box).  convergence_medium.npz (a 40-epoch single-thread reference run, ~15 min)
+    only with IDG_REGEN_SLOW=1 — `python oracle/regen_all.py --check` does all of it."""
+    import importlib.util
+    import os
+
+    ref = os.environ.get("IDG_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "models")):
+        pytest.skip("needs the reference tree (%s)" % ref)
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("idg_regen_all", os.path.join(here, "..", "oracle", "regen_all.py"))
+    regen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(regen)
+    res = regen.check(fast=os.environ.get("IDG_REGEN_SLOW") != "1", quiet=True)
+    assert len(res) >= 5
+    for f, bad in res.items():
+        assert not bad, "%s is not what the generators produce at HEAD: %s" % (f, bad[:6])
