@@ -140,6 +140,121 @@ __global__ __launch_bounds__(BLOCK) void grad_tail_adam_kernel(const float* __re
   }
 }
 
+// The same with any number of earlier terms (K > 3 propagation layers): terms[0..n_terms) added left to right, then `last`.
+constexpr int MEAN_TERMS_MAX = 15;
+struct MeanTerms {
+  const float* p[MEAN_TERMS_MAX];
+  int n;
+};
+__global__ __launch_bounds__(BLOCK) void rows_layer_mean_n_kernel(float* __restrict__ out, const int64_t* __restrict__ ids,
+                                                                  int64_t count, MeanTerms terms,
+                                                                  const float* __restrict__ last, float div, int64_t d) {
+  const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  if (j >= count) return;
+  const int64_t r = ids[j];
+  for (int64_t f = (threadIdx.x % WAVE) * 4; f < d; f += WAVE * 4) {
+    float4 s = *reinterpret_cast<const float4*>(last + j * d + f);
+    if (terms.n > 0) {
+      float4 t = *reinterpret_cast<const float4*>(terms.p[0] + r * d + f);
+      for (int k = 1; k < terms.n; ++k) {
+        const float4 x = *reinterpret_cast<const float4*>(terms.p[k] + r * d + f);
+        t.x += x.x, t.y += x.y, t.z += x.z, t.w += x.w;
+      }
+      s.x = t.x + s.x, s.y = t.y + s.y, s.z = t.z + s.z, s.w = t.w + s.w;
+    }
+    if (div != 1.0f) s.x = s.x / div, s.y = s.y / div, s.z = s.z / div, s.w = s.w / div;
+    *reinterpret_cast<float4*>(out + r * d + f) = s;
+  }
+}
+
+// ---- ascending ids of the non-zero entries of a flag vector, into a FIXED-capacity list (no host read-back): the
+// sharded step's touched-item agreement.  Three launches: per-block counts (COMPACT_SPAN flags per block), one block
+// scanning the counts, per-block ordered write; slots past the last id repeat it (a consumer that gathers, reduces and
+// scatters rows through the list then moves that row more than once — the same value every time).
+constexpr int COMPACT_PER_THREAD = 16;
+constexpr int COMPACT_SPAN = BLOCK * COMPACT_PER_THREAD;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int* total) {
+  // BLOCK threads; returns the exclusive prefix of v in thread order
+  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const int o = __shfl_up(inc, off, WAVE);
+    if (lane >= off) inc += o;
+  }
+  if (lane == WAVE - 1) lds[wave] = inc;
+  __syncthreads();
+  int base = 0, sum = 0;
+  for (int w = 0; w < BLOCK / WAVE; ++w) {
+    if (w < wave) base += lds[w];
+    sum += lds[w];
+  }
+  if (total) *total = sum;
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(BLOCK) void flags_count_kernel(const float* __restrict__ flags, int64_t n, int32_t* __restrict__ counts) {
+  __shared__ int lds[BLOCK / WAVE];
+  const int64_t i0 = (int64_t)blockIdx.x * COMPACT_SPAN + (int64_t)threadIdx.x * COMPACT_PER_THREAD;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < COMPACT_PER_THREAD; ++k)
+    if (i0 + k < n && flags[i0 + k] != 0.0f) ++c;
+  int total;
+  block_exclusive_scan(c, lds, &total);
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+// counts[0..nb) -> exclusive offsets in place (int64 running total kept in a register); counts[nb] = min(total, INT32_MAX)
+__global__ __launch_bounds__(BLOCK) void flags_scan_kernel(int32_t* __restrict__ counts, int64_t nb, int64_t* __restrict__ count_out) {
+  __shared__ int lds[BLOCK / WAVE];
+  int64_t run = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += BLOCK) {
+    const int64_t b = b0 + threadIdx.x;
+    const int v = b < nb ? counts[b] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, lds, &total);
+    // offsets beyond int32 cannot be addressed by the list anyway (its capacity is far below): saturate
+    const int64_t off = run + ex;
+    if (b < nb) counts[b] = off > 0x7fffffff ? 0x7fffffff : (int32_t)off;
+    run += total;
+  }
+  if (threadIdx.x == 0) {
+    counts[nb] = run > 0x7fffffff ? 0x7fffffff : (int32_t)run;
+    if (count_out) *count_out = run;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void flags_write_kernel(const float* __restrict__ flags, int64_t n,
+                                                            const int32_t* __restrict__ offsets, int64_t* __restrict__ ids,
+                                                            int64_t cap) {
+  __shared__ int lds[BLOCK / WAVE];
+  const int64_t i0 = (int64_t)blockIdx.x * COMPACT_SPAN + (int64_t)threadIdx.x * COMPACT_PER_THREAD;
+  int c = 0;
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < COMPACT_PER_THREAD; ++k)
+    if (i0 + k < n && flags[i0 + k] != 0.0f) ++c, m |= 1u << k;
+  int64_t at = (int64_t)offsets[blockIdx.x] + block_exclusive_scan(c, lds, nullptr);
+#pragma unroll
+  for (int k = 0; k < COMPACT_PER_THREAD; ++k)
+    if ((m >> k) & 1u) {
+      if (at < cap) ids[at] = i0 + k;
+      ++at;
+    }
+}
+
+// slots [total, cap) repeat the last id (total >= 1); an empty list is filled with row 0
+__global__ __launch_bounds__(BLOCK) void flags_pad_kernel(const int32_t* __restrict__ offsets, int64_t nb, int64_t* __restrict__ ids,
+                                                          int64_t cap) {
+  const int64_t total = offsets[nb];
+  const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= cap || j < total) return;
+  ids[j] = total > 0 ? ids[(total < cap ? total : cap) - 1] : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -194,6 +309,46 @@ int idg_rows_layer_mean_f32(float* out, const int64_t* ids, int64_t count, const
   return IDG_OK;
 }
 
+int idg_rows_layer_mean_n_f32(float* out, const int64_t* ids, int64_t count, const float* const* terms, int n_terms,
+                              const float* last, float div, int64_t d, void* stream) {
+  IDG_REQUIRE(out && ids && last && count >= 0 && d > 0 && d % 4 == 0 && div != 0.f, "idg_rows_layer_mean_n_f32: bad argument");
+  IDG_REQUIRE(n_terms >= 0 && n_terms <= MEAN_TERMS_MAX && (n_terms == 0 || terms),
+              "idg_rows_layer_mean_n_f32: 0 <= n_terms <= 15 term panels");
+  MeanTerms t;
+  t.n = n_terms;
+  uintptr_t align = (uintptr_t)out | (uintptr_t)last;
+  for (int k = 0; k < MEAN_TERMS_MAX; ++k) {
+    t.p[k] = k < n_terms ? terms[k] : nullptr;
+    IDG_REQUIRE(k >= n_terms || terms[k], "idg_rows_layer_mean_n_f32: NULL term panel");
+    align |= (uintptr_t)t.p[k];
+  }
+  IDG_REQUIRE(align % 16 == 0, "idg_rows_layer_mean_n_f32: panels must be 16-byte aligned");
+  if (count == 0) return IDG_OK;
+  hipLaunchKernelGGL(rows_layer_mean_n_kernel, dim3((unsigned)((count + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, out, ids, count, t, last, div, d);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+size_t idg_flags_compact_workspace_bytes(int64_t n) {
+  const int64_t nb = n > 0 ? (n + COMPACT_SPAN - 1) / COMPACT_SPAN : 0;
+  return (size_t)(nb + 1) * sizeof(int32_t);
+}
+
+int idg_flags_compact_f32(const float* flags, int64_t n, int64_t* ids, int64_t cap, int64_t* count, void* ws, void* stream) {
+  IDG_REQUIRE(flags && ids && ws && n > 0 && cap > 0, "idg_flags_compact_f32: bad argument");
+  IDG_REQUIRE(n <= (int64_t)0x7fffffff * COMPACT_SPAN, "idg_flags_compact_f32: flag vector too long");
+  const int64_t nb = (n + COMPACT_SPAN - 1) / COMPACT_SPAN;
+  int32_t* counts = reinterpret_cast<int32_t*>(ws);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(flags_count_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, flags, n, counts);
+  hipLaunchKernelGGL(flags_scan_kernel, dim3(1), dim3(BLOCK), 0, st, counts, nb, count);
+  hipLaunchKernelGGL(flags_write_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, flags, n, counts, ids, cap);
+  hipLaunchKernelGGL(flags_pad_kernel, dim3((unsigned)((cap + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, counts, nb, ids, cap);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
 int idg_grad_tail_adam_f32(const float* t, const float* g, float* G, const uint32_t* live_bits, int64_t row0, int64_t rows,
                            int64_t d, int include_layer0, float cnt, int store_grad, float* param, float* exp_avg,
                            float* exp_avg_sq, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
@@ -224,6 +379,15 @@ int idg_shard_prepare(const idg_shard_prep* p) {
   IDG_REQUIRE(p->n_own == 0 || p->own_users, "idg_shard_prepare: owned users without their id array");
   IDG_REQUIRE(p->n_slices >= 0 && (p->n_slices == 0 || (p->slice_graphs && p->slice_row0 && p->slice_units)),
               "idg_shard_prepare: slice tables missing");
+  // what the bitmaps and unit lists were SIZED for (a prepared object handed to another engine's batch would
+  // write outside them)
+  IDG_REQUIRE(p->B <= p->B_cap && p->n_own >= 0 && p->n_own <= p->B_cap,
+              "idg_shard_prepare: batch (B, n_own) larger than the capacity B_cap the buffers were sized for");
+  IDG_REQUIRE(p->n_local_users >= 0 && p->n_items_padded >= 0 && p->n_panel_rows >= p->n_local_users + p->B_cap,
+              "idg_shard_prepare: inconsistent panel geometry");
+  for (int j = 0; j < p->n_slices; ++j)
+    IDG_REQUIRE(p->slice_row0[j] >= 0 && p->slice_row0[j] % 32 == 0 && p->slice_row0[j] <= p->n_items_padded && p->slice_graphs[j],
+                "idg_shard_prepare: slice_row0 must be a multiple of 32 inside the item bitmap");
   void* side = p->side_stream;
   int rc;
 #define IDG_TRY(call) \

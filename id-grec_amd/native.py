@@ -62,6 +62,9 @@ PROTOTYPES = {
     "idg_rows_scatter_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
     "idg_rows_chain_store2_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
     "idg_rows_layer_mean_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp, C.c_float, C.c_int64, c_vp]),
+    "idg_rows_layer_mean_n_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int, c_vp, C.c_float, C.c_int64, c_vp]),
+    "idg_flags_compact_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "idg_flags_compact_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, c_vp, c_vp, c_vp]),
     "idg_grad_tail_adam_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int,
                                          c_vp, c_vp, c_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, c_vp]),
     "idg_shard_prepare": (C.c_int, [c_vp]),
@@ -172,7 +175,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
-ABI_VERSION = 133  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 134  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -434,9 +434,15 @@ def rows_chain_store2_raw(dst0, src0, dst1, src1, idx, nxt):
 
 
 def rows_layer_mean_raw(out, ids, terms, last, div):
-    """out[ids[j]] = (((a + b) + c)[ids[j]] + last[j]) / div, terms = up to three panels (idg_rows_layer_mean_f32)."""
+    """out[ids[j]] = (((a + b) + c)[ids[j]] + last[j]) / div, terms = up to three panels (idg_rows_layer_mean_f32); more
+    terms (K > 3 layers), added left to right the same way: idg_rows_layer_mean_n_f32."""
     terms = [t for t in terms if t is not None]
     _require_device(out, ids, last, *terms)
+    if len(terms) > 3:
+        arr = (C.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+        check(lib.idg_rows_layer_mean_n_f32(_ptr(out), _ptr(ids), int(ids.shape[0]), arr, len(terms), _ptr(last), float(div),
+                                            int(out.shape[1]), _stream()), "idg_rows_layer_mean_n_f32")
+        return
     a, b, c = (terms + [None, None, None])[:3]
     check(lib.idg_rows_layer_mean_f32(_ptr(out), _ptr(ids), int(ids.shape[0]), _ptr(a), _ptr(b), _ptr(c), _ptr(last),
                                       float(div), int(out.shape[1]), _stream()), "idg_rows_layer_mean_f32")
@@ -466,6 +472,23 @@ def subgraph_values_raw(row_of_entry, col_of_entry, edge_of_entry, kept_bits, di
     check(lib.idg_subgraph_values_f32(nnz, _ptr(row_of_entry), _ptr(col_of_entry), _ptr(edge_of_entry), _ptr(kept_bits),
                                       _ptr(dinv), _ptr(out), _stream()), "idg_subgraph_values_f32")
     return out
+
+
+def flags_compact_raw(flags, cap, ids=None, count=None, ws=None):
+    """ids[0..cap) = ascending indices of the non-zero entries of the float vector `flags`, slots past the last one
+    repeating it; count (int64 [1], optional) = their number.  No host synchronisation (idg_flags_compact_f32).
+    Returns (ids, ws) — pass both back to reuse the buffers."""
+    _require_device(flags, ids, count, ws)
+    if flags.dtype != torch.float32 or not flags.is_contiguous() or flags.dim() != 1:
+        raise TypeError("flags_compact_raw: contiguous float32 vector")
+    n = int(flags.shape[0])
+    if ids is None:
+        ids = torch.empty(int(cap), dtype=torch.int64, device=flags.device)
+    if ws is None:
+        ws = torch.empty(int(lib.idg_flags_compact_workspace_bytes(n)), dtype=torch.uint8, device=flags.device)
+    check(lib.idg_flags_compact_f32(_ptr(flags), n, _ptr(ids), int(cap), _ptr(count), _ptr(ws), _stream()),
+          "idg_flags_compact_f32")
+    return ids, ws
 
 
 def rows_gather_raw(dst, src, idx):

@@ -109,14 +109,19 @@ class GlobalBatch:
       own_users  int64 [B_g]  local ids of the owned triples' users: the user rows this rank's restricted products have
                  to produce / may gather from
       items      int64 [n_items <= 2B]  the batch's distinct item ids, ascending: the only item rows of the LAST forward
-                 layer anybody reads (the BPR loss gathers pos / neg rows) — what that layer's exchange carries"""
-    __slots__ = ("B", "pos", "neg", "own_src", "head_dst", "nxt", "own_users", "n_owned", "key", "items", "n_items")
+                 layer anybody reads (the BPR loss gathers pos / neg rows) — what that layer's exchange carries
+      touched_bound  host int or None: an upper bound of the number of item rows the batch touches (its own items + the
+                 items its users interacted with) computed from the GLOBAL user degrees — the same number on every rank,
+                 known before the step: the touched-item exchanges are sized by it and need no host read-back"""
+    __slots__ = ("B", "pos", "neg", "own_src", "head_dst", "nxt", "own_users", "n_owned", "key", "items", "n_items",
+                 "touched_bound")
     _next_key = 0
 
 
 class ShardedEngine:
     """One rank's share of the LightGCN step (models/LightGCN.py:36-72 + utility/utility_train/trainer.py:42-56 cut by
-    user rows; K <= 3 propagation layers).  Arrays are whatever `kernels` allocates (torch CUDA tensors in the product).
+    user rows; any number of propagation layers, GCN_layer in configure/LightGCN.txt:12).  Arrays are whatever `kernels`
+    allocates (torch CUDA tensors in the product).
 
     Layout.  Every local panel has rows [0, U_g) = this rank's users, [U_g, U_g + B) = B GUEST rows (row U_g + t carries
     triple t's user, whoever owns it), then ALL items padded to I_p rows ([U_g + B, U_g + B + I_p)).  The item rows are cut
@@ -140,7 +145,7 @@ class ShardedEngine:
 
     def __init__(self, kernels, comm, ui_csr, iu_csr, n_local_users, num_items, dim, n_layers, include_layer0=True,
                  reg_lambda=1e-4, lr=1e-3, batch_sparsity=True, batch_size=1024, user_lo=0, n_slices=None, item_cuts=None,
-                 live_rows_cap=None, live_rows_min_bytes=64 << 20, store_grad=True):
+                 live_rows_cap=None, live_rows_min_bytes=64 << 20, store_grad=True, global_user_degree=None):
         """batch_sparsity: use the batch's row bitmaps (kernels.prepare) — restricted products, stored gradient rows, no
         fills; False = every product dense over zero-filled gradient panels (the plain form, kept as an A/B check).
         batch_size: capacity of the guest rows (the global batch size).  user_lo: global id of this rank's first user.
@@ -150,15 +155,19 @@ class ShardedEngine:
         compact buffer of the touched-item exchanges (default 64 per triple; the same on every rank);
         live_rows_min_bytes: item panels smaller than this skip the touched-item forms (tests pass 0).
         store_grad: keep the finished gradient in G — the user rows and the OWNED item rows (tests read it; the step
-        does not: without it the last products feed Adam and write no gradient panel)."""
+        does not: without it the last products feed Adam and write no gradient panel).
+        global_user_degree: int array [U] of EVERY user's number of train items (the same array on every rank).  With it
+        the number of item rows a batch touches is bounded on the host (make_batch), the touched-item exchanges move that
+        many rows through a fixed-capacity id list built on the device, and the step has no host synchronisation; without
+        it the ranks read the list's length back (one synchronisation per step)."""
         self.k, self.comm = kernels, comm
         self.world, self.rank = int(getattr(comm, "world", 1)), int(getattr(comm, "rank", 0))
         self.batch_sparsity = bool(batch_sparsity)
         self._prepared = {}
         self.Ug, self.I, self.d, self.K = int(n_local_users), int(num_items), int(dim), int(n_layers)
-        if not 1 <= self.K <= 3:
-            raise ValueError("ShardedEngine: 1 <= n_layers <= 3 (the layer mean is formed by the last product's epilogue "
-                             "from at most three earlier terms); got %d" % self.K)
+        if not 1 <= self.K <= 15:
+            raise ValueError("ShardedEngine: 1 <= n_layers <= 15; got %d" % self.K)
+        self.user_degree = None if global_user_degree is None else np.asarray(global_user_degree, dtype=np.int64)
         self.B, self.lo = int(batch_size), int(user_lo)
         self.c0 = 1 if include_layer0 else 0
         self.cnt = float(self.K + self.c0)
@@ -205,13 +214,19 @@ class ShardedEngine:
         self.GF = z((n, dim))   # d loss / d FIN
         self.MU, self.VU = z((self.Ug, dim)), z((self.Ug, dim))        # Adam moments: the owned user rows ...
         self.MI, self.VI = z((max(off, 1), dim)), z((max(off, 1), dim))  # ... and the owned item rows (1/N of the table)
-        self.XU = [z((self.Ug, dim)) for _ in range(2 if self.K >= 2 else 1)]
+        self.XU = [z((self.Ug, dim)) for _ in range(max(self.K - 1, 1))]
         self.XI = [z((self.Ip, dim)) for _ in range(self.K)]
+        # more than three earlier layers do not fit one epilogue (sum_in .. sum_in3): from K = 4 on the user-side layer sum
+        # is carried from product to product (sum_in -> sum_out, left to right as torch.mean(torch.stack(...)) adds)
+        self.SU = z((self.Ug, dim)) if self.K + self.c0 > 4 else None
         self.CI = z((2 * self.B, dim))  # the batch's item rows, compact (last forward layer)
         # flags of the item rows some rank's batch users touch, and those rows, compact (up to 64 per triple)
         self.FL = z((self.I,))
         self.live_rows_min_bytes = int(live_rows_min_bytes)
-        self.CS = z((max(1, min(self.I, 64 * self.B if live_rows_cap is None else int(live_rows_cap))), dim))
+        default_cap = (128 if self.user_degree is not None else 64) * self.B  # (a bound is looser than a count)
+        self.CS = z((max(1, min(self.I, default_cap if live_rows_cap is None else int(live_rows_cap))), dim))
+        self._touch_misses, self._touch_skip = 0, 0   # consecutive overflows of CS; steps left before asking again
+        self.timeline = None  # StepTimeline while instrumented steps run (bench.py, after the timed region)
         self.loss = z((2,))
         self.guest_ids = kernels.to_device(np.arange(self.Ug, self.Ug + self.B, dtype=np.int64))
         # views handed to the kernels every step, made once (slicing a tensor costs the host ~1.5 us)
@@ -276,6 +291,10 @@ class ShardedEngine:
         gb.own_users = to(local[owned].astype(np.int64))
         items = np.unique(np.concatenate([np.asarray(pos, dtype=np.int64), np.asarray(neg, dtype=np.int64)]))
         gb.items, gb.n_items = to(items), len(items)
+        gb.touched_bound = None
+        if getattr(self, "user_degree", None) is not None:
+            # every distinct batch user contributes at most its degree, the batch at most its own items: >= the union
+            gb.touched_bound = int(min(self.I, self.user_degree[su[np.concatenate([[True], ~same])]].sum() + len(items)))
         GlobalBatch._next_key += 1
         gb.key = GlobalBatch._next_key  # (a counter: id(gb) can come back after a skipped batch is collected)
         return gb
@@ -290,7 +309,7 @@ class ShardedEngine:
         self._wait(self._ag)
         self._ag = []
 
-    def _item_side(self, X_u, Y_i, out_bits=None, x_rows=None, addend=None, mask=None, reduce="all"):
+    def _item_side(self, X_u, Y_i, out_bits=None, x_rows=None, addend=None, mask=None, reduce="all", tag="panel"):
         """Y_i[slice] = R_g^T[slice] . X_u (+ addend, on rank 0 only: the ranks' partials are summed), slice by slice;
         each slice's collective is issued as soon as the slice exists, so it runs under the following slices' products
         and under whatever the caller launches next.  reduce: "all" = all-reduce of the slice, "scatter" = reduce-scatter
@@ -303,15 +322,20 @@ class ShardedEngine:
                    mask=None if (add is None or mask is None) else k.bits_from(mask, r0),
                    out_rows=None if out_bits is None else k.bits_from(out_bits, r0), x_rows=x_rows)
             if reduce == "all":
+                self.comm.tag = tag
                 works.append(self.comm.all_reduce_async(y))
             elif reduce == "scatter":
+                self.comm.tag = tag
                 works.append(self.comm.reduce_scatter_async(self._slice_rows(Y_i, j, padded=True)))
         return works
 
-    def _sum_rows(self, panel, rows):
-        """all-reduce of the panel's rows `rows` = (ids, n) through the compact buffer (synchronous: small)."""
+    def _sum_rows(self, panel, rows, tag="rows"):
+        """all-reduce of the panel's rows `rows` = (ids, n) through the compact buffer (synchronous: small).  ids may
+        repeat its last entry (a list padded to a host-side bound): the repeated row is gathered, summed and written
+        back more than once, with the same value."""
         ids, n = rows
         self.k.gather_rows(self.CS[:n], panel, ids)
+        self.comm.tag = tag
         self.comm.wait(self.comm.all_reduce_async(self.CS[:n]))
         self.k.scatter_rows(panel, ids, self.CS[:n])
 
@@ -321,8 +345,12 @@ class ShardedEngine:
         and by FIN at the batch's items) and the first backward product's partials are zero elsewhere, so both travel as
         these rows instead of the [I, d] panel, and the products around them are restricted to them.
         One rank marks the bitmap locally.  Several ranks flag the items of the batch users they own
-        (idg_graph_flag_cols over their block of R), add the batch's items, sum the flags ([I] floats: 20 MB at
-        configs[4]) and read off the same ascending id list — the one host synchronisation of the step.
+        (idg_graph_flag_cols over their block of R), add the batch's items and sum the flags ([I] floats: 20 MB at
+        configs[4]); the ascending id list is built ON THE DEVICE into a list of gb.touched_bound slots (a host-side
+        bound from the global user degrees, the same on every rank; slots past the last id repeat it:
+        idg_flags_compact_f32) — no host synchronisation.  Without the degrees (global_user_degree=None) the list's
+        length is read back: one synchronisation per step, and after three consecutive batches that overflow the
+        compact buffer the engine stops asking for 64 steps.
         Sets prep.touched (bitmap) and self.touched_items = (ids, n) (several ranks) or leaves both None: K < 2, a panel
         too small to be worth it, or more rows than the compact buffer holds."""
         self.touched_items = None
@@ -332,11 +360,35 @@ class ShardedEngine:
         if self.world == 1:
             k.touched_local(self, prep, gb)
             return
-        k.flag_touched_items(self, prep, gb, self.FL)
-        self.comm.wait(self.comm.all_reduce_async(self.FL))
-        ids, n = k.nonzero_ids(self.FL)
-        if n == 0 or n > self.CS.shape[0]:
+        cap = self.CS.shape[0]
+        tl = self.timeline
+        if gb.touched_bound is not None:
+            if gb.touched_bound > cap:   # known before anything is launched, and the same on every rank
+                return
+            n = min(cap, -(-gb.touched_bound // 256) * 256)  # (whole 256-row blocks: fewer distinct collective sizes)
+            k.flag_touched_items(self, prep, gb, self.FL)
+            self.comm.tag = "flags"
+            self.comm.wait(self.comm.all_reduce_async(self.FL))
+            ids = k.compact_ids(self.FL, n)
+            self.touched_items = (ids, n)
+            k.touched_from_ids(self, prep, ids, n)
             return
+        if self._touch_skip > 0:
+            self._touch_skip -= 1
+            return
+        k.flag_touched_items(self, prep, gb, self.FL)
+        self.comm.tag = "flags"
+        self.comm.wait(self.comm.all_reduce_async(self.FL))
+        t0 = tl.host_sync_begin() if tl is not None else None
+        ids, n = k.nonzero_ids(self.FL)
+        if tl is not None:
+            tl.host_sync_end(t0)
+        if n == 0 or n > cap:
+            self._touch_misses += 1
+            if self._touch_misses >= 3:
+                self._touch_misses, self._touch_skip = 0, 64
+            return
+        self._touch_misses = 0
         self.touched_items = (ids, n)
         k.touched_from_ids(self, prep, ids, n)
 
@@ -357,6 +409,11 @@ class ShardedEngine:
         items_bits = prep.items if (train and prep is not None) else None
         users_bits = prep.own_users if (train and prep is not None) else None
         pending = []  # collectives of the previous layer's item side
+        # the user-side layer sum: at most three earlier terms fit the last product's epilogue; beyond that (K + c0 > 4)
+        # every product adds its output to the running sum SU (sum_in -> sum_out, the left-to-right order of
+        # torch.mean(torch.stack(...)), as idg_propagate_mean_f32 does on one device) and the last one divides
+        chain = self.SU is not None
+        acc = [P_u] if c0 else []  # terms not yet folded into SU (chain form)
         for layer in range(1, K + 1):
             last, pre = layer == K, layer == K - 1
             if pre and train:
@@ -372,22 +429,28 @@ class ShardedEngine:
             if last and train:
                 works = self._item_side(xu_prev, xi_new, out_bits=items_bits, reduce=None)
                 k.gather_rows(self.CI[:gb.n_items], xi_new, gb.items)
+                self.comm.tag = "F%d.items" % layer
                 works = [self.comm.all_reduce_async(self.CI[:gb.n_items])]
             elif pre and touched is not None:
                 works = self._item_side(xu_prev, xi_new, out_bits=touched, reduce=None)
                 if self.touched_items is not None:
-                    self._sum_rows(xi_new, self.touched_items)
+                    self._sum_rows(xi_new, self.touched_items, tag="F%d.touched" % layer)
             else:
-                works = self._item_side(xu_prev, xi_new)
+                works = self._item_side(xu_prev, xi_new, tag="F%d.panel" % layer)
             # user side (input: the previous layer's item rows, exchanged; layer 1: the item table itself)
             self._wait(pending)
             if layer == 1:
                 self._wait_item_table()
             if last:
-                terms = ([P_u] if c0 else []) + self.XU[: K - 1]
+                terms = acc if chain else ([P_u] if c0 else []) + self.XU[: K - 1]
                 k.spmm(self.G_ui, xi_prev, sums=terms, sum_out=fin_u, div=cnt, out_rows=users_bits)
+            elif chain and acc:
+                k.spmm(self.G_ui, xi_prev, Y=self.XU[layer - 1], sums=acc, sum_out=self.SU, out_rows=near if pre else None)
+                acc = [self.SU]
             else:
                 k.spmm(self.G_ui, xi_prev, Y=self.XU[layer - 1], out_rows=near if pre else None)
+                if chain:
+                    acc = [self.XU[layer - 1]]  # (no layer 0 in the mean: the sum starts with layer 1)
             pending = works
         self._wait(pending)
         # the layer mean at the item rows: the batch's (their last layer arrived as the compact row set), or all
@@ -427,9 +490,10 @@ class ShardedEngine:
             if first:
                 works = self._item_side(h_u, t_i, out_bits=touched, x_rows=live_u, addend=g_i, mask=items_bits, reduce=None)
                 if self.touched_items is not None:
-                    self._sum_rows(t_i, self.touched_items)
+                    self._sum_rows(t_i, self.touched_items, tag="B%d.touched" % step)
             else:
-                works = self._item_side(h_u, t_i, x_rows=live_u, addend=g_i, mask=items_bits if sparse else None)
+                works = self._item_side(h_u, t_i, x_rows=live_u, addend=g_i, mask=items_bits if sparse else None,
+                                        tag="B%d.panel" % step)
             # user side: R_g h_I + g_U
             self._wait(pending)
             k.spmm(self.G_ui, h_i, Y=t_u, addend=g_u, mask=users_bits, out_rows=near if first else None, x_rows=live_i)
@@ -438,7 +502,7 @@ class ShardedEngine:
             live_u, live_i = (near, touched) if first else (None, None)
         # last step, scaled by 1 / cnt
         t_i = self.XI[K - 1]
-        works = self._item_side(h_u, t_i, x_rows=live_u, reduce="scatter")
+        works = self._item_side(h_u, t_i, x_rows=live_u, reduce="scatter", tag="B%d.reduce_scatter" % K)
         self._wait(pending)
         adam = (self.P_u, self.MU, self.VU, self.lr, adam_step)
         if live_i is None:   # a dense launch: the owned users' Adam update rides in its epilogue
@@ -455,6 +519,7 @@ class ShardedEngine:
             if c > 0:
                 k.item_tail(blocks[0], blocks[1], blocks[2], items_bits, o0, c0, cnt, self.store_grad, blocks[3],
                             blocks[4], blocks[5], self.lr, adam_step)
+            self.comm.tag = "item_table.all_gather"
             self._ag.append(self.comm.all_gather_async(self._slice_rows(P_i, j, padded=True), blocks[3]))
         return self.G
 
@@ -492,6 +557,7 @@ class ShardedEngine:
                                                    + (self.guest_ids[:Bc],)
         fin_g, ego_g = guests[0], guests[1]
         k.gather_rows2(fin_g, self.FIN_u, ego_g, self.P_u, gb.own_src)
+        self.comm.tag = "guest_rows"
         w1 = self.comm.all_reduce_async(fin_g)
         w2 = self.comm.all_reduce_async(ego_g)
         if prep is None:
@@ -548,6 +614,126 @@ class ShardedEngine:
         n_users = float(sums[-1])
         return {"recall": sums[0:-1:3] / n_users, "precision": sums[1:-1:3] / n_users, "ndcg": sums[2:-1:3] / n_users,
                 "hit": np.zeros(len(top_k))}
+
+
+# --------------------------------------------------------------------------- per-collective timeline (instrumented steps)
+class StepTimeline:
+    """What a sub-6x multi-GPU line is diagnosed from: for a few INSTRUMENTED steps after the timed
+    region, per collective tag (ShardedEngine sets comm.tag before every collective): how long the collective itself
+    took on the stream it ran on, how long the step's stream stalled in wait() for it, its bytes and achieved bus
+    bandwidth; the host synchronisation of the touched-item agreement (if any); the step's GPU time.  HIP events only:
+    the instrumented steps are slower than the timed ones by the events' own cost (~5 us each) and are never timed as
+    the headline."""
+
+    def __init__(self, torch, world):
+        self.torch, self.world = torch, int(world)
+        self.records = []      # (tag, kind, bytes, ev_start, ev_end) — the collective on its stream
+        self.stalls = []       # (tag, ev_before_wait, ev_after_wait) on the step's stream
+        self.host_syncs = []   # seconds the host spent blocked in the touched-item read-back
+        self.steps = []        # (ev_begin, ev_end) per instrumented step
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def host_sync_begin(self):
+        import time
+
+        return time.perf_counter()
+
+    def host_sync_end(self, t0):
+        import time
+
+        self.host_syncs.append(time.perf_counter() - t0)
+
+    def summary(self):
+        """Per-step milliseconds (averages over the instrumented steps); call after torch.cuda.synchronize()."""
+        n = max(len(self.steps), 1)
+        per = {}
+        for tag, kind, nbytes, e0, e1 in self.records:
+            r = per.setdefault(tag, {"kind": kind, "calls": 0, "bytes": 0, "collective_ms": 0.0, "stall_ms": 0.0})
+            r["calls"] += 1
+            r["bytes"] += nbytes
+            r["collective_ms"] += e0.elapsed_time(e1)
+        for tag, e0, e1 in self.stalls:
+            r = per.setdefault(tag, {"kind": "?", "calls": 0, "bytes": 0, "collective_ms": 0.0, "stall_ms": 0.0})
+            r["stall_ms"] += e0.elapsed_time(e1)
+        bus = 2.0 * (self.world - 1) / self.world if self.world > 1 else 0.0
+        out = {}
+        for tag, r in per.items():
+            ms = r["collective_ms"] / n
+            factor = bus if r["kind"] == "all_reduce" else bus / 2.0  # reduce-scatter / all-gather: (N-1)/N of the buffer
+            out[tag] = {"kind": r["kind"], "calls_per_step": r["calls"] / n, "bytes_per_step": r["bytes"] / n,
+                        "collective_ms": ms, "main_stream_stall_ms": r["stall_ms"] / n,
+                        "bus_gbs": (r["bytes"] / n * factor / (ms * 1e-3) / 1e9) if ms > 0 else None}
+        step_ms = sum(a.elapsed_time(b) for a, b in self.steps) / n
+        stall = sum(v["main_stream_stall_ms"] for v in out.values())
+        return {"instrumented_steps": len(self.steps), "step_gpu_ms": step_ms, "main_stream_stall_ms": stall,
+                "compute_ms": step_ms - stall,
+                "host_sync_ms": (sum(self.host_syncs) / n * 1e3) if self.host_syncs else 0.0,
+                "collectives": out,
+                "what": "per training step, averaged over the instrumented steps (run after the timed region, HIP events "
+                        "around every collective and every wait): collective_ms = the collective on the stream it ran on "
+                        "(for collectives enqueued on the step's own stream that time is also a stall of the step); "
+                        "main_stream_stall_ms = the step's stream blocked in wait(); compute_ms = step_gpu_ms - stalls; "
+                        "bus_gbs = bytes x 2(N-1)/N (all-reduce) or (N-1)/N (reduce-scatter, all-gather) / collective_ms"}
+
+
+class TimelineComm:
+    """Wraps a comm (NativeComm / TorchComm / test comms) and fills a StepTimeline.  The collective's own duration is
+    measured on the stream it runs on when the inner comm says which (NativeComm.timed_stream); otherwise between two
+    events on the step's stream around the call (exact for collectives enqueued there, a lower bound — the issue cost —
+    for a process group's internal stream, whose end is then taken at the matching wait())."""
+
+    def __init__(self, inner, timeline):
+        self.inner, self.tl = inner, timeline
+        self.world, self.rank = inner.world, inner.rank
+        self.averages = getattr(inner, "averages", False)
+        self.tag = "untagged"
+
+    def _issue(self, kind, nbytes, call):
+        torch, tl = self.tl.torch, self.tl
+        e0, e1 = tl.event(), tl.event()
+        own = getattr(self.inner, "timed_stream", None)
+        stream = own(nbytes) if own is not None else None  # the torch stream the inner comm will run this one on
+        if stream is None:
+            e0.record()
+            work = call()
+            e1.record()
+            rec = [self.tag, kind, nbytes, e0, e1]
+            self.tl.records.append(rec)
+            return (work, rec if work is not None else None, self.tag)
+        issued = torch.cuda.Event()
+        issued.record()
+        stream.wait_event(issued)   # (what the inner comm does next: the start event sits behind the same dependency)
+        e0.record(stream)
+        work = call()
+        e1.record(stream)
+        self.tl.records.append([self.tag, kind, nbytes, e0, e1])
+        return (work, None, self.tag)
+
+    def all_reduce_async(self, t, average=False):
+        return self._issue("all_reduce", t.numel() * 4, lambda: self.inner.all_reduce_async(t, average))
+
+    def all_gather_async(self, out, t):
+        return self._issue("all_gather", out.numel() * 4, lambda: self.inner.all_gather_async(out, t))
+
+    def reduce_scatter_async(self, t):
+        return self._issue("reduce_scatter", t.numel() * 4, lambda: self.inner.reduce_scatter_async(t))
+
+    def wait(self, handle):
+        if handle is None:
+            return
+        work, rec, tag = handle
+        a, b = self.tl.event(), self.tl.event()
+        a.record()
+        self.inner.wait(work)
+        b.record()
+        self.tl.stalls.append((tag, a, b))
+        if rec is not None:
+            rec[4] = b  # a work object's collective ends (at the latest) where its wait() returns on the step's stream
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
 
 
 # --------------------------------------------------------------------------- product bindings
@@ -691,7 +877,21 @@ class HipKernels:
         ids = self.torch.nonzero(flags).reshape(-1)
         return ids, int(ids.numel())
 
+    def compact_ids(self, flags, n):
+        """Ascending ids of the non-zero flags in a list of n slots (the tail repeats the last id): built on the device,
+        nothing read back (idg_flags_compact_f32)."""
+        key = ("compact", flags.data_ptr())
+        buf = self._ws.get(key)
+        if buf is None or buf[0].shape[0] < n:
+            ids, ws = self.ops.flags_compact_raw(flags, n)
+            self._ws[key] = (ids, ws, flags)
+            return ids
+        ids = buf[0][:n]
+        self.ops.flags_compact_raw(flags, n, ids=ids, ws=buf[1])
+        return ids
+
     def touched_from_ids(self, eng, prep, ids, n):
+        ids = ids[:n]
         self.ops.bpr_touch_rows_raw(ids, ids, ids, 0, prep.touched_buf, clear_bits=eng.Ip)
         prep.touched = prep.touched_buf
         # n is known here (and bounded by the compact buffer): the products restricted to the touched items — layer K - 1's
@@ -730,7 +930,7 @@ class HipKernels:
 
     class _Prepared:
         __slots__ = ("own_users", "items", "touched_buf", "near_buf", "touched", "near", "bpr_bits", "ws", "rows_done", "done",
-                     "B", "busy", "units", "graphs", "args", "tables")
+                     "B", "busy", "units", "graphs", "args", "tables", "owner")
 
     def prepare(self, eng, gb):
         """Index-only work of a global batch on a side stream: the bitmap of the LOCAL user rows this rank owns in it,
@@ -740,9 +940,11 @@ class HipKernels:
         the guest rows.  Host cost matters here: raw stream handles and events allocated once."""
         torch, ops, lib = self.torch, self.ops, self.lib
         cap, n_users, n, d = eng.B, eng.Ug + eng.B, eng.Ug + eng.B + eng.Ip, eng.d
-        prep = next((p for p in self._pool if p.B == cap and not p.busy), None)
+        # (pooled per ENGINE: the cached arguments hold that engine's graph handles, slice tables and bitmap sizes — ADVICE r03)
+        prep = next((p for p in self._pool if p.owner is eng and p.B == cap and not p.busy), None)
         if prep is None:
             prep = self._Prepared()
+            prep.owner = eng
             words = lambda bits: torch.zeros((bits + 31) // 32 + 1, dtype=torch.int32, device=self.device)  # noqa: E731
             prep.own_users, prep.near_buf = words(eng.Ug), words(eng.Ug)
             prep.items, prep.touched_buf = words(eng.Ip), words(eng.Ip)
@@ -962,6 +1164,14 @@ class NativeComm:
     def _f32(self, t):
         assert t.is_cuda and t.dtype == self.torch.float32 and t.is_contiguous(), "NativeComm moves contiguous fp32 device tensors"
         return t.data_ptr()
+
+    def timed_stream(self, nbytes):
+        """The torch stream a collective of nbytes will run on when it is NOT the current one (TimelineComm), else None."""
+        if (self.world == 1 and not self._force) or nbytes < self.overlap_bytes:
+            return None
+        if self._own is None:
+            self._fork()  # creates the stream (the ring slot it takes is harmless)
+        return self._own
 
     def all_reduce_async(self, t, average=False):
         if self.world == 1 and not self._force:  # (the identity: nothing to enqueue; self_test() still runs RCCL itself)

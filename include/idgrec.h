@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 133 /* 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
+#define IDG_VERSION 134 /* 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+                           agreement without a host read-back), idg_shard_prepare validates its geometry.
+                           133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
                            _chain_store2 / _layer_mean, idg_grad_tail_adam_f32, idg_reduce_scatter_f32 */
 
@@ -556,6 +558,19 @@ int idg_grad_tail_adam_f32(const float* t, const float* g, float* G, const uint3
                            int64_t rows, int64_t d, int include_layer0, float cnt, int store_grad, float* param,
                            float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
                            int64_t step, void* stream);
+/* idg_rows_layer_mean_f32 for ANY number of earlier layers (GCN_layer is a free integer: configure/LightGCN.txt:12,
+ * models/LightGCN.py:43-48): out[ids[j], :] = ((...(terms[0] + terms[1]) + ...) + terms[n_terms-1])[ids[j]] + last[j]) / div,
+ * added left to right as torch.mean(torch.stack(...)) does; terms = HOST array of n_terms <= 15 device panels. */
+int idg_rows_layer_mean_n_f32(float* out, const int64_t* ids, int64_t count, const float* const* terms, int n_terms,
+                              const float* last, float div, int64_t d, void* stream);
+/* ids[0..cap) <- the indices i (ascending) with flags[i] != 0, flags a DEVICE float vector of n entries; slots past the
+ * last index repeat it (an empty vector: zeros); *count (device int64, nullable) <- the number of non-zero flags, which
+ * may exceed cap (the list then holds the first cap).  Asynchronous, no host read-back: the sharded step agrees on the
+ * item rows a batch touches (summed flag vectors) and moves a HOST-bounded number of rows through this
+ * list — a repeated row is gathered, reduced and scattered more than once with the same value.
+ * ws: idg_flags_compact_workspace_bytes(n). */
+size_t idg_flags_compact_workspace_bytes(int64_t n);
+int idg_flags_compact_f32(const float* flags, int64_t n, int64_t* ids, int64_t cap, int64_t* count, void* ws, void* stream);
 
 /* The index-only preparation of ONE global batch of the user-row-sharded step as one call (id-grec_amd/sharded.py
  * HipKernels.prepare did this in twelve: the host cost of a step is its calls).  On `side_stream`, ordered after

@@ -67,6 +67,9 @@ class OracleKernels:
         self.gather_rows(dst1, src1, idx)
 
     def scatter_rows(self, dst, idx, src):
+        # (a padded id list repeats its last id: every copy of that row must carry the same value)
+        rep = idx == idx[-1]
+        assert np.array_equal(src[rep], np.broadcast_to(src[rep][0], src[rep].shape), equal_nan=True)
         dst[idx] = src
 
     def _adjacent_items(self, eng, user_bits):
@@ -94,6 +97,12 @@ class OracleKernels:
     def nonzero_ids(self, flags):
         ids = np.nonzero(flags)[0].astype(np.int64)
         return ids, len(ids)
+
+    def compact_ids(self, flags, n):
+        """The device list of the product (idg_flags_compact_f32): n slots, ascending ids, the tail repeating the last."""
+        ids = np.nonzero(flags)[0].astype(np.int64)
+        assert 0 < len(ids) <= n, "the host-side bound must cover the touched items (%d > %d)" % (len(ids), n)
+        return np.concatenate([ids, np.full(n - len(ids), ids[-1], dtype=np.int64)])
 
     def touched_from_ids(self, eng, prep, ids, n):
         prep.touched = np.zeros(eng.Ip, dtype=bool)
@@ -288,7 +297,7 @@ def run(rank, world, port, mode, path, steps):
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         to_np = lambda a: a.cpu().numpy()  # noqa: E731
     n_slices = int(z["n_slices"]) if "n_slices" in z.files else 1
-    comm = sh.TorchComm(dist) if world > 1 or mode.startswith("cpu") else sh.NoComm()
+    comm = sh.TorchComm(dist) if world > 1 or mode.startswith("cpu") or mode == "gpu-timeline" else sh.NoComm()
     if mode == "cpu-deferred":
         comm = DeferredComm(comm)
     if mode == "gpu-async":
@@ -296,7 +305,13 @@ def run(rank, world, port, mode, path, steps):
     eng = sh.ShardedEngine(kern, comm, ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
                            batch_sparsity=mode not in ("gpu-dense", "cpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
                            live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None,
-                           live_rows_min_bytes=int(z["min_bytes"]) if "min_bytes" in z.files else 0)
+                           live_rows_min_bytes=int(z["min_bytes"]) if "min_bytes" in z.files else 0,
+                           global_user_degree=deg if ("degree_bound" in z.files and int(z["degree_bound"])) else None)
+    tl = None
+    if mode == "gpu-timeline":
+        tl = sh.StepTimeline(torch, world)
+        eng.comm = sh.TimelineComm(eng.comm, tl)
+        eng.timeline = tl
     Ug = hi - lo
     if mode.startswith("cpu"):
         eng.P[:Ug] = W0[lo:hi]
@@ -315,7 +330,13 @@ def run(rank, world, port, mode, path, steps):
         cur, nxt = nxt, (batch(s + 1) if s + 1 < steps else None)
         if nxt is not None and s % 2 == 0:  # every other step through the lookahead, the rest prepared in-step
             eng.prefetch(nxt[0])
+        if tl is not None:
+            ev = (tl.event(), tl.event())
+            ev[0].record()
         loss = eng.train_step(cur[0])
+        if tl is not None:
+            ev[1].record()
+            tl.steps.append(ev)
         losses.append(to_np(loss).copy())
     mine = cur[1][(cur[1][:, 0] >= lo) & (cur[1][:, 0] < hi)]
     touched = np.unique(mine[:, 0] - lo)  # local user rows of the LAST batch: the only FIN user rows guaranteed fresh
@@ -334,6 +355,11 @@ def run(rank, world, port, mode, path, steps):
     out = dict(P=strip(eng.P), FIN=strip(eng.FIN), G=strip(eng.G), losses=np.stack(losses), lo=lo, hi=hi, fin_rows=touched,
                fin_items=fin_items, own_items=own_items,
                touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1])
+    if tl is not None:
+        import json
+
+        torch.cuda.synchronize()
+        out["timeline"] = np.array(json.dumps(tl.summary()))
     if "test_users" in z.files:  # sharded evaluation: this rank's test users, its train rows as the exclusion lists
         tu, tptr, titems = z["test_users"], z["test_ptr"], z["test_items"]
         own = [(int(u), titems[tptr[j]:tptr[j + 1]].tolist()) for j, u in enumerate(tu) if lo <= u < hi]

@@ -235,6 +235,45 @@ def test_two_ranks_gloo_cpu_match_single_device(K, include0, d, n_slices, tmp_pa
     _check(p, outs, 3, rtol=1e-4, atol=2e-7)
 
 
+@pytest.mark.parametrize("K,include0,world", [(4, True, 2), (4, False, 2), (5, True, 3)])
+def test_more_than_three_layers(K, include0, world, tmp_path, golden_small):
+    """GCN_layer is a free integer (configure/LightGCN.txt:12, models/LightGCN.py:43): from four layers on the user-side
+    layer sum is carried from product to product (sum_in -> sum_out) and the item-side mean takes all its terms in one
+    rows kernel — left to right, torch.mean(torch.stack(...))'s order — on the golden graph and on the thin one (where
+    the restricted forms of layer K - 1 are active and unproduced rows are poisoned)."""
+    p = _problem(golden_small, K, include0, B=160, steps=3, d=64, n_slices=2)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    _check(p, _launch("cpu", path, 3, world=world), 3, rtol=1e-4, atol=2e-7)
+    p = _sparse_problem(K, include0, B=6, steps=3)
+    p["degree_bound"] = 1
+    path = str(tmp_path / "thin.npz")
+    np.savez(path, **p)
+    _check(p, _launch("cpu-deferred", path, 3, world=world), 3, rtol=1e-4, atol=2e-7)
+
+
+@pytest.mark.parametrize("K,include0,world", [(3, True, 2), (3, False, 3), (2, True, 2)])
+def test_touched_items_agreed_without_a_host_read_back(K, include0, world, tmp_path):
+    """With the global user degrees the number of touched item rows is BOUNDED on the host (the same bound on every
+    rank), the id list is built on the device into that many slots (its tail repeats the last id) and the exchanges move
+    that many rows: no host synchronisation in the step.  Same result; the exchanged row count is the
+    bound rounded up to 256, not the exact count."""
+    p = _sparse_problem(K, include0, B=6, steps=4)
+    p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("cpu-deferred", path, 4, world=world)
+    for o in outs:
+        assert int(o["touched_n"]) % 256 == 0 and 0 < int(o["touched_n"]) <= p["I"]
+    _check(p, outs, 4, rtol=1e-4, atol=2e-7)
+    # a bound beyond the compact buffer is known before the step starts: the panel form, on every rank alike
+    p["live_cap"] = 4
+    np.savez(path, **p)
+    outs = _launch("cpu", path, 2, world=world)
+    assert all(int(o["touched_n"]) == -1 for o in outs)
+    _check(p, outs, 2, rtol=1e-4, atol=2e-7)
+
+
 def test_first_backward_exchange_falls_back_to_the_panel(tmp_path, golden_small):
     """More live item rows in the first backward step than the compact buffer holds (here: a buffer of 4 rows): the
     step exchanges the sliced panel instead, same result."""
@@ -329,6 +368,58 @@ def test_restricted_forms_hip_kernels(K, include0, d, tmp_path):
     for o in outs:
         assert 0 < int(o["touched_n"]) < p["I"] // 2
     _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,include0,d", [(4, True, 64), (4, False, 256), (6, True, 64)])
+def test_more_than_three_layers_hip_kernels(K, include0, d, tmp_path, golden_small):
+    """K > 3 on the HIP kernels, two ranks on cuda:0: the epilogue chain of the user-side layer sum (in place: sum_in ==
+    sum_out) and idg_rows_layer_mean_n_f32; thin graph with the device-built id list as well."""
+    p = _problem(golden_small, K, include0, B=160, steps=3, d=d, n_slices=2)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    _check(p, _launch("gpu", path, 3), 3, rtol=1e-4, atol=2e-7, sparse=True)
+    p = _sparse_problem(K, include0, B=6, steps=3, d=d)
+    p["degree_bound"] = 1
+    path = str(tmp_path / "thin.npz")
+    np.savez(path, **p)
+    _check(p, _launch("gpu-async", path, 3), 3, rtol=1e-4, atol=2e-7, sparse=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,include0,d,world", [(3, True, 64, 2), (3, False, 256, 3), (2, True, 64, 2)])
+def test_touched_items_without_a_host_read_back_hip_kernels(K, include0, d, world, tmp_path):
+    """idg_flags_compact_f32 inside the step (two / three ranks on cuda:0): the id list of the touched items built on the
+    device into the host-side bound's slots, tail repeating the last id; the rows move through it twice per step."""
+    p = _sparse_problem(K, include0, B=6, steps=4, d=d)
+    p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("gpu-async", path, 4, world=world)
+    for o in outs:
+        assert int(o["touched_n"]) % 256 == 0 and 0 < int(o["touched_n"]) <= p["I"]
+    _check(p, outs, 4, rtol=1e-4, atol=2e-7, sparse=True)
+
+
+@pytest.mark.gpu
+def test_step_timeline_names_every_collective(tmp_path):
+    """StepTimeline / TimelineComm (what a multi-GPU bench line's `timeline` is made of): instrumented steps give the same
+    result, and every collective of the step shows up under its tag with bytes, time and the step stream's stall."""
+    import json
+
+    p = _sparse_problem(3, True, B=6, steps=3, d=64)
+    p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("gpu-timeline", path, 3)
+    _check(p, outs, 3, rtol=1e-4, atol=2e-7, sparse=True)
+    t = json.loads(str(outs[0]["timeline"]))
+    assert t["instrumented_steps"] == 3 and t["step_gpu_ms"] > 0 and t["compute_ms"] <= t["step_gpu_ms"]
+    tags = set(t["collectives"])
+    assert {"F1.panel", "flags", "F2.touched", "F3.items", "guest_rows", "B1.touched", "B2.panel", "B3.reduce_scatter",
+            "item_table.all_gather"} <= tags, tags
+    for v in t["collectives"].values():
+        assert v["bytes_per_step"] > 0 and v["calls_per_step"] > 0
 
 
 @pytest.mark.gpu
