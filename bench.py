@@ -82,6 +82,11 @@ def parse():
                    help="the multi-GPU lines' workload (synth-10M, d=256: BASELINE configs[4]) measured unsharded on ONE GPU in "
                         "this run: as `scale_point` of the default 1-GPU line (auto: only there) and as `single_gpu_reference` "
                         "/ `speedup_vs_1gpu` of a sharded line (auto: when the shape fits one GPU)")
+    p.add_argument("--worker", action="store_true",
+                   help="(internal) this process is a rank's WORKER: started by the rank's supervisor — the process the "
+                        "launcher started, which never touches the GPU — so that a hung collective can be ended from outside "
+                        "and the run retried once with --comm torch in fresh processes")
+    p.add_argument("--attempt", type=int, default=1, help="(internal) 1 = first try, 2 = the retry over torch.distributed")
     p.add_argument("--force-sharded", action="store_true",
                    help="run a multi-GPU path even at world size 1 (exercises the RCCL code path): the user-row-sharded one, "
                         "or the replicas with --parallel dp")
@@ -179,11 +184,27 @@ def cpu_baseline_scaled(args):
     return out
 
 
+BENCH_TIMEOUT_S = float(os.environ.get("IDG_BENCH_TIMEOUT", "1500"))  # both attempts of a multi-GPU run together
+
+
+def _error_line(args, world, message, **extra):
+    """The ONE JSON line of a multi-GPU run that did not produce a measurement."""
+    out = {"metric": "BPR triples/sec, LightGCN-%d dim=%s" % (args.layers, args.dim or 256), "value": None, "unit": "triples/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": args.workload or "synth-10M", "parallelism": "user-row shard x%d" % world}, "error": message}
+    out.update(extra)
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (torch.distributed.run,
     one per GPU) before this process has touched the GPU, relay rank 0's JSON line, leave with the launcher's exit code.
     (Never an exec: a process that has initialised HIP must not be replaced — and this one has not, but a child is the
-    form that is always safe.)"""
+    form that is always safe.)  The launcher runs in its own process group and under a deadline (the ranks' supervisors
+    keep their own, shorter ones): if it is still there after IDG_BENCH_TIMEOUT + 120 s the whole group is ended and a
+    JSON line with "error" is printed instead of nothing."""
+    import signal
     import socket
     import subprocess
 
@@ -193,11 +214,158 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    lines = [ln for ln in proc.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=BENCH_TIMEOUT_S + 120)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)  # the group this call created: launcher, supervisors, workers
+        except ProcessLookupError:
+            pass
+        stdout, _ = proc.communicate()
+        lines = [ln for ln in stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+        print(lines[-1] if lines else json.dumps(_error_line(args, args.gpus, "launcher still running after %.0f s: ended"
+                                                             % (BENCH_TIMEOUT_S + 120))), flush=True)
+        sys.exit(1)
+    lines = [ln for ln in stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
     if lines:
         print(lines[-1], flush=True)
     sys.exit(proc.returncode if proc.returncode or lines else 1)
+
+
+# ---- multi-GPU ranks: a supervisor per rank (the process the launcher started) and its worker (the process that runs)
+def _status_dir():
+    """A directory of THIS run's own: named after the launcher's pid (the parent of every rank's supervisor; the same
+    MASTER_PORT may serve the next run), handed to the workers through the environment."""
+    d = os.environ.get("IDG_BENCH_STATUS_DIR")
+    if not d:
+        d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "idg_bench_%d_%s_%d" % (os.getuid(), os.environ.get("MASTER_PORT", "0"),
+                                                                                  os.getppid()))
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    return d
+
+
+def _write(path, text):
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)  # readers never see half a file
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def worker_phase(args, name):
+    """Worker side: say where this rank is (the supervisor quotes it when the run is ended), and — tests only — stop
+    there for good: IDG_BENCH_TEST_HANG="rank:phase[:attempt]" stands in for a rank that never returns from a collective."""
+    rank = int(os.environ.get("RANK", "0"))
+    if args.worker:
+        _write(os.path.join(_status_dir(), "phase_a%d_r%d" % (args.attempt, rank)), name)
+    hang = os.environ.get("IDG_BENCH_TEST_HANG", "")
+    if hang:
+        parts = hang.split(":")
+        if parts[0] in ("*", str(rank)) and parts[1] == name and (len(parts) < 3 or int(parts[2]) == args.attempt):
+            print("[bench] rank %d: IDG_BENCH_TEST_HANG at phase %s" % (rank, name), file=sys.stderr, flush=True)
+            while True:
+                time.sleep(3600)
+
+
+def supervise_rank(args):
+    """What the launcher's rank process does for N > 1: it never touches the GPU.  It starts the rank's WORKER (this file
+    with --worker) as a child, watches it, its deadline and the other ranks' verdicts (files in a directory of this run's
+    own: one node, as the contract says), and
+      * on success relays rank 0's JSON line;
+      * when ANY rank fails or the deadline passes — a rank hung inside ncclCommInitRank or a collective keeps every other
+        rank waiting — ends its worker and starts the run ONCE more, in fresh processes, with --comm torch (torch's own
+        process group instead of the library's communicator) on a rendezvous of its own;
+      * when that fails too prints ONE JSON line with "error" (which attempt, which comm, the phase every rank had reached)
+        and leaves with a non-zero status — within IDG_BENCH_TIMEOUT seconds (default 1500: inside the driver's 1800)."""
+    import signal
+    import subprocess
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    sdir = _status_dir()
+    t_start = time.time()
+    child = [None]
+
+    def on_term(signum, frame):  # the launcher is ending the run: do not leave the worker behind
+        if child[0] is not None and child[0].poll() is None:
+            child[0].kill()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_term)
+    signal.signal(signal.SIGINT, on_term)
+    argv = [a for a in sys.argv[1:]]
+    summary = []
+    for attempt in (1, 2):
+        budget = min(0.6 * BENCH_TIMEOUT_S, 900.0) if attempt == 1 else max(BENCH_TIMEOUT_S - (time.time() - t_start) - 20.0, min(30.0, BENCH_TIMEOUT_S / 2))
+        deadline = time.time() + budget
+        env = dict(os.environ, IDG_BENCH_STATUS_DIR=sdir)
+        extra = ["--worker", "--attempt", str(attempt)]
+        if attempt == 2:
+            # a rendezvous of its own: the first attempt's keys stay in the launcher's store
+            env["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1 + (os.getuid() + int(os.environ["MASTER_PORT"])) % 89)
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"  # rank 0's worker hosts the store
+            extra += ["--comm", "torch"]
+        mine = os.path.join(sdir, "status_a%d_r%d" % (attempt, rank))
+        out_path = os.path.join(sdir, "stdout_a%d_r%d" % (attempt, rank))
+        with open(out_path, "wb") as out_f:
+            child[0] = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env, stdout=out_f)
+        verdict = None
+        while verdict is None:
+            rc = child[0].poll()
+            if rc is not None:
+                verdict = "done" if rc == 0 else "failed: worker exit status %d" % rc
+                break
+            others = [_read(os.path.join(sdir, "status_a%d_r%d" % (attempt, r))) for r in range(world) if r != rank]
+            if any(o is not None and o.startswith("failed") for o in others):
+                verdict = "failed: another rank failed"
+            elif time.time() > deadline:
+                verdict = "failed: no result after %.0f s (deadline of attempt %d)" % (budget, attempt)
+            else:
+                time.sleep(0.25)
+        if child[0].poll() is None:
+            child[0].kill()     # the exact process this supervisor started
+            child[0].wait()
+        _write(mine, verdict)
+        # every rank's verdict for this attempt (a rank that succeeded while another failed still goes round again: the
+        # measurement needs all of them)
+        t_wait = time.time() + 90
+        while time.time() < t_wait:
+            all_v = [_read(os.path.join(sdir, "status_a%d_r%d" % (attempt, r))) for r in range(world)]
+            if all(v is not None for v in all_v):
+                break
+            time.sleep(0.25)
+        all_v = [v or "unknown (no verdict)" for v in all_v]
+        phases = {str(r): (_read(os.path.join(sdir, "phase_a%d_r%d" % (attempt, r))) or "not started") for r in range(world)}
+        ok = all(v == "done" for v in all_v)
+        summary.append({"attempt": attempt, "comm": "torch" if attempt == 2 else args.comm, "verdicts": all_v,
+                        "phase_reached": phases, "seconds": round(time.time() - t_start, 1)})
+        if ok:
+            if rank == 0:
+                lines = [ln for ln in (_read(out_path) or "").splitlines() if ln.startswith("{")]
+                if not lines:
+                    print(json.dumps(_error_line(args, world, "rank 0's worker ended without a result line", attempts=summary)),
+                          flush=True)
+                    sys.exit(1)
+                line = json.loads(lines[-1])
+                if attempt == 2:
+                    line["retried"] = {"why": summary[0], "note": "first attempt ended by the watchdog; this line is the retry "
+                                                                "over torch.distributed's process group (--comm torch)"}
+                print(json.dumps(line), flush=True)
+            sys.exit(0)
+        print("[bench] rank %d: attempt %d failed: %s (phases %s)" % (rank, attempt, all_v, phases), file=sys.stderr, flush=True)
+    if rank == 0:
+        hung = [r for r, v in enumerate(summary[-1]["verdicts"]) if "deadline" in v or "another rank" in v]
+        print(json.dumps(_error_line(args, world, "both attempts failed (library communicator, then torch.distributed); ranks "
+                                                  "ended by the watchdog in the last attempt: %s" % hung, attempts=summary)),
+              flush=True)
+    sys.exit(1)
 
 
 def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None, before_engine=None):
@@ -266,6 +434,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         self_launch(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.worker and os.environ.get("IDG_BENCH_SUPERVISE", "1") != "0":
+        supervise_rank(args)  # never returns: the measurement runs in a worker process this one watches
+    worker_phase(args, "start")
     # stdout carries ONE line, the JSON.  Libraries print there too (RCCL announces its version on fd 1 when a
     # communicator comes up): hand fd 1 to stderr for the run and keep the real stdout for the result alone.
     sys.stdout.flush()
@@ -302,6 +473,7 @@ def main():
         import torch.distributed as dist_
 
         dist = dist_
+        worker_phase(args, "init_process_group")
         dist.init_process_group(args.backend)
 
     import idgrec_amd.ops as ops
@@ -318,7 +490,9 @@ def main():
         from idgrec_amd.replicated import run_replicated_bench
         from idgrec_amd.sharded import make_comm, run_sharded_bench
 
+        worker_phase(args, "make_comm")
         comm, comm_name = make_comm(dist, args.comm)
+        args.phase = lambda name: worker_phase(args, name)
         if form == "dp":
             out = run_replicated_bench(args, rank, world, dist, comm, comm_name)
         else:
@@ -337,14 +511,17 @@ def main():
                     out["replicas"]["what"] = ("NOT the headline: %d replicas of the yelp2018-shape graph, global batch %d x B — "
                                                "%d x the reference's batch_size per Adam step (trainer.py:36); one all-gather of "
                                                "gradient rows per step" % (world, world, world))
+        worker_phase(args, "cpu_baseline")
         if rank == 0 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_scaled(args)
         dist.barrier()
         if rank == 0:
             args.emit(out)
+        worker_phase(args, "teardown")
         if hasattr(comm, "close"):
             comm.close()
         dist.destroy_process_group()
+        worker_phase(args, "done")
         return
 
     wl = build_workload(args, rank, world)

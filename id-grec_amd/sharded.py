@@ -1350,6 +1350,8 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
 
     from . import synth as S
 
+    phase = getattr(args, "phase", None) or (lambda name: None)  # bench.py's supervisor quotes it if the run is ended
+    phase("graph")
     U, I, E = S.SHAPES[args.workload]
     d, K, B = args.dim, args.layers, args.batch
     # every rank needs the same global graph: large ones are drawn once per machine, then loaded
@@ -1357,7 +1359,8 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         users, items = S.generate_shared(U, I, E, 0, rank, dist.barrier)
     else:
         users, items = S.generate(U, I, E, seed=0)
-    bounds = partition_users_by_nnz(np.bincount(users, minlength=U), world)
+    user_degree = np.bincount(users, minlength=U)
+    bounds = partition_users_by_nnz(user_degree, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     ui, iu = shard_adjacency_from_edges(users, items, U, I, lo, hi)  # this rank's rows only: no global CSR
     nnz_global, n_edges = 2 * len(users), len(users)
@@ -1365,13 +1368,17 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     # critical path and a collective can start when its first slice exists: finer slices there
     n_slices = (8 if world >= 4 else 4) if I * d * 4 >= (256 << 20) else 1
     cuts = partition_users_by_nnz(np.bincount(items, minlength=I), n_slices)  # same cuts on every rank: global item degrees
-    need = (args.steps + args.warmup) * B
+    n_timeline = 3 if world > 1 or os.environ.get("IDG_BENCH_TIMELINE") == "1" else 0  # instrumented steps, after the timed ones
+    need = (args.steps + args.warmup + n_timeline) * B
     tri = S.draw_triples(args.seed, users, items, U, I, need)[0]  # the same global sequence on every rank
     edges = (users, items) if (rank == 0 and single_gpu_reference is not None) else None  # (rank 0 measures the 1-GPU point later)
     del users, items
+    phase("engine")
     kern = HipKernels()
+    # global_user_degree: the touched-item exchanges are sized by a host-side bound — no host synchronisation in the step
     eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
-                        n_slices=n_slices, item_cuts=cuts, store_grad=False)
+                        n_slices=n_slices, item_cuts=cuts, store_grad=False, global_user_degree=user_degree)
+    del user_degree
     nnz_ui, nnz_iu = len(ui[1]), len(iu[1])
     del ui, iu
     Ug = hi - lo
@@ -1385,7 +1392,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         del blk
     eng.item_rows(eng.P).copy_((torch.rand(I, d, generator=g) * 2 - 1) * bi)
     batches = [eng.make_batch(tri[i * B:(i + 1) * B, 0], tri[i * B:(i + 1) * B, 1], tri[i * B:(i + 1) * B, 2])
-               for i in range(args.steps + args.warmup)]
+               for i in range(args.steps + args.warmup + n_timeline)]
     last = args.warmup + args.steps - 1
 
     def step(i):
@@ -1394,10 +1401,12 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         return eng.train_step(batches[i])
 
     S.ramp_clocks()
+    phase("warmup")
     for i in range(args.warmup):
         step(i)
     dist.barrier()
     torch.cuda.synchronize()
+    phase("timed")
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
@@ -1409,6 +1418,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
                       device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    phase("after_timed")
     # coherence of the item table (updated by its owners, all-gathered): a checksum must agree on every rank
     chk = eng.item_rows(eng.P).double().sum().reshape(1)
     chk = chk if dist.get_backend() == "nccl" else chk.cpu()
@@ -1435,6 +1445,27 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
 
     t_iu = timed(item_side)
     n_touched = eng.touched_items[1] if eng.touched_items is not None else 0
+    # instrumented steps (every rank: they hold collectives): what each collective cost and how long the step's stream
+    # waited for it — the diagnosis of a line below the 6x target
+    timeline = None
+    if n_timeline:
+        phase("timeline")
+        tl = StepTimeline(torch, world)
+        eng._wait_item_table()
+        inner, eng.comm, eng.timeline = eng.comm, TimelineComm(eng.comm, tl), tl
+        for i in range(last + 1, last + 1 + n_timeline):
+            ev = (tl.event(), tl.event())
+            ev[0].record()
+            eng.train_step(batches[i])
+            ev[1].record()
+            tl.steps.append(ev)
+        eng._wait_item_table()
+        torch.cuda.synchronize()
+        eng.comm, eng.timeline = inner, None
+        timeline = tl.summary()
+        timeline["touched_item_rows_exchanged"] = eng.touched_items[1] if eng.touched_items is not None else 0
+        timeline["touched_item_agreement"] = ("device-built id list sized by a host-side bound: no host synchronisation"
+                                              if eng.user_degree is not None else "length read back: one host synchronisation")
     rows_form = n_touched > 0
     # panel-sized exchanges per step: forward layers 1..K-2, backward steps 2..K-1 as all-reduces (+ layer K-1 and the
     # first backward step when the touched-item form does not apply), and the last backward step as reduce-scatter +
@@ -1470,6 +1501,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
             "loss_last": [float(x) for x in eng.loss.cpu()],
             "host_issue_ms_per_step": t_enqueue / args.steps * 1e3,
             "item_table_coherent": bool(c_lo.item() == c_hi.item()),
+            "timeline": timeline,
             # per-step work every rank carries whatever N is (what caps the speed-up before any communication): O(I + B d)
             "replicated_bytes_per_step_per_rank": eng.replicated_bytes_per_step(),
             "roofline": {
@@ -1491,6 +1523,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         }
     del eng, batches, kern
     torch.cuda.empty_cache()
+    phase("single_gpu_reference")
     if single_gpu_reference is not None:
         # the SAME workload unsharded on ONE GPU, measured in this run (rank 0; the other ranks wait at the barrier)
         ref = None

@@ -79,3 +79,43 @@ def test_gpus_flag_launches_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_line(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["item_table_coherent"] is True and "speedup_vs_1gpu" not in d
+
+
+def test_hung_ranks_end_in_a_json_error_line():
+    """A multi-GPU run whose ranks never come back (IDG_BENCH_TEST_HANG stands in for a rank stuck in ncclCommInitRank or
+    a collective — here every rank stops at its first phase, before anything touches a GPU, so this runs anywhere): each
+    rank's supervisor ends its worker at the deadline, the run is tried once more with --comm torch in fresh processes,
+    and when that hangs too rank 0 prints ONE JSON line with "error", both attempts and the phase every rank had reached,
+    and the launcher exits non-zero — within the timeout, instead of leaving the driver to its 1800 s kill."""
+    import time
+
+    env = dict(_env(), IDG_BENCH_TEST_HANG="*:start", IDG_BENCH_TIMEOUT="16")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--workload", "medium", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert r.returncode != 0
+    d = _one_line(r.stdout)
+    assert d["value"] is None and d["n_gpus"] == 2 and "both attempts failed" in d["error"]
+    assert [a["attempt"] for a in d["attempts"]] == [1, 2] and [a["comm"] for a in d["attempts"]] == ["auto", "torch"]
+    for a in d["attempts"]:
+        assert all("deadline" in v or "another rank" in v for v in a["verdicts"]), a
+        assert a["phase_reached"] == {"0": "start", "1": "start"}
+    assert took < 120, took
+
+
+@pytest.mark.gpu
+def test_a_hung_first_attempt_is_retried_over_torch_distributed():
+    """Rank 1 hangs in the warm-up of the FIRST attempt only (two ranks sharing the GPU over gloo): the watchdog ends the
+    attempt, the retry in fresh processes with --comm torch measures, and the line says it was a retry and why."""
+    env = dict(_env(), IDG_BENCH_TEST_HANG="1:warmup:1", IDG_BENCH_TIMEOUT="150")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--parallel", "shard", "--workload",
+                        "medium", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--scale-point", "off"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["item_table_coherent"] is True
+    why = d["retried"]["why"]
+    assert why["attempt"] == 1 and why["phase_reached"]["1"] == "warmup" and any("deadline" in v for v in why["verdicts"])
+    t = d["timeline"]
+    assert t["instrumented_steps"] == 3 and "F1.panel" in t["collectives"] and t["host_sync_ms"] == 0.0
