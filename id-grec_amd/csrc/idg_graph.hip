@@ -95,6 +95,8 @@ struct LongRow {
 constexpr int EPI_PLAIN = 0;
 constexpr int EPI_NOISE = 1;  // SimGCL / XSimGCL perturbation of t = A.X
 constexpr int EPI_ADAM = 2;   // the value stored to sum_out is a finished gradient: apply the Adam update to its row
+constexpr int EPI_ACT = 3;    // t = tanh(t) (act 1) or t *= 1 - act_src[r]^2 (act 2: tanh's derivative) before anything is stored:
+//                               EGCF's layers (models/EGCF.py:46-84: activation_layer(torch.sparse.mm(...))) and their backward
 
 struct Epilogue {
   float* Y;             // [n_rows, ldy]   (nullable)
@@ -119,6 +121,10 @@ struct Epilogue {
   float* adam_v;
   float adam_w1, adam_beta2, adam_w2, adam_step_size, adam_bc2_sqrt, adam_eps;
   int adam_discard;     // the finished gradient feeds the update and is NOT written to sum_out (4 B / element less)
+  // EPI_ACT: applied to t = A.X (+ addend) of rows r < act_rows (0: every row), before Y / sum_out see it
+  int act;              // 0 none, 1 t = tanh(t), 2 t = t * (1 - act_src[r]^2)
+  const float* act_src; // act 2: the SAVED tanh output of the forward layer (same layout as Y)
+  int64_t act_rows;
 };
 
 }  // namespace
@@ -304,6 +310,15 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, in
   const int64_t o = r * ep.ldy + off;
   const bool live = ep.mask == nullptr || mask_bit(ep.mask, r);  // x + 0 == x: skipping a zero row is exact
   if (ep.addend && live) acc = add4(acc, *reinterpret_cast<const float4*>(ep.addend + o));
+  if (EPI == EPI_ACT && (ep.act_rows == 0 || r < ep.act_rows)) {
+    if (ep.act == 1) {
+      acc.x = tanhf(acc.x), acc.y = tanhf(acc.y), acc.z = tanhf(acc.z), acc.w = tanhf(acc.w);
+    } else if (ep.act == 2) {  // d tanh(z) / dz = 1 - tanh(z)^2, with tanh(z) read back (torch's tanh_backward: g * (1 - y*y))
+      const float4 y = *reinterpret_cast<const float4*>(ep.act_src + o);
+      acc.x = acc.x * (1.0f - y.x * y.x), acc.y = acc.y * (1.0f - y.y * y.y);
+      acc.z = acc.z * (1.0f - y.z * y.z), acc.w = acc.w * (1.0f - y.w * y.w);
+    }
+  }
   if (ep.Y) *reinterpret_cast<float4*>(ep.Y + o) = acc;
   if (ep.sum_out) {
     float4 s = acc;
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void spmm_tile_kernel(const Tile* __re
 // prefix-scanned and compacted in LDS, the vrow pointers are remapped, and the ordinary sequential
 // walk then runs over the live entries only.  Dropping a dead entry is exact (fmaf(v, +0, acc) ==
 // acc), the survivors keep their order, so results are bit-identical to the dense form.
-template <int LPR, int NB, bool FUSED>
+template <int LPR, int NB, bool FUSED, int EPI = EPI_PLAIN>
 __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __restrict__ tiles,
                                                                  const int64_t* __restrict__ vptr,
                                                                  const int32_t* __restrict__ vtgt,
@@ -724,7 +739,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   const int l = tid % LPR;
   int v = g;
   while (v < nv) {
-    do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI_PLAIN, FUSED>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx,
+    do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI, FUSED>(s_cv, s_pre[s_ptr[v]], s_pre[s_ptr[v + 1]], s_tgt[v], l, X, ldx, partials, d, ep, fx,
                                       s_part);
     int nxt = 0;
     if (l == 0) nxt = atomicAdd(&s_next, 1);
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   }
   if (t.n_local > 0) {
     __syncthreads();
-    combine_local<LPR, NB, EPI_PLAIN, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, nullptr, nullptr);
+    combine_local<LPR, NB, EPI, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, nullptr, nullptr);
   }
 }
 
@@ -1102,7 +1117,8 @@ __global__ __launch_bounds__(64) void spmm_xl_kernel(const int32_t* __restrict__
       acc = x_mask ? walk_masked<8>(cv + c, 0, len, X + off, ldx, x_mask, acc) : walk<8>(cv + c, 0, len, X + off, ldx, acc);
     }
     if (ep.noise_eps != 0.f) acc = perturb(ep, tgt, b * LPR + l, noise_row_scale<LPR, NB>(ep, tgt, l), acc);
-    epilogue_store(ep, tgt, off, acc);
+    if (ep.act) epilogue_store<EPI_ACT>(ep, tgt, off, acc);
+    else epilogue_store(ep, tgt, off, acc);
   }
 }
 
@@ -1143,6 +1159,8 @@ __global__ __launch_bounds__(FIX_WAYS * LPR) void spmm_fixup_kernel(const LongRo
       if (ep.noise_eps != 0.f) acc = perturb(ep, lr.row, b * LPR + l, noise_row_scale<LPR, NB>(ep, lr.row, l), acc);
       if (ep.adam_p)
         epilogue_store<EPI_ADAM>(ep, lr.row, off, acc);
+      else if (ep.act)
+        epilogue_store<EPI_ACT>(ep, lr.row, off, acc);
       else
         epilogue_store<EPI_PLAIN>(ep, lr.row, off, acc);
     }
@@ -1174,6 +1192,10 @@ __device__ __forceinline__ void generic_epilogue(const Epilogue& ep, int64_t r, 
   const int64_t o = r * ep.ldy + f;
   const bool live = ep.mask == nullptr || mask_bit(ep.mask, r);
   if (ep.addend && live) acc += ep.addend[o];
+  if (ep.act && (ep.act_rows == 0 || r < ep.act_rows)) {
+    if (ep.act == 1) acc = tanhf(acc);
+    else acc = acc * (1.0f - ep.act_src[o] * ep.act_src[o]);
+  }
   if (ep.Y) ep.Y[o] = acc;
   if (ep.sum_out) {
     float sres = acc;
@@ -1234,6 +1256,20 @@ __global__ __launch_bounds__(BLOCK) void perturb_rows_kernel(const float* __rest
     const float4 t = *reinterpret_cast<const float4*>(X + o);
     *reinterpret_cast<float4*>(Y + o) = perturb(ep, r, b * LPR + l, scale, t);
   }
+}
+
+// out[r] = g[r] * (1 - y[r]^2) at the rows flagged in `rows` (torch's tanh_backward at the batch's rows: where EGCF's
+// backward starts, models/EGCF.py:60 under autograd); other rows untouched.  One thread per 4 features.
+__global__ __launch_bounds__(BLOCK) void rows_tanh_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                              const uint32_t* __restrict__ rows, int64_t n, int64_t d4,
+                                                              float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n * d4) return;
+  const int64_t r = i / d4;
+  if (rows && !mask_bit(rows, r)) return;
+  const float4 a = reinterpret_cast<const float4*>(g)[i], b = reinterpret_cast<const float4*>(y)[i];
+  reinterpret_cast<float4*>(out)[i] = make_float4(a.x * (1.0f - b.x * b.x), a.y * (1.0f - b.y * b.y), a.z * (1.0f - b.z * b.z),
+                                                  a.w * (1.0f - b.w * b.w));
 }
 
 // The stand-alone perturbation for any width: one wave per row.
@@ -1362,6 +1398,9 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       if (ep.noise_eps != 0.f)
         hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_NOISE>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
                            X, ldx, partials, d, ep, fx, g->d_local, nullptr);
+      else if (ep.act && !x_mask)
+        hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_ACT>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt, g->d_cv,
+                           X, ldx, partials, d, ep, fx, g->d_local, nullptr);
       else if (x_mask)  // ... of a panel whose live rows are flagged too (a backward product between two small row sets)
         hipLaunchKernelGGL((spmm_units_kernel<LPR, NB, EPI_PLAIN, true>), ugrid, ublock, 0, st, units, ucap, g->d_vptr, g->d_vtgt,
                            g->d_cv, X, ldx, partials, d, ep, fx, g->d_local, x_mask);
@@ -1371,7 +1410,14 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       IDG_HIP(hipGetLastError());
       return IDG_OK;
     }
-    if (out_mask && ep.noise_eps != 0.f) {  // flagged rows of a perturbed layer (the noise of a row depends on that row only)
+    if (out_mask && ep.act && !x_mask) {  // flagged rows of an activated layer (EGCF's last forward layer)
+      if (fused_fix)
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true, EPI_ACT>), grid, block, 0, st, tile_order, g->d_vptr,
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
+      else
+        hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false, EPI_ACT>), grid, block, 0, st, tile_order, g->d_vptr,
+                           g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
+    } else if (out_mask && ep.noise_eps != 0.f) {  // flagged rows of a perturbed layer (the noise of a row depends on that row only)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, true, EPI_NOISE>), grid, block, 0, st, tile_order, g->d_vptr,
                            g->d_vtgt, g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
@@ -1392,6 +1438,13 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       else
         hipLaunchKernelGGL((spmm_tile_rows_kernel<LPR, NB, false>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
                            g->d_slot_row, g->d_cv, X, ldx, partials, d, ep, fx, out_mask, g->d_local, nullptr);
+    } else if (x_mask && ep.act) {  // sparse-input form with the activation's derivative in the epilogue
+      if (fused_fix)
+        hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, true, EPI_ACT>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask, g->d_local);
+      else
+        hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, false, EPI_ACT>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
+                           g->d_cv, X, ldx, partials, d, ep, fx, x_mask, g->d_local);
     } else if (x_mask) {  // sparse-input form (first backward layer)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
@@ -1403,6 +1456,8 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       IDG_TILE(8, true, 1, EPI_NOISE);
     } else if (ep.adam_p) {  // last backward product of a training step: Adam applied to each finished gradient row
       IDG_TILE(8, true, 1, EPI_ADAM);
+    } else if (ep.act) {     // EGCF: tanh / its derivative applied to each finished row
+      IDG_TILE(8, true, 1, EPI_ACT);
     } else switch (g->variant) {
       case 0: IDG_TILE(8, false, 1, EPI_PLAIN); break;
       case 1: IDG_TILE(8, true, 1, EPI_PLAIN); break;
@@ -2139,6 +2194,14 @@ int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d,
   ep.div = e->div;
   ep.accumulate = e->accumulate;
   ep.mask = e->mask;
+  if (e->act) {
+    IDG_REQUIRE(e->act == IDG_ACT_TANH || e->act == IDG_ACT_TANH_BWD, "idg_spmm_epi_f32: act is 0, IDG_ACT_TANH or IDG_ACT_TANH_BWD");
+    IDG_REQUIRE(e->act != IDG_ACT_TANH_BWD || (e->act_src && (uintptr_t)e->act_src % 16 == 0),
+                "idg_spmm_epi_f32: IDG_ACT_TANH_BWD needs act_src (the saved tanh outputs, 16-byte aligned)");
+    IDG_REQUIRE(e->act_rows >= 0 && !e->adam_param, "idg_spmm_epi_f32: act_rows >= 0; an activation and Adam do not share a launch");
+    IDG_REQUIRE(!(out_rows && x_rows), "idg_spmm_epi_f32: an activation with out_rows AND x_rows is not built");
+    ep.act = e->act, ep.act_src = e->act_src, ep.act_rows = e->act_rows;
+  }
   if (e->adam_param) {
     IDG_REQUIRE(e->sum_out && e->adam_exp_avg && e->adam_exp_avg_sq && e->adam_step >= 1,
                 "idg_spmm_epi_f32: the Adam epilogue needs sum_out (the gradient), both moments and a 1-based step");
@@ -2150,6 +2213,18 @@ int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d,
     ep.adam_discard = e->adam_discard_grad != 0;
   }
   return spmm_dispatch(g, X, ldx, d, ws, ep, (hipStream_t)stream, x_rows, out_rows);
+}
+
+int idg_rows_tanh_bwd_f32(const float* grad, const float* y, const uint32_t* rows, int64_t n, int64_t d, float* out,
+                          void* stream) {
+  IDG_REQUIRE(grad && y && out && n >= 0 && d > 0 && d % 4 == 0, "idg_rows_tanh_bwd_f32: bad argument (d must be a multiple of 4)");
+  IDG_REQUIRE(((uintptr_t)grad | (uintptr_t)y | (uintptr_t)out) % 16 == 0, "idg_rows_tanh_bwd_f32: panels must be 16-byte aligned");
+  if (n == 0) return IDG_OK;
+  const int64_t d4 = d / 4, total = n * d4;
+  hipLaunchKernelGGL(rows_tanh_bwd_kernel, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, grad,
+                     y, rows, n, d4, out);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
 }
 
 int idg_spmm_noise_f32(const idg_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, const uint32_t* out_rows,

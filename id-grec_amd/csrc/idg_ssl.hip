@@ -35,6 +35,7 @@ constexpr int GS = 8;   // split-K slices of the gradient products
 struct SslWs {
   uint32_t* bitmap;  // [(n+31)/32]
   int32_t* idx;      // [2B] ascending panel rows: the user set, then the item set
+  int32_t* idx2;     // [2B] view 2's rows when they differ from view 1's (idg_infonce_cross_f32), else == idx
   int32_t* counts;   // [2] sizes of the two sets (+2 pad)
   float* An;         // [2 views][2B][d] normalised rows
   float* den;        // [2 views][2B]   max(||x||, 1e-12)
@@ -59,6 +60,7 @@ SslWs ssl_layout(void* base, int64_t n, int64_t B, int64_t d) {
   };
   w.bitmap = reinterpret_cast<uint32_t*>(take((size_t)((n + 31) / 32) * 4));
   w.idx = reinterpret_cast<int32_t*>(take((size_t)2 * B * 4));
+  w.idx2 = reinterpret_cast<int32_t*>(take((size_t)2 * B * 4));
   w.counts = reinterpret_cast<int32_t*>(take(16));
   w.An = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
   w.den = reinterpret_cast<float*>(take((size_t)2 * 2 * B * 4));
@@ -137,17 +139,32 @@ __global__ __launch_bounds__(BLOCK) void ssl_copy_ids_kernel(const int64_t* __re
   if (i == 0) counts[0] = counts[1] = (int32_t)B;
 }
 
+// ---- cross form (models/EGCF.py:103: get_InfoNCE_loss(user_embedding, pos_embedding)): ONE set of B rows whose view-1
+// rows are the batch users and whose view-2 rows are the batch's positive items, raw ids in batch order
+__global__ __launch_bounds__(BLOCK) void ssl_cross_ids_kernel(const int64_t* __restrict__ users,
+                                                              const int64_t* __restrict__ items, int64_t B,
+                                                              int64_t num_users, int32_t* __restrict__ idx,
+                                                              int32_t* __restrict__ idx2, int32_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < B) {
+    idx[i] = (int32_t)users[i];
+    idx2[i] = (int32_t)(num_users + items[i]);
+  }
+  if (i == 0) counts[0] = (int32_t)B, counts[1] = 0;
+}
+
 // ---- normalise: one wave per (compact row, view)
 __global__ __launch_bounds__(BLOCK) void ssl_normalize_kernel(const float* __restrict__ view1,
                                                               const float* __restrict__ view2, int64_t d,
                                                               const int32_t* __restrict__ idx,
+                                                              const int32_t* __restrict__ idx2,
                                                               const int32_t* __restrict__ counts, int64_t B,
                                                               float* __restrict__ An, float* __restrict__ den) {
   const int lane = threadIdx.x % WAVE;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int v = blockIdx.y;
   if (r >= counts[0] + counts[1]) return;
-  const float* x = (v == 0 ? view1 : view2) + (int64_t)idx[r] * d;
+  const float* x = (v == 0 ? view1 : view2) + (int64_t)(v == 0 ? idx : idx2)[r] * d;
   float ss = 0.f;
   for (int64_t f = lane; f < d; f += WAVE) ss += x[f] * x[f];
   ss = wave_sum(ss);
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void ssl_loss_kernel(const float* __restrict
     if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss[set] = s[0] / (float)m;
+  if (threadIdx.x == 0) loss[set] = m > 0 ? s[0] / (float)m : 0.f;  // (the cross form has one set)
 }
 
 // ---- gradients with respect to the normalised rows: the two products  sum_k P_ik b_k  (side 0, rows i) and
@@ -322,29 +339,35 @@ __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restric
                                                           const float* __restrict__ Gp, const float* __restrict__ invttl,
                                                           const float* __restrict__ w, int64_t d, int64_t B,
                                                           const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ idx2,
                                                           const int32_t* __restrict__ counts, int dedup, float scale,
                                                           int accumulate, int both_views, float* g1, float* g2) {
   const int lane = threadIdx.x % WAVE;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int cu = counts[0], total = cu + counts[1];
   if (r >= total) return;
-  const int32_t id = idx[r];
   const int s_lo = r < cu ? 0 : cu, s_hi = r < cu ? cu : total;  // this row's set
-  // g1 == g2 (both_views): one wave adds both views' gradients into the shared panel row, view 1 first
+  // g1 == g2 (both_views): one wave adds both views' gradients into the shared panel, view 1 first.  The two views'
+  // rows are the same panel row (idx2 == idx) or different ones (the cross form, which always accumulates)
   const int v_lo = both_views ? 0 : blockIdx.y, v_hi = both_views ? 2 : blockIdx.y + 1;
   bool fresh = !accumulate;  // the first value written to a row that is not accumulated into replaces its content
-  bool first = true;
   for (int v = v_lo; v < v_hi; ++v) {
     float* out = v == 0 ? g1 : g2;
     if (!out) continue;
+    const int32_t* ix = v == 0 ? idx : idx2;
+    const int32_t id = ix[r];
     float* o = out + (int64_t)id * d;
-    // occurrences of `id` in the set, ascending; a de-duplicated set has exactly one: r itself
-    for (int c0 = dedup ? (int)r : s_lo; c0 < (dedup ? (int)r + 1 : s_hi); c0 += WAVE) {
-      unsigned long long match = dedup ? 1ull : __ballot(c0 + lane < s_hi && idx[c0 + lane] == id);
+    bool first = true, mine = true;
+    // occurrences of `id` in this view's list of the set, ascending; a de-duplicated set has exactly one: r itself
+    for (int c0 = dedup ? (int)r : s_lo; mine && c0 < (dedup ? (int)r + 1 : s_hi); c0 += WAVE) {
+      unsigned long long match = dedup ? 1ull : __ballot(c0 + lane < s_hi && ix[c0 + lane] == id);
       while (match) {
         const int64_t j = c0 + __builtin_ctzll(match);
         match &= match - 1;
-        if (first && j != r) return;  // an earlier occurrence owns this panel row
+        if (first && j != r) {  // an earlier occurrence owns this panel row (for this view)
+          mine = false;
+          break;
+        }
         first = false;
         const float* y = An + ((int64_t)v * 2 * B + j) * d;            // this view's normalised row
         const float* other = An + ((int64_t)(1 - v) * 2 * B + j) * d;  // b_i for view 1, a_k for view 2
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restric
         fresh = false;
       }
     }
-    if (!both_views) fresh = !accumulate;
+    if (!both_views || idx2 != idx) fresh = !accumulate;
   }
 }
 
@@ -380,16 +403,22 @@ size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d) {
   return ssl_layout(nullptr, n, B, d).bytes;
 }
 
-int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
-                         const int64_t* items, int64_t B, int64_t num_users, int dedup, float temperature, float* loss,
-                         float* g1, float* g2, float grad_scale, int accumulate, void* ws, void* stream) {
-  IDG_REQUIRE(view1 && view2 && users && items && loss && ws, "idg_infonce_pair_f32: NULL argument");
-  IDG_REQUIRE(n > 0 && d > 0 && B > 0 && num_users >= 0 && num_users <= n, "idg_infonce_pair_f32: bad sizes");
-  IDG_REQUIRE(B <= 46340, "idg_infonce_pair_f32: batch of %lld ids is too large for the in-batch logits matrix", (long long)B);
-  IDG_REQUIRE(temperature > 0.f, "idg_infonce_pair_f32: temperature must be positive");
+static int infonce_impl(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
+                        const int64_t* items, int64_t B, int64_t num_users, int dedup, int cross, float temperature, float* loss,
+                        float* g1, float* g2, float grad_scale, int accumulate, void* ws, void* stream, const char* who) {
+  IDG_REQUIRE(view1 && view2 && users && items && loss && ws, "%s: NULL argument", who);
+  IDG_REQUIRE(n > 0 && d > 0 && B > 0 && num_users >= 0 && num_users <= n, "%s: bad sizes", who);
+  IDG_REQUIRE(B <= 46340, "%s: batch of %lld ids is too large for the in-batch logits matrix", who, (long long)B);
+  IDG_REQUIRE(temperature > 0.f, "%s: temperature must be positive", who);
   hipStream_t st = (hipStream_t)stream;
   const SslWs w = ssl_layout(ws, n, B, d);
-  if (dedup) {
+  const int32_t* idx2 = w.idx;
+  const unsigned sets = cross ? 1u : 2u;
+  if (cross) {
+    hipLaunchKernelGGL(ssl_cross_ids_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, items, B,
+                       num_users, w.idx, w.idx2, w.counts);
+    idx2 = w.idx2;
+  } else if (dedup) {
     IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)((n + 31) / 32) * 4, st));
     // rows of the batch's users and (positive) items; the third id list is not used here: pass the items twice
     int rc = idg_bpr_touch_rows(users, items, items, B, num_users, w.bitmap, stream);
@@ -399,24 +428,41 @@ int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int6
     hipLaunchKernelGGL(ssl_copy_ids_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, items, B,
                        num_users, w.idx, w.counts);
   }
-  const unsigned row_blocks = (unsigned)((2 * B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
-  hipLaunchKernelGGL(ssl_normalize_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, view1, view2, d, w.idx, w.counts, B,
+  const int64_t rows_max = cross ? B : 2 * B;
+  const unsigned row_blocks = (unsigned)((rows_max + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  hipLaunchKernelGGL(ssl_normalize_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, view1, view2, d, w.idx, idx2, w.counts, B,
                      w.An, w.den);
   const unsigned tb = (unsigned)((B + TS - 1) / TS);
   const float inv_t = 1.0f / temperature;
-  hipLaunchKernelGGL(ssl_logits_kernel, dim3(tb, tb, 2), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
-  hipLaunchKernelGGL(ssl_rowstat_kernel, dim3((unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE)), 2), dim3(BLOCK), 0, st,
+  hipLaunchKernelGGL(ssl_logits_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
+  hipLaunchKernelGGL(ssl_rowstat_kernel, dim3((unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE)), sets), dim3(BLOCK), 0, st,
                      w.P, B, w.counts, inv_t, 10e-6f, w.invttl, w.w, w.lossrow);
-  hipLaunchKernelGGL(ssl_loss_kernel, dim3(2), dim3(BLOCK), 0, st, w.lossrow, w.counts, loss);
+  hipLaunchKernelGGL(ssl_loss_kernel, dim3(sets), dim3(BLOCK), 0, st, w.lossrow, w.counts, loss);
   if (g1 || g2) {
-    hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 4), dim3(BLOCK), 0, st, w.An, w.P, d, B,
-                       w.counts, w.invttl, w.w, w.G);
+    hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 2 * sets), dim3(BLOCK), 0, st, w.An, w.P, d,
+                       B, w.counts, w.invttl, w.w, w.G);
     const int both = (g1 && g1 == g2) ? 1 : 0;  // one panel for both views: a single wave per row adds them in turn
     hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, both ? 1 : 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w,
-                       d, B, w.idx, w.counts, dedup ? 1 : 0, grad_scale, accumulate ? 1 : 0, both, g1, g2);
+                       d, B, w.idx, idx2, w.counts, (dedup && !cross) ? 1 : 0, grad_scale, accumulate ? 1 : 0, both, g1, g2);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
+}
+
+int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
+                         const int64_t* items, int64_t B, int64_t num_users, int dedup, float temperature, float* loss,
+                         float* g1, float* g2, float grad_scale, int accumulate, void* ws, void* stream) {
+  return infonce_impl(view1, view2, n, d, users, items, B, num_users, dedup, 0, temperature, loss, g1, g2, grad_scale,
+                      accumulate, ws, stream, "idg_infonce_pair_f32");
+}
+
+int idg_infonce_cross_f32(const float* view, int64_t n, int64_t d, const int64_t* users, const int64_t* items, int64_t B,
+                          int64_t num_users, float temperature, float* loss, float* g, float grad_scale, void* ws,
+                          void* stream) {
+  // a_i = normalize(view[users[i]]), b_i = normalize(view[num_users + items[i]]), raw ids in batch order; the gradients
+  // of both sides are ADDED into g's rows (users' and items' rows are disjoint ranges of the panel)
+  return infonce_impl(view, view, n, d, users, items, B, num_users, 0, 1, temperature, loss, g, g, grad_scale, 1, ws, stream,
+                      "idg_infonce_cross_f32");
 }
 
 }  // extern "C"

@@ -1,0 +1,126 @@
+"""Fused, autograd-free training step of EGCF's `parallel` encoder (reference: models/EGCF.py:64-111 +
+utility/utility_train/trainer.py:42-56) as a fixed chain of C-ABI calls on preallocated panels — what engine.py is for the
+LightGCN family (61 % of an EGCF epoch was stock ATen kernels: tanh, cat, gathers, three InfoNCE terms and
+their autograd mirrors).
+
+Forward (n = U + I rows, users first; E = the item table, the ONLY parameter):
+    X0 = [tanh(R.E) ; E]                R = D_u^-1/2 R D_i^-1/2 (rectangular), tanh in the product's epilogue
+    X_k = tanh(A . X_{k-1}),  k = 1..K  A = the symmetric normalised adjacency; TOT = ((X_1 + X_2) + ...) + X_K
+    loss = BPR(TOT) + reg(E[pos], E[neg]) + ssl_lambda (InfoNCE(u, u) + InfoNCE(p, p) + InfoNCE(u, p))   raw batch rows
+The last layer and TOT are produced at the batch's rows only (their live-unit list).  Backward, with g = d loss / d TOT
+(stored at the batch's rows by the BPR scatter, the InfoNCE terms added into the same rows):
+    Z_K = g . (1 - X_K^2)                                     rows kernel, batch rows
+    Z_k = (A . Z_{k+1} + g) . (1 - X_k^2),  k = K-1..1        tanh' in the epilogue; the first product reads <= 3B live rows
+    W   = A . Z_1 (+ reg rows);  W[:U] *= 1 - X0[:U]^2        one launch: the derivative applies to the user rows only
+    dE  = R^T . W[:U] + W[U:]  -> Adam                         epilogue Adam on the item table, gradient not stored
+No torch arithmetic runs in a step (the three InfoNCE losses are summed by a 3-element torch.sum: the only stock kernel)."""
+import torch
+
+from . import native, ops
+
+
+class EgcfEngine:
+    def __init__(self, graph, user_graph, num_users, num_items, dim, n_layers, item_weight, reg_lambda, ssl_lambda,
+                 temperature, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, store_grad=False):
+        """graph: symmetric ops.Graph on [n, n]; user_graph: rectangular ops.Graph [U, I] with its transposed handle
+        (.T); item_weight: [I, d] initial table (copied into this engine's storage: see item_table())."""
+        self.G, self.R = graph, user_graph
+        self.U, self.I, self.d, self.K = int(num_users), int(num_items), int(dim), int(n_layers)
+        self.n = self.U + self.I
+        if not 1 <= self.K <= 4:
+            raise ValueError("EgcfEngine: 1 <= GCN_layer <= 4 (the layer sum is formed by the last product's epilogue)")
+        self.reg_lambda, self.ssl_lambda, self.temperature = float(reg_lambda), float(ssl_lambda), float(temperature)
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.store_grad = bool(store_grad)   # keep d loss / d E in grad_items() (tests); the step itself does not need it
+        dev = graph.device
+        self.device = dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        n, d = self.n, self.d
+        # EGO: the regulariser's view of the parameters — user rows are zero for good (EGCF has no user table: the loss's
+        # reg term covers the two item blocks, models/EGCF.py:95-96; a zero block adds exactly 0), item rows ARE the table
+        self.EGO = torch.zeros((n, d), **f32)
+        self.EGO[self.U:].copy_(item_weight)
+        self.X = [torch.empty((n, d), **f32) for _ in range(self.K + 1)]   # X0 .. XK (tanh outputs: kept for the backward)
+        self.TOT = torch.empty((n, d), **f32)
+        self.GT = torch.zeros((n, d), **f32)   # d loss / d TOT, rows of the batch
+        self.GE = torch.zeros((n, d), **f32)   # regulariser's gradient, rows of the batch
+        self.Z = [torch.empty((n, d), **f32) for _ in range(2)]            # backward ping-pong
+        self.M = torch.zeros((self.I, d), **f32)
+        self.V = torch.zeros((self.I, d), **f32)
+        self.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
+        self.units, self.units_B = None, -1
+        self.bpr_ws, self.bpr_B = None, -1
+        self.loss = torch.zeros(3, **f32)        # [bpr, reg_lambda * reg, ssl_lambda * (three InfoNCE terms)]
+        self._ssl = torch.zeros(4, **f32)        # user-user, pos-pos, user-pos (+ pad)
+        self.step_count = 0
+        self._final_version = -1
+        self._grad_items = None
+
+    def grad_items(self):
+        """d loss / d E of the last step ([I, d]; only with store_grad)."""
+        return self._grad_items
+
+    def item_table(self):
+        """The parameter storage ([I, d] view): what nn.Embedding.weight aliases."""
+        return self.EGO[self.U:]
+
+    # ---- forward over every row (evaluation): returns (users, items) views of TOT
+    @torch.no_grad()
+    def propagate(self, out_rows=None):
+        U, K, X = self.U, self.K, self.X
+        E = self.EGO[U:]
+        ops.spmm_epi_raw(self.R, E, Y=X[0][:U], act=native.ACT_TANH)
+        ops.lincomb_raw(X[0][U:], E, 1.0)
+        for k in range(1, K):
+            ops.spmm_epi_raw(self.G, X[k - 1], Y=X[k], act=native.ACT_TANH)
+        terms = X[1:K] + [None, None, None]
+        ops.spmm_epi_raw(self.G, X[K - 1], Y=X[K], sum_in=terms[0], sum_in2=terms[1] if terms[0] is not None else None,
+                         sum_in3=terms[2] if terms[1] is not None else None, sum_out=self.TOT, act=native.ACT_TANH,
+                         out_rows=out_rows)
+        return self.TOT[:U], self.TOT[U:]
+
+    def final_panels(self):
+        if self._final_version != self.step_count:
+            self.propagate()
+            self._final_version = self.step_count
+        return self.TOT[: self.U], self.TOT[self.U:]
+
+    # ---- one training step
+    @torch.no_grad()
+    def train_step(self, users, pos, neg, loss_out=None):
+        U, K, X, n, d = self.U, self.K, self.X, self.n, self.d
+        B = int(users.shape[0])
+        loss = self.loss if loss_out is None else loss_out
+        if self.bpr_B != B:
+            self.bpr_ws, self.bpr_B = ops.bpr_workspace(B, d, self.device), B
+        # index-only work: the batch's row bitmap, its live units, the sorted scatter plan
+        ops.bpr_touch_rows_raw(users, pos, neg, U, self.bitmap, clear_bits=n)
+        self.units = self.G.live_units(self.bitmap, 3 * B, ws=self.units if self.units_B == B else None)
+        self.units_B = B
+        ops.bpr_plan_raw(users, pos, neg, U, n, d, ws=self.bpr_ws)
+        self.propagate(out_rows=self.bitmap)
+        # losses: gradient rows STORED at the batch's rows (bitmap), the InfoNCE terms added into the same rows
+        ops.bpr_fused_raw(self.TOT, self.EGO, users, pos, neg, U, self.reg_lambda, self.GT, self.GE, loss=loss[:2],
+                          deterministic=2, touched=self.bitmap, ws=self.bpr_ws)
+        ops.infonce_pair_raw(self.TOT, self.TOT, users, pos, U, self.temperature, g1=self.GT, g2=self.GT, loss=self._ssl[:2],
+                             dedup=False, grad_scale=self.ssl_lambda, accumulate=True)
+        ops.infonce_cross_raw(self.TOT, users, pos, U, self.temperature, g=self.GT, loss=self._ssl[2:4],
+                              grad_scale=self.ssl_lambda)
+        torch.sum(self._ssl[:3], dim=0, keepdim=True, out=loss[2:3])
+        loss[2:3].mul_(self.ssl_lambda)
+        # backward
+        Za, Zb = self.Z
+        ops.rows_tanh_bwd_raw(self.GT, X[K], self.bitmap, Za)                      # Z_K at the batch's rows
+        x_rows = self.bitmap
+        for k in range(K - 1, 0, -1):
+            ops.spmm_epi_raw(self.G, Za, Y=Zb, addend=self.GT, mask=self.bitmap, act=native.ACT_TANH_BWD, act_src=X[k],
+                             x_rows=x_rows)
+            Za, Zb, x_rows = Zb, Za, None
+        ops.spmm_epi_raw(self.G, Za, Y=Zb, addend=self.GE, mask=self.bitmap, act=native.ACT_TANH_BWD, act_src=X[0],
+                         act_rows=U, x_rows=x_rows)
+        self.step_count += 1
+        ops.spmm_epi_raw(self.R.T, Zb[:U], addend=Zb[U:], sum_out=Za[U:],
+                         adam=(self.EGO[U:], self.M, self.V, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps),
+                         adam_discard_grad=not self.store_grad)
+        self._grad_items = Za[U:] if self.store_grad else None
+        return loss

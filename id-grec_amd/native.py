@@ -103,6 +103,9 @@ PROTOTYPES = {
     "idg_ngcf_tail_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
                                         c_vp, c_vp]),
     "idg_infonce_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "idg_infonce_cross_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, c_vp, c_vp,
+                                        C.c_float, c_vp, c_vp]),
+    "idg_rows_tanh_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_infonce_pair_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int, C.c_float,
                                        c_vp, c_vp, c_vp, C.c_float, C.c_int, c_vp, c_vp]),
     "idg_bpr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
@@ -160,7 +163,8 @@ class Epilogue(C.Structure):
                 ("ldy", C.c_int64), ("div", C.c_float), ("accumulate", C.c_int), ("mask", c_vp),
                 ("adam_param", c_vp), ("adam_exp_avg", c_vp), ("adam_exp_avg_sq", c_vp),
                 ("adam_lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("adam_step", C.c_int64), ("adam_discard_grad", C.c_int)]
+                ("adam_step", C.c_int64), ("adam_discard_grad", C.c_int),
+                ("act", C.c_int), ("act_src", c_vp), ("act_rows", C.c_int64)]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -175,6 +179,7 @@ try:
 except ImportError:  # host-only use (sampler / parser / adjacency) works without torch
     _torch = None
 
+ACT_TANH, ACT_TANH_BWD = 1, 2  # idg_epilogue.act
 ABI_VERSION = 134  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)

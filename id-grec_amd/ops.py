@@ -388,12 +388,14 @@ def spmm_ex_raw(graph, X, Y=None, addend=None, sum_in=None, sum_out=None, div=1.
 
 
 def spmm_epi_raw(graph, X, Y=None, addend=None, sum_in=None, sum_in2=None, sum_in3=None, sum_out=None, div=1.0,
-                 accumulate=False, mask=None, adam=None, out_rows=None, x_rows=None, adam_discard_grad=False):
+                 accumulate=False, mask=None, adam=None, out_rows=None, x_rows=None, adam_discard_grad=False, act=0,
+                 act_src=None, act_rows=0):
     """idg_spmm_epi_f32: the product with every epilogue option (include/idgrec.h, idg_epilogue).  mask: bitmap of the
     live rows of addend / sum_in* / the accumulate target; adam = (param, exp_avg, exp_avg_sq, lr, step[, beta1, beta2,
     eps]): the Adam update of the rows of `param` with gradient sum_out in the same launch (adam_discard_grad: without
-    writing that gradient).  out_rows and x_rows may be combined."""
-    _require_device(X, Y, addend, sum_in, sum_in2, sum_in3, sum_out, mask, out_rows, x_rows)
+    writing that gradient).  out_rows and x_rows may be combined.  act: native.ACT_TANH (t = tanh(t)) or
+    native.ACT_TANH_BWD (t *= 1 - act_src^2) applied to the rows below act_rows (0: all) before anything is stored."""
+    _require_device(X, Y, addend, sum_in, sum_in2, sum_in3, sum_out, mask, out_rows, x_rows, act_src)
     d = X.shape[1]
     for t in (X, Y, addend, sum_in, sum_in2, sum_in3, sum_out):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != d):
@@ -407,9 +409,39 @@ def spmm_epi_raw(graph, X, Y=None, addend=None, sum_in=None, sum_in2=None, sum_i
         e.adam_param, e.adam_exp_avg, e.adam_exp_avg_sq = _ptr(p), _ptr(m), _ptr(v)
         e.adam_lr, e.adam_beta1, e.adam_beta2, e.adam_eps, e.adam_step = float(lr), float(b1), float(b2), float(eps), int(step)
         e.adam_discard_grad = int(bool(adam_discard_grad))
+    if act:
+        e.act, e.act_src, e.act_rows = int(act), _ptr(act_src), int(act_rows)
     ws = graph._workspace("spmm", d)
     check(lib.idg_spmm_epi_f32(graph._h, _ptr(X), d, d, C.byref(e), _ptr(out_rows), _ptr(x_rows), _ptr(ws), _stream()),
           "idg_spmm_epi_f32")
+
+
+_ssl_ws = {}  # InfoNCE workspaces by (n, B, d, device): the pair and cross forms of one step share one
+
+
+def rows_tanh_bwd_raw(grad, y, rows, out):
+    """out[r] = grad[r] * (1 - y[r]^2) at the rows of the bitmap `rows` (None: all) — idg_rows_tanh_bwd_f32."""
+    _require_device(grad, y, rows, out)
+    check(lib.idg_rows_tanh_bwd_f32(_ptr(grad), _ptr(y), _ptr(rows), int(grad.shape[0]), int(grad.shape[1]), _ptr(out), _stream()),
+          "idg_rows_tanh_bwd_f32")
+
+
+def infonce_cross_raw(view, users, items, num_users, temperature, g=None, loss=None, grad_scale=1.0, ws=None):
+    """get_InfoNCE_loss(view[users], view[num_users + items], t) on the raw batch rows (models/EGCF.py:103), forward and
+    backward: loss [1] and the gradient rows ADDED into g (idg_infonce_cross_f32).  Returns (loss, ws)."""
+    _require_device(view, users, items, g, loss, ws)
+    n, d = view.shape
+    B = int(users.shape[0])
+    if loss is None:
+        loss = torch.zeros(2, dtype=torch.float32, device=view.device)
+    if ws is None:
+        key = (n, B, d, view.device)
+        ws = _ssl_ws.get(key)
+        if ws is None:
+            ws = _ssl_ws[key] = torch.empty(int(lib.idg_infonce_workspace_bytes(n, B, d)), dtype=torch.uint8, device=view.device)
+    check(lib.idg_infonce_cross_f32(_ptr(view), n, d, _ptr(users), _ptr(items), B, int(num_users), float(temperature), _ptr(loss),
+                                    _ptr(g), float(grad_scale), _ptr(ws), _stream()), "idg_infonce_cross_f32")
+    return loss, ws
 
 
 def rows_gather2_raw(dst0, src0, dst1, src1, idx):
@@ -1027,7 +1059,6 @@ def ngcf_layer_tail(S1, S2, b1, b2, negative_slope=0.2, p=0.0, stream=None):
 
 
 # ----------------------------------------------------------------------------------- InfoNCE
-_ssl_ws = {}
 
 
 def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None, g2=None, loss=None, dedup=True,

@@ -295,9 +295,23 @@ typedef struct idg_epilogue {
   int64_t adam_step;
   int adam_discard_grad; /* != 0: the finished gradient feeds the update and is not written to sum_out (which is still
                             READ at live rows when accumulate is set): one [n, d] write less per step */
+  /* EGCF's activated layers (models/EGCF.py:46-84: activation_layer(torch.sparse.mm(...)), nn.Tanh) and their backward:
+   * applied to t = (A.X)[r] (+ addend[r]) of the rows r < act_rows (0: every row) BEFORE Y / sum_out see it.
+   * IDG_ACT_TANH: t = tanh(t).  IDG_ACT_TANH_BWD: t = t * (1 - act_src[r]^2), act_src = the tanh outputs the forward
+   * layer saved (torch's tanh_backward).  Not together with Adam; with out_rows or with x_rows, not both. */
+  int act;
+  const float* act_src;
+  int64_t act_rows;
 } idg_epilogue;
+#define IDG_ACT_TANH 1
+#define IDG_ACT_TANH_BWD 2
 int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d, const idg_epilogue* epilogue,
                      const uint32_t* out_rows, const uint32_t* x_rows, void* ws, void* stream);
+/* out[r, :] = grad[r, :] * (1 - y[r, :]^2) for the rows flagged in `rows` (NULL: every row) of [n, d] panels: the backward
+ * of y = tanh(z) where the chain starts — EGCF's summed layer outputs at the batch's rows (models/EGCF.py:60,77).  Other
+ * rows of out are left untouched. */
+int idg_rows_tanh_bwd_f32(const float* grad, const float* y, const uint32_t* rows, int64_t n, int64_t d, float* out,
+                          void* stream);
 
 /* One perturbed layer (models/XSimGCL.py:51-54): Y = A.X;  Y += sign(Y) * normalize(u, dim=-1) * eps,
  * u ~ U[0,1)^d from Philox4x32-10(seed; stream_id, row, feature block).  d in {32,...,512}.
@@ -500,6 +514,13 @@ int idg_ngcf_tail_bwd_f32(const float* E, const float* gE, const float* gN, int6
  * of one id are added, in list order, into its panel row.
  * ---------------------------------------------------------------------------------- */
 size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d);
+/* The CROSS form (models/EGCF.py:103: get_InfoNCE_loss(user_embedding, pos_embedding, t) on the RAW batch rows):
+ * a_i = normalize(view[users[i]]), b_i = normalize(view[num_users + items[i]]), i < B in batch order, same loss as above
+ * in loss[0]; g (nullable): d loss / d view, ADDED (times grad_scale) into the rows of the batch's users and items —
+ * the occurrences of one id added in list order.  Same workspace. */
+int idg_infonce_cross_f32(const float* view, int64_t n, int64_t d, const int64_t* users, const int64_t* items,
+                          int64_t B, int64_t num_users, float temperature, float* loss, float* g, float grad_scale,
+                          void* ws, void* stream);
 int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d,
                          const int64_t* users, const int64_t* items, int64_t B, int64_t num_users,
                          int dedup, float temperature, float* loss, float* g1, float* g2,

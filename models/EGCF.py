@@ -19,9 +19,16 @@ import utility.utility_function.losses as losses
 import utility.utility_function.tools as tools
 import utility.utility_train.trainer as trainer
 from idgrec_amd import ops
+from idgrec_amd.egcf import EgcfEngine
 
 
 class EGCF(nn.Module):
+    #: the `parallel` encoder trains through a fused, autograd-free chain of library calls (idgrec_amd/egcf.py); the
+    #: `alternating` one through the differentiable operators below
+    supports_fused_step = True
+    n_fused_losses = 3
+    FUSED_WIDTHS = (32, 64, 128, 256, 512)
+
     def __init__(self, config, dataset, device):
         super(EGCF, self).__init__()
         self.config, self.dataset, self.device = config, dataset, device
@@ -44,10 +51,66 @@ class EGCF(nn.Module):
         self.activation_layer = nn.Tanh()
         self.activation = nn.Sigmoid()
         self._eval_cache = None
+        self._engine = None
 
     def train(self, mode=True):
         self._eval_cache = None
         return super().train(mode)
+
+    # ------------------------------------------------------------------ fused path (trainer protocol)
+    def fused_step_available(self):
+        w = self.item_embedding.weight
+        return (self.aggregate_mode == 'parallel' and w.is_cuda and w.dtype == torch.float32
+                and int(w.shape[1]) in self.FUSED_WIDTHS and 1 <= self.n_layers <= 4)
+
+    def engine(self):
+        """The fused engine; the item table lives in ITS storage (nn.Embedding.weight is re-pointed at it), so that the
+        regulariser's [n, d] view of the parameters and the table are one buffer."""
+        w = self.item_embedding.weight
+        if self._engine is None or w.data_ptr() != self._engine.item_table().data_ptr():
+            self._engine = EgcfEngine(self.Graph, self.user_Graph, self.dataset.num_users, self.dataset.num_items,
+                                      int(w.shape[1]), self.n_layers, w.data, self.reg_lambda, self.ssl_lambda,
+                                      self.temperature)
+            w.data = self._engine.item_table()
+        return self._engine
+
+    def prefetch_batch(self, users, pos, neg):
+        pass  # (the index-only work of a step is three small launches at the head of the step)
+
+    def fused_train_step(self, users, pos, neg, loss_out, optimizer):
+        """forward + backward + Adam as ONE chain of kernels; False (nothing done) unless `optimizer` is an
+        idgrec_amd.ops.Adam over exactly the item table.  The optimizer's state stays the single source of truth."""
+        w = self.item_embedding.weight
+        if not isinstance(optimizer, ops.Adam) or len(optimizer.param_groups) != 1:
+            return False
+        group = optimizer.param_groups[0]
+        if len(group["params"]) != 1 or group["params"][0] is not w:
+            return False
+        eng = self.engine()
+        st = optimizer.state[w]
+        if not st or st["exp_avg"].data_ptr() != eng.M.data_ptr():
+            if st:  # the optimizer has already stepped the other way: keep what it accumulated
+                eng.M.copy_(st["exp_avg"])
+                eng.V.copy_(st["exp_avg_sq"])
+            st.setdefault("step", 0)
+            st["exp_avg"], st["exp_avg_sq"] = eng.M, eng.V
+        eng.lr, eng.betas, eng.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
+        eng.step_count = int(st["step"])
+        self._eval_cache = None
+        eng.train_step(users, pos, neg, loss_out)
+        st["step"] = eng.step_count
+        return True
+
+    def fused_loss_and_grad(self, users, pos, neg, loss_out=None):
+        """The trainer's fallback when the optimizer is not ours: the differentiable operators under autograd."""
+        self._eval_cache = None
+        ll = self.forward(users, pos, neg)
+        self.zero_grad()
+        sum(ll).backward()
+        out = torch.stack([x.detach() for x in ll])
+        if loss_out is not None:
+            loss_out.copy_(out)
+        return out
 
     def alternating_aggregate(self):
         item = self.item_embedding.weight
@@ -85,8 +148,12 @@ class EGCF(nn.Module):
     def final_panels(self):
         if self._eval_cache is None:
             with torch.no_grad():
-                u, i = self.aggregate()
-                self._eval_cache = (u.contiguous(), i.contiguous())
+                if self._engine is not None and self.fused_step_available() \
+                        and self.item_embedding.weight.data_ptr() == self._engine.item_table().data_ptr():
+                    self._eval_cache = self._engine.propagate()  # the same chain the training step runs
+                else:
+                    u, i = self.aggregate()
+                    self._eval_cache = (u.contiguous(), i.contiguous())
         return self._eval_cache
 
     def get_rating_for_test(self, user):

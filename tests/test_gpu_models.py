@@ -751,6 +751,68 @@ def test_egcf_vs_reference(mode, tmp_path):
     assert ok, msg
 
 
+def test_egcf_fused_step_vs_reference(tmp_path):
+    """The fused, autograd-free EGCF step (idgrec_amd/egcf.py: tanh and its derivative in the products' epilogues, BPR +
+    the three raw-row InfoNCE terms through the library, Adam in the last epilogue) against the reference's own numbers
+    for the `parallel` encoder (egcf_small.npz): encoder outputs, the three losses, d loss / d item table, and the table
+    after the Adam step against torch.optim.Adam fed with the REFERENCE's gradient.  Then the model's fused_train_step
+    under the trainer's optimizer: same losses, same table as the engine on its own."""
+    import os
+
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from idgrec_amd.egcf import EgcfEngine
+    from models.EGCF import EGCF
+
+    eg = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "egcf_small.npz")))
+    cfg = dict(zip(eg["config_keys"].tolist(), eg["config_values"].tolist()))
+    cfg["mode"] = "parallel"
+    data = _data_with(tmp_path, eg, cfg)
+    tools.set_seed(2024)
+    m = EGCF(cfg, data, torch.device("cuda")).to("cuda")
+    W0 = m.item_embedding.weight.detach().clone()
+    U, I, d = data.num_users, data.num_items, W0.shape[1]
+    eng = EgcfEngine(m.Graph, m.user_Graph, U, I, d, m.n_layers, W0, m.reg_lambda, m.ssl_lambda, m.temperature, lr=1e-3,
+                     store_grad=True)
+    u, i = eng.propagate()
+    np.testing.assert_allclose(u.cpu().numpy(), eg["parallel_user"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(i.cpu().numpy(), eg["parallel_item"], rtol=1e-5, atol=1e-7)
+    full = eng.TOT.clone()
+    b = torch.from_numpy(eg["batch"]).cuda()
+    bu, bp, bn = b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous()
+    eng.TOT.fill_(float("nan"))  # the step produces the batch's rows only, and reads no other
+    loss = eng.train_step(bu, bp, bn).cpu().numpy()
+    rows = torch.unique(torch.cat([bu, U + bp, U + bn]))
+    assert torch.equal(eng.TOT[rows], full[rows]), "row-restricted last layer differs from the full one"
+    np.testing.assert_allclose(loss, eg["parallel_loss"], rtol=RTOL)
+    ref = eg["parallel_grad_item"]
+    np.testing.assert_allclose(eng.grad_items().cpu().numpy(), ref, rtol=1e-3, atol=3e-4 * np.abs(ref).max())
+    w = torch.nn.Parameter(W0.cpu().clone())
+    opt = torch.optim.Adam([w], lr=1e-3)
+    w.grad = torch.from_numpy(ref.copy())
+    opt.step()
+    moved = (w.detach() - W0.cpu()).abs() > 5e-4   # Adam's first step moves a weight by ~lr * sign(g): compare where g is not ~0
+    got = eng.item_table().cpu()
+    assert torch.allclose(got[moved], w.detach()[moved], rtol=0, atol=2e-5)
+    assert float((got - w.detach()).abs().max()) <= 2.1e-3  # (a gradient of rounding size may flip sign: one lr step each way)
+
+    # the model under the trainer's optimizer: the same chain
+    tools.set_seed(2024)
+    m2 = EGCF(cfg, data, torch.device("cuda")).to("cuda")
+    assert m2.fused_step_available()
+    opt2 = ops.Adam(list(m2.parameters()), lr=1e-3)
+    out = torch.zeros(3, device="cuda")
+    assert m2.fused_train_step(bu, bp, bn, out, opt2)
+    np.testing.assert_allclose(out.cpu().numpy(), loss, rtol=1e-6)
+    assert torch.equal(m2.item_embedding.weight.detach().cpu(), got) and int(opt2.state[m2.item_embedding.weight]["step"]) == 1
+    m2.eval()
+    users = torch.from_numpy(eg["rating_users"]).cuda()
+    r_fused = m2.get_rating_for_test(users)
+    m2._engine = None  # the same table through the differentiable operators
+    m2._eval_cache = None
+    np.testing.assert_allclose(r_fused.cpu().numpy(), m2.get_rating_for_test(users).cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_egcf_trainer_loop_runs(tmp_path, golden_small):
     import utility.utility_function.tools as tools
     from models.EGCF import Trainer
