@@ -25,8 +25,11 @@
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 #include <mutex>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "idg_common.h"
@@ -1543,6 +1546,26 @@ int64_t seg_len_for(int64_t len) {
   return std::min<int64_t>(std::max<int64_t>(s, 64), TILE_NNZ);
 }
 
+// [0, n) cut into contiguous pieces, one per worker thread (the schedule build's passes over the stored entries: at
+// configs[4] size — 4e8 entries — each sequential pass is ~0.5 s of the handle's creation).  fn(begin, end, worker).
+template <typename F>
+void parallel_ranges(int64_t n, F fn, int64_t min_per_thread = 1 << 20) {
+  int nt = (int)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u),
+                                  std::max<int64_t>(1, n / std::max<int64_t>(min_per_thread, 1)));
+  if (const char* v = std::getenv("IDG_BUILD_THREADS")) nt = std::max(1, std::min(nt, std::atoi(v)));
+  if (nt <= 1) {
+    fn((int64_t)0, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve((size_t)nt);
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+    th.emplace_back([=] { fn(b, e, t); });
+  }
+  for (auto& x : th) x.join();
+}
+
 struct DeviceGuard {
   int prev = -1;
   bool switched = false;
@@ -1590,9 +1613,20 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   IDG_REQUIRE(split_threshold >= 0, "idg_graph_create: negative split_threshold");
   for (int64_t r = 0; r < n_rows; ++r)
     IDG_REQUIRE(indptr[r + 1] >= indptr[r], "idg_graph_create: indptr not monotone at row %lld", (long long)r);
-  for (int64_t k = 0; k < nnz; ++k)
-    IDG_REQUIRE(indices[k] >= 0 && indices[k] < n_cols, "idg_graph_create: column %d outside [0,%lld) at entry %lld",
-                indices[k], (long long)n_cols, (long long)k);
+  {
+    std::atomic<int64_t> bad{-1};  // the first offending entry of the lowest range that has one is what the message names
+    parallel_ranges(nnz, [&](int64_t b, int64_t e, int) {
+      for (int64_t k = b; k < e; ++k)
+        if (indices[k] < 0 || indices[k] >= n_cols) {
+          int64_t cur = bad.load();
+          while ((cur < 0 || k < cur) && !bad.compare_exchange_weak(cur, k)) {
+          }
+          return;
+        }
+    });
+    const int64_t k = bad.load();
+    IDG_REQUIRE(k < 0, "idg_graph_create: column %d outside [0,%lld) at entry %lld", indices[k], (long long)n_cols, (long long)k);
+  }
   const int ndev = idg_device_count();
   if (ndev <= 0) return idg::fail(IDG_E_NODEVICE, "idg_graph_create: no HIP device visible (this library has no CPU path)");
   IDG_REQUIRE(device >= 0 && device < ndev, "idg_graph_create: device %d outside [0,%d)", device, ndev);
@@ -1784,15 +1818,24 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   g->n_tiles = (int64_t)tiles.size();
   g->n_xl = (int64_t)xl.size();
 
-  std::vector<ColVal> cv((size_t)nnz);
-  for (int64_t k = 0; k < nnz; ++k) cv[(size_t)k] = ColVal{indices[k], values[k]};
+  bool sort_tiles = true;
+  if (const char* v = std::getenv("IDG_TILE_SORT")) sort_tiles = std::atoi(v) != 0;
+  // (uninitialised: every entry is written exactly once below — by its tile's pass, or here when it belongs to no tile)
+  std::unique_ptr<ColVal[]> cv_store(new (std::nothrow) ColVal[(size_t)std::max<int64_t>(nnz, 1)]);
+  if (!cv_store) {
+    delete g;
+    return idg::fail(IDG_E_NOMEM, "idg_graph_create: out of host memory for the entry list");
+  }
+  ColVal* cv = cv_store.get();
+  if (!(sort_tiles && !tiles_plain.empty()) || !xl.empty())
+    parallel_ranges(nnz, [&](int64_t b, int64_t e, int) {
+      for (int64_t k = b; k < e; ++k) cv[(size_t)k] = ColVal{indices[k], values[k]};
+    });
   // Inside every tile the work units — a plain vrow, or a split row's run of segments — are laid out LONGEST FIRST.
   // The lane groups of a wave walk their vrows in lockstep (a round lasts as long as its longest walk) and draw
   // consecutive units from the tile's counter: sorted by length, the four (d = 64) walks of a round are of similar
   // length instead of random ones, and the tile ends with its short rows (longest-first list scheduling).  Only the
   // order of whole rows inside a tile changes: every row's entries, segments and summation order are untouched.
-  bool sort_tiles = true;
-  if (const char* v = std::getenv("IDG_TILE_SORT")) sort_tiles = std::atoi(v) != 0;
   if (sort_tiles && !tiles_plain.empty()) {
     std::vector<int64_t> vptr2(vptr);
     std::vector<int32_t> vtgt2(vtgt), vrow_row2(vrow_row);
@@ -1802,8 +1845,12 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
       int32_t v, n;
       int64_t len;
     };
+    // tiles are independent of each other here (each rewrites its own vrows, its own LocalRows and its own stretch of
+    // the entry list): ranges of tiles on worker threads
+    parallel_ranges((int64_t)tiles_plain.size(), [&](int64_t t_lo, int64_t t_hi, int) {
     std::vector<Unit> units;
-    for (const Tile& t : tiles_plain) {
+    for (int64_t ti = t_lo; ti < t_hi; ++ti) {
+      const Tile& t = tiles_plain[(size_t)ti];
       units.clear();
       for (int32_t v = t.vrow_begin; v < t.vrow_begin + t.n_vrows;) {
         const int32_t nseg = local_of[(size_t)v] != SIZE_MAX ? (int32_t)locals[local_of[(size_t)v]].n_seg : 1;
@@ -1825,8 +1872,10 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
           ++nv;
         }
       }
-      vptr2[(size_t)nv] = pos;  // == the next tile's first entry (or an xl vrow's start)
+      // (vptr2[nv] — the next tile's first entry, or an xl vrow's start — keeps the value it was copied with: tile
+      //  boundaries do not move)
     }
+    }, 256);
     vptr.swap(vptr2);
     vtgt.swap(vtgt2);
     vrow_row.swap(vrow_row2);
@@ -1834,7 +1883,13 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
 
   DeviceGuard guard;
   int rc = guard.enter(device);
-  if (rc == IDG_OK) rc = upload(&g->d_cv, cv);
+  if (rc == IDG_OK && nnz > 0) {
+    rc = [&]() -> int {
+      IDG_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cv), (size_t)nnz * sizeof(ColVal)));
+      IDG_HIP(hipMemcpy(g->d_cv, cv, (size_t)nnz * sizeof(ColVal), hipMemcpyHostToDevice));
+      return IDG_OK;
+    }();
+  }
   if (rc == IDG_OK) rc = upload(&g->d_vptr, vptr);
   if (rc == IDG_OK) rc = upload(&g->d_vtgt, vtgt);
   if (rc == IDG_OK) rc = upload(&g->d_tiles, tiles_plain);
@@ -1875,22 +1930,25 @@ int idg_graph_create_from_device(int device, int64_t n_rows, int64_t n_cols, int
   IDG_REQUIRE(out, "idg_graph_create_from_device: out is NULL");
   IDG_REQUIRE(n_rows >= 0 && nnz >= 0 && d_indptr && (nnz == 0 || (d_indices && d_values)),
               "idg_graph_create_from_device: bad argument");
-  // The row-block schedule (virtual rows, tiles, XCD bands, split tables) is built by the host code of idg_graph_create:
-  // the arrays are staged through host memory — ordered after `stream`, where the caller may just have produced them.
-  std::vector<int64_t> ip((size_t)n_rows + 1);
-  std::vector<int32_t> ix((size_t)nnz);
-  std::vector<float> dv((size_t)nnz);
+  // The row-block schedule (virtual rows, tiles, XCD bands, split tables) is built by the host code of idg_graph_create
+  // (multi-threaded over the stored entries; measured at configs[4] size — 15 M rows, 4e8 entries — on the GPU box's
+  // host: see DESIGN.md): the arrays are staged through host memory — ordered after `stream`, where the caller may just
+  // have produced them.  Uninitialised staging buffers (a std::vector would zero 3.3 GB first).
+  std::unique_ptr<int64_t[]> ip(new (std::nothrow) int64_t[(size_t)n_rows + 1]);
+  std::unique_ptr<int32_t[]> ix(new (std::nothrow) int32_t[(size_t)std::max<int64_t>(nnz, 1)]);
+  std::unique_ptr<float[]> dv(new (std::nothrow) float[(size_t)std::max<int64_t>(nnz, 1)]);
+  if (!ip || !ix || !dv) return idg::fail(IDG_E_NOMEM, "idg_graph_create_from_device: out of host memory");
   DeviceGuard guard;
   int rc = guard.enter(device);
   if (rc != IDG_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  IDG_HIP(hipMemcpyAsync(ip.data(), d_indptr, ip.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  IDG_HIP(hipMemcpyAsync(ip.get(), d_indptr, ((size_t)n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   if (nnz > 0) {
-    IDG_HIP(hipMemcpyAsync(ix.data(), d_indices, ix.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    IDG_HIP(hipMemcpyAsync(dv.data(), d_values, dv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    IDG_HIP(hipMemcpyAsync(ix.get(), d_indices, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    IDG_HIP(hipMemcpyAsync(dv.get(), d_values, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, st));
   }
   IDG_HIP(hipStreamSynchronize(st));
-  return idg_graph_create(device, n_rows, n_cols, nnz, ip.data(), ix.data(), dv.data(), flags, split_threshold, out);
+  return idg_graph_create(device, n_rows, n_cols, nnz, ip.get(), ix.get(), dv.get(), flags, split_threshold, out);
 }
 
 int idg_graph_destroy(idg_graph* g) {

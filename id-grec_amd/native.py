@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libidgrec.so")
+# IDG_LIB_PATH: another build of the same ABI (A/B timing of two library versions inside one GPU session)
+LIB_PATH = os.environ.get("IDG_LIB_PATH") or os.path.join(_HERE, "lib", "libidgrec.so")
 
 c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int32)
@@ -188,6 +189,8 @@ if lib.idg_version() != ABI_VERSION:
     raise ImportError("%s reports ABI version %d, this binding expects %d: the library is stale — rebuild it with "
                       "`python id-grec_amd/build.py`." % (LIB_PATH, lib.idg_version(), ABI_VERSION))
 for _name, (_res, _args) in PROTOTYPES.items():
+    if os.environ.get("IDG_LIB_PATH") and not hasattr(lib, _name):
+        continue  # an A/B build of an earlier revision of the same ABI: entry points added since are simply absent
     _fn = getattr(lib, _name)
     _fn.restype = _res
     _fn.argtypes = _args
