@@ -837,30 +837,46 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 // from about 16 user tiles on (calls of 1024 users: 7.9 vs 8.4 ms for the 31,668 users; of 4096: 3.9 vs 5.2 ms);
 // below that the two kernels tie at the launch floor (calls of 100 users, the reference's test_batch_size: 66 vs 69 ms
 // for 317 calls) and the alternating kernel, with its ~1024 short workgroups, is kept.
+static inline bool floor_phase(int form, int nc, int64_t ci, int k);
+
 static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr, int k = 0) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
   const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 forces a kernel
   const int forced = fv && *fv ? std::atoi(fv) : -1;
   const int form = forced >= 0 ? forced : (user_tiles >= 16 ? 1 : 0);
   if (form_out) *form_out = form;
-  int64_t nc = form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
-  // a many-chunk call of the producer / consumer kernel starts its chunks from a floor that needs at least k chunks
-  // (floor_phase): a few more, shorter chunks cost less than doing without it
-  if (form == 1 && nc > 1 && nc < k + 2 && k <= 64) nc = k + 2;
-  if (const char* v = std::getenv("IDG_TOPK_WGS"))
-    if (*v) nc = (std::atoll(v) + user_tiles - 1) / user_tiles;  // testing knob
+  const int64_t tuned = form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
   const int64_t max_nc = (I + 1023) / 1024;
-  if (const char* v = std::getenv("IDG_TOPK_CHUNKS"))
-    if (*v && std::atoll(v) > 0) nc = std::atoll(v);  // testing knob
-  nc = nc < 1 ? 1 : (nc > max_nc ? max_nc : nc);
-  int64_t ci = ((I + nc - 1) / nc + FT_SLAB - 1) / FT_SLAB * FT_SLAB;
-  nc = (I + ci - 1) / ci;
+  auto finish = [&](int64_t nc, int64_t* ci_out) {
+    if (const char* v = std::getenv("IDG_TOPK_WGS"))
+      if (*v) nc = (std::atoll(v) + user_tiles - 1) / user_tiles;  // testing knob
+    if (const char* v = std::getenv("IDG_TOPK_CHUNKS"))
+      if (*v && std::atoll(v) > 0) nc = std::atoll(v);  // testing knob
+    nc = nc < 1 ? 1 : (nc > max_nc ? max_nc : nc);
+    const int64_t ci = ((I + nc - 1) / nc + FT_SLAB - 1) / FT_SLAB * FT_SLAB;
+    *ci_out = ci;
+    return (I + ci - 1) / ci;
+  };
+  int64_t ci, nc = finish(tuned, &ci);
+  // A many-chunk call of the producer / consumer kernel starts its chunks from a floor that needs at least k chunks
+  // (floor_phase): a few more, shorter chunks cost less than doing without it — but only when the FINAL geometry (after
+  // the clamps) still qualifies; otherwise the tuned count stands (a bumped count that the clamp brings back
+  // below k, or chunks of fewer than four slabs, would run the many-short-chunks geometry WITHOUT a floor, and the
+  // partial-list workspace grows with the chunk count: calls of 17..256 user tiles at k + 2 chunks up to ~16x).
+  // Measured where it pays: calls of 1024 users (16 tiles) at yelp2018 / amazon-book size; beyond 64 user tiles the
+  // tuned count is already <= 8 chunks and the start-up the floor saves is a small share of a launch.
+  if (form == 1 && tuned > 1 && tuned < k + 2 && k <= 64 && user_tiles <= 64) {
+    int64_t ci2;
+    const int64_t nc2 = finish(k + 2, &ci2);
+    if (floor_phase(form, (int)nc2, ci2, k)) nc = nc2, ci = ci2;
+  }
   *n_chunks = (int)nc;
   *chunk_items = ci;
 }
 
 // Two-phase form (chunk maxima -> per-user starting floor): the producer / consumer kernel, one pass (k <= 64), at least
 // k chunks (the floor is the k-th largest of the chunk maxima) of at least two slabs.  IDG_TOPK_FLOOR=0 turns it off.
+static_assert(FLOOR_SLABS >= 1, "IDG_TOPK_FLOOR_SLABS must be >= 1: chunk_floor_kernel reads what the floor phase wrote");
 static inline bool floor_phase(int form, int nc, int64_t ci, int k) {
   const char* v = std::getenv("IDG_TOPK_FLOOR");
   if (v && *v && std::atoi(v) == 0) return false;

@@ -279,7 +279,10 @@ def run(rank, world, port, mode, path, steps):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rccl = mode.startswith("nccl")  # "nccl-native" / "nccl-torch": one DEVICE per rank, RCCL between them (needs >= world GPUs)
+    if rccl:
+        torch.cuda.set_device(rank)
+    dist.init_process_group("nccl" if rccl else "gloo", rank=rank, world_size=world)
     import idgrec_amd.sharded as sh
 
     z = np.load(path)
@@ -292,7 +295,8 @@ def run(rank, world, port, mode, path, steps):
     if mode.startswith("cpu"):
         kern, to_dev, to_np = OracleKernels(), (lambda a: np.ascontiguousarray(a)), (lambda a: a)
     else:
-        torch.cuda.set_device(0)
+        if not rccl:
+            torch.cuda.set_device(0)
         kern = sh.HipKernels()
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         to_np = lambda a: a.cpu().numpy()  # noqa: E731
@@ -302,6 +306,11 @@ def run(rank, world, port, mode, path, steps):
         comm = DeferredComm(comm)
     if mode == "gpu-async":
         comm = SideStreamComm(dist)
+    if rccl:
+        comm, comm_name = sh.make_comm(dist, mode.split("-", 1)[1])
+        assert ("libidgrec" in comm_name) == (mode == "nccl-native"), comm_name
+        if mode == "nccl-native":
+            comm.overlap_bytes = 1 << 16  # the second-stream route (>= 64 MB in production) on this small problem too
     eng = sh.ShardedEngine(kern, comm, ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
                            batch_sparsity=mode not in ("gpu-dense", "cpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
                            live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None,
@@ -373,8 +382,18 @@ def run(rank, world, port, mode, path, steps):
 
         res = eng.evaluate([u for u, _ in own], [t for _, t in own], ex_ptr, ex_items, [5, 10], reduce_sums)
         out.update(ev_recall=res["recall"], ev_precision=res["precision"], ev_ndcg=res["ndcg"])
+    if rccl:
+        # the item table, updated by its owners and all-gathered: a checksum must agree on every rank (what the bench
+        # line's item_table_coherent reports)
+        chk = eng.item_rows(eng.P).double().sum().reshape(1)
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        out["coherent"] = bool(lo_.item() == hi_.item())
     np.savez(path + ".out%d.npz" % rank, **out)
     dist.barrier()
+    if hasattr(comm, "close"):
+        comm.close()
     dist.destroy_process_group()
 
 

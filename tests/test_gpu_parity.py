@@ -1021,6 +1021,29 @@ def test_topk_calls_of_1024_users_start_from_a_floor(ops, d, sig):
             os.environ["IDG_TOPK_FLOOR"] = old
 
 
+@pytest.mark.parametrize("per_call", [2048, 4096, 8192])
+def test_topk_calls_of_a_few_thousand_users(ops, per_call):
+    """calls of 2048 / 4096 users (32 / 64 user tiles) still take the k + 2 chunk geometry with its starting
+    floor, calls of 8192 (128 tiles) keep the tuned chunk count — whichever geometry a call gets, its lists are the
+    ones ONE call over all users gives, ids and values; k = 20 and 64, train items masked, ties across chunk cuts."""
+    import idgrec_amd.synth as S
+
+    U, I, d = 16384, 38048, 64
+    users, items = S.generate(U, I, 400000, seed=13)
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    ip, ix = dev(ptr), dev(items.astype(np.int32))
+    g = torch.Generator(device="cuda").manual_seed(per_call)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
+    Ie[::89] = Ie[7]
+    every = torch.arange(U, device="cuda")
+    for k in (20, 64):
+        whole = ops.score_topk(Ue, Ie, every, k, ip, ix, return_values=True)
+        got = [ops.score_topk(Ue, Ie, every[s0:s0 + per_call], k, ip, ix, return_values=True) for s0 in range(0, U, per_call)]
+        assert torch.equal(torch.cat([x[0] for x in got]), whole[0]) and torch.equal(torch.cat([x[1] for x in got]), whole[1])
+
+
 def _row_bitmap(n, rows):
     bitmap = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
     np.bitwise_or.at(bitmap, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))

@@ -435,6 +435,31 @@ def test_two_ranks_hip_kernels_with_side_stream_collectives(K, include0, d, thin
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["native", "torch"])
+@pytest.mark.parametrize("K,include0,d,thin", [(3, True, 64, False), (3, False, 256, True), (4, True, 64, True)])
+def test_ranks_on_distinct_devices_over_rccl(K, include0, d, thin, kind, tmp_path, golden_small):
+    """RCCL BETWEEN DEVICES (everything above runs collectives over gloo, simulated comms, or RCCL at world size
+    1 where a collective is the identity): one rank per GPU, backend nccl, through both communicators — libidgrec's own
+    (second-stream route forced on: reduce-scatter in place, the in-place all-gather left in flight into the next step)
+    and torch.distributed's (reduce_scatter_tensor into a scratch block copied at wait(), all_gather_into_tensor with the
+    input aliasing its block of the output).  Six steps against the single-device oracle, item table coherent across the
+    ranks.  Needs at least two GPUs: skipped on the 1-GPU boxes of this pool — UNVERIFIED until a multi-GPU box runs it."""
+    import torch
+
+    world = min(torch.cuda.device_count(), 4)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL between distinct devices)")
+    p = _sparse_problem(K, include0, B=6, steps=6, d=d) if thin else _problem(golden_small, K, include0, B=160, steps=6, d=d, n_slices=3)
+    if thin:
+        p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("nccl-" + kind, path, 6, world=world)
+    assert all(bool(o["coherent"]) for o in outs)
+    _check(p, outs, 6, rtol=1e-4, atol=2e-7, sparse=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K,include0,d", [(3, True, 64), (2, False, 64), (3, False, 256)])
 def test_one_rank_hip_kernels_match_single_device(K, include0, d, tmp_path):
     """World size 1 (what `bench.py --force-sharded` runs): nothing is agreed or exchanged as rows, but the touched-item
