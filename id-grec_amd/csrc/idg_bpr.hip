@@ -32,6 +32,8 @@ struct BprArgs {
   const int64_t* pos;
   const int64_t* neg;
   int64_t num_users, B, d;
+  int64_t de;              // width of the ego rows (== d except for idg_bpr_fused_ex_f32: NGCF's 4d-wide final rows)
+  int reg_users;           // 0: the regulariser covers the two item blocks only (models/NGCF.py:125, EGCF.py:95-96)
   float inv_B, reg_scale;  // reg_scale = reg_lambda / B
   float* coef;             // [B]   d loss0 / d x_i (already / B)
   float* loss_i;           // [B]
@@ -59,14 +61,31 @@ __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
   const float* epp = a.ego + rp * a.d;
   const float* en = a.ego + rn * a.d;
   float sp = 0.f, sn = 0.f, qu = 0.f, qp = 0.f, qn = 0.f;
-  for (int64_t f = lane; f < a.d; f += WAVE) {
-    const float u = fu[f], p = fp[f], n = fn[f];
-    sp = __builtin_fmaf(u, p, sp);
-    sn = __builtin_fmaf(u, n, sn);
-    const float x = eu[f], y = epp[f], z = en[f];
-    qu = __builtin_fmaf(x, x, qu);
-    qp = __builtin_fmaf(y, y, qp);
-    qn = __builtin_fmaf(z, z, qn);
+  if (a.de == a.d && a.reg_users) {  // the LightGCN-family form: one pass over rows of one width
+    for (int64_t f = lane; f < a.d; f += WAVE) {
+      const float u = fu[f], p = fp[f], n = fn[f];
+      sp = __builtin_fmaf(u, p, sp);
+      sn = __builtin_fmaf(u, n, sn);
+      const float x = eu[f], y = epp[f], z = en[f];
+      qu = __builtin_fmaf(x, x, qu);
+      qp = __builtin_fmaf(y, y, qp);
+      qn = __builtin_fmaf(z, z, qn);
+    }
+  } else {
+    for (int64_t f = lane; f < a.d; f += WAVE) {
+      const float u = fu[f], p = fp[f], n = fn[f];
+      sp = __builtin_fmaf(u, p, sp);
+      sn = __builtin_fmaf(u, n, sn);
+    }
+    const float* eu2 = a.ego + ru * a.de;
+    const float* ep2 = a.ego + rp * a.de;
+    const float* en2 = a.ego + rn * a.de;
+    for (int64_t f = lane; f < a.de; f += WAVE) {
+      const float x = a.reg_users ? eu2[f] : 0.f, y = ep2[f], z = en2[f];
+      qu = __builtin_fmaf(x, x, qu);
+      qp = __builtin_fmaf(y, y, qp);
+      qn = __builtin_fmaf(z, z, qn);
+    }
   }
   sp = wave_sum(sp);
   sn = wave_sum(sn);
@@ -379,10 +398,17 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
     if (!live) continue;
     const int64_t o = (int64_t)row * a.d + f;
     float reg = 0.f;
-    if (a.g_ego) {
-      const float r1 = (a.reg_scale * up1) * a.ego[o];
+    if (a.g_ego && a.de == a.d) {
+      const float r1 = (a.reg_users || row >= a.num_users) ? (a.reg_scale * up1) * a.ego[o] : 0.f;
       reg = r1;
       for (int64_t t = j + 1; t < e; ++t) reg += r1;
+    }
+    if (a.de != a.d) {  // ego rows of another width: their gradient rows are written by the loop below
+      if (a.g_final) {
+        if (a.touched) a.g_final[o] = acc;
+        else a.g_final[o] += acc;
+      }
+      continue;
     }
     if (a.g_final && a.g_final == a.g_ego) {
       a.g_final[o] += acc + reg;
@@ -395,6 +421,16 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
         if (a.touched) a.g_ego[o] = reg;
         else a.g_ego[o] += reg;
       }
+    }
+  }
+  if (a.de != a.d && a.g_ego) {
+    for (int64_t f = lane; f < a.de; f += WAVE) {
+      const int64_t o = (int64_t)row * a.de + f;
+      const float r1 = (a.reg_users || row >= a.num_users) ? (a.reg_scale * up1) * a.ego[o] : 0.f;
+      float reg = r1;
+      for (int64_t t = j + 1; t < e; ++t) reg += r1;
+      if (a.touched) a.g_ego[o] = reg;
+      else a.g_ego[o] += reg;
     }
   }
 }
@@ -699,6 +735,8 @@ static int bpr_args(BprArgs& a, const BprWs& w, const float* final_panel, const 
   a.num_users = num_users;
   a.B = B;
   a.d = d;
+  a.de = d;
+  a.reg_users = 1;
   a.inv_B = 1.0f / (float)B;
   a.reg_scale = reg_lambda / (float)B;
   a.coef = reinterpret_cast<float*>(base + w.coef);
@@ -711,7 +749,8 @@ static int bpr_args(BprArgs& a, const BprWs& w, const float* final_panel, const 
 
 static int bpr_forward_impl(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
                             const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
-                            float reg_lambda, float* loss, void* ws, void* stream, bool reduce_now) {
+                            float reg_lambda, float* loss, void* ws, void* stream, bool reduce_now, int64_t de = 0,
+                            int reg_users = 1) {
   IDG_REQUIRE(loss, "idg_bpr_forward_f32: loss is NULL");
   hipStream_t st = (hipStream_t)stream;
   const BprWs w = bpr_layout(B > 0 ? B : 1, sort_temp_bytes(3 * B));
@@ -719,6 +758,8 @@ static int bpr_forward_impl(const float* final_panel, const float* ego_panel, in
   int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
                     "idg_bpr_forward_f32");
   if (rc != IDG_OK) return rc;
+  if (de > 0) a.de = de;
+  a.reg_users = reg_users;
   const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
   hipLaunchKernelGGL(bpr_triple_kernel, dim3(nb), dim3(BLOCK), 0, st, a);
   if (reduce_now) hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(1024), 0, st, a.loss_i, a.sq, B, reg_lambda, loss);
@@ -793,7 +834,7 @@ int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* ne
 static int bpr_backward_impl(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
                              const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t d,
                              float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
-                             uint32_t* touched, void* ws, void* stream, float* loss_out) {
+                             uint32_t* touched, void* ws, void* stream, float* loss_out, int64_t de = 0, int reg_users = 1) {
   hipStream_t st = (hipStream_t)stream;
   IDG_REQUIRE(!touched || (deterministic && g_final != g_ego),
               "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter and g_final distinct from g_ego");
@@ -803,6 +844,10 @@ static int bpr_backward_impl(const float* final_panel, const float* ego_panel, i
                     "idg_bpr_backward_f32");
   if (rc != IDG_OK) return rc;
   if (!g_final && !g_ego) return IDG_OK;
+  if (de > 0) a.de = de;
+  a.reg_users = reg_users;
+  IDG_REQUIRE((a.de == a.d && a.reg_users) || (deterministic && g_final != g_ego),
+              "idg_bpr: ego rows of another width / an item-only regulariser need the deterministic scatter and distinct panels");
   a.g_final = g_final;
   a.g_ego = g_ego;
   a.upstream = upstream;
@@ -846,6 +891,20 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
   if (rc != IDG_OK) return rc;
   return bpr_backward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr, g_final, g_ego,
                            deterministic, touched, ws, stream, ride ? loss : nullptr);
+}
+
+int idg_bpr_fused_ex_f32(const float* final_panel, int64_t d_final, const float* ego_panel, int64_t d_ego, int64_t num_users,
+                         int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, float reg_lambda,
+                         int reg_users, float* loss, float* g_final, float* g_ego, int deterministic, uint32_t* touched,
+                         void* ws, void* stream) {
+  IDG_REQUIRE(d_final > 0 && d_ego > 0, "idg_bpr_fused_ex_f32: bad widths");
+  IDG_REQUIRE(deterministic != 0, "idg_bpr_fused_ex_f32: deterministic scatter only");
+  const bool ride = g_final || g_ego;
+  int rc = bpr_forward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d_final, reg_lambda, loss, ws, stream,
+                            !ride, d_ego, reg_users ? 1 : 0);
+  if (rc != IDG_OK) return rc;
+  return bpr_backward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d_final, reg_lambda, nullptr, g_final,
+                           g_ego, deterministic, touched, ws, stream, ride ? loss : nullptr, d_ego, reg_users ? 1 : 0);
 }
 
 size_t idg_bpr_rows_message_floats(int64_t B, int64_t d) {

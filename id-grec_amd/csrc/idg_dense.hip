@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void ngcf_tail_fwd_kernel(const float* __res
                                                               const float* __restrict__ b1, const float* __restrict__ b2,
                                                               int64_t n, int64_t d, float slope, float p, uint64_t seed,
                                                               uint64_t stream, float* __restrict__ E,
-                                                              float* __restrict__ N) {
+                                                              float* __restrict__ N, int64_t ldn) {
   const int lane = threadIdx.x % 64;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
   if (r >= n) return;
@@ -175,22 +175,29 @@ __global__ __launch_bounds__(BLOCK) void ngcf_tail_fwd_kernel(const float* __res
   }
   ss = wsum(ss);
   const float den = fmaxf(sqrtf(ss), 1e-12f);
-  for (int64_t f = lane; f < d; f += 64) N[r * d + f] = E[r * d + f] / den;
+  for (int64_t f = lane; f < d; f += 64) N[r * ldn + f] = E[r * d + f] / den;
 }
 
 // gT = d loss / d t given gE (through the layer's output as next ego) and gN (through its normalised copy)
 __global__ __launch_bounds__(BLOCK) void ngcf_tail_bwd_kernel(const float* __restrict__ E, const float* __restrict__ gE,
                                                               const float* __restrict__ gN, int64_t n, int64_t d,
                                                               float slope, float p, uint64_t seed, uint64_t stream,
-                                                              float* __restrict__ gT) {
+                                                              float* __restrict__ gT, int64_t ldgn,
+                                                              const uint32_t* __restrict__ gn_rows) {
   const int lane = threadIdx.x % 64;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
   if (r >= n) return;
+  // gn_rows: bitmap of the rows where gN holds anything (a fused step's d loss / d final is stored at the batch's rows only)
+  if (gN && gn_rows && !((gn_rows[r >> 5] >> (r & 31)) & 1u)) gN = nullptr;
+  if (!gN && !gE) {  // nothing flows into this row
+    for (int64_t f = lane; f < d; f += 64) gT[r * d + f] = 0.f;
+    return;
+  }
   float ss = 0.f, dot = 0.f;
   for (int64_t f = lane; f < d; f += 64) {
     const float e = E[r * d + f];
     ss += e * e;
-    if (gN) dot += gN[r * d + f] * e;
+    if (gN) dot += gN[r * ldgn + f] * e;
   }
   ss = wsum(ss);
   dot = wsum(dot);
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void ngcf_tail_bwd_kernel(const float* __res
     float g = gE ? gE[r * d + f] : 0.f;
     if (gN) {
       // y = e / max(||e||, eps): dy/de = (I - y y^T) / ||e|| above the clamp, I / eps below it
-      const float gn = gN[r * d + f];
+      const float gn = gN[r * ldgn + f];
       g += nrm > 1e-12f ? (gn - dot * e / (den * den)) / den : gn / den;
     }
     const float k = keep_scale(p, seed, stream, r, f);
@@ -214,25 +221,159 @@ __global__ __launch_bounds__(BLOCK) void ngcf_tail_bwd_kernel(const float* __res
 
 extern "C" {
 
-int idg_ngcf_tail_f32(const float* S1, const float* S2, const float* b1, const float* b2, int64_t n, int64_t d,
-                      float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* E, float* N, void* stream) {
+int idg_ngcf_tail_ex_f32(const float* S1, const float* S2, const float* b1, const float* b2, int64_t n, int64_t d,
+                         float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* E, float* N, int64_t ldn,
+                         void* stream) {
   IDG_REQUIRE(S1 && b1 && b2 && E && N, "idg_ngcf_tail_f32: NULL argument");
-  IDG_REQUIRE(n >= 0 && d > 0 && p >= 0.f && p < 1.f, "idg_ngcf_tail_f32: bad sizes / drop probability");
+  IDG_REQUIRE(n >= 0 && d > 0 && ldn >= d && p >= 0.f && p < 1.f, "idg_ngcf_tail_f32: bad sizes / drop probability");
   if (n == 0) return IDG_OK;
   hipLaunchKernelGGL(ngcf_tail_fwd_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
-                     (hipStream_t)stream, S1, S2, b1, b2, n, d, negative_slope, p, seed, stream_id, E, N);
+                     (hipStream_t)stream, S1, S2, b1, b2, n, d, negative_slope, p, seed, stream_id, E, N, ldn);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_ngcf_tail_f32(const float* S1, const float* S2, const float* b1, const float* b2, int64_t n, int64_t d,
+                      float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* E, float* N, void* stream) {
+  return idg_ngcf_tail_ex_f32(S1, S2, b1, b2, n, d, negative_slope, p, seed, stream_id, E, N, d, stream);
+}
+
+int idg_ngcf_tail_bwd_ex_f32(const float* E, const float* gE, const float* gN, int64_t ldgn, const uint32_t* gn_rows, int64_t n,
+                             int64_t d, float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* gT,
+                             void* stream) {
+  IDG_REQUIRE(E && gT && (gE || gN), "idg_ngcf_tail_bwd_f32: NULL argument");
+  IDG_REQUIRE(n >= 0 && d > 0 && (!gN || ldgn >= d) && p >= 0.f && p < 1.f, "idg_ngcf_tail_bwd_f32: bad sizes / drop probability");
+  if (n == 0) return IDG_OK;
+  hipLaunchKernelGGL(ngcf_tail_bwd_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                     (hipStream_t)stream, E, gE, gN, n, d, negative_slope, p, seed, stream_id, gT, ldgn, gn_rows);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }
 
 int idg_ngcf_tail_bwd_f32(const float* E, const float* gE, const float* gN, int64_t n, int64_t d, float negative_slope,
                           float p, uint64_t seed, uint64_t stream_id, float* gT, void* stream) {
-  IDG_REQUIRE(E && gT && (gE || gN), "idg_ngcf_tail_bwd_f32: NULL argument");
-  IDG_REQUIRE(n >= 0 && d > 0 && p >= 0.f && p < 1.f, "idg_ngcf_tail_bwd_f32: bad sizes / drop probability");
-  if (n == 0) return IDG_OK;
-  hipLaunchKernelGGL(ngcf_tail_bwd_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
-                     (hipStream_t)stream, E, gE, gN, n, d, negative_slope, p, seed, stream_id, gT);
+  return idg_ngcf_tail_bwd_ex_f32(E, gE, gN, d, nullptr, n, d, negative_slope, p, seed, stream_id, gT, stream);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Glue of NGCF's fused step (id-grec_amd/ngcf.py): column sums (the bias gradients of models/NGCF.py:91-99: gradient of
+// a [1, d] row broadcast over n rows), a strided panel copy (layer 0's slot of the concatenated final rows, NGCF.py:108)
+// and the gathering of three gradient contributions at the batch's rows.  Deterministic (fixed slice and tree orders).
+namespace {
+
+constexpr int CS_SLICES = 512;
+
+// part[s][f] = sum of X[r][f] over the rows of slice s (rows in order); grid (CS_SLICES), BLOCK threads: thread t owns
+// column t % d' of row group t / d' ... kept simple: each thread strides over rows for its column(s), partial sums are
+// combined across the block's row groups in LDS in group order.
+__global__ __launch_bounds__(BLOCK) void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int64_t d,
+                                                               float* __restrict__ part) {
+  __shared__ float s_acc[BLOCK];
+  const int64_t rows_per = (n + CS_SLICES - 1) / CS_SLICES;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per, r1 = r0 + rows_per < n ? r0 + rows_per : n;
+  for (int64_t f0 = 0; f0 < d; f0 += BLOCK) {
+    // d <= BLOCK: groups = BLOCK / d rows in flight; d > BLOCK: one row at a time
+    const int64_t w = d - f0 < BLOCK ? d - f0 : BLOCK;
+    const int groups = (int)(BLOCK / w);
+    const int g = (int)(threadIdx.x / w), c = (int)(threadIdx.x % w);
+    float acc = 0.f;
+    if (g < groups)
+      for (int64_t r = r0 + g; r < r1; r += groups) acc += X[r * ldx + f0 + c];
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0) {
+      float t = acc;
+      for (int q = 1; q < groups; ++q) t += s_acc[q * w + c];
+      part[(int64_t)blockIdx.x * d + f0 + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void colsum_reduce_kernel(const float* __restrict__ part, int64_t d, float* __restrict__ out,
+                                                              float* __restrict__ out2, int accumulate) {
+  const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (f >= d) return;
+  float t = 0.f;
+  for (int s = 0; s < CS_SLICES; ++s) t += part[(int64_t)s * d + f];
+  out[f] = accumulate ? out[f] + t : t;
+  if (out2) out2[f] = accumulate ? out2[f] + t : t;
+}
+
+__global__ __launch_bounds__(BLOCK) void copy_cols_kernel(float* __restrict__ dst, int64_t ldd, const float* __restrict__ src,
+                                                          int64_t lds, int64_t n, int64_t d4) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n * d4) return;
+  const int64_t r = i / d4, c = i % d4;
+  reinterpret_cast<float4*>(dst + r * ldd)[c] = reinterpret_cast<const float4*>(src + r * lds)[c];
+}
+
+// dst[r] = dst[r] + a[r] (+ b[r]) at the rows flagged in `rows`
+__global__ __launch_bounds__(BLOCK) void rows_add2_kernel(float* __restrict__ dst, int64_t ldd, const float* __restrict__ a,
+                                                          int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                          const uint32_t* __restrict__ rows, int64_t n, int64_t d4) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n * d4) return;
+  const int64_t r = i / d4, c = i % d4;
+  if (!((rows[r >> 5] >> (r & 31)) & 1u)) return;
+  float4 x = reinterpret_cast<float4*>(dst + r * ldd)[c];
+  const float4 y = reinterpret_cast<const float4*>(a + r * lda)[c];
+  x.x += y.x, x.y += y.y, x.z += y.z, x.w += y.w;
+  if (b) {
+    const float4 z = reinterpret_cast<const float4*>(b + r * ldb)[c];
+    x.x += z.x, x.y += z.y, x.z += z.z, x.w += z.w;
+  }
+  reinterpret_cast<float4*>(dst + r * ldd)[c] = x;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t idg_colsum_workspace_bytes(int64_t d) { return d > 0 ? (size_t)CS_SLICES * (size_t)d * sizeof(float) : 0; }
+
+int idg_colsum_f32(const float* X, int64_t ldx, int64_t n, int64_t d, float* out, float* out2, int accumulate, void* ws,
+                   void* stream) {
+  IDG_REQUIRE(X && out && ws && n >= 0 && d > 0 && ldx >= d, "idg_colsum_f32: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(CS_SLICES), dim3(BLOCK), 0, st, X, ldx, n, d, part);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((d + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, part, d, out, out2,
+                     accumulate ? 1 : 0);
   IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_copy_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t n, int64_t d, void* stream) {
+  IDG_REQUIRE(dst && src && n >= 0 && d > 0 && d % 4 == 0 && ldd >= d && lds >= d && ldd % 4 == 0 && lds % 4 == 0,
+              "idg_copy_cols_f32: bad argument (widths and leading dimensions multiples of 4)");
+  IDG_REQUIRE(((uintptr_t)dst | (uintptr_t)src) % 16 == 0, "idg_copy_cols_f32: panels must be 16-byte aligned");
+  if (n == 0) return IDG_OK;
+  const int64_t total = n * (d / 4);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, dst, ldd,
+                     src, lds, n, d / 4);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_rows_add2_f32(float* dst, int64_t ldd, const float* a, int64_t lda, const float* b, int64_t ldb, const uint32_t* rows,
+                      int64_t n, int64_t d, void* stream) {
+  IDG_REQUIRE(dst && a && rows && n >= 0 && d > 0 && d % 4 == 0 && ldd % 4 == 0 && lda % 4 == 0 && (!b || ldb % 4 == 0),
+              "idg_rows_add2_f32: bad argument");
+  IDG_REQUIRE(((uintptr_t)dst | (uintptr_t)a | (uintptr_t)b) % 16 == 0, "idg_rows_add2_f32: panels must be 16-byte aligned");
+  if (n == 0) return IDG_OK;
+  const int64_t total = n * (d / 4);
+  hipLaunchKernelGGL(rows_add2_kernel, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, dst, ldd,
+                     a, lda, b, ldb, rows, n, d / 4);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_zero_f32(float* p, int64_t count, void* stream) {
+  IDG_REQUIRE(p && count >= 0, "idg_zero_f32: bad argument");
+  IDG_HIP(hipMemsetAsync(p, 0, (size_t)count * sizeof(float), (hipStream_t)stream));
   return IDG_OK;
 }
 

@@ -109,6 +109,17 @@ PROTOTYPES = {
     "idg_rows_tanh_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_infonce_pair_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int, C.c_float,
                                        c_vp, c_vp, c_vp, C.c_float, C.c_int, c_vp, c_vp]),
+    "idg_ngcf_tail_ex_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
+                                       c_vp, c_vp, C.c_int64, c_vp]),
+    "idg_ngcf_tail_bwd_ex_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float,
+                                           C.c_uint64, C.c_uint64, c_vp, c_vp]),
+    "idg_colsum_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "idg_colsum_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int, c_vp, c_vp]),
+    "idg_copy_cols_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp]),
+    "idg_rows_add2_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, c_vp]),
+    "idg_zero_f32": (C.c_int, [c_vp, C.c_int64, c_vp]),
+    "idg_bpr_fused_ex_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64,
+                                       C.c_float, C.c_int, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "idg_bpr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "idg_bpr_fused_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                     C.c_float, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
@@ -144,6 +155,7 @@ PROTOTYPES = {
                                      C.c_int, c_vp, c_vp, c_vp, c_vp]),
 }
 
+IDG_BPR_PLANNED = 2  # `deterministic` value: the sorted scatter plan is already in the workspace (idg_bpr_plan_f32)
 IDG_GRAPH_SYMMETRIC = 1
 IDG_GRAPH_EXACT_ORDER = 2
 

@@ -412,6 +412,15 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
                       int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
                       int64_t B, int64_t d, float reg_lambda, float* loss, float* g_final,
                       float* g_ego, int deterministic, uint32_t* touched, void* ws, void* stream);
+/* The same with final rows and ego rows of DIFFERENT widths and an optional item-only regulariser — NGCF (models/NGCF.py:
+ * 108-128): the scored rows are the concatenation of the layer outputs ([n, (K+1) d]), the regulariser covers
+ * item_embedding(positive) and item_embedding(negative) only (two blocks; reg_users = 0: the user block contributes
+ * nothing to loss[1] and a zero row to g_ego).  g_final [n, d_final], g_ego [n, d_ego]; deterministic scatter only
+ * (1, or IDG_BPR_PLANNED with the plan in ws). */
+int idg_bpr_fused_ex_f32(const float* final_panel, int64_t d_final, const float* ego_panel, int64_t d_ego,
+                         int64_t num_users, int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                         int64_t B, float reg_lambda, int reg_users, float* loss, float* g_final, float* g_ego,
+                         int deterministic, uint32_t* touched, void* ws, void* stream);
 /* The same computation as two calls, for callers that sit under an autograd engine:
  * forward writes loss[2] and keeps per-triple coefficients in ws; backward (same ws, same
  * inputs) scatters the gradients scaled by upstream[0] (for loss[0]) and upstream[1] (for
@@ -494,6 +503,27 @@ int idg_ngcf_tail_f32(const float* S1, const float* S2, const float* b1, const f
 int idg_ngcf_tail_bwd_f32(const float* E, const float* gE, const float* gN, int64_t n, int64_t d,
                           float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* gT,
                           void* stream);
+/* The forms a fused, autograd-free NGCF step uses (id-grec_amd/ngcf.py): N written with leading dimension ldn — straight
+ * into layer l's slot of the concatenated final rows (torch.cat(all_embeddings, dim=1), models/NGCF.py:108); gN read with
+ * leading dimension ldgn and only at the rows flagged in gn_rows (NULL: every row) — d loss / d final is stored at the
+ * batch's rows only; rows no gradient flows into get gT = 0. */
+int idg_ngcf_tail_ex_f32(const float* S1, const float* S2, const float* b1, const float* b2, int64_t n, int64_t d,
+                         float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* E, float* N,
+                         int64_t ldn, void* stream);
+int idg_ngcf_tail_bwd_ex_f32(const float* E, const float* gE, const float* gN, int64_t ldgn, const uint32_t* gn_rows,
+                             int64_t n, int64_t d, float negative_slope, float p, uint64_t seed, uint64_t stream_id,
+                             float* gT, void* stream);
+/* Glue of that step.  idg_colsum_f32: out[f] (+)= sum over the n rows of X[r, f] (and the same into out2 if not NULL: NGCF's
+ * two bias rows of a layer receive the same gradient), slices of rows summed in slice order; ws: idg_colsum_workspace_bytes(d).
+ * idg_copy_cols_f32: dst[r, 0:d] = src[r, 0:d] with leading dimensions ldd / lds.  idg_rows_add2_f32: dst[r] += a[r] (+ b[r])
+ * at the rows flagged in `rows`.  idg_zero_f32: count floats cleared on the stream. */
+size_t idg_colsum_workspace_bytes(int64_t d);
+int idg_colsum_f32(const float* X, int64_t ldx, int64_t n, int64_t d, float* out, float* out2, int accumulate, void* ws,
+                   void* stream);
+int idg_copy_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t n, int64_t d, void* stream);
+int idg_rows_add2_f32(float* dst, int64_t ldd, const float* a, int64_t lda, const float* b, int64_t ldb,
+                      const uint32_t* rows, int64_t n, int64_t d, void* stream);
+int idg_zero_f32(float* p, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: in-batch InfoNCE between two views, forward + backward

@@ -459,6 +459,71 @@ def test_ngcf_vs_reference(tmp_path, golden_small, golden_next):
     assert idx.shape == (32, 10)
 
 
+@pytest.mark.parametrize("drop", ["[0.0, 0.0, 0.0]", "[0.1, 0.1, 0.1]"])
+def test_ngcf_fused_step_vs_reference_and_autograd(drop, tmp_path, golden_small, golden_next):
+    """The fused, autograd-free NGCF step (idgrec_amd/ngcf.py: products, fp32-MFMA transforms, layer tails writing into the
+    concatenated final rows, BPR over (K+1)d-wide rows with the item-only regulariser, the whole backward chain, Adam in
+    the last product's epilogue and ONE Adam launch for the 12 small tensors): with message dropout off against the
+    REFERENCE's losses and gradients (next_small.npz); with the configured dropout against the differentiable operators
+    on the same dropout streams — losses, every gradient, every parameter after the update."""
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from models.NGCF import NGCF
+
+    g, nx = golden_small, golden_next
+    cfg = _cfg("NGCF", mess_drop_prob=drop)
+    data = _data_with(tmp_path, g, cfg)
+    b = torch.from_numpy(nx["batch"]).cuda()
+    bu, bp, bn = b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous()
+    lr = float(cfg["learn_rate"])
+
+    tools.set_seed(2024)
+    m1 = NGCF(cfg, data, torch.device("cuda")).to("cuda")
+    opt1 = ops.Adam(list(m1.parameters()), lr=lr)
+    ops.reset_noise_stream()
+    ll = m1(bu, bp, bn)
+    opt1.zero_grad()
+    sum(ll).backward()
+    grads1 = {k: v.grad.clone() for k, v in m1.named_parameters()}
+    opt1.step()
+
+    tools.set_seed(2024)
+    m2 = NGCF(cfg, data, torch.device("cuda")).to("cuda")
+    assert m2.fused_step_available()
+    opt2 = ops.Adam(list(m2.parameters()), lr=lr)
+    eng = m2.ngcf_engine()
+    eng.store_grad = True
+    ops.reset_noise_stream()
+    out = torch.zeros(2, device="cuda")
+    assert m2.fused_train_step(bu, bp, bn, out, opt2)
+    np.testing.assert_allclose(out.cpu().numpy(), [x.item() for x in ll], rtol=2e-5)
+    U = data.num_users
+    got = {"user_embedding.weight": eng.GRAD[:U], "item_embedding.weight": eng.GRAD[U:]}
+    for l in range(m2.n_layers):
+        for nm, gv in zip(("W_gcn_%d", "b_gcn_%d", "W_bi_%d", "b_bi_%d"), eng.small_grads()[l]):
+            got["weight_dict." + nm % l] = gv
+    assert set(got) == set(grads1)
+    for k, want in grads1.items():
+        scale = float(want.abs().max())
+        assert float((got[k] - want).abs().max()) <= 2e-4 * scale + 1e-12, k
+    if drop == "[0.0, 0.0, 0.0]":  # the reference's own numbers
+        np.testing.assert_allclose(out.cpu().numpy(), nx["ngcf_loss"], rtol=RTOL)
+        np.testing.assert_allclose(got["user_embedding.weight"].cpu().numpy(), nx["ngcf_grad_user"], rtol=1e-3, atol=1e-8)
+        np.testing.assert_allclose(got["item_embedding.weight"].cpu().numpy(), nx["ngcf_grad_item"], rtol=1e-3, atol=1e-8)
+        np.testing.assert_allclose(got["weight_dict.W_gcn_0"].cpu().numpy(), nx["ngcf_grad_W_gcn_0"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(got["weight_dict.b_bi_2"].cpu().numpy(), nx["ngcf_grad_b_bi_2"], rtol=1e-3, atol=1e-7)
+    # after the update: the same step size everywhere the gradient is above rounding level
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    for k in p1:
+        big = grads1[k].abs() > 1e-3 * grads1[k].abs().max()
+        assert torch.allclose(p2[k].detach()[big], p1[k].detach()[big], rtol=0, atol=0.05 * lr), k
+        assert float((p2[k].detach() - p1[k].detach()).abs().max()) <= 2.1 * lr, k
+    assert all(int(opt2.state[p]["step"]) == 1 for p in m2.parameters())
+    # a second step through the trainer's protocol keeps the optimizer's state consistent
+    assert m2.fused_train_step(bu, bp, bn, out, opt2) and all(int(opt2.state[p]["step"]) == 2 for p in m2.parameters())
+    assert torch.isfinite(out).all()
+
+
 def test_ngcf_node_dropout_trains(tmp_path, golden_small):
     """node_dropout = True (models/NGCF.py:56-79; the reference reads config['node_keep_prob'], a key its shipped
     config file does not have): a re-drawn edge mask per training forward, the plain graph in evaluation."""
