@@ -44,6 +44,7 @@ struct BprArgs {
   float* g_ego;
   const float* upstream;  // device [2]: d total / d loss[0], d total / d loss[1]; NULL = ones
   uint32_t* touched;      // bitmap of g_final rows written; when set, rows are STORED, not accumulated
+  int touched_preset;     // the bitmap already holds exactly these rows (idg_bpr_touch_rows): store mode, nothing written to it
   int atomic;
 };
 
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
   while (e < n3 && skeys[e] == row) ++e;
   const float up0 = a.upstream ? a.upstream[0] : 1.0f;
   const float up1 = a.upstream ? a.upstream[1] : 1.0f;
-  if (a.touched && lane == 0) atomicOr(a.touched + (row >> 5), 1u << (row & 31));
+  if (a.touched && !a.touched_preset && lane == 0) atomicOr(a.touched + (row >> 5), 1u << (row & 31));
   // The run's slots are resolved 64 at a time by the lanes in parallel (slot -> triple -> coefficient and the one or two
   // panel rows it reads): the sequential walk below then has ONE dependent load level per slot, with several slots'
   // row loads in flight, instead of three (a hub item's run is the kernel's critical path).  The additions keep
@@ -852,7 +853,10 @@ static int bpr_backward_impl(const float* final_panel, const float* ego_panel, i
   a.g_ego = g_ego;
   a.upstream = upstream;
   a.touched = touched;
-  idg::rows_changed(touched, (size_t)((n + 31) / 32) * sizeof(uint32_t));  // (the scatter sets bits in it)
+  a.touched_preset = (deterministic & IDG_BPR_TOUCHED_PRESET) ? 1 : 0;
+  deterministic &= ~IDG_BPR_TOUCHED_PRESET;
+  // (the scatter sets bits in it — unless the caller says they are set already: lists registered for the bitmap stay valid)
+  if (!a.touched_preset) idg::rows_changed(touched, (size_t)((n + 31) / 32) * sizeof(uint32_t));
   char* base = reinterpret_cast<char*>(ws);
   if (!deterministic) {
     const unsigned nb = (unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
@@ -886,7 +890,7 @@ int idg_bpr_fused_f32(const float* final_panel, const float* ego_panel, int64_t 
                       float reg_lambda, float* loss, float* g_final, float* g_ego, int deterministic,
                       uint32_t* touched, void* ws, void* stream) {
   // with a deterministic scatter the loss reduction rides in the scatter launch (same reduction tree, same bits)
-  const bool ride = deterministic != 0 && (g_final || g_ego);
+  const bool ride = (deterministic & ~IDG_BPR_TOUCHED_PRESET) != 0 && (g_final || g_ego);
   int rc = bpr_forward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, loss, ws, stream, !ride);
   if (rc != IDG_OK) return rc;
   return bpr_backward_impl(final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, nullptr, g_final, g_ego,

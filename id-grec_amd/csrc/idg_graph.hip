@@ -187,28 +187,29 @@ struct UnitList {
   const uint32_t* bitmap = nullptr;
   const int32_t* units = nullptr;
   int64_t cap = 0;
+  int kind = 0;  // 0: live work units of the bitmap's OUTPUT rows; 1: the tiles' entry lists compacted to the bitmap's INPUT rows
 };
 constexpr int MAX_UNIT_LISTS = 64;
 UnitList g_unit_lists[MAX_UNIT_LISTS];
 int g_unit_next = 0;
 std::mutex g_unit_mutex;
 
-void units_register(const void* sched, const uint32_t* bitmap, const int32_t* units, int64_t cap) {
+void units_register(const void* sched, const uint32_t* bitmap, const int32_t* units, int64_t cap, int kind = 0) {
   std::lock_guard<std::mutex> lock(g_unit_mutex);
   int at = -1;
   for (int i = 0; i < MAX_UNIT_LISTS; ++i)
-    if (g_unit_lists[i].sched == sched && g_unit_lists[i].bitmap == bitmap) at = i;
+    if (g_unit_lists[i].sched == sched && g_unit_lists[i].bitmap == bitmap && g_unit_lists[i].kind == kind) at = i;
   if (at < 0)
     for (int i = 0; i < MAX_UNIT_LISTS && at < 0; ++i)
       if (g_unit_lists[i].bitmap == nullptr) at = i;
   if (at < 0) at = g_unit_next, g_unit_next = (g_unit_next + 1) % MAX_UNIT_LISTS;  // full: the oldest slot is replaced
-  g_unit_lists[at] = UnitList{sched, bitmap, units, cap};
+  g_unit_lists[at] = UnitList{sched, bitmap, units, cap, kind};
 }
 
-bool units_find(const void* sched, const uint32_t* bitmap, const int32_t** units, int64_t* cap) {
+bool units_find(const void* sched, const uint32_t* bitmap, const int32_t** units, int64_t* cap, int kind = 0) {
   std::lock_guard<std::mutex> lock(g_unit_mutex);
   for (int i = 0; i < MAX_UNIT_LISTS; ++i)
-    if (g_unit_lists[i].sched == sched && g_unit_lists[i].bitmap == bitmap && bitmap != nullptr) {
+    if (g_unit_lists[i].sched == sched && g_unit_lists[i].bitmap == bitmap && bitmap != nullptr && g_unit_lists[i].kind == kind) {
       if (units) *units = g_unit_lists[i].units;
       if (cap) *cap = g_unit_lists[i].cap;
       return true;
@@ -751,6 +752,111 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_sparse_kernel(const Tile* __r
   if (t.n_local > 0) {
     __syncthreads();
     combine_local<LPR, NB, EPI, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, nullptr, nullptr);
+  }
+}
+
+// ---- the sparse-input form with its index-only half done AHEAD of time (round 4) -------------------------------------
+// Which entries of a tile point at live rows of the gathered panel depends on the bitmap only, not on the panel: the
+// flag / scan / compaction above is index-only work.  compact_inputs_kernel does it once per bitmap (on the caller's
+// side stream, with the batch's other index-only work, while the previous step is still running) and leaves, per tile,
+// the live entries in their original order at the tile's own offset of a second entry list, the compacted start of
+// every vrow and the tile's live count.  The product then stages those lists and runs the ORDINARY walk over them
+// (spmm_tile_compact_kernel): no dead entry is loaded, flagged or scanned on the critical path.  Dropping a dead entry
+// is exact and the survivors keep their order: bit-identical to the dense form and to spmm_tile_sparse_kernel.
+__global__ __launch_bounds__(BLOCK) void compact_inputs_kernel(const Tile* __restrict__ tiles, const int64_t* __restrict__ vptr,
+                                                               const ColVal* __restrict__ cv,
+                                                               const uint32_t* __restrict__ x_mask, ColVal* __restrict__ ccv,
+                                                               int32_t* __restrict__ cptr, int32_t* __restrict__ clive) {
+  __shared__ int s_pre[TILE_NNZ + 1];
+  __shared__ int s_wave[(TILE_NNZ / BLOCK) * (BLOCK / 64)];
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int lane = tid % 64, wave = tid / 64;
+  const int nv = t.n_vrows;
+  const int64_t nz0 = t.nnz_begin;
+  const int cnt = t.nnz_count;
+  const ColVal* src = cv + nz0;
+  constexpr int PER = TILE_NNZ / BLOCK;
+  ColVal e[PER];
+  bool live[PER];
+  int in_wave[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = k * BLOCK + tid;
+    e[k] = ColVal{};
+    if (i < cnt) e[k] = src[i];
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = k * BLOCK + tid;
+    live[k] = i < cnt && mask_bit(x_mask, e[k].col);
+    const unsigned long long m = __ballot(live[k]);
+    in_wave[k] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[k * (BLOCK / 64) + wave] = __popcll(m);
+  }
+  __syncthreads();
+  int before = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = k * BLOCK + tid;
+    int mine = before;
+    for (int w = 0; w < BLOCK / 64; ++w) {
+      const int c = s_wave[k * (BLOCK / 64) + w];
+      if (w < wave) mine += c;
+      before += c;
+    }
+    if (i < cnt) s_pre[i] = mine + in_wave[k];
+    if (live[k]) ccv[nz0 + mine + in_wave[k]] = e[k];
+  }
+  if (tid == 0) {
+    s_pre[cnt] = before;
+    clive[t.vrow_begin] = before;
+  }
+  __syncthreads();
+  for (int i = tid; i < nv; i += BLOCK) cptr[t.vrow_begin + i] = s_pre[(int)(vptr[t.vrow_begin + i] - nz0)];
+}
+
+template <int LPR, int NB, bool FUSED>
+__global__ __launch_bounds__(BLOCK) void spmm_tile_compact_kernel(const Tile* __restrict__ tiles,
+                                                                  const int32_t* __restrict__ vtgt,
+                                                                  const ColVal* __restrict__ ccv,
+                                                                  const int32_t* __restrict__ cptr,
+                                                                  const int32_t* __restrict__ clive,
+                                                                  const float* __restrict__ X, int64_t ldx,
+                                                                  float* __restrict__ partials, int64_t d, Epilogue ep,
+                                                                  FixCtx fx, const LocalRow* __restrict__ locals) {
+  __shared__ ColVal s_cv[TILE_NNZ];
+  __shared__ float4 s_part[LSLOTS * NB * LPR];
+  __shared__ int s_ptr[TILE_VROWS + 1];
+  __shared__ int s_tgt[TILE_VROWS];
+  __shared__ int s_next;
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int nv = t.n_vrows;
+  constexpr int GROUPS = BLOCK / LPR;
+  if (tid == 0) s_next = GROUPS;
+  const int cnt = clive[t.vrow_begin];
+  for (int i = tid; i < nv; i += BLOCK) s_ptr[i] = cptr[t.vrow_begin + i];
+  if (tid == 0) s_ptr[nv] = cnt;
+  for (int i = tid; i < nv; i += BLOCK) s_tgt[i] = vtgt[t.vrow_begin + i];
+  {
+    const ColVal* src = ccv + t.nnz_begin;
+    for (int i = tid; i < cnt; i += BLOCK) s_cv[i] = src[i];
+  }
+  __syncthreads();
+  const int g = tid / LPR;
+  const int l = tid % LPR;
+  int v = g;
+  while (v < nv) {
+    // (a vrow without a live entry still runs its epilogue: it owns an output row, or a partial of one)
+    do_vrow<LPR, NB, IDG_ROWS_UNROLL, EPI_PLAIN, FUSED>(s_cv, s_ptr[v], s_ptr[v + 1], s_tgt[v], l, X, ldx, partials, d, ep, fx, s_part);
+    int nxt = 0;
+    if (l == 0) nxt = atomicAdd(&s_next, 1);
+    v = __builtin_amdgcn_ds_bpermute(group_leader<LPR>() << 2, nxt);
+  }
+  if (t.n_local > 0) {
+    __syncthreads();
+    combine_local<LPR, NB, EPI_PLAIN, FUSED>(t, locals, s_part, g, l, partials, d, ep, fx, nullptr, nullptr);
   }
 }
 
@@ -1448,6 +1554,18 @@ int launch_fast(const idg_graph* g, const float* X, int64_t ldx, float* partials
       else
         hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, false, EPI_ACT>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
                            g->d_cv, X, ldx, partials, d, ep, fx, x_mask, g->d_local);
+    } else if (x_mask && !g->no_units && g->n_xl == 0 && units_find(g->d_cv, x_mask, &units, &ucap, 1)) {
+      // sparse-input form whose index-only half was done ahead of time (idg_graph_compact_inputs): the ordinary walk over
+      // the live entries of every tile
+      const ColVal* ccv = reinterpret_cast<const ColVal*>(units);
+      const int32_t* cptr = reinterpret_cast<const int32_t*>(ccv + g->nnz);
+      const int32_t* clive = cptr + g->n_vrows;
+      if (fused_fix)
+        hipLaunchKernelGGL((spmm_tile_compact_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vtgt, ccv, cptr, clive, X,
+                           ldx, partials, d, ep, fx, g->d_local);
+      else
+        hipLaunchKernelGGL((spmm_tile_compact_kernel<LPR, NB, false>), grid, block, 0, st, tile_order, g->d_vtgt, ccv, cptr, clive, X,
+                           ldx, partials, d, ep, fx, g->d_local);
     } else if (x_mask) {  // sparse-input form (first backward layer)
       if (fused_fix)
         hipLaunchKernelGGL((spmm_tile_sparse_kernel<LPR, NB, true>), grid, block, 0, st, tile_order, g->d_vptr, g->d_vtgt,
@@ -1954,6 +2072,7 @@ int idg_graph_create_from_device(int device, int64_t n_rows, int64_t n_cols, int
 int idg_graph_destroy(idg_graph* g) {
   if (!g) return IDG_OK;
   if (!g->borrowed && g->d_vptr) units_forget(g->d_vptr, nullptr);  // the schedule goes away: so do its unit lists
+  if (g->d_cv) units_forget(g->d_cv, nullptr);                         // ... and the entry lists compacted from these values
   if (g->device >= 0 && idg_device_count() > g->device) {
     DeviceGuard guard;
     if (guard.enter(g->device) == IDG_OK) {
@@ -2140,6 +2259,7 @@ int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const 
 int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap) {
   IDG_REQUIRE(g, "idg_graph_forget_live_units: NULL handle");
   units_forget(g->d_vptr, bitmap);
+  units_forget(g->d_cv, bitmap);  // (compacted entry lists: idg_graph_compact_inputs)
   return IDG_OK;
 }
 
@@ -2154,6 +2274,27 @@ int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units
                        g->d_row_unit, g->d_long, g->d_slot_unit, reinterpret_cast<int32_t*>(units_ws), max_rows + g->n_slots);
   IDG_HIP(hipGetLastError());
   return idg_graph_bind_live_units(g, bitmap, units_ws, max_rows);
+}
+
+size_t idg_graph_compact_inputs_bytes(const idg_graph* g) {
+  if (!g) return 0;
+  // the compacted entry list (the tiles' offsets are kept), a compacted start per vrow, a live count per tile (indexed by
+  // the tile's first vrow)
+  return (size_t)g->nnz * sizeof(ColVal) + 2 * (size_t)g->n_vrows * sizeof(int32_t) + 16;
+}
+
+int idg_graph_compact_inputs(const idg_graph* g, const uint32_t* bitmap, void* ws, void* stream) {
+  IDG_REQUIRE(g && bitmap && ws, "idg_graph_compact_inputs: bad argument");
+  IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_graph_compact_inputs: workspace must be 16-byte aligned");
+  if (g->n_tiles == 0 || g->n_xl > 0) return IDG_OK;  // (EXACT_ORDER handles with rows beyond a tile keep the in-kernel form)
+  ColVal* ccv = reinterpret_cast<ColVal*>(ws);
+  int32_t* cptr = reinterpret_cast<int32_t*>(ccv + g->nnz);
+  int32_t* clive = cptr + g->n_vrows;
+  hipLaunchKernelGGL(compact_inputs_kernel, dim3((unsigned)g->n_tiles), dim3(BLOCK), 0, (hipStream_t)stream, g->d_tiles, g->d_vptr,
+                     g->d_cv, bitmap, ccv, cptr, clive);
+  IDG_HIP(hipGetLastError());
+  units_register(g->d_cv, bitmap, reinterpret_cast<const int32_t*>(ws), g->nnz, 1);  // (keyed by the ENTRY list: copies of a handle share its schedule, not its values)
+  return IDG_OK;
 }
 
 int idg_graph_live_units_check(const void* units_ws, void* stream) {

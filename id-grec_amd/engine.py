@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from . import ops
+from . import native, ops
 
 
 class PropagationEngine:
@@ -56,6 +56,12 @@ class PropagationEngine:
         want = os.environ.get("IDG_FIELDS", "")
         self._fields = (self.graph is not None and self.deterministic and self.K in (2, 3)
                         and (want == "1" or (want != "0" and self.n >= 4_000_000)))
+        # IDG_COMPACT_INPUTS=1: the first backward product's flag / scan / compaction done ahead of time on the side stream
+        # (Graph.compact_inputs).  Measured and left OFF (HISTORY.md, round 4): the product drops 24.3 -> 20.6 us — what
+        # remains is the per-vrow cost of producing every output row — while the side-stream kernel takes 29 us of the same
+        # GPU: 0.2732 vs 0.2692 ms/step on one box.
+        self._compact = (self.graph is not None and self.deterministic and os.environ.get("IDG_COMPACT_INPUTS", "0") == "1"
+                         and self.graph.nnz * 8 <= (2 << 30))
         self._id_storage = None  # storages of the id tensors last ordered against the main stream
         self._pp = None     # ping-pong panels of the instrumented (layer-by-layer) forward
         self.fuse_adam = True  # train_step(): Adam in the last backward epilogue (False: separate idg_adam_step_f32)
@@ -101,6 +107,7 @@ class PropagationEngine:
         def __init__(self, words, device):
             self.bitmap = torch.zeros(words, dtype=torch.int32, device=device)
             self.units, self.units_B = None, -1  # live work units of the bitmap (Graph.live_units), rebuilt with it
+            self.compact = None  # the tiles' entry lists compacted to the bitmap's rows (Graph.compact_inputs), rebuilt with it
             self.hops = None  # [rows of the batch, + 1 hop, + 2 hops ...] (receptive-field propagation)
             self.use_fields = False
             self.ids = None
@@ -137,6 +144,10 @@ class PropagationEngine:
             # (... and much larger than THIS batch's neighbourhood: with ~256 distinct two-hop rows per batch row the
             #  field of a 2^20-triple batch is the graph, and the restricted kernels only cost: 355 vs 342 ms measured)
             slot.use_fields = self._fields and 3 * B * 256 <= self.n
+            # the first backward product gathers from the batch's <= 3B live rows: its flag / scan / compaction of every
+            # tile's entries is index-only too — done here, off the critical path (graphs whose entry list fits twice)
+            if self._compact and not slot.use_fields:
+                slot.compact = self.graph.compact_inputs(slot.bitmap, ws=slot.compact, stream=self._side_raw)
             if slot.use_fields:
                 if slot.hops is None:
                     slot.hops = [slot.bitmap] + [torch.zeros_like(slot.bitmap) for _ in range(self.K - 1)]
@@ -264,8 +275,11 @@ class PropagationEngine:
         slot.plan_done.wait(main.cuda_stream)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled
+        # (the bitmap already holds the batch's rows: with TOUCHED_PRESET the scatter stores its rows without writing it, so
+        #  the lists registered for it — the compacted inputs of the first backward product — stay valid)
         ops.bpr_fused_raw(self.final, self.params, users, pos, neg, self.U, self.reg_lambda, self.g_final,
-                          self.grad, loss=loss[:2], deterministic=2, touched=slot.bitmap, ws=slot.ws)
+                          self.grad, loss=loss[:2], deterministic=2 | native.IDG_BPR_TOUCHED_PRESET, touched=slot.bitmap,
+                          ws=slot.ws)
         if self.ssl is not None:
             # d(ssl_lambda * InfoNCE)/d view_1 + d(...)/d view_2 join the BPR gradient in g_final's (stored) rows
             ops.infonce_pair_raw(self._views[0], self._views[1], users, pos, self.U, temperature, g1=self.g_final,

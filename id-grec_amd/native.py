@@ -53,6 +53,8 @@ PROTOTYPES = {
     "idg_graph_remask": (C.c_int, [c_vp, c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp]),
     "idg_graph_masked_copy": (C.c_int, [c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp, C.POINTER(c_vp)]),
     "idg_graph_info": (C.c_int, [c_vp, c_i64p]),
+    "idg_graph_compact_inputs_bytes": (C.c_size_t, [c_vp]),
+    "idg_graph_compact_inputs": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "idg_graph_long_rows": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p]),
     "idg_spmm_workspace_bytes": (C.c_size_t, [c_vp, C.c_int64]),
     "idg_spmm_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, c_vp]),
@@ -109,6 +111,8 @@ PROTOTYPES = {
     "idg_rows_tanh_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
     "idg_infonce_pair_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int, C.c_float,
                                        c_vp, c_vp, c_vp, C.c_float, C.c_int, c_vp, c_vp]),
+    "idg_ngcf_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "idg_ngcf_wgrad_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, c_vp]),
     "idg_ngcf_tail_ex_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
                                        c_vp, c_vp, C.c_int64, c_vp]),
     "idg_ngcf_tail_bwd_ex_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float,
@@ -155,6 +159,7 @@ PROTOTYPES = {
                                      C.c_int, c_vp, c_vp, c_vp, c_vp]),
 }
 
+IDG_BPR_TOUCHED_PRESET = 4  # OR-ed into `deterministic`: the touched bitmap already holds the batch's rows
 IDG_BPR_PLANNED = 2  # `deterministic` value: the sorted scatter plan is already in the workspace (idg_bpr_plan_f32)
 IDG_GRAPH_SYMMETRIC = 1
 IDG_GRAPH_EXACT_ORDER = 2

@@ -73,7 +73,8 @@ class NgcfEngine:
         self.M, self.V = torch.zeros((n, d), **f32), torch.zeros((n, d), **f32)
         self.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
         self.bpr_ws, self.bpr_B = None, -1
-        self.cs_ws = torch.empty(int(lib.idg_colsum_workspace_bytes(d)), dtype=torch.uint8, device=dev)
+        self.wg_ws = torch.empty(int(lib.idg_ngcf_wgrad_workspace_bytes(d, d)), dtype=torch.uint8, device=dev)
+        self._per = per
         self.loss = torch.zeros(2, **f32)
         self.step_count = 0
         self._streams = None
@@ -128,15 +129,14 @@ class NgcfEngine:
         gE = None
         for l in range(K - 1, -1, -1):
             wg, bg, wb, bb = self._views[l]
-            gwg, gbg, gwb, gbb = self._gviews[l]
             seed, sid = self._streams[l]
             slot = self.GFIN.data_ptr() + 4 * (l + 1) * d
             check(lib.idg_ngcf_tail_bwd_ex_f32(p_(self.E[l]), p_(gE), C.c_void_p(slot), D, p_(self.bitmap), n, d, self.slope,
                                                self.p[l], C.c_uint64(seed), C.c_uint64(sid), p_(self.gT), st),
                   "idg_ngcf_tail_bwd_ex_f32")
-            check(lib.idg_colsum_f32(p_(self.gT), d, n, d, p_(gbg), p_(gbb), 0, p_(self.cs_ws), st), "idg_colsum_f32")
-            ops.linear_wgrad_raw(self.SIDE[l], self.gT, out=gwg)
-            ops.linear_wgrad_raw(self.BI[l], self.gT, out=gwb)
+            # the layer's four parameter gradients in one pass over (side, ego * side, gT), straight into the flat buffer
+            check(lib.idg_ngcf_wgrad_f32(p_(self.SIDE[l]), p_(self.BI[l]), p_(self.gT), n, d, d,
+                                         C.c_void_p(self.SG.data_ptr() + 4 * l * self._per), p_(self.wg_ws), st), "idg_ngcf_wgrad_f32")
             ego_prev = self.P if l == 0 else self.E[l - 1]
             g_ego = self.g_ego[l & 1]
             check(lib.idg_ngcf_transform_bwd_f32(p_(self.gT), p_(self.SIDE[l]), p_(ego_prev), p_(wg), p_(wb), n, d, d,

@@ -165,6 +165,21 @@ class Graph:
         """Raises if the list in `ws` could not hold every row of its bitmap (idg_graph_live_units_check; synchronises)."""
         check(lib.idg_graph_live_units_check(_ptr(ws), _stream() if stream is None else stream), "idg_graph_live_units_check")
 
+    def compact_inputs(self, bitmap, ws=None, stream=None):
+        """idg_graph_compact_inputs: the tiles' entry lists compacted to the live INPUT rows of `bitmap`, built on `stream`
+        and registered for it; a product naming the bitmap as x_rows / gout mask then walks them.  Returns the buffer
+        (keep it alive while the bitmap is in use; pass it back to rebuild in place)."""
+        _require_device(bitmap, ws)
+        if ws is None:
+            ws = torch.empty(int(lib.idg_graph_compact_inputs_bytes(self._h)), dtype=torch.uint8, device=self.device)
+        check(lib.idg_graph_compact_inputs(self._h, _ptr(bitmap), _ptr(ws), _stream() if stream is None else stream),
+              "idg_graph_compact_inputs")
+        for t in (bitmap, ws):
+            if not getattr(t, "_idg_units_finalizer", False):
+                weakref.finalize(t, _forget_units_of, weakref.ref(self), bitmap.data_ptr())
+                t._idg_units_finalizer = True
+        return ws
+
     def bind_live_units(self, bitmap, ws, max_rows):
         """Register an existing list (built on a handle with the same schedule: the base of a masked / revalued copy)."""
         check(lib.idg_graph_bind_live_units(self._h, _ptr(bitmap), _ptr(ws), int(max_rows)), "idg_graph_bind_live_units")

@@ -188,6 +188,16 @@ int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units
 int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows);
 int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap);
 int idg_graph_live_units_check(const void* units_ws, void* stream);
+/* The first backward product of a training step gathers from a panel with <= 3B live rows (d loss / d final: the batch's
+ * rows).  Which stored entries point at live rows is index-only work: idg_graph_compact_inputs does it ahead of time (on
+ * `stream`, typically the caller's side stream) — per tile the live entries, in their order, a compacted start per virtual
+ * row and a live count — and registers the result for `bitmap` exactly as idg_graph_live_units registers a unit list (same
+ * validity rules: every library call that writes the bitmap drops it; idg_graph_forget_live_units drops it).  A product
+ * naming that bitmap as x_rows (idg_spmm_epi_f32, idg_propagate_mean_bwd*_f32's gout_mask) then walks the compacted
+ * lists with the ordinary kernel: bit-identical to the in-kernel compaction and to the dense product.
+ * ws: idg_graph_compact_inputs_bytes(g) bytes, 16-byte aligned, owned by the caller while registered. */
+size_t idg_graph_compact_inputs_bytes(const idg_graph* g);
+int idg_graph_compact_inputs(const idg_graph* g, const uint32_t* bitmap, void* ws, void* stream);
 
 /* The batch's receptive field (no reference counterpart: the reference propagates the whole graph every step,
  * models/LightGCN.py:36-52, although the loss reads the final layer at the batch's rows only).  Layer K is needed at the
@@ -454,6 +464,10 @@ int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t
                             const float* ego_panel, float reg_lambda, float* g_final, float* g_ego,
                             uint32_t* touched, int touched_is_clear, float* loss, void* stream);
 #define IDG_BPR_PLANNED 2
+/* OR-ed into `deterministic` together with a `touched` bitmap: the bitmap ALREADY holds exactly the batch's rows
+ * (idg_bpr_touch_rows on the same ids) — the scatter stores its rows as with any touched bitmap but does not write the
+ * bitmap, so unit / compacted-input lists registered for it stay valid for the backward products that follow. */
+#define IDG_BPR_TOUCHED_PRESET 4
 int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      int64_t num_users, int64_t n, void* ws, void* stream);
 int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
@@ -476,6 +490,13 @@ size_t idg_linear_wgrad_workspace_bytes(int64_t n, int64_t d1, int64_t d2);
 int idg_linear_wgrad_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n,
                          int64_t d1, int64_t d2, float* w_grad, int accumulate, void* ws,
                          void* stream);
+
+/* The four parameter gradients of one NGCF layer in one pass over the rows: out = [g W_gcn (d1 x d2) | g b_gcn (d2) |
+ * g W_bi (d1 x d2) | g b_bi (d2)] with g W_gcn = side^T gT, g W_bi = bi^T gT (bi = ego * side as idg_ngcf_transform_f32
+ * left it), g b_* = column sums of gT (models/NGCF.py:91-99 under autograd).  d1, d2 multiples of 64; deterministic. */
+size_t idg_ngcf_wgrad_workspace_bytes(int64_t d1, int64_t d2);
+int idg_ngcf_wgrad_f32(const float* side, const float* bi, const float* gT, int64_t n, int64_t d1, int64_t d2,
+                       float* out, void* ws, void* stream);
 
 /* NGCF's two per-layer transforms (models/NGCF.py:88-99: torch.matmul(side, W_gcn) and torch.matmul(ego * side, W_bi))
  * on the fp32 matrix cores in one pass over the rows: S[n, d2] = side . W1 + (ego * side) . W2 (the two bias rows are

@@ -190,6 +190,18 @@ def test_masked_backward_is_bit_identical_and_never_reads_dead_rows(ops, K, inc,
         G.propagate_mean_bwd_raw(dev(poisoned), K, inc, out=base, accumulate=True, mask=dev(words.view(np.int32)))
         want = ref + 0.25 * torch.from_numpy(live).cuda()[:, None]
         assert torch.allclose(base, want, rtol=1e-6, atol=1e-7)
+        # round 4: the tiles' entry lists compacted to the bitmap's rows AHEAD of the product (index-only work, registered
+        # for the bitmap like a unit list): the first product walks them with the ordinary kernel — same bits, dead rows
+        # still never read; a library write to the bitmap drops the registration (the in-kernel form takes over)
+        if d != 48:
+            bm = dev(words.view(np.int32))
+            ws = G.compact_inputs(bm)
+            got2 = G.propagate_mean_bwd_raw(dev(poisoned), K, inc, mask=bm)
+            assert torch.equal(ref, got2), "compacted-input form differs"
+            ops.bitmap_clear_raw(bm, n)          # the list is dropped with the bitmap's contents ...
+            bm.copy_(dev(words.view(np.int32)))  # ... (restored behind the library's back: no list is registered now)
+            assert torch.equal(ref, G.propagate_mean_bwd_raw(dev(poisoned), K, inc, mask=bm))
+            del ws
 
 
 @pytest.mark.parametrize("K,inc,d,kw", [(3, True, 64, {}), (1, False, 64, {}), (2, True, 256, {}), (3, True, 64, dict(split_threshold=64)),
