@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
   // slab: the loop then goes round again.  (Round 1's 32-entry windows per user PAIR took 8 dependent compare / ballot
   // / branch rounds per slab: 40 % of the select's cycles, measured in the producer / consumer kernel below.)
   const int mu = lane >> 2, mj = lane & 3;
-  int64_t m_cur = 0, m_end = 0, m_cur0 = 0;
+  int64_t m_cur = 0, m_end = 0;
   if (excl_indptr && b0 + FT_UPW * wave + mu < Bt) {
     const int64_t uid = users[b0 + FT_UPW * wave + mu];
     int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
       if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
       else hi = mid;
     }
-    m_cur = m_cur0 = lo;
+    m_cur = lo;
   }
   int32_t m_win = (excl_indptr && m_cur + mj < m_end) ? excl_items[m_cur + mj] : 0x7fffffff;
   unsigned long long best[FT_UPW], tau[FT_UPW];  // per user of this wave: list (lane = rank) and its k-th key
@@ -424,18 +424,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
                                                                     unsigned long long* __restrict__ partial,
                                                                     const unsigned long long* __restrict__ bound,
                                                                     float* __restrict__ chunk_max,
-                                                                    const float* __restrict__ floor0, int floor_slabs,
-                                                                    uint32_t* __restrict__ pub, int* __restrict__ pub_cnt) {
-  // floor_slabs > 0 (not MAXONLY): the two phases of a many-chunk call in ONE launch.  Phase A: every (tile, chunk)
-  // workgroup scores the first floor_slabs slabs of its chunk, keeps each user's maximum and PUBLISHES it (an
-  // order-preserving 32-bit key in pub[b, chunk]; agent-scope store, then a release increment of the (tile, consumer wave)
-  // arrival counter).  It then waits — bounded: the workgroups of a tile are launched together and do the same work, but
-  // nothing guarantees they are co-resident — for the other chunks' maxima, takes the k-th largest of what has arrived
-  // (to 16 bits of the key: a conservative floor; nothing arrived = no floor) and runs phase B, the ordinary pass over
-  // all its slabs, from that floor.  Any subset of published maxima gives a valid lower bound of the final k-th score, so
-  // the lists are the ones the two-launch form and the plain form give.
-  const bool two_phase = !MAXONLY && floor_slabs > 0;
-  const bool have_floor = floor0 != nullptr || two_phase;
+                                                                    const float* __restrict__ floor0) {
   __shared__ float s_buf[2][FT_USERS * FT_LD];
   __shared__ __attribute__((aligned(16))) float s_floor[FT_USERS];  // per user: score of its k-th key (consumers publish)
   __shared__ uint32_t s_flag[2][FT_USERS];                          // per slab buffer and user: a candidate may exist
@@ -500,16 +489,9 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
       IDG_PIN8(a0, 0); IDG_PIN8(a0, 8); IDG_PIN8(a0, 16); IDG_PIN8(a0, 24);
       IDG_PIN8(a1, 0); IDG_PIN8(a1, 8); IDG_PIN8(a1, 16); IDG_PIN8(a1, 24);
 #undef IDG_PIN8
-      int gs = 0;  // slabs done over both phases: buffer parity, the same on both sides of the barriers
-      for (int phase = two_phase ? 0 : 1; phase < 2; ++phase) {
-      const int ns = phase == 0 ? (floor_slabs < n_slabs ? floor_slabs : n_slabs) : n_slabs;
-      if (phase == 1 && two_phase) {  // back to the chunk's first slab (the load issued past phase A's last slab is dropped)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa0), "+v"(pa1) : : "memory");
-        vnext = V + (j0 < I ? j0 : I - 1) * 64 + 32 * h;
-      }
       IDG_LD(pa0, vnext, 0);
       IDG_LD(pa1, vnext, 16);
-      for (int t = 0; t < ns; ++t, ++gs) {
+      for (int t = 0; t < n_slabs; ++t) {
         const float* vrow = vnext;
         {
           const int64_t jn = j0 + (int64_t)(t + 1) * FT_SLAB;
@@ -538,16 +520,15 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
 #if !defined(IDG_TOPK_PROBE) || IDG_TOPK_PROBE != 4
         IDG_PIECE(3, pb0, pb1);
 #endif
-        float* s_score = s_buf[gs & 1];
+        float* s_score = s_buf[t & 1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
           s_score[row * FT_LD + 32 * wave + i] = acc0[r];
           s_score[(32 + row) * FT_LD + 32 * wave + i] = acc1[r];
         }
-        flag_candidates(acc0, acc1, s_floor, s_flag[gs & 1], h);
-        __syncthreads();  // barrier gs
-      }
+        flag_candidates(acc0, acc1, s_floor, s_flag[t & 1], h);
+        __syncthreads();  // barrier t
       }
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa0), "+v"(pa1) : : "memory");
 #undef IDG_LD
@@ -556,10 +537,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
 #undef IDG_PIECE
       return;
     }
-    int gs = 0;
-    for (int phase = two_phase ? 0 : 1; phase < 2; ++phase) {
-    const int ns = phase == 0 ? (floor_slabs < n_slabs ? floor_slabs : n_slabs) : n_slabs;
-    for (int t = 0; t < ns; ++t, ++gs) {
+    for (int t = 0; t < n_slabs; ++t) {
       const int64_t slab = c_lo + (int64_t)t * FT_SLAB;
       const int64_t j = slab + 32 * wave + i;
       const float* vrow = V + (j < I ? j : I - 1) * d;
@@ -595,17 +573,16 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bb[q], acc1, 0, 0, 0);
         }
       }
-      // slab gs goes to buffer gs & 1, last read (slab gs - 2) before barrier gs - 1, which this wave has passed
-      float* s_score = s_buf[gs & 1];
+      // slab t goes to buffer t & 1, last read (slab t - 2) before barrier t - 1, which this wave has passed
+      float* s_score = s_buf[t & 1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         s_score[row * FT_LD + 32 * wave + i] = acc0[r];
         s_score[(32 + row) * FT_LD + 32 * wave + i] = acc1[r];
       }
-      flag_candidates(acc0, acc1, s_floor, s_flag[gs & 1], h);
-      __syncthreads();  // barrier gs
-    }
+      flag_candidates(acc0, acc1, s_floor, s_flag[t & 1], h);
+      __syncthreads();  // barrier t
     }
     return;
   }
@@ -628,7 +605,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
   // loop then goes round again.  (The alternating kernel's 32-entry windows per user PAIR cost 8 dependent
   // compare / ballot / branch rounds per slab: 6,500 of this wave's ~16,000 cycles per slab, measured.)
   const int mu = lane >> 2, mj = lane & 3;
-  int64_t m_cur = 0, m_end = 0, m_cur0 = 0;
+  int64_t m_cur = 0, m_end = 0;
   if (excl_indptr && b0 + FT_UPW * wave + mu < Bt) {
     const int64_t uid = users[b0 + FT_UPW * wave + mu];
     int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
@@ -638,7 +615,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
       if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
       else hi = mid;
     }
-    m_cur = m_cur0 = lo;
+    m_cur = lo;
   }
   int32_t m_win = (excl_indptr && m_cur + mj < m_end) ? excl_items[m_cur + mj] : 0x7fffffff;
   // Per user of this wave: the list (lane = rank).  Its k-th key is wave-uniform, but it is fetched where needed with
@@ -675,18 +652,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
     return any;
   };
 
-  int gs = 0;  // slabs consumed over both phases (buffer parity)
-  for (int phase = two_phase ? 0 : 1; phase < 2; ++phase) {
-  const bool maxonly = MAXONLY || phase == 0;
-  const int ns = phase == 0 ? (floor_slabs < n_slabs ? floor_slabs : n_slabs) : n_slabs;
-  if (phase == 1 && two_phase) {  // phase B starts at the chunk's first slab again: the masking cursors go back with it
-    m_cur = m_cur0;
-    m_win = (excl_indptr && m_cur + mj < m_end) ? excl_items[m_cur + mj] : 0x7fffffff;
-  }
-  for (int t = 0; t < ns; ++t, ++gs) {
+  for (int t = 0; t < n_slabs; ++t) {
     const int64_t slab = c_lo + (int64_t)t * FT_SLAB;
-    __syncthreads();  // barrier gs: slab gs is complete in buffer gs & 1
-    float* s_score = s_buf[gs & 1];
+    __syncthreads();  // barrier t: slab t is complete in buffer t & 1
+    float* s_score = s_buf[t & 1];
     const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
     if (excl_indptr) {
       const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
@@ -705,7 +674,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
     }
     const bool in0 = slab + lane < c_hi, in1 = slab + 64 + lane < c_hi;
     const uint32_t not_item0 = ~(uint32_t)(slab + lane), not_item1 = ~(uint32_t)(slab + 64 + lane);
-    if (maxonly) {
+    if (MAXONLY) {
       // phase one of a many-chunk call: the best score per user over the chunk's first FLOOR_SLABS slabs, nothing else
       // (lane uu keeps user uu's running maximum)
       for (int uu = 0; uu < FT_UPW; ++uu) {
@@ -715,49 +684,11 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
         if (lane == uu) my_floor = fmaxf(my_floor, m);
       }
-      if (MAXONLY) {
-        if (t + 1 == ns && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt)
-          chunk_max[(b0 + FT_UPW * wave + lane) * n_chunks + blockIdx.x] = my_floor;
-        continue;
-      }
-      if (t + 1 < ns) continue;
-      // ---- end of phase A: publish this chunk's maxima, collect the others', take the k-th largest as the floor
-      const int64_t ub0 = b0 + FT_UPW * wave;  // this wave's first user
-      if (lane < FT_UPW && ub0 + lane < Bt) {
-        const uint32_t fb = __float_as_uint(my_floor);
-        const uint32_t key = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);  // order-preserving, never 0 for a score
-        __hip_atomic_store(pub + (ub0 + lane) * n_chunks + blockIdx.x, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      int* cnt = pub_cnt + (int64_t)blockIdx.y * (BLOCK / WAVE) + wave;
-      if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      for (int spin = 0; spin < 400; ++spin) {  // bounded (~25 us): whatever has arrived by then is used
-        if (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= n_chunks) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      my_floor = -__builtin_inff();
-      for (int uu = 0; uu < FT_UPW; ++uu) {
-        if (ub0 + uu >= Bt) break;
-        // lane c (< n_chunks <= 64) holds chunk c's key; the k-th largest by a radix descent over the key's upper 16 bits:
-        // one v_cmp per bit (its result is the ballot), the count is a scalar popcount
-        const uint32_t key = lane < n_chunks
-                                 ? __hip_atomic_load(pub + (ub0 + uu) * n_chunks + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                 : 0u;
-        uint32_t pre = 0u;
-#pragma unroll
-        for (int bit = 31; bit >= 16; --bit) {
-          const uint32_t cand = pre | (1u << bit);
-          if (__popcll(__ballot(key >= cand)) >= k) pre = cand;
-        }
-        // pre <= the k-th largest key (lower bits dropped: conservative); pre == 0: fewer than k maxima have arrived
-        if (lane == uu && pre != 0u) {
-          const uint32_t fb = (pre & 0x80000000u) ? (pre & 0x7fffffffu) : ~pre;
-          my_floor = __uint_as_float(fb);
-        }
-      }
-      if (lane < FT_UPW) s_floor[FT_UPW * wave + lane] = my_floor;  // the producers flag against it from now on
+      if (t + 1 == n_slabs && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt)
+        chunk_max[(b0 + FT_UPW * wave + lane) * n_chunks + blockIdx.x] = my_floor;
       continue;
     }
-    if (t == 0 && !have_floor) {
+    if (t == 0 && !floor0) {
       // first slab of the chunk: one 128-key sorting network per user fills its list
       for (int uu = 0; uu < FT_UPW; ++uu) {
         const int u = FT_UPW * wave + uu;
@@ -781,8 +712,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
     // the wave's users; the flags are cleared for the slab after next, which reuses this buffer
     uint32_t fl_ = 0u;
     if (lane < FT_UPW) {
-      fl_ = s_flag[gs & 1][FT_UPW * wave + lane];
-      s_flag[gs & 1][FT_UPW * wave + lane] = 0u;
+      fl_ = s_flag[t & 1][FT_UPW * wave + lane];
+      s_flag[t & 1][FT_UPW * wave + lane] = 0u;
     }
     const uint32_t cand = (uint32_t)__ballot(fl_ != 0u);
 #if defined(IDG_TOPK_PROBE) && IDG_TOPK_PROBE == 1  // (timing probe 1, wrong results: the producers on their own)
@@ -804,7 +735,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
         c1 = c1 < bd ? c1 : 0ull;
       }
       float fl0 = -__builtin_inff();
-      if (have_floor) {  // nothing below the user's starting floor can reach the final list (the chunk's list may stay short)
+      if (floor0) {  // nothing below the user's starting floor can reach the final list (the chunk's list may stay short)
         fl0 = __shfl(my_floor, uu, WAVE);
         c0 = s0 >= fl0 ? c0 : 0ull;
         c1 = s1 >= fl0 ? c1 : 0ull;
@@ -814,7 +745,6 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
       const bool ch1 = offer(best[uu], tk, c1);
       if ((ch0 || ch1) && lane == 0) s_floor[u] = fmaxf(fl0, floor_of(tk));
     }
-  }
   }
 #pragma unroll
   for (int uu = 0; uu < FT_UPW; ++uu) {
@@ -952,13 +882,6 @@ static inline bool floor_phase(int form, int nc, int64_t ci, int k) {
   if (v && *v && std::atoi(v) == 0) return false;
   return form == 1 && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
 }
-// ... as ONE launch (the chunk maxima published and collected inside the main kernel: no second start-up, no floor
-// launch) when a lane per chunk suffices; IDG_TOPK_FLOOR=2 keeps the two-launch form (A/B timing).
-static inline bool floor_in_kernel(int nc) {
-  const char* v = std::getenv("IDG_TOPK_FLOOR");
-  if (v && *v && std::atoi(v) == 2) return false;
-  return nc <= 64;
-}
 
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   (void)d;
@@ -969,7 +892,7 @@ size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes + (two-phase form) one
   // maximum per (user, chunk) and one starting floor per user
   return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
-         (floor_phase(form, nc, ci, k) ? ((size_t)Bt * (size_t)nc + (size_t)Bt + 64) * sizeof(float) : 0);
+         (floor_phase(form, nc, ci, k) ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
 }
 
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt,
@@ -994,19 +917,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   unsigned long long* bound = k > 64 ? partial + (size_t)Bt * (size_t)nc * 64 : nullptr;
   float* chunk_max = nullptr;
   float* floor0 = nullptr;
-  uint32_t* pub = nullptr;
-  int* pub_cnt = nullptr;
-  int inkernel_slabs = 0;
-  if (floor_phase(form, nc, ci, k) && floor_in_kernel(nc)) {
-    // one launch: the published maxima (keys, 0 = not yet) and the arrival counters are cleared here
-    pub = reinterpret_cast<uint32_t*>(partial + (size_t)Bt * (size_t)nc * 64);
-    pub_cnt = reinterpret_cast<int*>(pub + (size_t)Bt * (size_t)nc);
-    const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
-    IDG_REQUIRE(user_tiles * (BLOCK / WAVE) <= Bt + 64, "idg_score_topk_f32: internal: counter block too small");
-    IDG_HIP(hipMemsetAsync(pub, 0, ((size_t)Bt * (size_t)nc + (size_t)user_tiles * (BLOCK / WAVE)) * sizeof(uint32_t), st));
-    const int slabs_per_chunk = (int)(ci / FT_SLAB);
-    inkernel_slabs = slabs_per_chunk / 2 < FLOOR_SLABS ? slabs_per_chunk / 2 : FLOOR_SLABS;
-  } else if (floor_phase(form, nc, ci, k)) {
+  if (floor_phase(form, nc, ci, k)) {
     chunk_max = reinterpret_cast<float*>(partial + (size_t)Bt * (size_t)nc * 64);
     floor0 = chunk_max + (size_t)Bt * (size_t)nc;
     const bool d64 = d == 64 && (uintptr_t)user_panel % 16 == 0 && (uintptr_t)item_panel % 16 == 0;
@@ -1015,7 +926,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
 #define IDG_MAXONLY(SIG, D64)                                                                                              \
   hipLaunchKernelGGL((score_topk_spec_kernel<SIG, D64, true>), grid, dim3(SP_BLOCK), 0, st, user_panel, item_panel, users, \
                      Bt, I, d, ci, excl_indptr, excl_items, floor_slabs, partial, (const unsigned long long*)nullptr,     \
-                     chunk_max, (const float*)nullptr, 0, (uint32_t*)nullptr, (int*)nullptr)
+                     chunk_max, (const float*)nullptr)
     if (apply_sigmoid && d64) IDG_MAXONLY(true, true);
     else if (apply_sigmoid) IDG_MAXONLY(true, false);
     else if (d64) IDG_MAXONLY(false, true);
@@ -1031,8 +942,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
       const bool d64 = d == 64 && (uintptr_t)user_panel % 16 == 0 && (uintptr_t)item_panel % 16 == 0;
 #define IDG_SPEC(SIG, D64)                                                                                           \
   hipLaunchKernelGGL((score_topk_spec_kernel<SIG, D64>), grid, dim3(SP_BLOCK), 0, st, user_panel, item_panel, users, \
-                     Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in, (float*)nullptr, (const float*)floor0,          \
-                     inkernel_slabs, pub, pub_cnt)
+                     Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in, (float*)nullptr, (const float*)floor0)
       if (apply_sigmoid && d64) IDG_SPEC(true, true);
       else if (apply_sigmoid) IDG_SPEC(true, false);
       else if (d64) IDG_SPEC(false, true);
