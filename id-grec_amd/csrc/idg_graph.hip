@@ -1700,6 +1700,36 @@ struct DeviceGuard {
   }
 };
 
+// ---- the three looks at the stored entries when they live on the device (graph_build, idg_graph_create_from_device) ----
+__global__ __launch_bounds__(BLOCK) void check_columns_kernel(const int32_t* __restrict__ indices, int64_t nnz, int64_t n_cols,
+                                                              int64_t* __restrict__ first_bad) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += stride) {
+    const int32_t c = indices[k];
+    if (c < 0 || c >= n_cols) {  // the lowest offending position wins (reported in the error message)
+      unsigned long long* p = reinterpret_cast<unsigned long long*>(first_bad);
+      unsigned long long cur = *p;
+      while ((cur == ~0ull || (unsigned long long)k < cur) && atomicCAS(p, cur, (unsigned long long)k) != cur) cur = *p;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void gather_columns_kernel(const int32_t* __restrict__ indices, const int64_t* __restrict__ where,
+                                                               int64_t count, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < count) out[i] = where[i] >= 0 ? indices[where[i]] : 0;
+}
+
+// 16 lanes per virtual row: cv[vptr[v] + j] = (indices[src[v] + j], values[src[v] + j])
+__global__ __launch_bounds__(BLOCK) void fill_entries_kernel(const int32_t* __restrict__ indices, const float* __restrict__ values,
+                                                             const int64_t* __restrict__ vptr, const int64_t* __restrict__ src,
+                                                             int64_t n_vrows, ColVal* __restrict__ cv) {
+  const int64_t v = (int64_t)blockIdx.x * (BLOCK / 16) + threadIdx.x / 16;
+  if (v >= n_vrows) return;
+  const int64_t b = vptr[v], e = vptr[v + 1], s = src[v];
+  for (int64_t j = b + threadIdx.x % 16; j < e; j += 16) cv[j] = ColVal{indices[s + (j - b)], values[s + (j - b)]};
+}
+
 template <typename T>
 int upload(T** dst, const std::vector<T>& src) {
   *dst = nullptr;
@@ -1719,19 +1749,25 @@ int idg_device_count(void) {
   return n;
 }
 
-int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
-                     const int32_t* indices, const float* values, uint32_t flags, int64_t split_threshold,
-                     idg_graph** out) {
+// The schedule build.  indptr is a HOST array either way (the row pointer is all the schedule itself depends on: virtual
+// rows, tiles, launch orders, split tables).  The stored entries are either host arrays (indices / values: the entry list
+// is laid out on the host and uploaded) or DEVICE arrays (d_indices / d_values, indices == values == NULL: the three
+// places that look at an entry — the range check, the tiles' median columns, the layout of the (col, val) list in tile
+// order — run as kernels on `st`, and nothing of size nnz crosses the bus).
+static int graph_build(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                       const int32_t* indices, const float* values, const int32_t* d_indices, const float* d_values,
+                       hipStream_t st, uint32_t flags, int64_t split_threshold, idg_graph** out) {
+  const bool on_device = indices == nullptr && nnz > 0;
   IDG_REQUIRE(out, "idg_graph_create: out is NULL");
   IDG_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "idg_graph_create: negative size");
-  IDG_REQUIRE(indptr && (nnz == 0 || (indices && values)), "idg_graph_create: NULL CSR array");
+  IDG_REQUIRE(indptr && (nnz == 0 || (indices && values) || (d_indices && d_values)), "idg_graph_create: NULL CSR array");
   IDG_REQUIRE(n_rows < ((int64_t)1 << 31) && n_cols < ((int64_t)1 << 31), "idg_graph_create: more than 2^31 rows/cols");
   IDG_REQUIRE(indptr[0] == 0 && indptr[n_rows] == nnz, "idg_graph_create: indptr[0]=%lld indptr[n]=%lld nnz=%lld",
               (long long)indptr[0], (long long)indptr[n_rows], (long long)nnz);
   IDG_REQUIRE(split_threshold >= 0, "idg_graph_create: negative split_threshold");
   for (int64_t r = 0; r < n_rows; ++r)
     IDG_REQUIRE(indptr[r + 1] >= indptr[r], "idg_graph_create: indptr not monotone at row %lld", (long long)r);
-  {
+  if (!on_device) {
     std::atomic<int64_t> bad{-1};  // the first offending entry of the lowest range that has one is what the message names
     parallel_ranges(nnz, [&](int64_t b, int64_t e, int) {
       for (int64_t k = b; k < e; ++k)
@@ -1748,6 +1784,26 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   const int ndev = idg_device_count();
   if (ndev <= 0) return idg::fail(IDG_E_NODEVICE, "idg_graph_create: no HIP device visible (this library has no CPU path)");
   IDG_REQUIRE(device >= 0 && device < ndev, "idg_graph_create: device %d outside [0,%d)", device, ndev);
+  DeviceGuard guard;
+  {
+    const int rc0 = guard.enter(device);
+    if (rc0 != IDG_OK) return rc0;
+  }
+  if (on_device) {  // the range check of the column ids, on the device
+    int64_t* d_bad = nullptr;
+    IDG_HIP(hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(int64_t)));
+    int64_t bad = -1;
+    hipError_t e1 = hipMemcpyAsync(d_bad, &bad, sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e1 == hipSuccess) {
+      hipLaunchKernelGGL(check_columns_kernel, dim3((unsigned)std::min<int64_t>((nnz + BLOCK - 1) / BLOCK, 1 << 16)), dim3(BLOCK), 0,
+                         st, d_indices, nnz, n_cols, d_bad);
+      e1 = hipMemcpyAsync(&bad, d_bad, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+    }
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+    (void)hipFree(d_bad);
+    IDG_HIP(e1);
+    IDG_REQUIRE(bad < 0, "idg_graph_create_from_device: a column id outside [0,%lld) at entry %lld", (long long)n_cols, (long long)bad);
+  }
 
   idg_graph* g = new (std::nothrow) idg_graph;
   if (!g) return idg::fail(IDG_E_NOMEM, "idg_graph_create: out of memory");
@@ -1900,9 +1956,34 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
     banded = true;
     const size_t nt = tiles.size();
     std::vector<int32_t> med(nt);
-    for (size_t t = 0; t < nt; ++t) {
-      const int64_t b = tiles[t].nnz_begin, e = b + tile_nnz(tiles[t]);
-      med[t] = e > b ? indices[(b + e) / 2] : 0;  // cheap proxy: the middle stored entry's column
+    if (!on_device) {
+      for (size_t t = 0; t < nt; ++t) {
+        const int64_t b = tiles[t].nnz_begin, e = b + tile_nnz(tiles[t]);
+        med[t] = e > b ? indices[(b + e) / 2] : 0;  // cheap proxy: the middle stored entry's column
+      }
+    } else {  // the same lookups as one gather on the device
+      std::vector<int64_t> where(nt);
+      for (size_t t = 0; t < nt; ++t) {
+        const int64_t b = tiles[t].nnz_begin, e = b + tile_nnz(tiles[t]);
+        where[t] = e > b ? (b + e) / 2 : -1;
+      }
+      int64_t* d_where = nullptr;
+      int32_t* d_med = nullptr;
+      hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&d_where), nt * sizeof(int64_t));
+      if (e1 == hipSuccess) e1 = hipMalloc(reinterpret_cast<void**>(&d_med), nt * sizeof(int32_t));
+      if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_where, where.data(), nt * sizeof(int64_t), hipMemcpyHostToDevice, st);
+      if (e1 == hipSuccess) {
+        hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)((nt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d_indices, d_where,
+                           (int64_t)nt, d_med);
+        e1 = hipMemcpyAsync(med.data(), d_med, nt * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+      }
+      if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+      (void)hipFree(d_where);
+      (void)hipFree(d_med);
+      if (e1 != hipSuccess) {
+        delete g;
+        IDG_HIP(e1);
+      }
     }
     std::vector<size_t> order(nt);
     for (size_t t = 0; t < nt; ++t) order[t] = t;
@@ -1939,13 +2020,17 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
   bool sort_tiles = true;
   if (const char* v = std::getenv("IDG_TILE_SORT")) sort_tiles = std::atoi(v) != 0;
   // (uninitialised: every entry is written exactly once below — by its tile's pass, or here when it belongs to no tile)
-  std::unique_ptr<ColVal[]> cv_store(new (std::nothrow) ColVal[(size_t)std::max<int64_t>(nnz, 1)]);
-  if (!cv_store) {
+  std::unique_ptr<ColVal[]> cv_store(on_device ? nullptr : new (std::nothrow) ColVal[(size_t)std::max<int64_t>(nnz, 1)]);
+  if (!on_device && !cv_store) {
     delete g;
     return idg::fail(IDG_E_NOMEM, "idg_graph_create: out of host memory for the entry list");
   }
   ColVal* cv = cv_store.get();
-  if (!(sort_tiles && !tiles_plain.empty()) || !xl.empty())
+  // device mode: where (in CSR order) the entries of each vrow of the FINAL order come from; the list itself is laid out by
+  // fill_entries_kernel once the vrow pointers are uploaded
+  std::vector<int64_t> src_of_vrow;
+  if (on_device) src_of_vrow.assign(vptr.begin(), vptr.end() - 1);
+  if (!on_device && (!(sort_tiles && !tiles_plain.empty()) || !xl.empty()))
     parallel_ranges(nnz, [&](int64_t b, int64_t e, int) {
       for (int64_t k = b; k < e; ++k) cv[(size_t)k] = ColVal{indices[k], values[k]};
     });
@@ -1985,7 +2070,9 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
           vptr2[(size_t)nv] = pos;
           vtgt2[(size_t)nv] = vtgt[(size_t)(u.v + q)];
           vrow_row2[(size_t)nv] = vrow_row[(size_t)(u.v + q)];
-          for (int64_t k = b; k < e; ++k) cv[(size_t)(pos + (k - b))] = ColVal{indices[k], values[k]};
+          if (on_device) src_of_vrow[(size_t)nv] = b;
+          else
+            for (int64_t k = b; k < e; ++k) cv[(size_t)(pos + (k - b))] = ColVal{indices[k], values[k]};
           pos += e - b;
           ++nv;
         }
@@ -1999,9 +2086,8 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
     vrow_row.swap(vrow_row2);
   }
 
-  DeviceGuard guard;
-  int rc = guard.enter(device);
-  if (rc == IDG_OK && nnz > 0) {
+  int rc = IDG_OK;
+  if (nnz > 0 && !on_device) {
     rc = [&]() -> int {
       IDG_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cv), (size_t)nnz * sizeof(ColVal)));
       IDG_HIP(hipMemcpy(g->d_cv, cv, (size_t)nnz * sizeof(ColVal), hipMemcpyHostToDevice));
@@ -2009,6 +2095,24 @@ int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, co
     }();
   }
   if (rc == IDG_OK) rc = upload(&g->d_vptr, vptr);
+  if (rc == IDG_OK && on_device) {
+    // the (col, val) list in tile order, laid out on the device: entry k of vrow v comes from CSR position
+    // src_of_vrow[v] + (k - vptr[v])
+    rc = [&]() -> int {
+      int64_t* d_src = nullptr;
+      IDG_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_cv), (size_t)nnz * sizeof(ColVal)));
+      IDG_HIP(hipMalloc(reinterpret_cast<void**>(&d_src), src_of_vrow.size() * sizeof(int64_t)));
+      hipError_t e1 = hipMemcpyAsync(d_src, src_of_vrow.data(), src_of_vrow.size() * sizeof(int64_t), hipMemcpyHostToDevice, st);
+      if (e1 == hipSuccess) {
+        hipLaunchKernelGGL(fill_entries_kernel, dim3((unsigned)((g->n_vrows + BLOCK / 16 - 1) / (BLOCK / 16))), dim3(BLOCK), 0, st,
+                           d_indices, d_values, g->d_vptr, d_src, g->n_vrows, g->d_cv);
+        e1 = hipStreamSynchronize(st);
+      }
+      (void)hipFree(d_src);
+      IDG_HIP(e1);
+      return IDG_OK;
+    }();
+  }
   if (rc == IDG_OK) rc = upload(&g->d_vtgt, vtgt);
   if (rc == IDG_OK) rc = upload(&g->d_tiles, tiles_plain);
   if (rc == IDG_OK && banded) rc = upload(&g->d_tiles_banded, tiles_banded);
@@ -2048,25 +2152,37 @@ int idg_graph_create_from_device(int device, int64_t n_rows, int64_t n_cols, int
   IDG_REQUIRE(out, "idg_graph_create_from_device: out is NULL");
   IDG_REQUIRE(n_rows >= 0 && nnz >= 0 && d_indptr && (nnz == 0 || (d_indices && d_values)),
               "idg_graph_create_from_device: bad argument");
-  // The row-block schedule (virtual rows, tiles, XCD bands, split tables) is built by the host code of idg_graph_create
-  // (multi-threaded over the stored entries; measured at configs[4] size — 15 M rows, 4e8 entries — on the GPU box's
-  // host: see DESIGN.md): the arrays are staged through host memory — ordered after `stream`, where the caller may just
-  // have produced them.  Uninitialised staging buffers (a std::vector would zero 3.3 GB first).
+  // The row-block schedule (virtual rows, tiles, XCD bands, split tables) depends on the ROW POINTER only: that array —
+  // 8 (n + 1) bytes — is what visits the host (ordered after `stream`, where the caller may just have produced the CSR).
+  // The column ids and values stay where they are: range check, the tiles' median columns and the layout of the
+  // (col, val) list in tile order are kernels on `stream` (graph_build).  Measured at configs[4] size (15 M rows, 4e8
+  // entries): see DESIGN.md §6.
   std::unique_ptr<int64_t[]> ip(new (std::nothrow) int64_t[(size_t)n_rows + 1]);
-  std::unique_ptr<int32_t[]> ix(new (std::nothrow) int32_t[(size_t)std::max<int64_t>(nnz, 1)]);
-  std::unique_ptr<float[]> dv(new (std::nothrow) float[(size_t)std::max<int64_t>(nnz, 1)]);
-  if (!ip || !ix || !dv) return idg::fail(IDG_E_NOMEM, "idg_graph_create_from_device: out of host memory");
-  DeviceGuard guard;
-  int rc = guard.enter(device);
-  if (rc != IDG_OK) return rc;
+  if (!ip) return idg::fail(IDG_E_NOMEM, "idg_graph_create_from_device: out of host memory");
   hipStream_t st = (hipStream_t)stream;
-  IDG_HIP(hipMemcpyAsync(ip.get(), d_indptr, ((size_t)n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  if (nnz > 0) {
-    IDG_HIP(hipMemcpyAsync(ix.get(), d_indices, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    IDG_HIP(hipMemcpyAsync(dv.get(), d_values, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost, st));
+  {
+    DeviceGuard guard;
+    int rc = guard.enter(device);
+    if (rc != IDG_OK) return rc;
+    IDG_HIP(hipMemcpyAsync(ip.get(), d_indptr, ((size_t)n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    IDG_HIP(hipStreamSynchronize(st));
   }
-  IDG_HIP(hipStreamSynchronize(st));
-  return idg_graph_create(device, n_rows, n_cols, nnz, ip.get(), ix.get(), dv.get(), flags, split_threshold, out);
+  if (nnz == 0) {
+    static const int32_t no_idx = 0;
+    static const float no_val = 0.f;
+    return graph_build(device, n_rows, n_cols, nnz, ip.get(), &no_idx, &no_val, nullptr, nullptr, st, flags, split_threshold, out);
+  }
+  return graph_build(device, n_rows, n_cols, nnz, ip.get(), nullptr, nullptr, d_indices, d_values, st, flags, split_threshold, out);
+}
+
+int idg_graph_create(int device, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* indptr,
+                     const int32_t* indices, const float* values, uint32_t flags, int64_t split_threshold,
+                     idg_graph** out) {
+  IDG_REQUIRE(indptr && (nnz == 0 || (indices && values)), "idg_graph_create: NULL CSR array");
+  static const int32_t no_idx = 0;
+  static const float no_val = 0.f;
+  return graph_build(device, n_rows, n_cols, nnz, indptr, nnz > 0 ? indices : &no_idx, nnz > 0 ? values : &no_val, nullptr,
+                     nullptr, nullptr, flags, split_threshold, out);
 }
 
 int idg_graph_destroy(idg_graph* g) {

@@ -990,6 +990,26 @@ def test_graph_from_the_references_device_tensor(ops, golden_small):
     assert torch.equal(G1.spmm_raw(X), G2.spmm_raw(X))
     assert torch.equal(G1.propagate_mean_raw(X, 3, True), G2.propagate_mean_raw(X, 3, True))
     assert torch.allclose(G2.spmm_raw(X), torch.sparse.mm(coo, X), rtol=1e-5, atol=1e-7)
+    # round 4: only the row pointer visits the host; the entry list is laid out on the device.  The same at yelp2018
+    # size (thousands of tiles, split and chunked rows, XCD bands chosen from device-gathered median columns), with
+    # exact_order (rows longer than a tile) and a custom split threshold; a bad column id is caught by the device check
+    import idgrec_amd.host as H
+    import idgrec_amd.synth as S
+
+    Uy, Iy, Ey = S.SHAPES["yelp2018"]
+    uy, iy = S.generate(Uy, Iy, Ey, seed=0)
+    ipy, ixy, dvy = H.build_norm_adj(Uy, Iy, uy, iy)
+    ny = Uy + Iy
+    csr = torch.sparse_csr_tensor(dev(ipy), dev(ixy.astype(np.int64)), dev(dvy), size=(ny, ny))
+    Xy = torch.randn(ny, 64, device="cuda") * 0.1
+    for kw in (dict(), dict(exact_order=True), dict(split_threshold=64)):
+        Ga, Gb = ops.Graph(ipy, ixy, dvy, ny, ny, **kw), ops.Graph.from_torch_sparse(csr, **kw)
+        assert Ga.info() == Gb.info()
+        assert all(np.array_equal(a, b) for a, b in zip(Ga.long_rows(), Gb.long_rows()))
+        assert torch.equal(Ga.spmm_raw(Xy), Gb.spmm_raw(Xy)) and torch.equal(Ga.propagate_mean_raw(Xy, 3, True), Gb.propagate_mean_raw(Xy, 3, True))
+    bad = torch.sparse_csr_tensor(dev(ipy), dev(ixy.astype(np.int64)), dev(dvy), size=(ny, ny - 5), check_invariants=False)
+    with pytest.raises(RuntimeError, match="column id outside"):
+        ops.Graph.from_torch_sparse(bad, symmetric=False)
 
 
 @pytest.mark.parametrize("d,sig", [(64, True), (64, False), (128, True)])
