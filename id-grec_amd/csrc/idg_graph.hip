@@ -230,6 +230,12 @@ void units_forget(const void* sched, const void* bitmap, size_t bytes = 0) {
       g_unit_lists[i] = UnitList{};
   }
 }
+// every list (of either kind, on any schedule) that lives in the caller's buffer `ws`
+void units_forget_ws(const void* ws) {
+  std::lock_guard<std::mutex> lock(g_unit_mutex);
+  for (int i = 0; i < MAX_UNIT_LISTS; ++i)
+    if (ws != nullptr && g_unit_lists[i].units == ws) g_unit_lists[i] = UnitList{};
+}
 }  // namespace
 
 namespace idg {
@@ -2369,6 +2375,11 @@ size_t idg_graph_live_units_bytes(const idg_graph* g, int64_t max_rows) {
 int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows) {
   IDG_REQUIRE(g && bitmap && units_ws && max_rows >= 0, "idg_graph_bind_live_units: bad argument");
   units_register(g->d_vptr, bitmap, reinterpret_cast<const int32_t*>(units_ws), max_rows + g->n_slots);
+  return IDG_OK;
+}
+
+int idg_graph_forget_units_ws(const void* ws) {
+  units_forget_ws(ws);
   return IDG_OK;
 }
 

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "idg_graph_remask": (C.c_int, [c_vp, c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp]),
     "idg_graph_masked_copy": (C.c_int, [c_vp, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, c_vp, C.POINTER(c_vp)]),
     "idg_graph_info": (C.c_int, [c_vp, c_i64p]),
+    "idg_graph_forget_units_ws": (C.c_int, [c_vp]),
     "idg_graph_compact_inputs_bytes": (C.c_size_t, [c_vp]),
     "idg_graph_compact_inputs": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "idg_graph_long_rows": (C.c_int, [c_vp, c_i64p, c_i64p, c_i64p]),

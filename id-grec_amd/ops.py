@@ -55,6 +55,13 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None  # ctypes converts int / None for void* parameters
 
 
+def _forget_units_ws(ws_ptr):
+    """Finalizer of a list buffer: whatever is registered IN that buffer goes (a newer list of the same bitmap, built into
+    another buffer, stays: ADVICE r03)."""
+    if lib is not None:
+        lib.idg_graph_forget_units_ws(ws_ptr)
+
+
 def _forget_units_of(graph_ref, bitmap_ptr):
     g = graph_ref()
     if g is not None and getattr(g, "_h", None) and lib is not None:
@@ -154,10 +161,14 @@ class Graph:
               "idg_graph_live_units")
         # the registration names two caller-owned buffers: it must not outlive either (the allocator may hand the same
         # address to something else).  One finalizer per tensor object, however often the list is rebuilt.
-        for t in (bitmap, ws):
-            if not getattr(t, "_idg_units_finalizer", False):
-                weakref.finalize(t, _forget_units_of, weakref.ref(self), bitmap.data_ptr())
-                t._idg_units_finalizer = True
+        # (the bitmap's finalizer forgets by bitmap, the list buffer's by buffer: a dying OLD buffer must not take a NEW
+        #  registration of the same bitmap with it)
+        if not getattr(bitmap, "_idg_units_finalizer", False):
+            weakref.finalize(bitmap, _forget_units_of, weakref.ref(self), bitmap.data_ptr())
+            bitmap._idg_units_finalizer = True
+        if not getattr(ws, "_idg_units_finalizer", False):
+            weakref.finalize(ws, _forget_units_ws, ws.data_ptr())
+            ws._idg_units_finalizer = True
         return ws
 
     @staticmethod
@@ -174,10 +185,14 @@ class Graph:
             ws = torch.empty(int(lib.idg_graph_compact_inputs_bytes(self._h)), dtype=torch.uint8, device=self.device)
         check(lib.idg_graph_compact_inputs(self._h, _ptr(bitmap), _ptr(ws), _stream() if stream is None else stream),
               "idg_graph_compact_inputs")
-        for t in (bitmap, ws):
-            if not getattr(t, "_idg_units_finalizer", False):
-                weakref.finalize(t, _forget_units_of, weakref.ref(self), bitmap.data_ptr())
-                t._idg_units_finalizer = True
+        # (the bitmap's finalizer forgets by bitmap, the list buffer's by buffer: a dying OLD buffer must not take a NEW
+        #  registration of the same bitmap with it)
+        if not getattr(bitmap, "_idg_units_finalizer", False):
+            weakref.finalize(bitmap, _forget_units_of, weakref.ref(self), bitmap.data_ptr())
+            bitmap._idg_units_finalizer = True
+        if not getattr(ws, "_idg_units_finalizer", False):
+            weakref.finalize(ws, _forget_units_ws, ws.data_ptr())
+            ws._idg_units_finalizer = True
         return ws
 
     def bind_live_units(self, bitmap, ws, max_rows):

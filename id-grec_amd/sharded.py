@@ -987,12 +987,19 @@ class HipKernels:
     def release(self, prep):
         prep.busy = False  # its buffers go back to the pool; reuse is ordered by the fork event of the next prepare()
 
+    def close(self):
+        """The pooled bitmaps and unit lists die with this object: nothing may stay registered under their addresses.
+        Called by whoever owns the engine when it is done (the bench does); __del__ is only the safety net."""
+        for prep in self._pool:
+            for ws in prep.units.values():
+                self.lib.idg_graph_forget_units_ws(ws.data_ptr())
+            for g in prep.graphs:
+                g.forget_live_units()
+        self._pool = []
+
     def __del__(self):
-        # the pooled bitmaps and unit lists die with this object: nothing may stay registered under their addresses
         try:
-            for prep in self._pool:
-                for g in prep.graphs:
-                    g.forget_live_units()
+            self.close()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
@@ -1521,6 +1528,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
                 "exchange_rows": {"touched_items": n_touched, "items": I},
             },
         }
+    kern.close()
     del eng, batches, kern
     torch.cuda.empty_cache()
     phase("single_gpu_reference")

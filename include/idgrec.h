@@ -187,6 +187,10 @@ size_t idg_graph_live_units_bytes(const idg_graph* g, int64_t max_rows);
 int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream);
 int idg_graph_bind_live_units(const idg_graph* g, const uint32_t* bitmap, const void* units_ws, int64_t max_rows);
 int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap);
+/* Drop every registered list (unit lists and compacted entry lists, of any handle) that lives in the buffer `ws`: what a
+ * caller does before it frees or reuses a list buffer (the registration names the buffer; ADVICE r03: forgetting by bitmap
+ * alone drops a NEW registration of the same bitmap when an OLD buffer dies). */
+int idg_graph_forget_units_ws(const void* ws);
 int idg_graph_live_units_check(const void* units_ws, void* stream);
 /* The first backward product of a training step gathers from a panel with <= 3B live rows (d loss / d final: the batch's
  * rows).  Which stored entries point at live rows is index-only work: idg_graph_compact_inputs does it ahead of time (on
