@@ -362,7 +362,7 @@ int idg_ngcf_tail_bwd_f32(const float* E, const float* gE, const float* gN, int6
 // and the gathering of three gradient contributions at the batch's rows.  Deterministic (fixed slice and tree orders).
 namespace {
 
-constexpr int CS_SLICES = 512;
+constexpr int CS_SLICES = 256;
 
 // part[s][f] = sum of X[r][f] over the rows of slice s (rows in order); grid (CS_SLICES), BLOCK threads: thread t owns
 // column t % d' of row group t / d' ... kept simple: each thread strides over rows for its column(s), partial sums are
@@ -389,16 +389,6 @@ __global__ __launch_bounds__(BLOCK) void colsum_partial_kernel(const float* __re
     }
     __syncthreads();
   }
-}
-
-__global__ __launch_bounds__(BLOCK) void colsum_reduce_kernel(const float* __restrict__ part, int64_t d, float* __restrict__ out,
-                                                              float* __restrict__ out2, int accumulate) {
-  const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (f >= d) return;
-  float t = 0.f;
-  for (int s = 0; s < CS_SLICES; ++s) t += part[(int64_t)s * d + f];
-  out[f] = accumulate ? out[f] + t : t;
-  if (out2) out2[f] = accumulate ? out2[f] + t : t;
 }
 
 __global__ __launch_bounds__(BLOCK) void copy_cols_kernel(float* __restrict__ dst, int64_t ldd, const float* __restrict__ src,
@@ -433,13 +423,13 @@ extern "C" {
 
 size_t idg_colsum_workspace_bytes(int64_t d) { return d > 0 ? (size_t)CS_SLICES * (size_t)d * sizeof(float) : 0; }
 
-int idg_colsum_f32(const float* X, int64_t ldx, int64_t n, int64_t d, float* out, float* out2, int accumulate, void* ws,
-                   void* stream) {
+int idg_colsum_f32(const float* X, int64_t ldx, int64_t n, int64_t d, float* out, int accumulate, void* ws, void* stream) {
   IDG_REQUIRE(X && out && ws && n >= 0 && d > 0 && ldx >= d, "idg_colsum_f32: bad argument");
   hipStream_t st = (hipStream_t)stream;
   float* part = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(CS_SLICES), dim3(BLOCK), 0, st, X, ldx, n, d, part);
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((d + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, part, d, out, out2,
+  // the slices are added in slice order, 16 lane groups per 64 columns (wgrad_reduce_kernel's fixed tree)
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64 * RG), 0, st, part, (int64_t)CS_SLICES, d, out,
                      accumulate ? 1 : 0);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
@@ -467,12 +457,6 @@ int idg_rows_add2_f32(float* dst, int64_t ldd, const float* a, int64_t lda, cons
   hipLaunchKernelGGL(rows_add2_kernel, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, dst, ldd,
                      a, lda, b, ldb, rows, n, d / 4);
   IDG_HIP(hipGetLastError());
-  return IDG_OK;
-}
-
-int idg_zero_f32(float* p, int64_t count, void* stream) {
-  IDG_REQUIRE(p && count >= 0, "idg_zero_f32: bad argument");
-  IDG_HIP(hipMemsetAsync(p, 0, (size_t)count * sizeof(float), (hipStream_t)stream));
   return IDG_OK;
 }
 

@@ -119,10 +119,9 @@ PROTOTYPES = {
     "idg_ngcf_tail_bwd_ex_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                            C.c_uint64, C.c_uint64, c_vp, c_vp]),
     "idg_colsum_workspace_bytes": (C.c_size_t, [C.c_int64]),
-    "idg_colsum_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int, c_vp, c_vp]),
+    "idg_colsum_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_int, c_vp, c_vp]),
     "idg_copy_cols_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp]),
     "idg_rows_add2_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, c_vp]),
-    "idg_zero_f32": (C.c_int, [c_vp, C.c_int64, c_vp]),
     "idg_bpr_fused_ex_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64,
                                        C.c_float, C.c_int, c_vp, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "idg_bpr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),

@@ -977,6 +977,23 @@ def linear_wgrad_raw(X, G, out=None, accumulate=False):
     return out
 
 
+_colsum_ws = {}
+
+
+def colsum_raw(X, out=None, accumulate=False):
+    """out[f] (+)= sum_r X[r, f] (idg_colsum_f32: row slices summed in slice order, deterministic)."""
+    _require_device(X, out)
+    X = _f32c(X, "X")
+    n, d = X.shape
+    if out is None:
+        out = torch.empty(d, dtype=torch.float32, device=X.device)
+    ws = _colsum_ws.get((d, X.device))
+    if ws is None:
+        ws = _colsum_ws[(d, X.device)] = torch.empty(int(lib.idg_colsum_workspace_bytes(d)), dtype=torch.uint8, device=X.device)
+    check(lib.idg_colsum_f32(_ptr(X), d, n, d, _ptr(out), int(bool(accumulate)), _ptr(ws), _stream()), "idg_colsum_f32")
+    return out
+
+
 class _TallLinear(torch.autograd.Function):
     """Y = X @ W for X [n, d1] with n >> d1, d2 (NGCF's per-layer transforms).  Forward and the input gradient are
     ordinary small (NN) GEMMs; the weight gradient X^T @ gY is all reduction and goes to idg_linear_wgrad_f32."""
@@ -1077,7 +1094,7 @@ class _NgcfTail(torch.autograd.Function):
         gT = torch.empty_like(E)
         check(lib.idg_ngcf_tail_bwd_f32(_ptr(E), _ptr(gE), _ptr(gN), n, d, slope, p, C.c_uint64(seed), C.c_uint64(sid),
                                         _ptr(gT), _stream()), "idg_ngcf_tail_bwd_f32")
-        gb = gT.sum(dim=0)
+        gb = colsum_raw(gT)  # the two bias rows receive the same gradient: the column sums of gT
         return gT, (gT if ctx.needs_input_grad[1] else None), gb.reshape(shape1), gb.reshape(shape2), None, None, None
 
 

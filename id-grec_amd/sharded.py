@@ -861,6 +861,9 @@ class HipKernels:
     # ---- the touched items (ShardedEngine._agree_touched_items) and the users near the batch's items
     def touched_local(self, eng, prep, gb):
         """One rank: the bitmap of the touched items from this rank's rows alone, and the near users."""
+        # (a torch-side write of a bitmap: allowed here because nothing is ever registered for touched_buf at world size 1 —
+        #  its unit lists are built by touched_from_ids, which only runs on several ranks — and mark_cols below is a library
+        #  write of the same bitmap, which drops whatever was)
         prep.touched_buf.copy_(prep.items)
         eng.G_ui.mark_cols(prep.own_users, prep.touched_buf)
         prep.touched = prep.touched_buf

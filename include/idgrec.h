@@ -538,17 +538,15 @@ int idg_ngcf_tail_ex_f32(const float* S1, const float* S2, const float* b1, cons
 int idg_ngcf_tail_bwd_ex_f32(const float* E, const float* gE, const float* gN, int64_t ldgn, const uint32_t* gn_rows,
                              int64_t n, int64_t d, float negative_slope, float p, uint64_t seed, uint64_t stream_id,
                              float* gT, void* stream);
-/* Glue of that step.  idg_colsum_f32: out[f] (+)= sum over the n rows of X[r, f] (and the same into out2 if not NULL: NGCF's
- * two bias rows of a layer receive the same gradient), slices of rows summed in slice order; ws: idg_colsum_workspace_bytes(d).
- * idg_copy_cols_f32: dst[r, 0:d] = src[r, 0:d] with leading dimensions ldd / lds.  idg_rows_add2_f32: dst[r] += a[r] (+ b[r])
- * at the rows flagged in `rows`.  idg_zero_f32: count floats cleared on the stream. */
+/* Glue of that step.  idg_copy_cols_f32: dst[r, 0:d] = src[r, 0:d] with leading dimensions ldd / lds.  idg_rows_add2_f32:
+ * dst[r] += a[r] (+ b[r]) at the rows flagged in `rows`.  idg_colsum_f32: out[f] (+)= sum over the n rows of X[r, f] — the
+ * gradient of a bias row broadcast over n rows (the differentiable layer tail's backward; the fused step gets it from
+ * idg_ngcf_wgrad_f32) — slices of rows summed in slice order; ws: idg_colsum_workspace_bytes(d). */
 size_t idg_colsum_workspace_bytes(int64_t d);
-int idg_colsum_f32(const float* X, int64_t ldx, int64_t n, int64_t d, float* out, float* out2, int accumulate, void* ws,
-                   void* stream);
+int idg_colsum_f32(const float* X, int64_t ldx, int64_t n, int64_t d, float* out, int accumulate, void* ws, void* stream);
 int idg_copy_cols_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t n, int64_t d, void* stream);
 int idg_rows_add2_f32(float* dst, int64_t ldd, const float* a, int64_t lda, const float* b, int64_t ldb,
                       const uint32_t* rows, int64_t n, int64_t d, void* stream);
-int idg_zero_f32(float* p, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: in-batch InfoNCE between two views, forward + backward

@@ -538,6 +538,44 @@ def test_linear_wgrad_vs_float64(ops, n, d1, d2):
     assert torch.allclose(Xt.grad, X2.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("n,d", [(69716, 64), (1000, 256), (257, 100), (3, 7)])
+def test_colsum_and_ngcf_wgrad_vs_float64(ops, n, d):
+    """idg_colsum_f32 (the bias gradients of the differentiable NGCF tail) and — for d a multiple of 64 —
+    idg_ngcf_wgrad_f32 (ALL four parameter gradients of a layer in one pass, the fused step's form) against float64:
+    [W_gcn | b_gcn | W_bi | b_bi] = [side^T gT | colsum gT | bi^T gT | colsum gT], same bits on a second call."""
+    import ctypes as C
+
+    from idgrec_amd.native import check, lib
+
+    rng = np.random.default_rng(n + d)
+    G = (rng.standard_normal((n, d)) * 0.01).astype(np.float32)
+    ref = G.astype(np.float64).sum(axis=0)
+    got = ops.colsum_raw(dev(G))
+    assert (np.abs(got.cpu().numpy() - ref) <= 2e-6 * np.abs(G.astype(np.float64)).sum(axis=0) + 1e-30).all()
+    assert torch.equal(got, ops.colsum_raw(dev(G)))
+    acc = ops.colsum_raw(dev(G), out=got.clone(), accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 2 * got.cpu().numpy(), rtol=1e-6)
+    if d % 64:
+        return
+    S = rng.standard_normal((n, d)).astype(np.float32)
+    Bi = rng.standard_normal((n, d)).astype(np.float32)
+    out = torch.empty(2 * d * d + 2 * d, device="cuda")
+    ws = torch.empty(int(lib.idg_ngcf_wgrad_workspace_bytes(d, d)), dtype=torch.uint8, device="cuda")
+    p_ = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    s_d, b_d, g_d = dev(S), dev(Bi), dev(G)
+    check(lib.idg_ngcf_wgrad_f32(p_(s_d), p_(b_d), p_(g_d), n, d, d, p_(out), p_(ws), ops._stream()), "idg_ngcf_wgrad_f32")
+    o = out.cpu().numpy()
+    for lo, left in ((0, S), (d * d + d, Bi)):
+        want = left.astype(np.float64).T @ G.astype(np.float64)
+        scale = np.abs(left.astype(np.float64)).T @ np.abs(G.astype(np.float64))
+        assert (np.abs(o[lo:lo + d * d].reshape(d, d) - want) <= 2e-6 * scale + 1e-30).all()
+    for lo in (d * d, 2 * d * d + d):
+        assert (np.abs(o[lo:lo + d] - ref) <= 2e-6 * np.abs(G.astype(np.float64)).sum(axis=0) + 1e-30).all()
+    out2 = torch.empty_like(out)
+    check(lib.idg_ngcf_wgrad_f32(p_(s_d), p_(b_d), p_(g_d), n, d, d, p_(out2), p_(ws), ops._stream()), "idg_ngcf_wgrad_f32")
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("p", [0.0, 0.3])
 def test_ngcf_layer_tail_vs_torch_ops(ops, p):
     """leaky_relu((S1 + b1) + (S2 + b2)) -> dropout -> (E, normalize(E)) and its backward against the stock op chain
