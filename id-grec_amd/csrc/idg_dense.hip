@@ -316,6 +316,90 @@ __global__ __launch_bounds__(BLOCK) void ngcf_tail_bwd_kernel(const float* __res
   }
 }
 
+// The same two kernels for d % 4 == 0, d <= 256 (every shipped width): d / 4 lanes per row, 16 bytes per lane, 64 / LPR rows
+// per wave — the one-wave-per-row form above moves 256 B per memory instruction at d = 64 and ran at a third of the
+// streaming rate (round 4).  Same per-element arithmetic; the row's sum of squares is formed 4 elements per lane, then
+// across the row's lanes.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LPR);
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(BLOCK) void ngcf_tail_fwd_vec_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                                  const float* __restrict__ b1, const float* __restrict__ b2,
+                                                                  int64_t n, float slope, float p, uint64_t seed, uint64_t stream,
+                                                                  float* __restrict__ E, float* __restrict__ N, int64_t ldn) {
+  constexpr int d = LPR * 4;
+  const int l = threadIdx.x % LPR;
+  const int64_t r = (int64_t)blockIdx.x * (BLOCK / LPR) + threadIdx.x / LPR;
+  if (r >= n) return;  // whole lane groups leave together
+  const int64_t f = 4 * l;
+  const float4 s1 = *reinterpret_cast<const float4*>(S1 + r * d + f);
+  const float4 s2 = S2 ? *reinterpret_cast<const float4*>(S2 + r * d + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 c1 = *reinterpret_cast<const float4*>(b1 + f), c2 = *reinterpret_cast<const float4*>(b2 + f);
+  const float sv[4] = {s1.x, s1.y, s1.z, s1.w}, tv[4] = {s2.x, s2.y, s2.z, s2.w};
+  const float bv[4] = {c1.x, c1.y, c1.z, c1.w}, dv[4] = {c2.x, c2.y, c2.z, c2.w};
+  float e[4], ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float t = (sv[c] + bv[c]) + (tv[c] + dv[c]);
+    const float a = t > 0.f ? t : t * slope;
+    e[c] = a * keep_scale(p, seed, stream, r, f + c);
+    ss += e[c] * e[c];
+  }
+  ss = row_sum<LPR>(ss);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);
+  *reinterpret_cast<float4*>(E + r * d + f) = make_float4(e[0], e[1], e[2], e[3]);
+  *reinterpret_cast<float4*>(N + r * ldn + f) = make_float4(e[0] / den, e[1] / den, e[2] / den, e[3] / den);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(BLOCK) void ngcf_tail_bwd_vec_kernel(const float* __restrict__ E, const float* __restrict__ gE,
+                                                                  const float* __restrict__ gN, int64_t n, float slope, float p,
+                                                                  uint64_t seed, uint64_t stream, float* __restrict__ gT,
+                                                                  int64_t ldgn, const uint32_t* __restrict__ gn_rows) {
+  constexpr int d = LPR * 4;
+  const int l = threadIdx.x % LPR;
+  const int64_t r = (int64_t)blockIdx.x * (BLOCK / LPR) + threadIdx.x / LPR;
+  if (r >= n) return;
+  const int64_t f = 4 * l;
+  if (gN && gn_rows && !((gn_rows[r >> 5] >> (r & 31)) & 1u)) gN = nullptr;
+  if (!gN && !gE) {
+    *reinterpret_cast<float4*>(gT + r * d + f) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float4 e4 = *reinterpret_cast<const float4*>(E + r * d + f);
+  const float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+  float gn[4] = {0.f, 0.f, 0.f, 0.f}, ge[4] = {0.f, 0.f, 0.f, 0.f};
+  if (gN) {
+    const float4 x = *reinterpret_cast<const float4*>(gN + r * ldgn + f);
+    gn[0] = x.x, gn[1] = x.y, gn[2] = x.z, gn[3] = x.w;
+  }
+  if (gE) {
+    const float4 x = *reinterpret_cast<const float4*>(gE + r * d + f);
+    ge[0] = x.x, ge[1] = x.y, ge[2] = x.z, ge[3] = x.w;
+  }
+  float ss = 0.f, dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) ss += ev[c] * ev[c], dot += gn[c] * ev[c];
+  ss = row_sum<LPR>(ss);
+  dot = row_sum<LPR>(dot);
+  const float nrm = sqrtf(ss);
+  const float den = fmaxf(nrm, 1e-12f);
+  float out[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float g = ge[c];
+    if (gN) g += nrm > 1e-12f ? (gn[c] - dot * ev[c] / (den * den)) / den : gn[c] / den;
+    const float k = keep_scale(p, seed, stream, r, f + c);
+    out[c] = g * k * (ev[c] > 0.f ? 1.0f : (ev[c] < 0.f ? slope : (k > 0.f ? slope : 0.f)));
+  }
+  *reinterpret_cast<float4*>(gT + r * d + f) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -326,8 +410,18 @@ int idg_ngcf_tail_ex_f32(const float* S1, const float* S2, const float* b1, cons
   IDG_REQUIRE(S1 && b1 && b2 && E && N, "idg_ngcf_tail_f32: NULL argument");
   IDG_REQUIRE(n >= 0 && d > 0 && ldn >= d && p >= 0.f && p < 1.f, "idg_ngcf_tail_f32: bad sizes / drop probability");
   if (n == 0) return IDG_OK;
+  const bool vec = ldn % 4 == 0 && (((uintptr_t)S1 | (uintptr_t)S2 | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)E | (uintptr_t)N) % 16 == 0);
+#define IDG_TAILF(LPR)                                                                                                       \
+  hipLaunchKernelGGL((ngcf_tail_fwd_vec_kernel<LPR>), dim3((unsigned)((n + BLOCK / LPR - 1) / (BLOCK / LPR))), dim3(BLOCK), 0,   \
+                     (hipStream_t)stream, S1, S2, b1, b2, n, negative_slope, p, seed, stream_id, E, N, ldn)
+  if (vec && d == 64) IDG_TAILF(16);
+  else if (vec && d == 32) IDG_TAILF(8);
+  else if (vec && d == 128) IDG_TAILF(32);
+  else if (vec && d == 256) IDG_TAILF(64);
+  else
   hipLaunchKernelGGL(ngcf_tail_fwd_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
                      (hipStream_t)stream, S1, S2, b1, b2, n, d, negative_slope, p, seed, stream_id, E, N, ldn);
+#undef IDG_TAILF
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }
@@ -343,8 +437,18 @@ int idg_ngcf_tail_bwd_ex_f32(const float* E, const float* gE, const float* gN, i
   IDG_REQUIRE(E && gT && (gE || gN), "idg_ngcf_tail_bwd_f32: NULL argument");
   IDG_REQUIRE(n >= 0 && d > 0 && (!gN || ldgn >= d) && p >= 0.f && p < 1.f, "idg_ngcf_tail_bwd_f32: bad sizes / drop probability");
   if (n == 0) return IDG_OK;
+  const bool vec = (!gN || ldgn % 4 == 0) && (((uintptr_t)E | (uintptr_t)gE | (uintptr_t)gN | (uintptr_t)gT) % 16 == 0);
+#define IDG_TAILB(LPR)                                                                                                       \
+  hipLaunchKernelGGL((ngcf_tail_bwd_vec_kernel<LPR>), dim3((unsigned)((n + BLOCK / LPR - 1) / (BLOCK / LPR))), dim3(BLOCK), 0,   \
+                     (hipStream_t)stream, E, gE, gN, n, negative_slope, p, seed, stream_id, gT, ldgn, gn_rows)
+  if (vec && d == 64) IDG_TAILB(16);
+  else if (vec && d == 32) IDG_TAILB(8);
+  else if (vec && d == 128) IDG_TAILB(32);
+  else if (vec && d == 256) IDG_TAILB(64);
+  else
   hipLaunchKernelGGL(ngcf_tail_bwd_kernel, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
                      (hipStream_t)stream, E, gE, gN, n, d, negative_slope, p, seed, stream_id, gT, ldgn, gn_rows);
+#undef IDG_TAILB
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }
@@ -544,13 +648,40 @@ __global__ __launch_bounds__(BLOCK) void ngcf_transform_bwd_kernel(const float* 
   const int64_t n_waves = (int64_t)gridDim.x * (BLOCK / 64);
   const int64_t k1 = (wave % nkt) * 32;  // this wave's input features; lane i supplies the weights of feature k1 + i
   const int64_t rt_stride = n_waves / nkt;
+  // d2 = 64 (every shipped configuration): this wave's 2 x 32 weights per lane are the same for every row tile it walks —
+  // loaded ONCE into registers, as the forward kernel does (round 4: they were re-read per tile, two thirds of the
+  // kernel's load instructions)
+  const bool keep = d2 == 64;
+  float kw1[32], kw2[32];
+  if (keep) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 u = *reinterpret_cast<const float4*>(W1 + (k1 + i) * d2 + 32 * h + 4 * q);
+      const float4 v = *reinterpret_cast<const float4*>(W2 + (k1 + i) * d2 + 32 * h + 4 * q);
+      kw1[4 * q + 0] = u.x, kw1[4 * q + 1] = u.y, kw1[4 * q + 2] = u.z, kw1[4 * q + 3] = u.w;
+      kw2[4 * q + 0] = v.x, kw2[4 * q + 1] = v.y, kw2[4 * q + 2] = v.z, kw2[4 * q + 3] = v.w;
+    }
+  }
   for (int64_t rt = wave / nkt; rt < n_rt; rt += rt_stride) {
     const int64_t r0 = rt * 32;
     const int64_t row = r0 + i < n ? r0 + i : n - 1;
     f32x16 acc1, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f, acc2[r] = 0.f;
-    for (int64_t cc = 0; cc < d2; cc += 64) {  // (d2 = 64: one pass; the weight runs are L1 / L2 hits after the first tile)
+    if (keep) {
+      float a[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(gS + row * d2 + 32 * h + 4 * q);
+        a[4 * q + 0] = x.x, a[4 * q + 1] = x.y, a[4 * q + 2] = x.z, a[4 * q + 3] = x.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], kw1[s], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], kw2[s], acc2, 0, 0, 0);
+      }
+    } else
+    for (int64_t cc = 0; cc < d2; cc += 64) {  // (the weight runs are L1 / L2 hits after the first tile)
       const int64_t c0 = cc + 32 * h;
       float a[32], w1[32], w2[32];
 #pragma unroll
