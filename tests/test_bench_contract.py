@@ -108,7 +108,7 @@ def test_hung_ranks_end_in_a_json_error_line():
 def test_a_hung_first_attempt_is_retried_over_torch_distributed():
     """Rank 1 hangs in the warm-up of the FIRST attempt only (two ranks sharing the GPU over gloo): the watchdog ends the
     attempt, the retry in fresh processes with --comm torch measures, and the line says it was a retry and why."""
-    env = dict(_env(), IDG_BENCH_TEST_HANG="1:warmup:1", IDG_BENCH_TIMEOUT="150")
+    env = dict(_env(), IDG_BENCH_TEST_HANG="1:warmup:1", IDG_BENCH_TIMEOUT="200")  # 120 s for the hung attempt, >= 60 s for the retry
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--parallel", "shard", "--workload",
                         "medium", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--scale-point", "off"], cwd=ROOT,
                        env=env, capture_output=True, text=True, timeout=900)
