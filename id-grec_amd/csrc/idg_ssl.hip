@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "idg_common.h"
 
@@ -41,6 +42,10 @@ struct SslWs {
   float* An;         // [2 views][2B][d] normalised rows
   float* den;        // [2 views][2B]   max(||x||, 1e-12)
   float* P;          // [2 sets][B][B]
+  float* PT;         // [2 sets][B][B] the same matrices transposed (MFMA gradient products: both operands K-contiguous)
+  float* AnT;        // [2 views][2 sets][d][B] the normalised rows transposed, set-local column index
+  float* coef;       // [2 sets][B] w_i / ttl_i (scales the second gradient product's operand)
+  float* contrib;    // [2 views][2B][d] every list position's own gradient row (raw-id lists: summed per id afterwards)
   float* invttl;     // [2B]
   float* w;          // [2B]
   float* lossrow;    // [2B]
@@ -67,6 +72,10 @@ SslWs ssl_layout(void* base, int64_t n, int64_t B, int64_t d) {
   w.An = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
   w.den = reinterpret_cast<float*>(take((size_t)2 * 2 * B * 4));
   w.P = reinterpret_cast<float*>(take((size_t)2 * B * B * 4));
+  w.PT = reinterpret_cast<float*>(take((size_t)2 * B * B * 4));
+  w.AnT = reinterpret_cast<float*>(take((size_t)2 * 2 * d * B * 4));
+  w.coef = reinterpret_cast<float*>(take((size_t)2 * B * 4));
+  w.contrib = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
   w.invttl = reinterpret_cast<float*>(take((size_t)2 * B * 4));
   w.w = reinterpret_cast<float*>(take((size_t)2 * B * 4));
   w.lossrow = reinterpret_cast<float*>(take((size_t)2 * B * 4));
@@ -176,7 +185,8 @@ __global__ __launch_bounds__(BLOCK) void ssl_normalize_kernel(const float* __res
                                                               const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ idx2,
                                                               const int32_t* __restrict__ counts, int64_t B,
-                                                              float* __restrict__ An, float* __restrict__ den) {
+                                                              float* __restrict__ An, float* __restrict__ den,
+                                                              float* __restrict__ AnT) {
   const int lane = threadIdx.x % WAVE;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int v = blockIdx.y;
@@ -187,7 +197,14 @@ __global__ __launch_bounds__(BLOCK) void ssl_normalize_kernel(const float* __res
   ss = wave_sum(ss);
   const float nrm = fmaxf(sqrtf(ss), 1e-12f);  // torch.nn.functional.normalize: x / max(||x||, eps)
   float* y = An + ((int64_t)v * 2 * B + r) * d;
-  for (int64_t f = lane; f < d; f += WAVE) y[f] = x[f] / nrm;
+  // (AnT, MFMA path: the same values with the row index running fastest, per set: [view][set][f][row within the set])
+  const int set = r < counts[0] ? 0 : 1;
+  float* yt = AnT ? AnT + ((int64_t)(v * 2 + set) * d) * B + (r - (set ? counts[0] : 0)) : nullptr;
+  for (int64_t f = lane; f < d; f += WAVE) {
+    const float q = x[f] / nrm;
+    y[f] = q;
+    if (yt) yt[f * B] = q;
+  }
   if (lane == 0) den[(int64_t)v * 2 * B + r] = nrm;
 }
 
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void ssl_logits_kernel(const float* __restri
 __global__ __launch_bounds__(BLOCK) void ssl_rowstat_kernel(const float* __restrict__ P, int64_t B,
                                                             const int32_t* __restrict__ counts, float inv_t, float eps,
                                                             float* __restrict__ invttl, float* __restrict__ w,
-                                                            float* __restrict__ lossrow) {
+                                                            float* __restrict__ lossrow, float* __restrict__ coef) {
   const int set = blockIdx.y;
   const int m = counts[set];
   const int lane = threadIdx.x % WAVE;
@@ -254,7 +271,9 @@ __global__ __launch_bounds__(BLOCK) void ssl_rowstat_kernel(const float* __restr
     const int64_t o = (set == 0 ? 0 : counts[0]) + i;
     invttl[o] = 1.0f / s;
     lossrow[o] = -logf(r + eps);
-    w[o] = -r * inv_t / ((float)m * (r + eps));
+    const float wv = -r * inv_t / ((float)m * (r + eps));
+    w[o] = wv;
+    if (coef) coef[(int64_t)set * B + i] = wv * (1.0f / s);  // == w[o] * invttl[o], as the SIMT gradient kernel forms it
   }
 }
 
@@ -348,16 +367,172 @@ __global__ __launch_bounds__(BLOCK) void ssl_grad_kernel(const float* __restrict
   }
 }
 
+// ---- the two GEMM-shaped stages on the fp32 matrix cores (round 4; d % 64 == 0 and B % 4 == 0, every shipped
+// configuration; otherwise the SIMT kernels above) -------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation.  Lane (i, h) feeds row i's K-values [kc + 32h, kc + 32h + 32)
+// as the A operand and column i's as the B operand — one contiguous 128-byte run per lane and 64-deep chunk, nothing
+// staged through LDS; C/D map: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ void load32(const float* __restrict__ p, float (&v)[32]) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float4 x = *reinterpret_cast<const float4*>(p + 4 * q);
+    v[4 * q + 0] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
+  }
+}
+
+// P[set][i][k] = exp(<a_i, b_k> / t) and PT[set][k][i] = the same value (the second gradient product reads P by columns):
+// a 64 x 64 tile per workgroup, one 32 x 32 MFMA tile per wave, the transposed copy through a wave-private LDS tile.
+__global__ __launch_bounds__(BLOCK) void ssl_logits_mfma_kernel(const float* __restrict__ An, int64_t d, int64_t B,
+                                                                const int32_t* __restrict__ counts, float inv_t,
+                                                                float* __restrict__ P, float* __restrict__ PT) {
+  __shared__ float s_t[BLOCK / WAVE][32][33];
+  const int set = blockIdx.z;
+  const int m = counts[set];
+  const int i0 = blockIdx.y * TS, k0 = blockIdx.x * TS;
+  if (i0 >= m || k0 >= m) return;  // block-uniform
+  const int64_t base = set == 0 ? 0 : counts[0];
+  const float* A = An + base * d;
+  const float* Bm = An + ((int64_t)2 * B + base) * d;
+  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, i = lane & 31, h = lane >> 5;
+  const int ti = i0 + 32 * (wave >> 1), tk = k0 + 32 * (wave & 1);
+  const float* arow = A + (int64_t)(ti + i < m ? ti + i : m - 1) * d + 32 * h;
+  const float* brow = Bm + (int64_t)(tk + i < m ? tk + i : m - 1) * d + 32 * h;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int64_t kc = 0; kc < d; kc += 64) {
+    float a[32], b[32];
+    load32(arow + kc, a);
+    load32(brow + kc, b);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+  }
+  float* Ps = P + (int64_t)set * B * B;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int lr = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float v = expf(acc[r] * inv_t);
+    if (ti + lr < m && tk + i < m) Ps[(int64_t)(ti + lr) * B + tk + i] = v;
+    s_t[wave][lr][i] = v;
+  }
+  if (PT == nullptr) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* Ts = PT + (int64_t)set * B * B;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int lr = (r & 3) + 8 * (r >> 2) + 4 * h;  // a COLUMN of the tile here: row lr of the transposed one
+    if (tk + lr < m && ti + i < m) Ts[(int64_t)(tk + lr) * B + ti + i] = s_t[wave][i][lr];
+  }
+}
+
+// The two gradient products on the matrix cores: side 0  G[r][f] = sum_c P[r][c] b_c[f],  side 1  G[k][f] = sum_i PT[k][i]
+// (w_i / ttl_i) a_i[f].  Operands K-contiguous: rows of P / PT, and rows of AnT (the other view's normalised rows,
+// transposed per set).  64 rows x 64 features per workgroup, the reduction index cut into GS slices as in the SIMT form;
+// raw slice sums go to Gp[side][slice][row][f] (ssl_final_kernel adds them in slice order).
+//   grid: (feature tiles * GS, row tiles, set * 2 + side)
+__global__ __launch_bounds__(BLOCK) void ssl_grad_mfma_kernel(const float* __restrict__ P, const float* __restrict__ PT,
+                                                              const float* __restrict__ AnT, const float* __restrict__ coef,
+                                                              int64_t d, int64_t B, const int32_t* __restrict__ counts,
+                                                              float* __restrict__ Gp) {
+  const int set = blockIdx.z >> 1, side = blockIdx.z & 1;
+  const int m = counts[set];
+  const int slice = blockIdx.x % GS;
+  const int64_t f0 = (int64_t)(blockIdx.x / GS) * TS;
+  const int r0 = blockIdx.y * TS;
+  if (r0 >= m) return;
+  const int64_t base = set == 0 ? 0 : counts[0];
+  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, i = lane & 31, h = lane >> 5;
+  const int tr = r0 + 32 * (wave >> 1);
+  const int64_t tf = f0 + 32 * (wave & 1);
+  const float* M = (side == 0 ? P : PT) + (int64_t)set * B * B + (int64_t)(tr + i < m ? tr + i : m - 1) * B;
+  // the OTHER view's rows: side 0 mixes b (view 2), side 1 mixes a (view 1)
+  const float* XT = AnT + ((int64_t)((side == 0 ? 1 : 0) * 2 + set) * d + (tf + i < d ? tf + i : d - 1)) * B;
+  const float* cf = coef + (int64_t)set * B;
+  const int per = ((m + GS - 1) / GS + TS - 1) / TS * TS;  // reduction indices per slice (a multiple of 64)
+  const int c_lo = slice * per, c_hi = c_lo + per < m ? c_lo + per : m;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+    const int c = c0 + 32 * h;
+    float a[32], b[32];
+    if (c0 + 64 <= c_hi) {
+      load32(M + c, a);
+      load32(XT + c, b);
+      if (side == 1) {
+        float w[32];
+        load32(cf + c, w);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) a[q] *= w[q];
+      }
+    } else {  // the slice's last, partial chunk: nothing beyond c_hi is read (those entries were never written)
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const bool in = c + q < c_hi;
+        a[q] = in ? (side == 1 ? M[c + q] * cf[c + q] : M[c + q]) : 0.f;
+        b[q] = in ? XT[c + q] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+  }
+  float* out = Gp + (((int64_t)side * GS + slice) * 2 * B + base) * d;
+  if (tf + i < d) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tr + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < m) out[(int64_t)row * d + tf + i] = acc[r];
+    }
+  }
+}
+
 // ---- slices -> dL/d(normalised row) -> back through normalize() -> the views' gradient rows.
 //   One wave per (compact row, view): view 1 rows take side 0 (Ga), view 2 rows side 1 (Gb).
 //   With duplicate ids in a set (dedup == 0) the occurrences of one id all feed the same panel row: the wave of
 //   the FIRST occurrence adds them up in list order (deterministic), the others leave.
-__global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restrict__ An, const float* __restrict__ den,
-                                                          const float* __restrict__ Gp, const float* __restrict__ invttl,
-                                                          const float* __restrict__ w, int64_t d, int64_t B,
+// Stage 1 (every list position on its own wave): position j's gradient row for view v — slices added in slice order, back
+// through normalize() — into contrib[v][j].  Fully parallel: a hub item that occurs 40 times in a raw list used to have
+// all 40 rows computed one after the other by the wave of its first occurrence (72 us per call at yelp2018 size).
+__global__ __launch_bounds__(BLOCK) void ssl_contrib_kernel(const float* __restrict__ An, const float* __restrict__ den,
+                                                            const float* __restrict__ Gp, const float* __restrict__ invttl,
+                                                            const float* __restrict__ w, int64_t d, int64_t B,
+                                                            const int32_t* __restrict__ counts, float scale,
+                                                            float* __restrict__ contrib) {
+  const int lane = threadIdx.x % WAVE;
+  const int64_t j = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  const int v = blockIdx.y;
+  if (j >= counts[0] + counts[1]) return;
+  const float* y = An + ((int64_t)v * 2 * B + j) * d;            // this view's normalised row
+  const float* other = An + ((int64_t)(1 - v) * 2 * B + j) * d;  // b_i for view 1, a_k for view 2
+  const float nrm = den[(int64_t)v * 2 * B + j];
+  const float wr = w[j], itr = invttl[j];
+  const bool clamped = nrm <= 1e-12f;  // normalize() divided by the constant eps: Jacobian 1/eps, no projection
+  auto grad = [&](int64_t f) {
+    float acc = 0.f;
+    for (int sl = 0; sl < GS; ++sl) acc += Gp[(((int64_t)v * GS + sl) * 2 * B + j) * d + f];
+    return v == 0 ? wr * (other[f] - itr * acc) : wr * other[f] - acc;
+  };
+  float dot = 0.f;  // the projection needs <g, y> over the whole row first
+  for (int64_t f = lane; f < d; f += WAVE) dot += grad(f) * y[f];
+  dot = wave_sum(dot);
+  float* c = contrib + ((int64_t)v * 2 * B + j) * d;
+  for (int64_t f = lane; f < d; f += WAVE) {
+    const float g = grad(f);
+    c[f] = scale * (clamped ? g / nrm : (g - dot * y[f]) / nrm);
+  }
+}
+
+// Stage 2: the views' gradient rows.  One wave per (compact row, view): view 1 rows take contrib[0], view 2 rows contrib[1].
+//   With duplicate ids in a set (dedup == 0) the occurrences of one id all feed the same panel row: the wave of
+//   the FIRST occurrence adds them up in list order (deterministic), the others leave.
+__global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restrict__ contrib, int64_t d, int64_t B,
                                                           const int32_t* __restrict__ idx,
                                                           const int32_t* __restrict__ idx2,
-                                                          const int32_t* __restrict__ counts, int dedup, float scale,
+                                                          const int32_t* __restrict__ counts, int dedup,
                                                           int accumulate, int both_views, float* g1, float* g2,
                                                           const uint32_t* __restrict__ dup) {
   const int lane = threadIdx.x % WAVE;
@@ -390,24 +565,8 @@ __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restric
           break;
         }
         first = false;
-        const float* y = An + ((int64_t)v * 2 * B + j) * d;            // this view's normalised row
-        const float* other = An + ((int64_t)(1 - v) * 2 * B + j) * d;  // b_i for view 1, a_k for view 2
-        const float nrm = den[(int64_t)v * 2 * B + j];
-        const float wr = w[j], itr = invttl[j];
-        const bool clamped = nrm <= 1e-12f;  // normalize() divided by the constant eps: Jacobian 1/eps, no projection
-        auto grad = [&](int64_t f) {
-          float acc = 0.f;
-          for (int sl = 0; sl < GS; ++sl) acc += Gp[(((int64_t)v * GS + sl) * 2 * B + j) * d + f];
-          return v == 0 ? wr * (other[f] - itr * acc) : wr * other[f] - acc;
-        };
-        float dot = 0.f;  // the projection needs <g, y> over the whole row first
-        for (int64_t f = lane; f < d; f += WAVE) dot += grad(f) * y[f];
-        dot = wave_sum(dot);
-        for (int64_t f = lane; f < d; f += WAVE) {
-          const float g = grad(f);
-          const float val = scale * (clamped ? g / nrm : (g - dot * y[f]) / nrm);
-          o[f] = fresh ? val : o[f] + val;
-        }
+        const float* c = contrib + ((int64_t)v * 2 * B + j) * d;
+        for (int64_t f = lane; f < d; f += WAVE) o[f] = fresh ? c[f] : o[f] + c[f];
         fresh = false;
       }
     }
@@ -459,20 +618,35 @@ static int infonce_impl(const float* view1, const float* view2, int64_t n, int64
     dup = w.dup;
   }
   const unsigned row_blocks = (unsigned)((rows_max + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  // the GEMM-shaped stages run on the fp32 matrix cores when every operand run is 16-byte aligned (IDG_SSL_MFMA=0: the SIMT
+  // kernels, A/B timing)
+  static const bool mfma_off = [] { const char* v = std::getenv("IDG_SSL_MFMA"); return v && *v && std::atoi(v) == 0; }();
+  const bool mfma = !mfma_off && d % 64 == 0 && B % 4 == 0;
+  const bool grads = g1 || g2;
   hipLaunchKernelGGL(ssl_normalize_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, view1, view2, d, w.idx, idx2, w.counts, B,
-                     w.An, w.den);
+                     w.An, w.den, (mfma && grads) ? w.AnT : nullptr);
   const unsigned tb = (unsigned)((B + TS - 1) / TS);
   const float inv_t = 1.0f / temperature;
-  hipLaunchKernelGGL(ssl_logits_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
+  if (mfma)
+    hipLaunchKernelGGL(ssl_logits_mfma_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P,
+                       grads ? w.PT : nullptr);
+  else
+    hipLaunchKernelGGL(ssl_logits_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
   hipLaunchKernelGGL(ssl_rowstat_kernel, dim3((unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE)), sets), dim3(BLOCK), 0, st,
-                     w.P, B, w.counts, inv_t, 10e-6f, w.invttl, w.w, w.lossrow);
+                     w.P, B, w.counts, inv_t, 10e-6f, w.invttl, w.w, w.lossrow, (mfma && grads) ? w.coef : nullptr);
   hipLaunchKernelGGL(ssl_loss_kernel, dim3(sets), dim3(BLOCK), 0, st, w.lossrow, w.counts, loss);
   if (g1 || g2) {
-    hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 2 * sets), dim3(BLOCK), 0, st, w.An, w.P, d,
-                       B, w.counts, w.invttl, w.w, w.G);
+    if (mfma)
+      hipLaunchKernelGGL(ssl_grad_mfma_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 2 * sets), dim3(BLOCK), 0, st, w.P, w.PT,
+                         w.AnT, w.coef, d, B, w.counts, w.G);
+    else
+      hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 2 * sets), dim3(BLOCK), 0, st, w.An, w.P, d,
+                         B, w.counts, w.invttl, w.w, w.G);
     const int both = (g1 && g1 == g2) ? 1 : 0;  // one panel for both views: a single wave per row adds them in turn
-    hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, both ? 1 : 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w,
-                       d, B, w.idx, idx2, w.counts, (dedup && !cross) ? 1 : 0, grad_scale, accumulate ? 1 : 0, both, g1, g2, dup);
+    hipLaunchKernelGGL(ssl_contrib_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w, d, B, w.counts,
+                       grad_scale, w.contrib);
+    hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, both ? 1 : 2), dim3(BLOCK), 0, st, w.contrib, d, B, w.idx, idx2, w.counts,
+                       (dedup && !cross) ? 1 : 0, accumulate ? 1 : 0, both, g1, g2, dup);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
