@@ -1,0 +1,5 @@
+cd /tmp && export TMPDIR=/tmp
+for m in EGCF NGCF; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r04c_$m -o $m -- python3 $GRAFT_REPO_ROOT/scripts/e2e_epoch.py $m 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_r04c_$m.log 2>&1
+grep -a "Training time" $GRAFT_REPO_ROOT/gpurun_out/prof_r04c_$m.log | tail -1
+done
