@@ -17,6 +17,7 @@ No torch arithmetic runs in a step (the three InfoNCE losses are summed by a 3-e
 import torch
 
 from . import native, ops
+from .engine import BatchPrep
 
 
 class EgcfEngine:
@@ -47,9 +48,7 @@ class EgcfEngine:
         self.Z = [torch.empty((n, d), **f32) for _ in range(2)]            # backward ping-pong
         self.M = torch.zeros((self.I, d), **f32)
         self.V = torch.zeros((self.I, d), **f32)
-        self.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
-        self.units, self.units_B = None, -1
-        self.bpr_ws, self.bpr_B = None, -1
+        self.prep = BatchPrep(self.U, n, d, dev, units_graph=graph)  # bitmap, live units, scatter plan: side stream, one batch ahead
         self.loss = torch.zeros(3, **f32)        # [bpr, reg_lambda * reg, ssl_lambda * (three InfoNCE terms)]
         self._ssl = torch.zeros(4, **f32)        # user-user, pos-pos, user-pos (+ pad)
         self.step_count = 0
@@ -89,19 +88,15 @@ class EgcfEngine:
     @torch.no_grad()
     def train_step(self, users, pos, neg, loss_out=None):
         U, K, X, n, d = self.U, self.K, self.X, self.n, self.d
-        B = int(users.shape[0])
         loss = self.loss if loss_out is None else loss_out
-        if self.bpr_B != B:
-            self.bpr_ws, self.bpr_B = ops.bpr_workspace(B, d, self.device), B
-        # index-only work: the batch's row bitmap, its live units, the sorted scatter plan
-        ops.bpr_touch_rows_raw(users, pos, neg, U, self.bitmap, clear_bits=n)
-        self.units = self.G.live_units(self.bitmap, 3 * B, ws=self.units if self.units_B == B else None)
-        self.units_B = B
-        ops.bpr_plan_raw(users, pos, neg, U, n, d, ws=self.bpr_ws)
-        self.propagate(out_rows=self.bitmap)
+        # index-only work (the batch's row bitmap, its live units, the sorted scatter plan): prepared on the side stream by
+        # prefetch() during the previous step, or right now
+        slot = self.prep.take(users, pos, neg)
+        bitmap = slot.bitmap
+        self.propagate(out_rows=bitmap)
         # losses: gradient rows STORED at the batch's rows (bitmap), the InfoNCE terms added into the same rows
         ops.bpr_fused_raw(self.TOT, self.EGO, users, pos, neg, U, self.reg_lambda, self.GT, self.GE, loss=loss[:2],
-                          deterministic=2, touched=self.bitmap, ws=self.bpr_ws)
+                          deterministic=2 | native.IDG_BPR_TOUCHED_PRESET, touched=bitmap, ws=slot.ws)
         ops.infonce_pair_raw(self.TOT, self.TOT, users, pos, U, self.temperature, g1=self.GT, g2=self.GT, loss=self._ssl[:2],
                              dedup=False, grad_scale=self.ssl_lambda, accumulate=True)
         ops.infonce_cross_raw(self.TOT, users, pos, U, self.temperature, g=self.GT, loss=self._ssl[2:4],
@@ -110,17 +105,22 @@ class EgcfEngine:
         loss[2:3].mul_(self.ssl_lambda)
         # backward
         Za, Zb = self.Z
-        ops.rows_tanh_bwd_raw(self.GT, X[K], self.bitmap, Za)                      # Z_K at the batch's rows
-        x_rows = self.bitmap
+        ops.rows_tanh_bwd_raw(self.GT, X[K], bitmap, Za)                           # Z_K at the batch's rows
+        x_rows = bitmap
         for k in range(K - 1, 0, -1):
-            ops.spmm_epi_raw(self.G, Za, Y=Zb, addend=self.GT, mask=self.bitmap, act=native.ACT_TANH_BWD, act_src=X[k],
+            ops.spmm_epi_raw(self.G, Za, Y=Zb, addend=self.GT, mask=bitmap, act=native.ACT_TANH_BWD, act_src=X[k],
                              x_rows=x_rows)
             Za, Zb, x_rows = Zb, Za, None
-        ops.spmm_epi_raw(self.G, Za, Y=Zb, addend=self.GE, mask=self.bitmap, act=native.ACT_TANH_BWD, act_src=X[0],
+        ops.spmm_epi_raw(self.G, Za, Y=Zb, addend=self.GE, mask=bitmap, act=native.ACT_TANH_BWD, act_src=X[0],
                          act_rows=U, x_rows=x_rows)
         self.step_count += 1
         ops.spmm_epi_raw(self.R.T, Zb[:U], addend=Zb[U:], sum_out=Za[U:],
                          adam=(self.EGO[U:], self.M, self.V, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps),
                          adam_discard_grad=not self.store_grad)
         self._grad_items = Za[U:] if self.store_grad else None
+        self.prep.release(slot)
         return loss
+
+    def prefetch(self, users, pos, neg):
+        """One-batch lookahead of the index-only work of the NEXT step (side stream)."""
+        self.prep.prefetch(users, pos, neg)

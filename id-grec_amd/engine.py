@@ -380,3 +380,77 @@ class PropagationEngine:
     def rating(self, users):
         fin = self.propagate()
         return ops.score_dense(fin[: self.U], fin[self.U:], users)
+
+
+class BatchPrep:
+    """The index-only work of a batch — the bitmap of its <= 3B panel rows, (optionally) the live work units of that bitmap
+    on a graph, the sorted scatter plan of its (row, slot) pairs — on a SIDE stream, one batch ahead of the step that uses
+    it: what PropagationEngine does for the LightGCN family, for engines with their own step (EgcfEngine, NgcfEngine).
+    Two slots: the batch being processed and the one prepared ahead.
+
+        prep.prefetch(users, pos, neg)            # the trainer's lookahead (optional)
+        slot = prep.take(users, pos, neg)         # the step: finds the prepared slot (or prepares now), orders the main
+        ...  slot.bitmap / slot.units / slot.ws   #   stream behind it
+        prep.release(slot)                        # after the last launch that reads them
+    """
+
+    class _Slot:
+        def __init__(self, words, device):
+            self.bitmap = torch.zeros(words, dtype=torch.int32, device=device)
+            self.units, self.ws, self.B = None, None, -1
+            self.done, self.free_ev, self.free = ops.LocalEvent(), ops.LocalEvent(), None
+            self.key, self.ids, self.stamp = None, None, 0
+
+    def __init__(self, num_users, n_rows, dim, device, units_graph=None):
+        self.U, self.n, self.d, self.device, self.graph = int(num_users), int(n_rows), int(dim), device, units_graph
+        self._slots = [self._Slot((self.n + 31) // 32, device) for _ in range(2)]
+        self._side = ops.side_stream(device)
+        self._side_raw = self._side.cuda_stream
+        self._fork = ops.LocalEvent()
+        self._id_storage, self._stamp = None, 0
+
+    def _prepare(self, slot, users, pos, neg):
+        main = torch.cuda.current_stream()
+        B = int(users.shape[0])
+        if slot.B != B:
+            slot.ws, slot.units, slot.B = ops.bpr_workspace(B, self.d, self.device), None, B
+        if slot.free is not None:
+            slot.free.wait(self._side_raw)  # the step that last used this slot has consumed it
+        # the side stream must not read the ids before the main stream has produced them: once per storage (batches are
+        # slices of one epoch-long tensor), as PropagationEngine._prepare does
+        src = (users.untyped_storage().data_ptr(), pos.untyped_storage().data_ptr(), neg.untyped_storage().data_ptr())
+        if slot.free is None or src != self._id_storage:
+            self._id_storage = src
+            self._fork.record(main.cuda_stream)
+            self._fork.wait(self._side_raw)
+        ops.bpr_touch_rows_raw(users, pos, neg, self.U, slot.bitmap, stream=self._side_raw, clear_bits=self.n)
+        if self.graph is not None:
+            slot.units = self.graph.live_units(slot.bitmap, 3 * B, ws=slot.units, stream=self._side_raw)
+        ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
+        slot.done.record(self._side_raw)
+        slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
+        slot.ids = (users, pos, neg)  # alive until the side stream has read them
+
+    def _next(self):
+        free = [sl for sl in self._slots if sl.key is None]
+        slot = min(free if free else self._slots, key=lambda sl: sl.stamp)
+        self._stamp += 1
+        slot.stamp = self._stamp
+        return slot
+
+    def prefetch(self, users, pos, neg):
+        self._prepare(self._next(), users, pos, neg)
+
+    def take(self, users, pos, neg):
+        key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), int(users.shape[0]))
+        slot = next((sl for sl in self._slots if sl.key == key), None)
+        if slot is None:
+            slot = self._next()
+            self._prepare(slot, users, pos, neg)
+        slot.key = None
+        slot.done.wait(torch.cuda.current_stream().cuda_stream)
+        return slot
+
+    def release(self, slot):
+        slot.free = slot.free_ev
+        slot.free.record(torch.cuda.current_stream().cuda_stream)

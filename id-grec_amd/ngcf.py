@@ -20,6 +20,7 @@ import ctypes as C
 import torch
 
 from . import native, ops
+from .engine import BatchPrep
 
 lib, check = native.lib, native.check
 
@@ -71,8 +72,7 @@ class NgcfEngine:
         self.g_ego = [panel(), panel()]
         self.GRAD = panel()
         self.M, self.V = torch.zeros((n, d), **f32), torch.zeros((n, d), **f32)
-        self.bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
-        self.bpr_ws, self.bpr_B = None, -1
+        self.prep = BatchPrep(self.U, n, d, dev)  # the batch's row bitmap and scatter plan: side stream, one batch ahead
         self.wg_ws = torch.empty(int(lib.idg_ngcf_wgrad_workspace_bytes(d, d)), dtype=torch.uint8, device=dev)
         self._per = per
         self.loss = torch.zeros(2, **f32)
@@ -116,22 +116,20 @@ class NgcfEngine:
         st = ops._stream()
         B = int(users.shape[0])
         loss = self.loss if loss_out is None else loss_out
-        if self.bpr_B != B:
-            self.bpr_ws, self.bpr_B = ops.bpr_workspace(B, d, self.device), B
-        ops.bpr_touch_rows_raw(users, pos, neg, U, self.bitmap, clear_bits=n)
-        ops.bpr_plan_raw(users, pos, neg, U, n, d, ws=self.bpr_ws)
+        slot = self.prep.take(users, pos, neg)
+        bitmap = slot.bitmap
         self.forward(streams)
         check(lib.idg_bpr_fused_ex_f32(p_(self.FINAL), D, p_(self.P), d, U, n, p_(users), p_(pos), p_(neg), B, self.reg_lambda, 0,
-                                       p_(loss), p_(self.GFIN), p_(self.GE), native.IDG_BPR_PLANNED, p_(self.bitmap),
-                                       p_(self.bpr_ws), st), "idg_bpr_fused_ex_f32")
+                                       p_(loss), p_(self.GFIN), p_(self.GE), native.IDG_BPR_PLANNED | native.IDG_BPR_TOUCHED_PRESET,
+                                       p_(bitmap), p_(slot.ws), st), "idg_bpr_fused_ex_f32")
         # backward
         self.step_count += 1
         gE = None
         for l in range(K - 1, -1, -1):
             wg, bg, wb, bb = self._views[l]
             seed, sid = self._streams[l]
-            slot = self.GFIN.data_ptr() + 4 * (l + 1) * d
-            check(lib.idg_ngcf_tail_bwd_ex_f32(p_(self.E[l]), p_(gE), C.c_void_p(slot), D, p_(self.bitmap), n, d, self.slope,
+            slot_ptr = self.GFIN.data_ptr() + 4 * (l + 1) * d
+            check(lib.idg_ngcf_tail_bwd_ex_f32(p_(self.E[l]), p_(gE), C.c_void_p(slot_ptr), D, p_(bitmap), n, d, self.slope,
                                                self.p[l], C.c_uint64(seed), C.c_uint64(sid), p_(self.gT), st),
                   "idg_ngcf_tail_bwd_ex_f32")
             # the layer's four parameter gradients in one pass over (side, ego * side, gT), straight into the flat buffer
@@ -147,10 +145,15 @@ class NgcfEngine:
                 gE = nxt
             else:
                 # the batch's rows of slot 0 (ego_0 is itself part of the final rows) and of the regulariser's gradient
-                check(lib.idg_rows_add2_f32(p_(g_ego), d, p_(self.GFIN), D, p_(self.GE), d, p_(self.bitmap), n, d, st),
+                check(lib.idg_rows_add2_f32(p_(g_ego), d, p_(self.GFIN), D, p_(self.GE), d, p_(bitmap), n, d, st),
                       "idg_rows_add2_f32")
                 ops.spmm_epi_raw(self.G, self.g_side, addend=g_ego, sum_out=self.GRAD,
                                  adam=(self.P, self.M, self.V, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps),
                                  adam_discard_grad=not self.store_grad)
         ops.adam_step_raw(self.SW, self.SG, self.SM, self.SV, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps)
+        self.prep.release(slot)
         return loss
+
+    def prefetch(self, users, pos, neg):
+        """One-batch lookahead of the index-only work of the NEXT step (side stream)."""
+        self.prep.prefetch(users, pos, neg)

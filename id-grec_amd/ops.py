@@ -39,6 +39,14 @@ def _require_device(*tensors):
                 "move the model and inputs to the GPU (device='cuda')." % t.device)
 
 
+def _require_ids(*tensors):
+    """The raw entry points read ids as contiguous int64 (the reference's batches, trainer.py:27-29): anything else
+    would be read past its end."""
+    for t in tensors:
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            raise TypeError("batch ids must be contiguous int64 tensors (got %s, contiguous=%s)" % (t.dtype, t.is_contiguous()))
+
+
 def _f32c(t, name):
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
@@ -868,6 +876,7 @@ def bpr_touch_rows_raw(users, pos, neg, num_users, bitmap, stream=None, clear_bi
     """Set the bits of the panel rows this batch touches (idg_bpr_touch_rows); bitmap: int32 [ceil(n/32)], zeroed
     by the caller or here when clear_bits = n.  stream: raw handle of the stream to launch on (default: current)."""
     _require_device(users, pos, neg, bitmap)
+    _require_ids(users, pos, neg)
     st = _stream() if stream is None else stream
     if clear_bits:
         check(lib.idg_bitmap_clear(_ptr(bitmap), int(clear_bits), st), "idg_bitmap_clear")
@@ -886,6 +895,7 @@ def bpr_plan_raw(users, pos, neg, num_users, n, d, ws=None, stream=None):
     stream.  Index-only work: run it on a side stream while the propagation is in flight, then call
     bpr_fused_raw(..., deterministic=2)."""
     _require_device(users, pos, neg)
+    _require_ids(users, pos, neg)
     B = users.shape[0]
     ws = _bpr_ws(B, d, users.device) if ws is None else ws
     check(lib.idg_bpr_plan_f32(_ptr(users), _ptr(pos), _ptr(neg), B, int(num_users), int(n), _ptr(ws),
@@ -899,6 +909,7 @@ def bpr_fused_raw(final_panel, ego_panel, users, pos, neg, num_users, reg_lambda
     touched: zeroed int32 bitmap [ceil(n/32)]; if given, reached g_final rows are stored + flagged and
     g_final needs no zero-fill (feed the bitmap to Graph.propagate_mean_bwd_raw(mask=...))."""
     _require_device(final_panel, ego_panel, users, pos, neg, g_final, g_ego)
+    _require_ids(users, pos, neg)
     n, d = final_panel.shape
     B = users.shape[0]
     loss = torch.empty(2, dtype=torch.float32, device=final_panel.device) if loss is None else loss

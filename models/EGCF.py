@@ -75,7 +75,9 @@ class EGCF(nn.Module):
         return self._engine
 
     def prefetch_batch(self, users, pos, neg):
-        pass  # (the index-only work of a step is three small launches at the head of the step)
+        """The trainer's one-batch lookahead: the next batch's bitmap / live units / scatter plan on the side stream."""
+        if self.fused_step_available():
+            self.engine().prefetch(users, pos, neg)
 
     def fused_train_step(self, users, pos, neg, loss_out, optimizer):
         """forward + backward + Adam as ONE chain of kernels; False (nothing done) unless `optimizer` is an

@@ -65,7 +65,9 @@ class NGCF(PackedRecommender):
         return eng
 
     def prefetch_batch(self, users, pos, neg):
-        pass
+        """The trainer's one-batch lookahead: the next batch's bitmap / scatter plan on the side stream."""
+        if self.fused_step_available():
+            self.ngcf_engine().prefetch(users, pos, neg)
 
     def fused_train_step(self, users, pos, neg, loss_out, optimizer):
         """forward + backward + every Adam update as ONE chain of kernels; False (nothing done) unless `optimizer` is an

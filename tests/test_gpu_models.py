@@ -895,6 +895,46 @@ def test_egcf_trainer_loop_runs(tmp_path, golden_small):
     assert len(losses_) == 2 and losses_[1] < losses_[0]
 
 
+@pytest.mark.parametrize("mname", ["EGCF", "NGCF"])
+def test_batch_lookahead_changes_nothing(mname, tmp_path, golden_small):
+    """The side-stream preparation of the NEXT batch (engine.BatchPrep: row bitmap, live units, scatter plan — called by the
+    trainer through prefetch_batch) is index-only work: four steps over four different batches with the lookahead equal,
+    bit for bit, the same steps without it — losses and every parameter."""
+    import importlib
+
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+
+    cls = getattr(importlib.import_module("models." + mname), mname)
+    cfg = _cfg(mname)
+    data = _data_with(tmp_path, golden_small, cfg)
+    gen = torch.Generator().manual_seed(7)
+    B, steps = 192, 4
+    epoch = torch.stack([torch.randint(0, data.num_users, (B * steps,), generator=gen),
+                         torch.randint(0, data.num_items, (B * steps,), generator=gen),
+                         torch.randint(0, data.num_items, (B * steps,), generator=gen)]).cuda()  # int64 ids, as the trainer's
+    batches = [tuple(epoch[c, s * B:(s + 1) * B] for c in range(3)) for s in range(steps)]
+    runs = []
+    for ahead in (False, True):
+        tools.set_seed(2024)
+        m = cls(cfg, data, torch.device("cuda")).to("cuda")
+        assert m.fused_step_available()
+        opt = ops.Adam(list(m.parameters()), lr=float(cfg["learn_rate"]))
+        ops.reset_noise_stream()
+        out = torch.zeros(steps, m.n_fused_losses, device="cuda")
+        if ahead:
+            m.prefetch_batch(*batches[0])
+        for s in range(steps):
+            if ahead and s + 1 < steps:
+                m.prefetch_batch(*batches[s + 1])
+            assert m.fused_train_step(*batches[s], out[s], opt)
+        torch.cuda.synchronize()
+        runs.append((out.cpu(), {k: v.detach().cpu().clone() for k, v in m.named_parameters()}))
+    assert torch.isfinite(runs[0][0]).all() and torch.equal(runs[0][0], runs[1][0])
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
+
+
 def test_sparsity_test_evaluation_path(tmp_path, golden_small, capsys):
     """sparsity_test = 1 (batch_test.py:110-170): the four interaction-count buckets are evaluated through the fused
     top-K path and printed in the reference's format; the first bucket is what general_test returns."""
