@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libidgrec.so")
 SOURCES = ["idg_host.cpp", "idg_comm.cpp", "idg_stream.cpp", "idg_graph.hip", "idg_bpr.hip", "idg_score.hip", "idg_ssl.hip", "idg_dense.hip",
-           "idg_shard.hip"]
+           "idg_ngcf.hip", "idg_shard.hip"]
 ARCH = "gfx950"
 
 
@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(ROOT, "include", "idgrec.h"), os.path.join(CSRC, "idg_common.h")]
+    headers = [os.path.join(ROOT, "include", "idgrec.h"), os.path.join(CSRC, "idg_common.h"), os.path.join(CSRC, "idg_dropout.h")]
     # -ffp-contract=off: the kernels spell out every fused multiply-add they want (fmaf); left to itself the compiler
     # contracts a*b+c differently in different instantiations of the same source, and paths that must agree bit for
     # bit (single- vs multi-panel kernels, epilogue vs stand-alone perturbation) then differ in the last place

@@ -118,6 +118,11 @@ PROTOTYPES = {
                                        c_vp, c_vp, C.c_int64, c_vp]),
     "idg_ngcf_tail_bwd_ex_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                            C.c_uint64, C.c_uint64, c_vp, c_vp]),
+    "idg_ngcf_layer_fwd_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_uint64,
+                                         C.c_uint64, c_vp, c_vp, C.c_int64, c_vp]),
+    "idg_ngcf_layer_bwd_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "idg_ngcf_layer_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float,
+                                         C.c_float, C.c_uint64, C.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "idg_colsum_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "idg_colsum_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_int, c_vp, c_vp]),
     "idg_copy_cols_f32": (C.c_int, [c_vp, C.c_int64, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp]),
@@ -198,7 +203,7 @@ except ImportError:  # host-only use (sampler / parser / adjacency) works withou
     _torch = None
 
 ACT_TANH, ACT_TANH_BWD = 1, 2  # idg_epilogue.act
-ABI_VERSION = 134  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 135  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

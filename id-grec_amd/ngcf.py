@@ -14,8 +14,13 @@ Backward, l = K..1, with gN_l = layer l's slot of d loss / d final (stored at th
 and for l = 1 the batch's rows of slot 0 and of the regulariser's gradient join g_ego, and the product's epilogue applies
 Adam to the embedding panel.  The 4K small tensors live in ONE flat buffer (views handed back to the nn.Parameters): one
 Adam launch for all of them.  Node dropout (off in configure/NGCF.txt) is not part of this chain: the model then trains
-through the differentiable operators."""
+through the differentiable operators.
+
+d = 64 (round 4): the three launches of a layer's forward and the four of its backward are ONE kernel each
+(idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32, csrc/idg_ngcf.hip): 64-row tiles staged once in LDS, S, ego * side and gT
+never stored — E, N, g_side, g_ego bit-identical to the chain above, parameter gradients summed in another fixed order."""
 import ctypes as C
+import os
 
 import torch
 
@@ -61,19 +66,25 @@ class NgcfEngine:
             self._views.append(tuple(vs))
             self._gviews.append(tuple(self.SG[a:a + s[0] * s[1]].view(s) for a, s in cuts))
         panel = lambda: torch.empty((n, d), **f32)  # noqa: E731
+        # d = 64: one kernel per layer and direction (idg_ngcf_layer_fwd_f32 / _bwd_f32: S, ego * side and gT never reach
+        # memory); other widths: the transform / tail / parameter-gradient chain.  IDG_NGCF_LAYER=0 forces the chain.
+        self.fused_layer = d == 64 and os.environ.get("IDG_NGCF_LAYER", "1") != "0"
         self.SIDE = [panel() for _ in range(K)]
-        self.BI = [panel() for _ in range(K)]
         self.E = [panel() for _ in range(K)]
-        self.S = panel()
+        if not self.fused_layer:
+            self.BI = [panel() for _ in range(K)]
+            self.S = panel()
+            self.gT = panel()
         self.FINAL = torch.empty((n, self.D), **f32)
         self.GFIN = torch.empty((n, self.D), **f32)
         self.GE = torch.empty((n, d), **f32)
-        self.gT, self.g_side = panel(), panel()
+        self.g_side = panel()
         self.g_ego = [panel(), panel()]
         self.GRAD = panel()
         self.M, self.V = torch.zeros((n, d), **f32), torch.zeros((n, d), **f32)
         self.prep = BatchPrep(self.U, n, d, dev)  # the batch's row bitmap and scatter plan: side stream, one batch ahead
-        self.wg_ws = torch.empty(int(lib.idg_ngcf_wgrad_workspace_bytes(d, d)), dtype=torch.uint8, device=dev)
+        ws_bytes = lib.idg_ngcf_layer_bwd_workspace_bytes(d) if self.fused_layer else lib.idg_ngcf_wgrad_workspace_bytes(d, d)
+        self.wg_ws = torch.empty(int(ws_bytes), dtype=torch.uint8, device=dev)
         self._per = per
         self.loss = torch.zeros(2, **f32)
         self.step_count = 0
@@ -100,12 +111,17 @@ class NgcfEngine:
         for l in range(K):
             wg, bg, wb, bb = self._views[l]
             self.G.spmm_raw(ego, out=self.SIDE[l])
-            check(lib.idg_ngcf_transform_f32(p_(self.SIDE[l]), p_(ego), p_(wg), p_(wb), n, d, d, p_(self.S), p_(self.BI[l]), st),
-                  "idg_ngcf_transform_f32")
             seed, sid = self._streams[l]
             slot = self.FINAL.data_ptr() + 4 * (l + 1) * d
-            check(lib.idg_ngcf_tail_ex_f32(p_(self.S), None, p_(bg), p_(bb), n, d, self.slope, self.p[l], C.c_uint64(seed),
-                                           C.c_uint64(sid), p_(self.E[l]), C.c_void_p(slot), D, st), "idg_ngcf_tail_ex_f32")
+            if self.fused_layer:
+                check(lib.idg_ngcf_layer_fwd_f32(p_(self.SIDE[l]), p_(ego), p_(wg), p_(wb), p_(bg), p_(bb), n, d, self.slope,
+                                                 self.p[l], C.c_uint64(seed), C.c_uint64(sid), p_(self.E[l]), C.c_void_p(slot), D,
+                                                 st), "idg_ngcf_layer_fwd_f32")
+            else:
+                check(lib.idg_ngcf_transform_f32(p_(self.SIDE[l]), p_(ego), p_(wg), p_(wb), n, d, d, p_(self.S), p_(self.BI[l]),
+                                                 st), "idg_ngcf_transform_f32")
+                check(lib.idg_ngcf_tail_ex_f32(p_(self.S), None, p_(bg), p_(bb), n, d, self.slope, self.p[l], C.c_uint64(seed),
+                                               C.c_uint64(sid), p_(self.E[l]), C.c_void_p(slot), D, st), "idg_ngcf_tail_ex_f32")
             ego = self.E[l]
         return self.FINAL
 
@@ -129,16 +145,23 @@ class NgcfEngine:
             wg, bg, wb, bb = self._views[l]
             seed, sid = self._streams[l]
             slot_ptr = self.GFIN.data_ptr() + 4 * (l + 1) * d
-            check(lib.idg_ngcf_tail_bwd_ex_f32(p_(self.E[l]), p_(gE), C.c_void_p(slot_ptr), D, p_(bitmap), n, d, self.slope,
-                                               self.p[l], C.c_uint64(seed), C.c_uint64(sid), p_(self.gT), st),
-                  "idg_ngcf_tail_bwd_ex_f32")
-            # the layer's four parameter gradients in one pass over (side, ego * side, gT), straight into the flat buffer
-            check(lib.idg_ngcf_wgrad_f32(p_(self.SIDE[l]), p_(self.BI[l]), p_(self.gT), n, d, d,
-                                         C.c_void_p(self.SG.data_ptr() + 4 * l * self._per), p_(self.wg_ws), st), "idg_ngcf_wgrad_f32")
             ego_prev = self.P if l == 0 else self.E[l - 1]
             g_ego = self.g_ego[l & 1]
-            check(lib.idg_ngcf_transform_bwd_f32(p_(self.gT), p_(self.SIDE[l]), p_(ego_prev), p_(wg), p_(wb), n, d, d,
-                                                 p_(self.g_side), p_(g_ego), st), "idg_ngcf_transform_bwd_f32")
+            w_grads = C.c_void_p(self.SG.data_ptr() + 4 * l * self._per)  # the layer's four, straight into the flat buffer
+            if self.fused_layer:
+                check(lib.idg_ngcf_layer_bwd_f32(p_(self.E[l]), p_(gE), C.c_void_p(slot_ptr), D, p_(bitmap), p_(self.SIDE[l]),
+                                                 p_(ego_prev), p_(wg), p_(wb), n, d, self.slope, self.p[l], C.c_uint64(seed),
+                                                 C.c_uint64(sid), p_(self.g_side), p_(g_ego), w_grads, p_(self.wg_ws), st),
+                      "idg_ngcf_layer_bwd_f32")
+            else:
+                check(lib.idg_ngcf_tail_bwd_ex_f32(p_(self.E[l]), p_(gE), C.c_void_p(slot_ptr), D, p_(bitmap), n, d, self.slope,
+                                                   self.p[l], C.c_uint64(seed), C.c_uint64(sid), p_(self.gT), st),
+                      "idg_ngcf_tail_bwd_ex_f32")
+                # the four parameter gradients in one pass over (side, ego * side, gT)
+                check(lib.idg_ngcf_wgrad_f32(p_(self.SIDE[l]), p_(self.BI[l]), p_(self.gT), n, d, d, w_grads, p_(self.wg_ws), st),
+                      "idg_ngcf_wgrad_f32")
+                check(lib.idg_ngcf_transform_bwd_f32(p_(self.gT), p_(self.SIDE[l]), p_(ego_prev), p_(wg), p_(wb), n, d, d,
+                                                     p_(self.g_side), p_(g_ego), st), "idg_ngcf_transform_bwd_f32")
             if l > 0:
                 nxt = self.g_ego[(l & 1) ^ 1]
                 self.G.spmm_raw(self.g_side, addend=g_ego, out=nxt)   # G symmetric: the backward of side = G . ego

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 134 /* 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 135 /* 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -538,6 +538,22 @@ int idg_ngcf_tail_ex_f32(const float* S1, const float* S2, const float* b1, cons
 int idg_ngcf_tail_bwd_ex_f32(const float* E, const float* gE, const float* gN, int64_t ldgn, const uint32_t* gn_rows,
                              int64_t n, int64_t d, float negative_slope, float p, uint64_t seed, uint64_t stream_id,
                              float* gT, void* stream);
+/* One NGCF layer as ONE kernel per direction, d = 64 (csrc/idg_ngcf.hip; models/NGCF.py:88-108 and its autograd):
+ *   forward : E = dropout(leaky_relu(side . W1 + (ego * side) . W2 + b1 + b2)), N = normalize(E)  — N with leading dimension
+ *             ldn (layer l's slot of the concatenated final rows); nothing else is stored;
+ *   backward: from E, gE (nullable), gN (nullable; ldgn, gn_rows as idg_ngcf_tail_bwd_ex_f32), side and the layer's input
+ *             ego: g_side, g_ego [n, 64] and w_grads = [g W1 (64 x 64) | g b1 (64) | g W2 (64 x 64) | g b2 (64)].
+ * E, N, g_side, g_ego are bit-identical to idg_ngcf_transform_f32 + idg_ngcf_tail_ex_f32 and their backward forms; the
+ * parameter gradients are sums over the rows in a fixed order of their own (slices of rows on persistent workgroups).
+ * Any other d: IDG_E_INVALID (use the chain).  ws: idg_ngcf_layer_bwd_workspace_bytes(d). */
+int idg_ngcf_layer_fwd_f32(const float* side, const float* ego, const float* W1, const float* W2, const float* b1,
+                           const float* b2, int64_t n, int64_t d, float negative_slope, float p, uint64_t seed,
+                           uint64_t stream_id, float* E, float* N, int64_t ldn, void* stream);
+size_t idg_ngcf_layer_bwd_workspace_bytes(int64_t d);
+int idg_ngcf_layer_bwd_f32(const float* E, const float* gE, const float* gN, int64_t ldgn, const uint32_t* gn_rows,
+                           const float* side, const float* ego, const float* W1, const float* W2, int64_t n, int64_t d,
+                           float negative_slope, float p, uint64_t seed, uint64_t stream_id, float* g_side, float* g_ego,
+                           float* w_grads, void* ws, void* stream);
 /* Glue of that step.  idg_copy_cols_f32: dst[r, 0:d] = src[r, 0:d] with leading dimensions ldd / lds.  idg_rows_add2_f32:
  * dst[r] += a[r] (+ b[r]) at the rows flagged in `rows`.  idg_colsum_f32: out[f] (+)= sum over the n rows of X[r, f] — the
  * gradient of a bias row broadcast over n rows (the differentiable layer tail's backward; the fused step gets it from

@@ -1555,3 +1555,64 @@ def test_propagate_views_single_backward(ops, golden_small):
     want = G.propagate_mean_bwd_raw(g0 + g1 + g2, 3, False)
     assert torch.allclose(E0.grad, want, rtol=1e-5, atol=1e-7)
     assert torch.allclose(ref0, G.propagate_mean_bwd_raw(g0, 3, False), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,p_drop,with_ge,masked", [(1000, 0.0, True, False), (4133, 0.1, True, True), (69716, 0.1, False, True),
+                                                     (63, 0.3, True, False)])
+def test_ngcf_layer_kernels_equal_the_chain(n, p_drop, with_ge, masked):
+    """idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction, d = 64) against the chain
+    they replace (transform + tail; tail' + parameter gradients + transform'): E, N, g_side, g_ego bit for bit, the
+    parameter gradients (another summation order) against float64 sums within 2e-5 of their scale."""
+    import ctypes as C
+
+    from idgrec_amd import native, ops
+
+    lib, check = native.lib, native.check
+    d, D = 64, 256
+    g = torch.Generator(device="cuda").manual_seed(n)
+    rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)  # noqa: E731
+    side, ego = rnd(n, d) * 0.3, rnd(n, d) * 0.3
+    W1, W2, b1, b2 = rnd(d, d) * 0.1, rnd(d, d) * 0.1, rnd(d) * 0.1, rnd(d) * 0.1
+    seed, sid, slope = 1234, 7, 0.2
+    p_ = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    st = ops._stream()
+    # forward
+    S, BI = torch.empty(n, d, device="cuda"), torch.empty(n, d, device="cuda")
+    E0, E1 = torch.empty(n, d, device="cuda"), torch.empty(n, d, device="cuda")
+    F0, F1 = torch.full((n, D), 7.0, device="cuda"), torch.full((n, D), 7.0, device="cuda")
+    slot = lambda F: C.c_void_p(F.data_ptr() + 4 * 2 * d)  # noqa: E731
+    check(lib.idg_ngcf_transform_f32(p_(side), p_(ego), p_(W1), p_(W2), n, d, d, p_(S), p_(BI), st), "t")
+    check(lib.idg_ngcf_tail_ex_f32(p_(S), None, p_(b1), p_(b2), n, d, slope, p_drop, C.c_uint64(seed), C.c_uint64(sid), p_(E0),
+                                   slot(F0), D, st), "tail")
+    check(lib.idg_ngcf_layer_fwd_f32(p_(side), p_(ego), p_(W1), p_(W2), p_(b1), p_(b2), n, d, slope, p_drop, C.c_uint64(seed),
+                                     C.c_uint64(sid), p_(E1), slot(F1), D, st), "fwd")
+    assert torch.equal(E0, E1) and torch.equal(F0, F1)
+    assert float(F1[:, :2 * d].min()) == 7.0 and float(F1[:, 3 * d:].max()) == 7.0  # only the slot was written
+    # backward
+    gE = rnd(n, d) if with_ge else None
+    gF = rnd(n, D)
+    bitmap = None
+    if masked:
+        rows = torch.randperm(n, device="cuda", generator=g)[:max(1, n // 20)]
+        bits = torch.zeros((n + 31) // 32 * 32, dtype=torch.bool, device="cuda")
+        bits[rows] = True
+        w = (bits.view(-1, 32).to(torch.int64) << torch.arange(32, device="cuda")).sum(1)
+        bitmap = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+    gslot = C.c_void_p(gF.data_ptr() + 4 * 2 * d)
+    gT = torch.empty(n, d, device="cuda")
+    check(lib.idg_ngcf_tail_bwd_ex_f32(p_(E0), p_(gE), gslot, D, p_(bitmap), n, d, slope, p_drop, C.c_uint64(seed), C.c_uint64(sid),
+                                       p_(gT), st), "tb")
+    gs0, ge0, gs1, ge1 = (torch.empty(n, d, device="cuda") for _ in range(4))
+    check(lib.idg_ngcf_transform_bwd_f32(p_(gT), p_(side), p_(ego), p_(W1), p_(W2), n, d, d, p_(gs0), p_(ge0), st), "trb")
+    ws = torch.empty(int(lib.idg_ngcf_layer_bwd_workspace_bytes(d)), dtype=torch.uint8, device="cuda")
+    wg = torch.empty(2 * d * d + 2 * d, device="cuda")
+    check(lib.idg_ngcf_layer_bwd_f32(p_(E1), p_(gE), gslot, D, p_(bitmap), p_(side), p_(ego), p_(W1), p_(W2), n, d, slope, p_drop,
+                                     C.c_uint64(seed), C.c_uint64(sid), p_(gs1), p_(ge1), p_(wg), p_(ws), st), "bwd")
+    assert torch.equal(gs0, gs1) and torch.equal(ge0, ge1)
+    t64, s64, b64 = gT.double(), side.double(), (side * ego).double()
+    want = torch.cat([(s64.t() @ t64).reshape(-1), t64.sum(0), (b64.t() @ t64).reshape(-1), t64.sum(0)])
+    scale = float(want.abs().max())
+    assert float((wg.double() - want).abs().max()) <= 2e-5 * scale + 1e-12
+    # other widths are refused, not mis-computed
+    assert lib.idg_ngcf_layer_fwd_f32(p_(side), p_(ego), p_(W1), p_(W2), p_(b1), p_(b2), n, 128, slope, p_drop, C.c_uint64(seed),
+                                      C.c_uint64(sid), p_(E1), slot(F1), D, st) != 0
