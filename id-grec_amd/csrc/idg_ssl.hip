@@ -36,14 +36,15 @@ constexpr int GS = 8;   // split-K slices of the gradient products
 struct SslWs {
   uint32_t* bitmap;  // [(n+31)/32]
   uint32_t* dup;     // [(n+31)/32] raw-id lists (dedup = 0): rows that occur more than once in their list
+  int32_t* meta;     // [64] raw-id lists: [0] arrival ticket of ssl_mark_dups_kernel, [1 + 2 v] / [2 + 2 v] number of list
+                     //      positions of view v whose id occurs more than once: in set 0 / in both sets (cleared with the bitmaps)
+  int32_t* dlist;    // [2 views][2B] those positions, ascending
   int32_t* idx;      // [2B] ascending panel rows: the user set, then the item set
   int32_t* idx2;     // [2B] view 2's rows when they differ from view 1's (idg_infonce_cross_f32), else == idx
   int32_t* counts;   // [2] sizes of the two sets (+2 pad)
   float* An;         // [2 views][2B][d] normalised rows
   float* den;        // [2 views][2B]   max(||x||, 1e-12)
   float* P;          // [2 sets][B][B]
-  float* PT;         // [2 sets][B][B] the same matrices transposed (MFMA gradient products: both operands K-contiguous)
-  float* AnT;        // [2 views][2 sets][d][B] the normalised rows transposed, set-local column index
   float* coef;       // [2 sets][B] w_i / ttl_i (scales the second gradient product's operand)
   float* contrib;    // [2 views][2B][d] every list position's own gradient row (raw-id lists: summed per id afterwards)
   float* invttl;     // [2B]
@@ -66,14 +67,14 @@ SslWs ssl_layout(void* base, int64_t n, int64_t B, int64_t d) {
   };
   w.bitmap = reinterpret_cast<uint32_t*>(take((size_t)((n + 31) / 32) * 4));
   w.dup = reinterpret_cast<uint32_t*>(take((size_t)((n + 31) / 32) * 4));
+  w.meta = reinterpret_cast<int32_t*>(take(256));
+  w.dlist = reinterpret_cast<int32_t*>(take((size_t)2 * 2 * B * 4));
   w.idx = reinterpret_cast<int32_t*>(take((size_t)2 * B * 4));
   w.idx2 = reinterpret_cast<int32_t*>(take((size_t)2 * B * 4));
   w.counts = reinterpret_cast<int32_t*>(take(16));
   w.An = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
   w.den = reinterpret_cast<float*>(take((size_t)2 * 2 * B * 4));
   w.P = reinterpret_cast<float*>(take((size_t)2 * B * B * 4));
-  w.PT = reinterpret_cast<float*>(take((size_t)2 * B * B * 4));
-  w.AnT = reinterpret_cast<float*>(take((size_t)2 * 2 * d * B * 4));
   w.coef = reinterpret_cast<float*>(take((size_t)2 * B * 4));
   w.contrib = reinterpret_cast<float*>(take((size_t)2 * 2 * B * d * 4));
   w.invttl = reinterpret_cast<float*>(take((size_t)2 * B * 4));
@@ -168,14 +169,65 @@ __global__ __launch_bounds__(BLOCK) void ssl_cross_ids_kernel(const int64_t* __r
 // once; the gradient kernel then skips its scan of the whole list for them (a batch of 2048 raw ids: 32 rounds of load /
 // compare / ballot per row, 124 us per call at yelp2018 size — two thirds of it for rows that have no second occurrence).
 __global__ __launch_bounds__(BLOCK) void ssl_mark_dups_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ idx2,
-                                                              int64_t count, uint32_t* __restrict__ seen,
-                                                              uint32_t* __restrict__ dup) {
+                                                              int64_t count, const int32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ seen, uint32_t* __restrict__ dup,
+                                                              int32_t* __restrict__ meta, int32_t* __restrict__ dlist,
+                                                              int64_t B) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= count) return;
-  for (int v = 0; v < (idx2 != idx ? 2 : 1); ++v) {
-    const int32_t id = (v == 0 ? idx : idx2)[i];
-    const uint32_t bit = 1u << (id & 31);
-    if (atomicOr(seen + (id >> 5), bit) & bit) atomicOr(dup + (id >> 5), bit);
+  const int views = idx2 != idx ? 2 : 1;
+  if (i < count) {
+    for (int v = 0; v < views; ++v) {
+      const int32_t id = (v == 0 ? idx : idx2)[i];
+      const uint32_t bit = 1u << (id & 31);
+      if (atomicOr(seen + (id >> 5), bit) & bit) atomicOr(dup + (id >> 5), bit);
+    }
+  }
+  // The block that arrives last lists, per view, the POSITIONS whose id occurs more than once, ascending: the gradient
+  // kernel's ordered per-id sums then walk these few hundred positions instead of the whole list (44 -> 15 us per call
+  // at B = 2048 with popular items repeating, round 4).  (Device-scope atomics above; fence + ticket; the bits are read
+  // back past the L1.)
+  __shared__ int s_last;
+  __shared__ int s_wave[BLOCK / WAVE];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(meta, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+  const int cu = counts[0], total = cu + counts[1];
+  for (int v = 0; v < views; ++v) {
+    const int32_t* ix = v == 0 ? idx : idx2;
+    int32_t* out = dlist + (int64_t)v * 2 * B;
+    int at = 0, at_set0 = 0;
+    for (int p0 = 0; p0 < total; p0 += BLOCK) {
+      const int pos = p0 + (int)threadIdx.x;
+      bool f = false;
+      if (pos < total) {
+        const int32_t id = ix[pos];
+        f = (__hip_atomic_load(dup + (id >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (id & 31)) & 1u;
+      }
+      const unsigned long long m = __ballot(f);
+      if (lane == 0) s_wave[wave] = __popcll(m);
+      __syncthreads();
+      int before = 0, all = 0;
+#pragma unroll
+      for (int q = 0; q < BLOCK / WAVE; ++q) {
+        before += q < wave ? s_wave[q] : 0;
+        all += s_wave[q];
+      }
+      if (f) out[at + before + __popcll(m & ((1ull << lane) - 1ull))] = pos;
+      // positions of set 0 among this chunk's flagged ones (the chunk that straddles cu: count them exactly)
+      const unsigned long long m0 = __ballot(f && pos < cu);
+      __syncthreads();
+      if (lane == 0) s_wave[wave] = __popcll(m0);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < BLOCK / WAVE; ++q) at_set0 += s_wave[q];
+      at += all;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) meta[1 + 2 * v] = at_set0, meta[2 + 2 * v] = at;
   }
 }
 
@@ -185,8 +237,7 @@ __global__ __launch_bounds__(BLOCK) void ssl_normalize_kernel(const float* __res
                                                               const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ idx2,
                                                               const int32_t* __restrict__ counts, int64_t B,
-                                                              float* __restrict__ An, float* __restrict__ den,
-                                                              float* __restrict__ AnT) {
+                                                              float* __restrict__ An, float* __restrict__ den) {
   const int lane = threadIdx.x % WAVE;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int v = blockIdx.y;
@@ -197,14 +248,7 @@ __global__ __launch_bounds__(BLOCK) void ssl_normalize_kernel(const float* __res
   ss = wave_sum(ss);
   const float nrm = fmaxf(sqrtf(ss), 1e-12f);  // torch.nn.functional.normalize: x / max(||x||, eps)
   float* y = An + ((int64_t)v * 2 * B + r) * d;
-  // (AnT, MFMA path: the same values with the row index running fastest, per set: [view][set][f][row within the set])
-  const int set = r < counts[0] ? 0 : 1;
-  float* yt = AnT ? AnT + ((int64_t)(v * 2 + set) * d) * B + (r - (set ? counts[0] : 0)) : nullptr;
-  for (int64_t f = lane; f < d; f += WAVE) {
-    const float q = x[f] / nrm;
-    y[f] = q;
-    if (yt) yt[f * B] = q;
-  }
+  for (int64_t f = lane; f < d; f += WAVE) y[f] = x[f] / nrm;
   if (lane == 0) den[(int64_t)v * 2 * B + r] = nrm;
 }
 
@@ -382,12 +426,10 @@ __device__ __forceinline__ void load32(const float* __restrict__ p, float (&v)[3
   }
 }
 
-// P[set][i][k] = exp(<a_i, b_k> / t) and PT[set][k][i] = the same value (the second gradient product reads P by columns):
-// a 64 x 64 tile per workgroup, one 32 x 32 MFMA tile per wave, the transposed copy through a wave-private LDS tile.
+// P[set][i][k] = exp(<a_i, b_k> / t): a 64 x 64 tile per workgroup, one 32 x 32 MFMA tile per wave.
 __global__ __launch_bounds__(BLOCK) void ssl_logits_mfma_kernel(const float* __restrict__ An, int64_t d, int64_t B,
                                                                 const int32_t* __restrict__ counts, float inv_t,
-                                                                float* __restrict__ P, float* __restrict__ PT) {
-  __shared__ float s_t[BLOCK / WAVE][32][33];
+                                                                float* __restrict__ P) {
   const int set = blockIdx.z;
   const int m = counts[set];
   const int i0 = blockIdx.y * TS, k0 = blockIdx.x * TS;
@@ -413,31 +455,27 @@ __global__ __launch_bounds__(BLOCK) void ssl_logits_mfma_kernel(const float* __r
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int lr = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const float v = expf(acc[r] * inv_t);
-    if (ti + lr < m && tk + i < m) Ps[(int64_t)(ti + lr) * B + tk + i] = v;
-    s_t[wave][lr][i] = v;
-  }
-  if (PT == nullptr) return;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float* Ts = PT + (int64_t)set * B * B;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int lr = (r & 3) + 8 * (r >> 2) + 4 * h;  // a COLUMN of the tile here: row lr of the transposed one
-    if (tk + lr < m && ti + i < m) Ts[(int64_t)(tk + lr) * B + ti + i] = s_t[wave][i][lr];
+    if (ti + lr < m && tk + i < m) Ps[(int64_t)(ti + lr) * B + tk + i] = expf(acc[r] * inv_t);
   }
 }
 
-// The two gradient products on the matrix cores: side 0  G[r][f] = sum_c P[r][c] b_c[f],  side 1  G[k][f] = sum_i PT[k][i]
-// (w_i / ttl_i) a_i[f].  Operands K-contiguous: rows of P / PT, and rows of AnT (the other view's normalised rows,
-// transposed per set).  64 rows x 64 features per workgroup, the reduction index cut into GS slices as in the SIMT form;
-// raw slice sums go to Gp[side][slice][row][f] (ssl_final_kernel adds them in slice order).
+// The two gradient products on the matrix cores: side 0  G[r][f] = sum_c P[r][c] b_c[f],  side 1  G[k][f] = sum_i P[i][k]
+// (w_i / ttl_i) a_i[f].  64 output rows x 64 features per workgroup, the reduction index cut into GS slices as in the SIMT
+// form; raw slice sums go to Gp[side][slice][row][f] (ssl_final_kernel adds them in slice order).
+// Operands through LDS (round 4): per 64-deep chunk the workgroup reads the 64 x 64 block of P it needs — rows r, columns c
+// for side 0; rows i, columns k for side 1, scaled by w_i / ttl_i on the way in — and the 64 rows of the other view, both
+// as whole 256-byte runs (16 lanes x 16 bytes), into padded tiles; the MFMA operands come out of the tiles, side 1's P
+// operand by columns.  Before, every lane read its own row of P, of a transposed copy PT, and of transposed copies of the
+// normalised rows (64 cache lines per load instruction; the copies written by the logits / normalise kernels):
+// 47 -> 28 us per call at B = 2048, and the logits kernel no longer writes PT (30 -> 20 us).  Same K order: same sums.
 //   grid: (feature tiles * GS, row tiles, set * 2 + side)
-__global__ __launch_bounds__(BLOCK) void ssl_grad_mfma_kernel(const float* __restrict__ P, const float* __restrict__ PT,
-                                                              const float* __restrict__ AnT, const float* __restrict__ coef,
-                                                              int64_t d, int64_t B, const int32_t* __restrict__ counts,
-                                                              float* __restrict__ Gp) {
+constexpr int GLD = TS + 4;  // LDS row stride (floats): rows 16-byte aligned, 16 rows of b128 reads cover all banks
+
+__global__ __launch_bounds__(BLOCK) void ssl_grad_mfma_kernel(const float* __restrict__ P, const float* __restrict__ An,
+                                                              const float* __restrict__ coef, int64_t d, int64_t B,
+                                                              const int32_t* __restrict__ counts, float* __restrict__ Gp) {
+  __shared__ __attribute__((aligned(16))) float s_p[TS * GLD];  // side 0: [output row][reduction index]; side 1: [reduction index][output row]
+  __shared__ __attribute__((aligned(16))) float s_x[TS * GLD];  // [reduction index][feature]
   const int set = blockIdx.z >> 1, side = blockIdx.z & 1;
   const int m = counts[set];
   const int slice = blockIdx.x % GS;
@@ -445,12 +483,11 @@ __global__ __launch_bounds__(BLOCK) void ssl_grad_mfma_kernel(const float* __res
   const int r0 = blockIdx.y * TS;
   if (r0 >= m) return;
   const int64_t base = set == 0 ? 0 : counts[0];
-  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, i = lane & 31, h = lane >> 5;
-  const int tr = r0 + 32 * (wave >> 1);
-  const int64_t tf = f0 + 32 * (wave & 1);
-  const float* M = (side == 0 ? P : PT) + (int64_t)set * B * B + (int64_t)(tr + i < m ? tr + i : m - 1) * B;
+  const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE, i = lane & 31, h = lane >> 5;
+  const int tr = 32 * (wave >> 1), tf = 32 * (wave & 1);  // this wave's 32 x 32 tile inside the block's 64 x 64
+  const float* Ps = P + (int64_t)set * B * B;
   // the OTHER view's rows: side 0 mixes b (view 2), side 1 mixes a (view 1)
-  const float* XT = AnT + ((int64_t)((side == 0 ? 1 : 0) * 2 + set) * d + (tf + i < d ? tf + i : d - 1)) * B;
+  const float* X = An + ((int64_t)(side == 0 ? 2 * B : 0) + base) * d + f0;
   const float* cf = coef + (int64_t)set * B;
   const int per = ((m + GS - 1) / GS + TS - 1) / TS * TS;  // reduction indices per slice (a multiple of 64)
   const int c_lo = slice * per, c_hi = c_lo + per < m ? c_lo + per : m;
@@ -458,35 +495,55 @@ __global__ __launch_bounds__(BLOCK) void ssl_grad_mfma_kernel(const float* __res
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
-    const int c = c0 + 32 * h;
-    float a[32], b[32];
-    if (c0 + 64 <= c_hi) {
-      load32(M + c, a);
-      load32(XT + c, b);
-      if (side == 1) {
-        float w[32];
-        load32(cf + c, w);
 #pragma unroll
-        for (int q = 0; q < 32; ++q) a[q] *= w[q];
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + BLOCK * j, rr = e >> 4, c4 = (e & 15) * 4;
+      // block of P: LDS row rr = P row (side 0: r0 + rr; side 1: c0 + rr), columns (side 0: c0 ...; side 1: r0 ...).
+      // Whatever lies beyond the set or the slice is staged as 0 (never read from memory: it was never written)
+      const int prow = side == 0 ? r0 + rr : c0 + rr, pcol = (side == 0 ? c0 : r0) + c4;
+      const int row_end = side == 0 ? m : c_hi, col_end = side == 0 ? c_hi : m;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (prow < row_end) {
+        const float* src = Ps + (int64_t)prow * B + pcol;
+        if (pcol + 4 <= col_end) v = *reinterpret_cast<const float4*>(src);
+        else {
+          if (pcol + 0 < col_end) v.x = src[0];
+          if (pcol + 1 < col_end) v.y = src[1];
+          if (pcol + 2 < col_end) v.z = src[2];
+        }
+        if (side == 1) {
+          const float w = cf[prow];
+          v.x *= w, v.y *= w, v.z *= w, v.w *= w;
+        }
       }
-    } else {  // the slice's last, partial chunk: nothing beyond c_hi is read (those entries were never written)
+      *reinterpret_cast<float4*>(s_p + rr * GLD + c4) = v;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + rr < c_hi) x = *reinterpret_cast<const float4*>(X + (int64_t)(c0 + rr) * d + c4);
+      *reinterpret_cast<float4*>(s_x + rr * GLD + c4) = x;
+    }
+    __syncthreads();
+    float a[32];
+    if (side == 0) {
+      const float* pa = s_p + (tr + i) * GLD + 32 * h;
 #pragma unroll
-      for (int q = 0; q < 32; ++q) {
-        const bool in = c + q < c_hi;
-        a[q] = in ? (side == 1 ? M[c + q] * cf[c + q] : M[c + q]) : 0.f;
-        b[q] = in ? XT[c + q] : 0.f;
+      for (int q = 0; q < 8; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(pa + 4 * q);
+        a[4 * q + 0] = t.x, a[4 * q + 1] = t.y, a[4 * q + 2] = t.z, a[4 * q + 3] = t.w;
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) a[q] = s_p[(32 * h + q) * GLD + tr + i];
     }
 #pragma unroll
-    for (int q = 0; q < 32; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+    for (int q = 0; q < 32; ++q)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], s_x[(32 * h + q) * GLD + tf + i], acc, 0, 0, 0);
+    __syncthreads();
   }
   float* out = Gp + (((int64_t)side * GS + slice) * 2 * B + base) * d;
-  if (tf + i < d) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = tr + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < m) out[(int64_t)row * d + tf + i] = acc[r];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int row = r0 + tr + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row < m) out[(int64_t)row * d + f0 + tf + i] = acc[r];
   }
 }
 
@@ -534,12 +591,12 @@ __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restric
                                                           const int32_t* __restrict__ idx2,
                                                           const int32_t* __restrict__ counts, int dedup,
                                                           int accumulate, int both_views, float* g1, float* g2,
-                                                          const uint32_t* __restrict__ dup) {
+                                                          const uint32_t* __restrict__ dup, const int32_t* __restrict__ meta,
+                                                          const int32_t* __restrict__ dlist) {
   const int lane = threadIdx.x % WAVE;
   const int64_t r = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   const int cu = counts[0], total = cu + counts[1];
   if (r >= total) return;
-  const int s_lo = r < cu ? 0 : cu, s_hi = r < cu ? cu : total;  // this row's set
   // g1 == g2 (both_views): one wave adds both views' gradients into the shared panel, view 1 first.  The two views'
   // rows are the same panel row (idx2 == idx) or different ones (the cross form, which always accumulates)
   const int v_lo = both_views ? 0 : blockIdx.y, v_hi = both_views ? 2 : blockIdx.y + 1;
@@ -550,25 +607,71 @@ __global__ __launch_bounds__(BLOCK) void ssl_final_kernel(const float* __restric
     const int32_t* ix = v == 0 ? idx : idx2;
     const int32_t id = ix[r];
     float* o = out + (int64_t)id * d;
-    bool first = true, mine = true;
     // a de-duplicated set has exactly one occurrence of `id`: r itself — and so has a raw list whose dup bit for the id
     // is clear (ssl_mark_dups_kernel)
     const bool single = dedup || (dup && !((dup[id >> 5] >> (id & 31)) & 1u));
-    // occurrences of `id` in this view's list of the set, ascending
-    for (int c0 = single ? (int)r : s_lo; mine && c0 < (single ? (int)r + 1 : s_hi); c0 += WAVE) {
-      unsigned long long match = single ? 1ull : __ballot(c0 + lane < s_hi && ix[c0 + lane] == id);
-      while (match) {
-        const int64_t j = c0 + __builtin_ctzll(match);
-        match &= match - 1;
-        if (first && j != r) {  // an earlier occurrence owns this panel row (for this view)
-          mine = false;
+    // occurrences of `id` in this view's list of the set, ascending: r itself, or — an id that repeats — found among the
+    // listed positions of repeating ids (ssl_mark_dups_kernel; idx2 == idx: one list serves both views), this set's part
+    const int lv = idx2 != idx ? v : 0;
+    const int32_t* dl = dlist + (int64_t)lv * 2 * B;
+    const int d_lo = single ? (int)r : (r < cu ? 0 : meta[1 + 2 * lv]);
+    const int d_hi = single ? (int)r + 1 : (r < cu ? meta[1 + 2 * lv] : meta[2 + 2 * lv]);
+    bool mine = true;  // the wave of the FIRST occurrence owns the panel row (for this view)
+    if (!single) {
+      mine = false;
+      for (int c0 = d_lo; c0 < d_hi; c0 += WAVE) {
+        const bool in = c0 + lane < d_hi;
+        const int32_t pos = in ? dl[c0 + lane] : 0;
+        const unsigned long long match = __ballot(in && ix[pos] == id);
+        if (match) {
+          mine = __shfl(pos, __builtin_ctzll(match), WAVE) == (int32_t)r;
           break;
         }
-        first = false;
-        const float* c = contrib + ((int64_t)v * 2 * B + j) * d;
-        for (int64_t f = lane; f < d; f += WAVE) o[f] = fresh ? c[f] : o[f] + c[f];
-        fresh = false;
       }
+    }
+    if (mine) {
+      // The row's sum is carried in a register and stored once: as a read-modify-write of the panel row per occurrence a
+      // popular item's 40 occurrences were 40 dependent store -> load round trips (the kernel's critical path: 44 us per
+      // call).  Up to four occurrences' rows are loaded together; the additions keep list order (same sums as before).
+      for (int64_t f0 = 0; f0 < d; f0 += WAVE) {
+        const int64_t f = f0 + lane;
+        const bool live = f < d;
+        bool have = !fresh;
+        float acc = (have && live) ? o[f] : 0.f;
+        for (int c0 = d_lo; c0 < d_hi; c0 += WAVE) {
+          int32_t pos_l = (int32_t)r;
+          unsigned long long match = 1ull;
+          if (!single) {
+            const bool in = c0 + lane < d_hi;
+            pos_l = in ? dl[c0 + lane] : 0;
+            match = __ballot(in && ix[pos_l] == id);
+          }
+          while (match) {
+            int64_t js[4];
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              js[q] = 0;
+              if (match) {
+                js[q] = single ? r : (int64_t)__shfl(pos_l, __builtin_ctzll(match), WAVE);
+                match &= match - 1;
+                cnt = q + 1;
+              }
+            }
+            float cv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cv[q] = (q < cnt && live) ? contrib[((int64_t)v * 2 * B + js[q]) * d + f] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (q < cnt) {
+                acc = have ? acc + cv[q] : cv[q];
+                have = true;
+              }
+          }
+        }
+        if (live) o[f] = acc;
+      }
+      fresh = false;
     }
     if (!both_views || idx2 != idx) fresh = !accumulate;
   }
@@ -611,10 +714,10 @@ static int infonce_impl(const float* view1, const float* view2, int64_t n, int64
   }
   const int64_t rows_max = cross ? B : 2 * B;
   if ((cross || !dedup) && (g1 || g2)) {  // raw lists: flag the rows that occur more than once (bitmap and dup are adjacent)
-    IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)(reinterpret_cast<char*>(w.dup) - reinterpret_cast<char*>(w.bitmap)) +
-                                           (size_t)((n + 31) / 32) * 4, st));
+    // (bitmap, dup and the ticket / counts block are adjacent: one fill)
+    IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)(reinterpret_cast<char*>(w.meta) - reinterpret_cast<char*>(w.bitmap)) + 256, st));
     hipLaunchKernelGGL(ssl_mark_dups_kernel, dim3((unsigned)((rows_max + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, w.idx, idx2,
-                       cross ? B : rows_max, w.bitmap, w.dup);
+                       cross ? B : rows_max, w.counts, w.bitmap, w.dup, w.meta, w.dlist, B);
     dup = w.dup;
   }
   const unsigned row_blocks = (unsigned)((rows_max + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
@@ -624,12 +727,11 @@ static int infonce_impl(const float* view1, const float* view2, int64_t n, int64
   const bool mfma = !mfma_off && d % 64 == 0 && B % 4 == 0;
   const bool grads = g1 || g2;
   hipLaunchKernelGGL(ssl_normalize_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, view1, view2, d, w.idx, idx2, w.counts, B,
-                     w.An, w.den, (mfma && grads) ? w.AnT : nullptr);
+                     w.An, w.den);
   const unsigned tb = (unsigned)((B + TS - 1) / TS);
   const float inv_t = 1.0f / temperature;
   if (mfma)
-    hipLaunchKernelGGL(ssl_logits_mfma_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P,
-                       grads ? w.PT : nullptr);
+    hipLaunchKernelGGL(ssl_logits_mfma_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
   else
     hipLaunchKernelGGL(ssl_logits_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
   hipLaunchKernelGGL(ssl_rowstat_kernel, dim3((unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE)), sets), dim3(BLOCK), 0, st,
@@ -637,8 +739,8 @@ static int infonce_impl(const float* view1, const float* view2, int64_t n, int64
   hipLaunchKernelGGL(ssl_loss_kernel, dim3(sets), dim3(BLOCK), 0, st, w.lossrow, w.counts, loss);
   if (g1 || g2) {
     if (mfma)
-      hipLaunchKernelGGL(ssl_grad_mfma_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 2 * sets), dim3(BLOCK), 0, st, w.P, w.PT,
-                         w.AnT, w.coef, d, B, w.counts, w.G);
+      hipLaunchKernelGGL(ssl_grad_mfma_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 2 * sets), dim3(BLOCK), 0, st, w.P, w.An,
+                         w.coef, d, B, w.counts, w.G);
     else
       hipLaunchKernelGGL(ssl_grad_kernel, dim3((unsigned)((d + TS - 1) / TS) * GS, tb, 2 * sets), dim3(BLOCK), 0, st, w.An, w.P, d,
                          B, w.counts, w.invttl, w.w, w.G);
@@ -646,7 +748,7 @@ static int infonce_impl(const float* view1, const float* view2, int64_t n, int64
     hipLaunchKernelGGL(ssl_contrib_kernel, dim3(row_blocks, 2), dim3(BLOCK), 0, st, w.An, w.den, w.G, w.invttl, w.w, d, B, w.counts,
                        grad_scale, w.contrib);
     hipLaunchKernelGGL(ssl_final_kernel, dim3(row_blocks, both ? 1 : 2), dim3(BLOCK), 0, st, w.contrib, d, B, w.idx, idx2, w.counts,
-                       (dedup && !cross) ? 1 : 0, accumulate ? 1 : 0, both, g1, g2, dup);
+                       (dedup && !cross) ? 1 : 0, accumulate ? 1 : 0, both, g1, g2, dup, w.meta, w.dlist);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;
