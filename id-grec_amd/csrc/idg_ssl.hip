@@ -686,40 +686,51 @@ size_t idg_infonce_workspace_bytes(int64_t n, int64_t B, int64_t d) {
   return ssl_layout(nullptr, n, B, d).bytes;
 }
 
-static int infonce_impl(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
-                        const int64_t* items, int64_t B, int64_t num_users, int dedup, int cross, float temperature, float* loss,
-                        float* g1, float* g2, float grad_scale, int accumulate, void* ws, void* stream, const char* who) {
-  IDG_REQUIRE(view1 && view2 && users && items && loss && ws, "%s: NULL argument", who);
-  IDG_REQUIRE(n > 0 && d > 0 && B > 0 && num_users >= 0 && num_users <= n, "%s: bad sizes", who);
-  IDG_REQUIRE(B <= 46340, "%s: batch of %lld ids is too large for the in-batch logits matrix", who, (long long)B);
-  IDG_REQUIRE(temperature > 0.f, "%s: temperature must be positive", who);
-  hipStream_t st = (hipStream_t)stream;
-  const SslWs w = ssl_layout(ws, n, B, d);
-  const int32_t* idx2 = w.idx;
-  const unsigned sets = cross ? 1u : 2u;
-  const uint32_t* dup = nullptr;
+// The id-list stage of a call — index-only work: the ascending unique rows of the batch (mode 0), its raw lists (1) or the
+// cross form's two lists (2), and for raw lists the repeat flags and the listed positions of repeating ids.
+static int infonce_ids(const int64_t* users, const int64_t* items, int64_t B, int64_t num_users, int64_t n, const SslWs& w,
+                       int mode, hipStream_t st) {
+  const bool cross = mode == 2, dedup = mode == 0;
   if (cross) {
     hipLaunchKernelGGL(ssl_cross_ids_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, items, B,
                        num_users, w.idx, w.idx2, w.counts);
-    idx2 = w.idx2;
   } else if (dedup) {
     IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)((n + 31) / 32) * 4, st));
     // rows of the batch's users and (positive) items; the third id list is not used here: pass the items twice
-    int rc = idg_bpr_touch_rows(users, items, items, B, num_users, w.bitmap, stream);
+    int rc = idg_bpr_touch_rows(users, items, items, B, num_users, w.bitmap, (void*)st);
     if (rc != IDG_OK) return rc;
     hipLaunchKernelGGL(ssl_compact_kernel, dim3(1), dim3(1024), 0, st, w.bitmap, n, num_users, w.idx, w.counts, 2 * B);
   } else {
     hipLaunchKernelGGL(ssl_copy_ids_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, items, B,
                        num_users, w.idx, w.counts);
   }
-  const int64_t rows_max = cross ? B : 2 * B;
-  if ((cross || !dedup) && (g1 || g2)) {  // raw lists: flag the rows that occur more than once (bitmap and dup are adjacent)
-    // (bitmap, dup and the ticket / counts block are adjacent: one fill)
+  if (!dedup) {  // raw lists: flag the rows that occur more than once (bitmap, dup and the ticket / counts block are adjacent: one fill)
+    const int64_t rows_max = cross ? B : 2 * B;
     IDG_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)(reinterpret_cast<char*>(w.meta) - reinterpret_cast<char*>(w.bitmap)) + 256, st));
-    hipLaunchKernelGGL(ssl_mark_dups_kernel, dim3((unsigned)((rows_max + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, w.idx, idx2,
-                       cross ? B : rows_max, w.counts, w.bitmap, w.dup, w.meta, w.dlist, B);
-    dup = w.dup;
+    hipLaunchKernelGGL(ssl_mark_dups_kernel, dim3((unsigned)((rows_max + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, w.idx,
+                       cross ? w.idx2 : w.idx, rows_max, w.counts, w.bitmap, w.dup, w.meta, w.dlist, B);
   }
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+static int infonce_impl(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
+                        const int64_t* items, int64_t B, int64_t num_users, int dedup, int cross, int planned, float temperature,
+                        float* loss, float* g1, float* g2, float grad_scale, int accumulate, void* ws, void* stream, const char* who) {
+  IDG_REQUIRE(view1 && view2 && users && items && loss && ws, "%s: NULL argument", who);
+  IDG_REQUIRE(n > 0 && d > 0 && B > 0 && num_users >= 0 && num_users <= n, "%s: bad sizes", who);
+  IDG_REQUIRE(B <= 46340, "%s: batch of %lld ids is too large for the in-batch logits matrix", who, (long long)B);
+  IDG_REQUIRE(temperature > 0.f, "%s: temperature must be positive", who);
+  hipStream_t st = (hipStream_t)stream;
+  const SslWs w = ssl_layout(ws, n, B, d);
+  const int32_t* idx2 = cross ? w.idx2 : w.idx;
+  const unsigned sets = cross ? 1u : 2u;
+  if (!planned) {  // (planned: idg_infonce_plan has left the lists in this workspace, typically on another stream, a batch ahead)
+    int rc = infonce_ids(users, items, B, num_users, n, w, cross ? 2 : (dedup ? 0 : 1), st);
+    if (rc != IDG_OK) return rc;
+  }
+  const uint32_t* dup = (cross || !dedup) ? w.dup : nullptr;
+  const int64_t rows_max = cross ? B : 2 * B;
   const unsigned row_blocks = (unsigned)((rows_max + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
   // the GEMM-shaped stages run on the fp32 matrix cores when every operand run is 16-byte aligned (IDG_SSL_MFMA=0: the SIMT
   // kernels, A/B timing)
@@ -754,20 +765,34 @@ static int infonce_impl(const float* view1, const float* view2, int64_t n, int64
   return IDG_OK;
 }
 
+int idg_infonce_plan(const int64_t* users, const int64_t* items, int64_t B, int64_t num_users, int64_t n, int64_t d, int mode,
+                     void* ws, void* stream) {
+  IDG_REQUIRE(users && items && ws, "idg_infonce_plan: NULL argument");
+  IDG_REQUIRE(n > 0 && d > 0 && B > 0 && B <= 46340 && num_users >= 0 && num_users <= n, "idg_infonce_plan: bad sizes");
+  IDG_REQUIRE(mode >= 0 && mode <= 2, "idg_infonce_plan: mode %d (0 unique ids, 1 raw lists, 2 cross form)", mode);
+  return infonce_ids(users, items, B, num_users, n, ssl_layout(ws, n, B, d), mode, (hipStream_t)stream);
+}
+
 int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int64_t d, const int64_t* users,
                          const int64_t* items, int64_t B, int64_t num_users, int dedup, float temperature, float* loss,
                          float* g1, float* g2, float grad_scale, int accumulate, void* ws, void* stream) {
-  return infonce_impl(view1, view2, n, d, users, items, B, num_users, dedup, 0, temperature, loss, g1, g2, grad_scale,
-                      accumulate, ws, stream, "idg_infonce_pair_f32");
+  return infonce_impl(view1, view2, n, d, users, items, B, num_users, dedup & 1, 0, (dedup & IDG_SSL_PLANNED) ? 1 : 0, temperature,
+                      loss, g1, g2, grad_scale, accumulate, ws, stream, "idg_infonce_pair_f32");
+}
+
+int idg_infonce_cross_ex_f32(const float* view, int64_t n, int64_t d, const int64_t* users, const int64_t* items, int64_t B,
+                             int64_t num_users, float temperature, float* loss, float* g, float grad_scale, int planned, void* ws,
+                             void* stream) {
+  // a_i = normalize(view[users[i]]), b_i = normalize(view[num_users + items[i]]), raw ids in batch order; the gradients
+  // of both sides are ADDED into g's rows (users' and items' rows are disjoint ranges of the panel)
+  return infonce_impl(view, view, n, d, users, items, B, num_users, 0, 1, planned ? 1 : 0, temperature, loss, g, g, grad_scale, 1,
+                      ws, stream, "idg_infonce_cross_f32");
 }
 
 int idg_infonce_cross_f32(const float* view, int64_t n, int64_t d, const int64_t* users, const int64_t* items, int64_t B,
                           int64_t num_users, float temperature, float* loss, float* g, float grad_scale, void* ws,
                           void* stream) {
-  // a_i = normalize(view[users[i]]), b_i = normalize(view[num_users + items[i]]), raw ids in batch order; the gradients
-  // of both sides are ADDED into g's rows (users' and items' rows are disjoint ranges of the panel)
-  return infonce_impl(view, view, n, d, users, items, B, num_users, 0, 1, temperature, loss, g, g, grad_scale, 1, ws, stream,
-                      "idg_infonce_cross_f32");
+  return idg_infonce_cross_ex_f32(view, n, d, users, items, B, num_users, temperature, loss, g, grad_scale, 0, ws, stream);
 }
 
 }  // extern "C"

@@ -48,7 +48,7 @@ class EgcfEngine:
         self.Z = [torch.empty((n, d), **f32) for _ in range(2)]            # backward ping-pong
         self.M = torch.zeros((self.I, d), **f32)
         self.V = torch.zeros((self.I, d), **f32)
-        self.prep = BatchPrep(self.U, n, d, dev, units_graph=graph)  # bitmap, live units, scatter plan: side stream, one batch ahead
+        self.prep = BatchPrep(self.U, n, d, dev, units_graph=graph, extra=self._plan_ssl)  # bitmap, live units, scatter plan: side stream, one batch ahead
         self.loss = torch.zeros(3, **f32)        # [bpr, reg_lambda * reg, ssl_lambda * (three InfoNCE terms)]
         self._ssl = torch.zeros(4, **f32)        # user-user, pos-pos, user-pos (+ pad)
         self.step_count = 0
@@ -97,10 +97,11 @@ class EgcfEngine:
         # losses: gradient rows STORED at the batch's rows (bitmap), the InfoNCE terms added into the same rows
         ops.bpr_fused_raw(self.TOT, self.EGO, users, pos, neg, U, self.reg_lambda, self.GT, self.GE, loss=loss[:2],
                           deterministic=2 | native.IDG_BPR_TOUCHED_PRESET, touched=bitmap, ws=slot.ws)
+        # (their id lists, repeat flags and positions are in the slot's two workspaces: _plan_ssl, side stream)
         ops.infonce_pair_raw(self.TOT, self.TOT, users, pos, U, self.temperature, g1=self.GT, g2=self.GT, loss=self._ssl[:2],
-                             dedup=False, grad_scale=self.ssl_lambda, accumulate=True)
+                             dedup=False, grad_scale=self.ssl_lambda, accumulate=True, ws=slot.ssl_ws[0], planned=True)
         ops.infonce_cross_raw(self.TOT, users, pos, U, self.temperature, g=self.GT, loss=self._ssl[2:4],
-                              grad_scale=self.ssl_lambda)
+                              grad_scale=self.ssl_lambda, ws=slot.ssl_ws[1], planned=True)
         torch.sum(self._ssl[:3], dim=0, keepdim=True, out=loss[2:3])
         loss[2:3].mul_(self.ssl_lambda)
         # backward
@@ -120,6 +121,16 @@ class EgcfEngine:
         self._grad_items = Za[U:] if self.store_grad else None
         self.prep.release(slot)
         return loss
+
+    def _plan_ssl(self, slot, users, pos, neg, stream):
+        """BatchPrep's hook: the id-list stages of the step's two InfoNCE calls (raw user / item lists; the cross form), each
+        into a workspace of the slot's own."""
+        B = int(users.shape[0])
+        if getattr(slot, "ssl_B", -1) != B:
+            slot.ssl_ws = (ops.infonce_workspace(self.n, B, self.d, self.device), ops.infonce_workspace(self.n, B, self.d, self.device))
+            slot.ssl_B = B
+        ops.infonce_plan_raw(users, pos, self.U, self.n, self.d, ops.SSL_RAW, slot.ssl_ws[0], stream=stream)
+        ops.infonce_plan_raw(users, pos, self.U, self.n, self.d, ops.SSL_CROSS, slot.ssl_ws[1], stream=stream)
 
     def prefetch(self, users, pos, neg):
         """One-batch lookahead of the index-only work of the NEXT step (side stream)."""

@@ -112,6 +112,7 @@ class PropagationEngine:
             self.use_fields = False
             self.ids = None
             self.ws = None
+            self.ssl_ws, self.ssl_key = None, None  # InfoNCE workspace holding this batch's id lists (ops.infonce_plan_raw)
             self.key = None
             self.rows_done = self.plan_done = None
             self.free = None  # = free_ev once recorded on the main stream: the step that used this slot is done
@@ -155,10 +156,26 @@ class PropagationEngine:
                     self.graph.expand_rows(slot.hops[j - 1], slot.hops[j], stream=self._side_raw)
             slot.rows_done.record(self._side_raw)  # needed by the last forward layer
         ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
-        slot.plan_done.record(self._side_raw)  # needed by the gradient scatter
+        if self.graph is not None and (self.ssl is not None or self.xssl is not None or self.sgl is not None):
+            # the id-list stage of the step's InfoNCE call (unique rows of the batch; SGL: raw lists, their repeat flags
+            # and positions) is index-only too: ~19 us of small launches per call off the main stream
+            mode = ops.SSL_RAW if self.sgl is not None else ops.SSL_UNIQUE
+            if slot.ssl_ws is None or slot.ssl_key is None or slot.ssl_key[0] != B:
+                slot.ssl_ws = ops.infonce_workspace(self.n, B, self.d, self.device)
+            ops.infonce_plan_raw(users, pos, self.U, self.n, self.d, mode, slot.ssl_ws, stream=self._side_raw)
+            slot.ssl_key = (B, mode)
+        slot.plan_done.record(self._side_raw)  # needed by the gradient scatter (and by the InfoNCE call behind it)
         slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
         slot.ids = (users, pos, neg)  # keeps the id tensors alive until the side stream has read them (a caller's temporaries
         #                               would otherwise return to the allocator, and be rewritten, while still being read)
+
+    @staticmethod
+    def _ssl_plan(slot, users, mode):
+        """Keyword arguments of the step's InfoNCE call: the slot's workspace with the id lists already in it — when this
+        slot was prepared for this batch size and list form (an engine switched to an SSL form after a prefetch: no)."""
+        if slot.ssl_ws is not None and slot.ssl_key == (int(users.shape[0]), mode):
+            return {"ws": slot.ssl_ws, "planned": True}
+        return {}
 
     def _take_slot(self):
         """Next slot of the ring: one whose batch has been consumed the longest ago (or never filled); when every slot
@@ -283,7 +300,8 @@ class PropagationEngine:
         if self.ssl is not None:
             # d(ssl_lambda * InfoNCE)/d view_1 + d(...)/d view_2 join the BPR gradient in g_final's (stored) rows
             ops.infonce_pair_raw(self._views[0], self._views[1], users, pos, self.U, temperature, g1=self.g_final,
-                                 g2=self.g_final, loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True)
+                                 g2=self.g_final, loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True,
+                                 **self._ssl_plan(slot, users, ops.SSL_UNIQUE))
             torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
             loss[2:3].mul_(ssl_lambda)
         if self.sgl is not None:
@@ -291,7 +309,8 @@ class PropagationEngine:
             g_1.zero_()
             g_2.zero_()
             ops.infonce_pair_raw(self._views[0], self._views[1], users, pos, self.U, temperature, g1=g_1, g2=g_2,
-                                 loss=self._ssl_loss, dedup=False, grad_scale=ssl_lambda, accumulate=True)
+                                 loss=self._ssl_loss, dedup=False, grad_scale=ssl_lambda, accumulate=True,
+                                 **self._ssl_plan(slot, users, ops.SSL_RAW))
             torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
             loss[2:3].mul_(ssl_lambda)
             # three encoders, three backward propagations (each sub-graph is its own symmetric operator), one gradient
@@ -311,7 +330,8 @@ class PropagationEngine:
             g_view = self._views[1]
             g_view.zero_()
             ops.infonce_pair_raw(self._views[0], self.final, users, pos, self.U, temperature, g1=g_view, g2=self.g_final,
-                                 loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True)
+                                 loss=self._ssl_loss, grad_scale=ssl_lambda, accumulate=True,
+                                 **self._ssl_plan(slot, users, ops.SSL_UNIQUE))
             torch.sum(self._ssl_loss, dim=0, keepdim=True, out=loss[2:3])
             loss[2:3].mul_(ssl_lambda)
             self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True, mask=slot.bitmap)
@@ -401,8 +421,11 @@ class BatchPrep:
             self.done, self.free_ev, self.free = ops.LocalEvent(), ops.LocalEvent(), None
             self.key, self.ids, self.stamp = None, None, 0
 
-    def __init__(self, num_users, n_rows, dim, device, units_graph=None):
+    def __init__(self, num_users, n_rows, dim, device, units_graph=None, extra=None):
+        """extra(slot, users, pos, neg, raw_stream): more index-only work of the batch, enqueued on the side stream before the
+        slot's `done` event (EgcfEngine: the id lists of its two InfoNCE calls)."""
         self.U, self.n, self.d, self.device, self.graph = int(num_users), int(n_rows), int(dim), device, units_graph
+        self.extra = extra
         self._slots = [self._Slot((self.n + 31) // 32, device) for _ in range(2)]
         self._side = ops.side_stream(device)
         self._side_raw = self._side.cuda_stream
@@ -427,6 +450,8 @@ class BatchPrep:
         if self.graph is not None:
             slot.units = self.graph.live_units(slot.bitmap, 3 * B, ws=slot.units, stream=self._side_raw)
         ops.bpr_plan_raw(users, pos, neg, self.U, self.n, self.d, ws=slot.ws, stream=self._side_raw)
+        if self.extra is not None:
+            self.extra(slot, users, pos, neg, self._side_raw)
         slot.done.record(self._side_raw)
         slot.key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B)
         slot.ids = (users, pos, neg)  # alive until the side stream has read them

@@ -110,6 +110,9 @@ PROTOTYPES = {
     "idg_infonce_cross_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, c_vp, c_vp,
                                         C.c_float, c_vp, c_vp]),
     "idg_rows_tanh_bwd_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp]),
+    "idg_infonce_plan": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp]),
+    "idg_infonce_cross_ex_f32": (C.c_int, [c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_float, c_vp, c_vp,
+                                           C.c_float, C.c_int, c_vp, c_vp]),
     "idg_infonce_pair_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int, C.c_float,
                                        c_vp, c_vp, c_vp, C.c_float, C.c_int, c_vp, c_vp]),
     "idg_ngcf_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
@@ -164,6 +167,7 @@ PROTOTYPES = {
                                      C.c_int, c_vp, c_vp, c_vp, c_vp]),
 }
 
+IDG_SSL_PLANNED = 2  # OR-ed into idg_infonce_pair_f32's `dedup`: the id lists are in the workspace already (idg_infonce_plan)
 IDG_BPR_TOUCHED_PRESET = 4  # OR-ed into `deterministic`: the touched bitmap already holds the batch's rows
 IDG_BPR_PLANNED = 2  # `deterministic` value: the sorted scatter plan is already in the workspace (idg_bpr_plan_f32)
 IDG_GRAPH_SYMMETRIC = 1
@@ -203,7 +207,7 @@ except ImportError:  # host-only use (sampler / parser / adjacency) works withou
     _torch = None
 
 ACT_TANH, ACT_TANH_BWD = 1, 2  # idg_epilogue.act
-ABI_VERSION = 135  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 136  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -464,7 +464,25 @@ def rows_tanh_bwd_raw(grad, y, rows, out):
           "idg_rows_tanh_bwd_f32")
 
 
-def infonce_cross_raw(view, users, items, num_users, temperature, g=None, loss=None, grad_scale=1.0, ws=None):
+SSL_UNIQUE, SSL_RAW, SSL_CROSS = 0, 1, 2  # idg_infonce_plan modes
+
+
+def infonce_workspace(n, B, d, device):
+    """A workspace of idg_infonce_*_f32 for [n, d] panels and batches of B ids (one per batch in flight)."""
+    return torch.empty(int(lib.idg_infonce_workspace_bytes(int(n), int(B), int(d))), dtype=torch.uint8, device=device)
+
+
+def infonce_plan_raw(users, items, num_users, n, d, mode, ws, stream=None):
+    """idg_infonce_plan: the id-list stage of an InfoNCE call (index-only work) into `ws`, on `stream` (raw handle; default:
+    the current stream) — then infonce_pair_raw / infonce_cross_raw(..., ws=ws, planned=True) on the stream that has
+    waited for it."""
+    _require_device(users, items, ws)
+    _require_ids(users, items)
+    check(lib.idg_infonce_plan(_ptr(users), _ptr(items), users.shape[0], int(num_users), int(n), int(d), int(mode), _ptr(ws),
+                               _stream() if stream is None else stream), "idg_infonce_plan")
+
+
+def infonce_cross_raw(view, users, items, num_users, temperature, g=None, loss=None, grad_scale=1.0, ws=None, planned=False):
     """get_InfoNCE_loss(view[users], view[num_users + items], t) on the raw batch rows (models/EGCF.py:103), forward and
     backward: loss [1] and the gradient rows ADDED into g (idg_infonce_cross_f32).  Returns (loss, ws)."""
     _require_device(view, users, items, g, loss, ws)
@@ -477,8 +495,8 @@ def infonce_cross_raw(view, users, items, num_users, temperature, g=None, loss=N
         ws = _ssl_ws.get(key)
         if ws is None:
             ws = _ssl_ws[key] = torch.empty(int(lib.idg_infonce_workspace_bytes(n, B, d)), dtype=torch.uint8, device=view.device)
-    check(lib.idg_infonce_cross_f32(_ptr(view), n, d, _ptr(users), _ptr(items), B, int(num_users), float(temperature), _ptr(loss),
-                                    _ptr(g), float(grad_scale), _ptr(ws), _stream()), "idg_infonce_cross_f32")
+    check(lib.idg_infonce_cross_ex_f32(_ptr(view), n, d, _ptr(users), _ptr(items), B, int(num_users), float(temperature), _ptr(loss),
+                                       _ptr(g), float(grad_scale), int(bool(planned)), _ptr(ws), _stream()), "idg_infonce_cross_f32")
     return loss, ws
 
 
@@ -1120,7 +1138,7 @@ def ngcf_layer_tail(S1, S2, b1, b2, negative_slope=0.2, p=0.0, stream=None):
 
 
 def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None, g2=None, loss=None, dedup=True,
-                     grad_scale=1.0, accumulate=False):
+                     grad_scale=1.0, accumulate=False, ws=None, planned=False):
     """idg_infonce_pair_f32: loss[2] = InfoNCE over unique(users) rows and over num_users + unique(items) rows of
     the two [n, d] view panels; g1 / g2 (optional, pre-zeroed) receive d(loss[0] + loss[1]) / d view rows."""
     _require_device(view1, view2, users, items, g1, g2, loss)
@@ -1130,14 +1148,18 @@ def infonce_pair_raw(view1, view2, users, items, num_users, temperature, g1=None
     B = users.shape[0]
     if view2.shape != view1.shape or items.shape[0] != B:
         raise ValueError("infonce_pair_raw: view panels / id lists of different shapes")
-    key = (n, B, d, view1.device)
-    ws = _ssl_ws.get(key)
     if ws is None:
-        ws = _ssl_ws[key] = torch.empty(int(lib.idg_infonce_workspace_bytes(n, B, d)), dtype=torch.uint8, device=view1.device)
+        if planned:
+            raise ValueError("infonce_pair_raw: planned=True needs the workspace idg_infonce_plan wrote into")
+        key = (n, B, d, view1.device)
+        ws = _ssl_ws.get(key)
+        if ws is None:
+            ws = _ssl_ws[key] = infonce_workspace(n, B, d, view1.device)
     if loss is None:
         loss = torch.empty(2, dtype=torch.float32, device=view1.device)
     check(lib.idg_infonce_pair_f32(_ptr(view1), _ptr(view2), n, d, _ptr(users), _ptr(items), B, int(num_users),
-                                   int(bool(dedup)), float(temperature), _ptr(loss), _ptr(g1), _ptr(g2), float(grad_scale),
+                                   int(bool(dedup)) | (native.IDG_SSL_PLANNED if planned else 0), float(temperature), _ptr(loss),
+                                   _ptr(g1), _ptr(g2), float(grad_scale),
                                    int(bool(accumulate)), _ptr(ws), _stream()),
           "idg_infonce_pair_f32")
     return loss

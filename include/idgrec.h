@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 135 /* 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 136 /* 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -594,6 +594,18 @@ int idg_infonce_pair_f32(const float* view1, const float* view2, int64_t n, int6
                          const int64_t* users, const int64_t* items, int64_t B, int64_t num_users,
                          int dedup, float temperature, float* loss, float* g1, float* g2,
                          float grad_scale, int accumulate, void* ws, void* stream);
+/* The id-list stage of a call on its own — index-only work (unique / raw / cross lists of the batch, the repeat flags and
+ * positions of raw lists) that a training loop runs on a side stream one batch ahead, as idg_bpr_plan_f32 does for the
+ * scatter plan: idg_infonce_plan(..., mode, ws, stream) with mode 0 = unique ids (dedup = 1), 1 = raw lists (dedup = 0),
+ * 2 = the cross form; then the matching call on the SAME workspace with IDG_SSL_PLANNED OR-ed into `dedup`
+ * (idg_infonce_pair_f32) or planned != 0 (idg_infonce_cross_ex_f32) skips the stage.  The caller orders the two streams
+ * and keeps one workspace per batch in flight. */
+#define IDG_SSL_PLANNED 2
+int idg_infonce_plan(const int64_t* users, const int64_t* items, int64_t B, int64_t num_users, int64_t n, int64_t d,
+                     int mode, void* ws, void* stream);
+int idg_infonce_cross_ex_f32(const float* view, int64_t n, int64_t d, const int64_t* users, const int64_t* items,
+                             int64_t B, int64_t num_users, float temperature, float* loss, float* g, float grad_scale,
+                             int planned, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: dense Adam step  (torch.optim.Adam defaults, utility/utility_train/trainer.py:11,56:

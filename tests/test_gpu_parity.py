@@ -1159,6 +1159,46 @@ def test_topk_exact_order_on_integer_embeddings(ops, per_call, d):
         np.testing.assert_allclose(sig_v[c0:c0 + 500], 1.0 / (1.0 + np.exp(-np.take_along_axis(M, want_s, 1))), rtol=3e-7, atol=0)
 
 
+@pytest.mark.parametrize("mode", ["unique", "raw", "cross"])
+def test_infonce_id_lists_planned_ahead_equal_the_in_call_stage(ops, mode):
+    """idg_infonce_plan (the id-list stage of an InfoNCE call, run by the engines on the side stream one batch ahead) +
+    the call with IDG_SSL_PLANNED / planned = 1 on that workspace: loss and gradient rows bit-identical to the call that
+    builds the lists itself — for the unique-id, raw-list and cross forms, with ids that repeat up to ~40 times, and again
+    after the workspace has been used for another batch (stale lists must not survive a re-plan)."""
+    U, I, d, B = 3000, 5000, 64, 1024
+    n = U + I
+    g = torch.Generator(device="cuda").manual_seed(5)
+    v1, v2 = torch.randn(n, d, device="cuda", generator=g), torch.randn(n, d, device="cuda", generator=g)
+    batches = []
+    for _ in range(2):
+        users = torch.randint(0, U, (B,), device="cuda", generator=g)
+        items = (torch.rand(B, device="cuda", generator=g) ** 3 * I).long()
+        batches.append((users, items))
+    ws = ops.infonce_workspace(n, B, d, "cuda")
+    side = torch.cuda.Stream()
+    for users, items in batches:
+        outs = []
+        for planned in (False, True):
+            g1, g2 = torch.zeros(n, d, device="cuda"), torch.zeros(n, d, device="cuda")
+            loss = torch.zeros(2, device="cuda")
+            kw = {}
+            if planned:
+                side.wait_stream(torch.cuda.current_stream())
+                ops.infonce_plan_raw(users, items, U, n, d, {"unique": ops.SSL_UNIQUE, "raw": ops.SSL_RAW, "cross": ops.SSL_CROSS}[mode],
+                                     ws, stream=side.cuda_stream)
+                torch.cuda.current_stream().wait_stream(side)
+                kw = {"ws": ws, "planned": True}
+            if mode == "cross":
+                ops.infonce_cross_raw(v1, users, items, U, 0.2, g=g1, loss=loss, grad_scale=0.5, **kw)
+            else:
+                ops.infonce_pair_raw(v1, v2, users, items, U, 0.2, g1=g1, g2=g2, loss=loss, dedup=mode == "unique", grad_scale=0.5,
+                                     accumulate=True, **kw)
+            outs.append((loss.clone(), g1, g2))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        assert torch.isfinite(outs[0][0]).all() and float(outs[0][1].abs().sum()) > 0
+
+
 def _row_bitmap(n, rows):
     bitmap = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
     np.bitwise_or.at(bitmap, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
