@@ -184,16 +184,17 @@ __global__ __launch_bounds__(BLOCK) void ssl_mark_dups_kernel(const int32_t* __r
   }
   // The block that arrives last lists, per view, the POSITIONS whose id occurs more than once, ascending: the gradient
   // kernel's ordered per-id sums then walk these few hundred positions instead of the whole list (44 -> 15 us per call
-  // at B = 2048 with popular items repeating, round 4).  (Device-scope atomics above; fence + ticket; the bits are read
-  // back past the L1.)
+  // at B = 2048 with popular items repeating, round 4).  (Device-scope atomics above; drained + ticket; the bits are
+  // read back past the L1.)
   __shared__ int s_last;
   __shared__ int s_wave[BLOCK / WAVE];
-  __threadfence();
+  // (the idiom of the split-row combine in idg_graph.hip: agent-scope atomics above, drained, then a relaxed agent-scope
+  //  ticket; the reader loads past its L1.  A __threadfence() here writes the XCD's whole L2 back: measured +7 us per call)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(meta, 1) == (int)gridDim.x - 1;
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(meta, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
   const int cu = counts[0], total = cu + counts[1];
   for (int v = 0; v < views; ++v) {
