@@ -309,7 +309,13 @@ __global__ __launch_bounds__(BLOCK) void ssl_rowstat_kernel(const float* __restr
   if (i >= m) return;
   const float* row = P + (int64_t)set * B * B + i * B;
   float s = 0.f;
-  for (int k = lane; k < m; k += WAVE) s += row[k];
+  for (int k0 = lane; k0 < m; k0 += 8 * WAVE) {  // eight loads in flight, added in the order of the plain loop
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = k0 + q * WAVE < m ? row[k0 + q * WAVE] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
   s = wave_sum(s);
   if (lane == 0) {
     const float r = row[i] / s;
