@@ -433,37 +433,86 @@ __device__ __forceinline__ void load32(const float* __restrict__ p, float (&v)[3
   }
 }
 
-// P[set][i][k] = exp(<a_i, b_k> / t): a 64 x 64 tile per workgroup, one 32 x 32 MFMA tile per wave.
-__global__ __launch_bounds__(BLOCK) void ssl_logits_mfma_kernel(const float* __restrict__ An, int64_t d, int64_t B,
-                                                                const int32_t* __restrict__ counts, float inv_t,
-                                                                float* __restrict__ P) {
+// P[set][i][k] = exp(<a_i, b_k> / t): a 128 x 128 (or 64 x 128) tile per workgroup, 2 x 2 (1 x 2) MFMA tiles per wave.  The 128 rows of
+// either view are read once per 64-deep chunk, coalesced, into padded LDS tiles and the MFMA operands come out of those
+// (round 4; with one 32 x 32 tile per wave fed by row-per-lane global loads — 64 cache lines per load instruction, every
+// operand row fetched by two waves of 32 workgroups — the kernel took 28 us for 7 us of MFMA work).  Same K order per
+// element as before: same values.
+constexpr int LT = 128;        // tile columns (rows of view 2); tile rows (of view 1) = 64 RT
+constexpr int LLD = TS + 4;    // LDS row stride (floats)
+
+// RT = 2: 128 x 128 per workgroup.  RT = 1: 64 x 128 (32 x 64 per wave) — twice the workgroups, for calls whose grid would
+// otherwise leave half the chip idle (the cross form's single set at B = 2048: 256 tiles of 128 x 128).
+template <int RT>
+__global__ __launch_bounds__(BLOCK, 2) void ssl_logits_mfma_kernel(const float* __restrict__ An, int64_t d, int64_t B,
+                                                                   const int32_t* __restrict__ counts, float inv_t,
+                                                                   float* __restrict__ P) {
+  constexpr int LTR = 64 * RT;
+  __shared__ __attribute__((aligned(16))) float s_a[LTR * LLD];
+  __shared__ __attribute__((aligned(16))) float s_b[LT * LLD];
   const int set = blockIdx.z;
   const int m = counts[set];
-  const int i0 = blockIdx.y * TS, k0 = blockIdx.x * TS;
+  const int i0 = blockIdx.y * LTR, k0 = blockIdx.x * LT;
   if (i0 >= m || k0 >= m) return;  // block-uniform
   const int64_t base = set == 0 ? 0 : counts[0];
   const float* A = An + base * d;
   const float* Bm = An + ((int64_t)2 * B + base) * d;
-  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, i = lane & 31, h = lane >> 5;
-  const int ti = i0 + 32 * (wave >> 1), tk = k0 + 32 * (wave & 1);
-  const float* arow = A + (int64_t)(ti + i < m ? ti + i : m - 1) * d + 32 * h;
-  const float* brow = Bm + (int64_t)(tk + i < m ? tk + i : m - 1) * d + 32 * h;
-  f32x16 acc;
+  const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE, i = lane & 31, h = lane >> 5;
+  const int wr = 32 * RT * (wave >> 1), wc = 64 * (wave & 1);  // this wave's (32 RT) x 64 part of the tile
+  f32x16 acc[RT][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][0][r] = 0.f, acc[rt][1][r] = 0.f;
   for (int64_t kc = 0; kc < d; kc += 64) {
-    float a[32], b[32];
-    load32(arow + kc, a);
-    load32(brow + kc, b);
 #pragma unroll
-    for (int q = 0; q < 32; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + BLOCK * j, rr = e >> 4, c4 = (e & 15) * 4;
+      // (rows past the set: a valid row, never stored)
+      if (rr < LTR) {
+        const int ra = i0 + rr < m ? i0 + rr : m - 1;
+        *reinterpret_cast<float4*>(s_a + rr * LLD + c4) = *reinterpret_cast<const float4*>(A + (int64_t)ra * d + kc + c4);
+      }
+      const int rb = k0 + rr < m ? k0 + rr : m - 1;
+      *reinterpret_cast<float4*>(s_b + rr * LLD + c4) = *reinterpret_cast<const float4*>(Bm + (int64_t)rb * d + kc + c4);
+    }
+    __syncthreads();
+    float a[RT][32];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float* pa = s_a + (wr + 32 * rt + i) * LLD + 32 * h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(pa + 4 * q);
+        a[rt][4 * q + 0] = x.x, a[rt][4 * q + 1] = x.y, a[rt][4 * q + 2] = x.z, a[rt][4 * q + 3] = x.w;
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float* pb = s_b + (wc + 32 * ct + i) * LLD + 32 * h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 y = *reinterpret_cast<const float4*>(pb + 4 * q);
+        const float ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][4 * q + c], ys[c], acc[rt][ct], 0, 0, 0);
+      }
+    }
+    __syncthreads();
   }
   float* Ps = P + (int64_t)set * B * B;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int lr = (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (ti + lr < m && tk + i < m) Ps[(int64_t)(ti + lr) * B + tk + i] = expf(acc[r] * inv_t);
-  }
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wr + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h, col = k0 + wc + 32 * ct + i;
+        if (row < m && col < m) Ps[(int64_t)row * B + col] = expf(acc[rt][ct][r] * inv_t);
+      }
 }
 
 // The two gradient products on the matrix cores: side 0  G[r][f] = sum_c P[r][c] b_c[f],  side 1  G[k][f] = sum_i P[i][k]
@@ -748,8 +797,14 @@ static int infonce_impl(const float* view1, const float* view2, int64_t n, int64
                      w.An, w.den);
   const unsigned tb = (unsigned)((B + TS - 1) / TS);
   const float inv_t = 1.0f / temperature;
-  if (mfma)
-    hipLaunchKernelGGL(ssl_logits_mfma_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
+  if (mfma) {
+    const unsigned tc = (unsigned)((B + LT - 1) / LT);
+    if ((int64_t)tc * tc * sets >= 512)  // enough 128 x 128 tiles for two workgroups on every CU
+      hipLaunchKernelGGL(ssl_logits_mfma_kernel<2>, dim3(tc, tc, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
+    else
+      hipLaunchKernelGGL(ssl_logits_mfma_kernel<1>, dim3(tc, (unsigned)((B + 63) / 64), sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts,
+                         inv_t, w.P);
+  }
   else
     hipLaunchKernelGGL(ssl_logits_kernel, dim3(tb, tb, sets), dim3(BLOCK), 0, st, w.An, d, B, w.counts, inv_t, w.P);
   hipLaunchKernelGGL(ssl_rowstat_kernel, dim3((unsigned)((B + (BLOCK / WAVE) - 1) / (BLOCK / WAVE)), sets), dim3(BLOCK), 0, st,
