@@ -35,6 +35,12 @@ int idg_stream_wait_event(void* stream, void* event) {
   return IDG_OK;
 }
 
+int idg_event_synchronize(void* event) {
+  IDG_REQUIRE(event, "idg_event_synchronize: NULL event");
+  IDG_HIP(hipEventSynchronize((hipEvent_t)event));
+  return IDG_OK;
+}
+
 int idg_event_query(void* event, int* done) {
   IDG_REQUIRE(event && done, "idg_event_query: NULL argument");
   const hipError_t e = hipEventQuery((hipEvent_t)event);

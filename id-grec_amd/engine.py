@@ -37,7 +37,11 @@ class PropagationEngine:
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
         words = (self.n + 31) // 32
         # two slots: the batch being processed and the one prepared ahead (measured: 3 or 4 change nothing)
-        self._slots = [self._Slot(words if graph is not None else 1, dev) for _ in range(2)] if self.deterministic else None
+        # three prepared-batch slots: the batch in its step, the one prepared ahead, and one whose last user (two steps back)
+        # the host has SEEN complete — see _pace()
+        self._slots = [self._Slot(words if graph is not None else 1, dev) for _ in range(3)] if self.deterministic else None
+        self._ends = []  # end-of-step events of the last steps, oldest first
+        self._paced = os.environ.get("IDG_PACE", "1") != "0"
         self.touched = None
         self._stamp = 0
         self._loss3 = torch.zeros(3, **f32)  # [bpr, reg_lambda * reg, ssl_lambda * InfoNCE]
@@ -239,13 +243,23 @@ class PropagationEngine:
         # index-only work done on a side stream (by prefetch() during the previous step, or right now).
         key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), users.shape[0])
         slot = next((sl for sl in self._slots if sl.key == key), None)
+        ahead = slot is not None
         if slot is None:  # not prefetched: prepare it now (the main stream then waits for the side stream)
             slot = self._take_slot()
             self._prepare(slot, users, pos, neg)
         slot.key = None
         self.touched = slot.bitmap
-        # the BPR kernel reads the layer mean at the batch rows only: the last layer is restricted to them
-        slot.rows_done.wait(main.cuda_stream)
+        # Pacing.  The host enqueues a step in less time than the device runs it and would get hundreds of steps ahead; it
+        # now blocks until the step before the previous one has finished (two steps stay queued: the device never runs dry).
+        # A batch prepared ahead — its preparation started when ITS slot's last step, three back, had finished — is then
+        # complete by the time its step is enqueued, the host can see that (event query), and the step's stream does not
+        # need the wait: a barrier packet costs 4.5 us between two kernels whether or not its event has fired.
+        if self._paced and len(self._ends) >= 2:
+            self._ends[-2].synchronize()
+            del self._ends[:-2]
+        ready = ahead and self._paced and slot.plan_done.query()
+        if not ready:
+            (slot.plan_done if ahead else slot.rows_done).wait(main.cuda_stream)
         if self.ssl is not None:
             # SimGCL (models/SimGCL.py:62-66): the clean pass and two perturbed ones, read at rows of the batch only
             # (unique users / positives are a subset of the bitmap); the first product is shared between the passes
@@ -289,7 +303,8 @@ class PropagationEngine:
             sub_1.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[0], out_rows=slot.bitmap)
             sub_2.propagate_mean_raw(self.params, self.K, self.inc, out=self._views[1], out_rows=slot.bitmap)
         assert self.exchange is None or not three, "gradient-row exchange: LightGCN-family steps only"
-        slot.plan_done.wait(main.cuda_stream)
+        if not ahead:
+            slot.plan_done.wait(main.cuda_stream)
         # reached rows of g_final and of the regulariser gradient (self.grad) are STORED and the backward
         # propagation reads flagged rows only: neither panel is ever zero-filled
         # (the bitmap already holds the batch's rows: with TOUCHED_PRESET the scatter stores its rows without writing it, so
@@ -322,6 +337,7 @@ class PropagationEngine:
                                   self.betas[1], self.eps)
             slot.free = slot.free_ev
             slot.free.record(main.cuda_stream)
+            self._ends.append(slot.free)
             self._final_version = -1
             return loss
         if self.xssl is not None:
@@ -343,6 +359,7 @@ class PropagationEngine:
                                   self.betas[1], self.eps)
             slot.free = slot.free_ev
             slot.free.record(main.cuda_stream)
+            self._ends.append(slot.free)
             self._final_version = -1
             return loss
         mask = slot.bitmap
@@ -362,6 +379,7 @@ class PropagationEngine:
             self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True, mask=mask)
         slot.free = slot.free_ev
         slot.free.record(main.cuda_stream)
+        self._ends.append(slot.free)
         self._final_version = -1
         return loss
 
@@ -406,7 +424,7 @@ class BatchPrep:
     """The index-only work of a batch — the bitmap of its <= 3B panel rows, (optionally) the live work units of that bitmap
     on a graph, the sorted scatter plan of its (row, slot) pairs — on a SIDE stream, one batch ahead of the step that uses
     it: what PropagationEngine does for the LightGCN family, for engines with their own step (EgcfEngine, NgcfEngine).
-    Two slots: the batch being processed and the one prepared ahead.
+    Three slots: the batch being processed, the one prepared ahead, and one whose last step the host has seen complete.
 
         prep.prefetch(users, pos, neg)            # the trainer's lookahead (optional)
         slot = prep.take(users, pos, neg)         # the step: finds the prepared slot (or prepares now), orders the main
@@ -426,7 +444,9 @@ class BatchPrep:
         slot's `done` event (EgcfEngine: the id lists of its two InfoNCE calls)."""
         self.U, self.n, self.d, self.device, self.graph = int(num_users), int(n_rows), int(dim), device, units_graph
         self.extra = extra
-        self._slots = [self._Slot((self.n + 31) // 32, device) for _ in range(2)]
+        self._slots = [self._Slot((self.n + 31) // 32, device) for _ in range(3)]  # (three: see PropagationEngine's pacing)
+        self._ends = []
+        self._paced = os.environ.get("IDG_PACE", "1") != "0"
         self._side = ops.side_stream(device)
         self._side_raw = self._side.cuda_stream
         self._fork = ops.LocalEvent()
@@ -469,13 +489,21 @@ class BatchPrep:
     def take(self, users, pos, neg):
         key = (users.data_ptr(), pos.data_ptr(), neg.data_ptr(), int(users.shape[0]))
         slot = next((sl for sl in self._slots if sl.key == key), None)
+        ahead = slot is not None
         if slot is None:
             slot = self._next()
             self._prepare(slot, users, pos, neg)
         slot.key = None
-        slot.done.wait(torch.cuda.current_stream().cuda_stream)
+        # the host stays at most two steps ahead of the device; a batch prepared ahead is then known to be ready when its
+        # step is enqueued, and the step's stream needs no wait (PropagationEngine.loss_and_grad: 4.5 us per barrier packet)
+        if self._paced and len(self._ends) >= 2:
+            self._ends[-2].synchronize()
+            del self._ends[:-2]
+        if not (ahead and self._paced and slot.done.query()):
+            slot.done.wait(torch.cuda.current_stream().cuda_stream)
         return slot
 
     def release(self, slot):
         slot.free = slot.free_ev
         slot.free.record(torch.cuda.current_stream().cuda_stream)
+        self._ends.append(slot.free)

@@ -142,6 +142,7 @@ PROTOTYPES = {
     "idg_event_record": (C.c_int, [c_vp, c_vp]),
     "idg_stream_wait_event": (C.c_int, [c_vp, c_vp]),
     "idg_event_query": (C.c_int, [c_vp, C.POINTER(C.c_int)]),
+    "idg_event_synchronize": (C.c_int, [c_vp]),
     "idg_comm_load": (C.c_int, [C.c_char_p]),
     "idg_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
     "idg_comm_unique_id": (C.c_int, [c_vp]),
@@ -207,7 +208,7 @@ except ImportError:  # host-only use (sampler / parser / adjacency) works withou
     _torch = None
 
 ACT_TANH, ACT_TANH_BWD = 1, 2  # idg_epilogue.act
-ABI_VERSION = 136  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 137  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -788,6 +788,10 @@ class LocalEvent:
         """Make `stream` wait for the recorded work."""
         check(lib.idg_stream_wait_event(stream, self._h), "idg_stream_wait_event")
 
+    def synchronize(self):
+        """Block the host until the recorded work has completed."""
+        check(lib.idg_event_synchronize(self._h), "idg_event_synchronize")
+
     def query(self):
         import ctypes as C
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 136 /* 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 137 /* 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -737,6 +737,10 @@ int idg_event_destroy(void* event);
 int idg_event_record(void* event, void* stream);
 int idg_stream_wait_event(void* stream, void* event);
 int idg_event_query(void* event, int* done);
+/* Block the calling host thread until the recorded work has completed (hipEventSynchronize): the engines use it to stay
+ * at most two steps ahead of the device, so that a batch prepared on the side stream is KNOWN to be ready (idg_event_query)
+ * when its step is enqueued and the step's stream does not have to wait for it. */
+int idg_event_synchronize(void* event);
 
 /* ------------------------------------------------------------------------------------
  * MULTI-GPU: RCCL collectives on the caller's stream (the reference is single-device,
