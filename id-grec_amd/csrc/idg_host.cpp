@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -280,7 +281,14 @@ int idg_ratings_open(const char* path, idg_ratings** out, int64_t* n_edges, int6
         return idg::fail(IDG_E_IO, "idg_ratings_open: %s line %lld: not an integer", path, (long long)line_no);
       }
       int64_t v = 0;
-      while (q < eol && *q >= '0' && *q <= '9') v = v * 10 + (*q++ - '0');
+      while (q < eol && *q >= '0' && *q <= '9') {
+        const int digit = *q++ - '0';
+        if (v > (INT64_MAX - digit) / 10) {  // (Python's int() would take it; no id of a data set is this large: refuse, do not wrap)
+          delete r;
+          return idg::fail(IDG_E_IO, "idg_ratings_open: %s line %lld: number does not fit 64 bits", path, (long long)line_no);
+        }
+        v = v * 10 + digit;
+      }
       if (negative) v = -v;
       if (!have_user) {
         user = v;

@@ -188,3 +188,16 @@ def test_bench_triples_are_deterministic_and_cover_both_sampling_paths():
     for t in (a[0], c[0]):
         assert all((int(u), int(p)) in pos for u, p, _ in t[:500])          # positives are train edges
         assert all((int(u), int(n)) not in pos for u, _, n in t[:500])      # negatives are not
+
+
+def test_rating_file_numbers_beyond_64_bits_are_refused(tmp_path):
+    """A token of more digits than int64 holds used to wrap (signed overflow, found under UBSan): now an I/O error naming the
+    line — the reference's int() would take it, but no data set has such ids and a wrapped id is a silent wrong answer."""
+    p = tmp_path / "train.txt"
+    p.write_text("0 1 2\n1 99999999999999999999999999999999\n")
+    with pytest.raises(Exception) as e:
+        H.parse_ratings(str(p))
+    assert "line 2" in str(e.value) and "64 bits" in str(e.value)
+    p.write_text("0 9223372036854775807\n")  # the largest int64 itself still parses
+    users, items, lines, mu, mi = H.parse_ratings(str(p))
+    assert int(items[0]) == 9223372036854775807 and int(mi) == 9223372036854775807
