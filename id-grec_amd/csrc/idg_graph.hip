@@ -433,6 +433,49 @@ __device__ __forceinline__ float4 walk(CVPtr cv, int s, int e, const float* __re
   return acc;
 }
 
+// walk() for an entry list in GLOBAL memory (the one-wave-per-unit kernel reads the CSR entries where they lie): a round of
+// walk() is two dependent memory round trips — the entries, then the panel rows they name — and the row's chain of rounds
+// is what the launch lasts (a 512-entry chunk: 64 rounds).  Here the NEXT round's entries are loaded before this round's
+// rows are waited for, so a round costs the longer of the two trips instead of their sum.  Same entries, same order of
+// fmaf: bit-identical.
+#ifndef IDG_WALK_PREFETCH
+#define IDG_WALK_PREFETCH 1
+#endif
+template <int UNROLL>
+__device__ __forceinline__ float4 walk_global(const ColVal* __restrict__ cv, int e, const float* __restrict__ Xl, int64_t ldx,
+                                              float4 acc) {
+#if IDG_WALK_PREFETCH
+  if (e < 2 * UNROLL) return walk<UNROLL>(cv, 0, e, Xl, ldx, acc);
+  ColVal p[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) p[u] = cv[u];
+  int j = 0;
+  for (; j + 2 * UNROLL <= e; j += UNROLL) {
+    float4 x[UNROLL];
+    ColVal pn[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) pn[u] = cv[j + UNROLL + u];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc = fma4(p[u].val, x[u], acc);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) p[u] = pn[u];
+  }
+  {  // the last full round (its entries are in p already)
+    float4 x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) x[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)p[u].col * ldx);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc = fma4(p[u].val, x[u], acc);
+    j += UNROLL;
+  }
+  return walk<UNROLL>(cv, j, e, Xl, ldx, acc);  // the remainder (< UNROLL entries), as walk() finishes a row
+#else
+  return walk<UNROLL>(cv, 0, e, Xl, ldx, acc);
+#endif
+}
+
 // The same walk over a panel whose all-zero rows are flagged in a bitmap: entries that point at a
 // zero row are skipped (fmaf(v, +0, acc) == acc for the finite, non-negative-zero operands here),
 // so only live rows are fetched.  Used by the first backward layer, whose input has <= 3B live rows.
@@ -1148,7 +1191,7 @@ __global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32
       for (int64_t c = s; c < e; c += (1 << 20)) {
         const int len = (int)((e - c) < (1 << 20) ? (e - c) : (1 << 20));
         acc = XM ? walk_masked<IDG_UNITS_UNROLL>(cv + c, 0, len, X + off, ldx, x_mask, acc)
-                 : walk<IDG_UNITS_UNROLL>(cv + c, 0, len, X + off, ldx, acc);
+                 : walk_global<IDG_UNITS_UNROLL>(cv + c, len, X + off, ldx, acc);
       }
       if (poison) acc = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
       if (tgt >= 0) {
@@ -1172,7 +1215,7 @@ __global__ __launch_bounds__(IDG_UNITS_BLOCK) void spmm_units_kernel(const int32
     for (int b = 0; b < NB; ++b) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       acc = XM ? walk_masked<IDG_UNITS_UNROLL>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, x_mask, acc)
-               : walk<IDG_UNITS_UNROLL>(cv + s, 0, (int)(e - s), X + (b * LPR + l) * 4, ldx, acc);
+               : walk_global<IDG_UNITS_UNROLL>(cv + s, (int)(e - s), X + (b * LPR + l) * 4, ldx, acc);
       part[q * W + b * LPR + l] = acc;
     }
   }
