@@ -401,6 +401,7 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
         t_all += time.perf_counter() - t_x  # not part of the scale point's own time
     eng = PropagationEngine(graph, U, I, dim, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
                             params=S.xavier_uniform_panel(U, I, dim, args.seed).cuda())
+    eng.store_grad = False  # (as the trainer path: see main())
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
 
     def step(i):
@@ -541,6 +542,9 @@ def main():
         c = tools.read_configuration(os.path.join(ROOT, "configure", "SimGCL.txt"), "SimGCL")
         eng.ssl = (float(c["epsilon"]), float(c["temperature"]), float(c["ssl_lambda"]))
     eng.fuse_adam = not args.separate_adam
+    # the step of the trainer path (PackedRecommender.fused_train_step): the Adam update consumes the finished gradient in
+    # the last backward product's epilogue and the [n, d] gradient panel is not written out (nobody reads it after a step)
+    eng.store_grad = os.environ.get("IDG_BENCH_STORE_GRAD") == "1"  # (A/B knob: "1" = the panel is written out as well)
     tri = torch.from_numpy(wl["triples"]).cuda()
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
     losses = torch.zeros((args.steps + args.warmup, 3 if args.model == "SimGCL" else 2), dtype=torch.float32, device="cuda")
@@ -587,7 +591,9 @@ def main():
                                % (args.workload, U, I, wl["E"], nnz, args.model, K, d, B,
                                   "clean + 2 perturbed propagations + fused BPR + InfoNCE + one shared backward propagation + dense Adam"
                                   if args.model == "SimGCL" else "propagate + fused BPR + backward propagate + dense Adam"),
-                   "batch": B, "dim": d, "layers": K, "scatter": "atomic" if args.atomic else "deterministic"},
+                   "batch": B, "dim": d, "layers": K, "scatter": "atomic" if args.atomic else "deterministic",
+                   "gradient_panel": "consumed by the Adam update in the last backward product's epilogue, not written out "
+                                     "(the trainer path's setting; weights, moments and losses are those of the stored form)"},
         "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[-1].sum().item())],
         "host_issue_ms_per_step": t_issue / args.steps * 1e3,
     }

@@ -2716,6 +2716,7 @@ static int propagate_common(const idg_graph* g, const float* in, float* out, int
           ep.adam_p = adam->adam_p, ep.adam_m = adam->adam_m, ep.adam_v = adam->adam_v;
           ep.adam_w1 = adam->adam_w1, ep.adam_beta2 = adam->adam_beta2, ep.adam_w2 = adam->adam_w2;
           ep.adam_step_size = adam->adam_step_size, ep.adam_bc2_sqrt = adam->adam_bc2_sqrt, ep.adam_eps = adam->adam_eps;
+          ep.adam_discard = adam->adam_discard;
         }
       }
     }
@@ -2932,6 +2933,10 @@ static int bwd_adam_impl(const idg_graph* g, const float* gout, const uint32_t* 
   // The update rides in the epilogue of the LAST product when that is a launch of the dense tiled kernel
   // (K >= 2, tiled widths); otherwise the two steps simply run one after the other.  Same bits either way.
   const bool tiled = (d == 32 || d == 64 || d == 128 || d == 256 || d == 512) && (uintptr_t)gout % 16 == 0;
+  // IDG_ADAM_DISCARD_GRAD OR-ed into `accumulate`: the finished gradient feeds the update and is not written back to gE0
+  // (whose rows are then only an INPUT: the rows the loss kernel stored for this step) — 4 B per element less to store
+  const bool discard = (accumulate & IDG_ADAM_DISCARD_GRAD) != 0;
+  accumulate &= ~IDG_ADAM_DISCARD_GRAD;
   if (K < 2 || !tiled) {
     const int rc = idg_propagate_mean_bwd_f32(g, gout, gout_mask, gE0, K, include_layer0, d, accumulate, ws, stream);
     if (rc != IDG_OK) return rc;
@@ -2939,6 +2944,7 @@ static int bwd_adam_impl(const idg_graph* g, const float* gout, const uint32_t* 
   }
   Epilogue adam{};
   adam_constants(adam, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step);
+  adam.adam_discard = discard ? 1 : 0;
   return propagate_common(g, gout, gE0, K, include_layer0, d, ws, (hipStream_t)stream, true, accumulate, gout_mask, 0.f, 0, 0,
                           nullptr, &adam, fields);
 }

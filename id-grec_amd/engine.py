@@ -32,6 +32,10 @@ class PropagationEngine:
         self.params = torch.empty((self.n, self.d), **f32) if params is None else params
         assert self.params.is_cuda and self.params.is_contiguous() and self.params.shape == (self.n, self.d)
         self.grad = torch.zeros((self.n, self.d), **f32)      # d loss / d E0
+        # train_step() with the Adam update in the last backward product's epilogue: does self.grad receive the finished
+        # gradient too?  True (the default): yes — loss_and_grad() semantics, what the parity tests read.  False: the update
+        # consumes it in registers and the 4 B per element are not stored (what a trainer that only wants the step sets)
+        self.store_grad = True
         self.exp_avg = self.exp_avg_sq = None                 # Adam moments: allocated by the first train_step()
         self.final = torch.empty((self.n, self.d), **f32) if graph is not None else None
         self.g_final = torch.zeros((self.n, self.d), **f32) if graph is not None else None
@@ -370,11 +374,11 @@ class PropagationEngine:
             self.graph.propagate_mean_bwd_adam_fields_raw(self.g_final, self.K, self.inc, self.grad, True,
                                                           slot.hops[: self.K - 1] + [None], self.params, self.exp_avg,
                                                           self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
-                                                          self.betas[1], self.eps)
+                                                          self.betas[1], self.eps, discard_grad=not self.store_grad)
         elif _adam_step > 0:
             self.graph.propagate_mean_bwd_adam_raw(self.g_final, self.K, self.inc, self.grad, True, mask, self.params,
                                                    self.exp_avg, self.exp_avg_sq, self.lr, _adam_step, self.betas[0],
-                                                   self.betas[1], self.eps)
+                                                   self.betas[1], self.eps, discard_grad=not self.store_grad)
         else:
             self.graph.propagate_mean_bwd_raw(self.g_final, self.K, self.inc, out=self.grad, accumulate=True, mask=mask)
         slot.free = slot.free_ev

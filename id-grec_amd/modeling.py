@@ -163,9 +163,15 @@ class PackedRecommender(nn.Module):
         eng.lr, eng.betas, eng.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
         eng.step_count = int(st_u["step"])
         self._eval_cache = None
+        # the update consumes the gradient inside the last product's epilogue; the panel is written out only on request
+        # (model.keep_fused_grad = True): otherwise .grad reads None after a fused step, as after zero_grad(set_to_none=True)
+        eng.store_grad = bool(getattr(self, "keep_fused_grad", False))
         eng.train_step(users, pos, neg, loss_out)
         st_u["step"] = st_i["step"] = eng.step_count
-        uw.grad, iw.grad = eng.grad[:U], eng.grad[U:]
+        if eng.store_grad:
+            uw.grad, iw.grad = eng.grad[:U], eng.grad[U:]
+        else:
+            uw.grad = iw.grad = None
         return True
 
     def prefetch_batch(self, users, pos, neg):

@@ -168,6 +168,7 @@ PROTOTYPES = {
                                      C.c_int, c_vp, c_vp, c_vp, c_vp]),
 }
 
+IDG_ADAM_DISCARD_GRAD = 2  # OR-ed into `accumulate` of idg_propagate_mean_bwd_adam(_fields)_f32: do not write the gradient back
 IDG_SSL_PLANNED = 2  # OR-ed into idg_infonce_pair_f32's `dedup`: the id lists are in the workspace already (idg_infonce_plan)
 IDG_BPR_TOUCHED_PRESET = 4  # OR-ed into `deterministic`: the touched bitmap already holds the batch's rows
 IDG_BPR_PLANNED = 2  # `deterministic` value: the sorted scatter plan is already in the workspace (idg_bpr_plan_f32)
@@ -208,7 +209,7 @@ except ImportError:  # host-only use (sampler / parser / adjacency) works withou
     _torch = None
 
 ACT_TANH, ACT_TANH_BWD = 1, 2  # idg_epilogue.act
-ABI_VERSION = 137  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 138  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

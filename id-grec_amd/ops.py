@@ -378,7 +378,7 @@ class Graph:
         return out
 
     def propagate_mean_bwd_adam_fields_raw(self, gout, K, include_layer0, out, accumulate, step_rows, param, exp_avg,
-                                           exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+                                           exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, discard_grad=False):
         """idg_propagate_mean_bwd_adam_fields_f32: step k's input is zero outside step_rows[k-1] (None = dense)."""
         _require_device(gout, out, param, exp_avg, exp_avg_sq, *[b for b in step_rows if b is not None])
         gout = _f32c(gout, "gout")
@@ -387,16 +387,17 @@ class Graph:
             raise ValueError("step_rows needs K entries, the first a bitmap")
         ws = self._workspace("prop", d)
         check(lib.idg_propagate_mean_bwd_adam_fields_f32(self._h, _ptr(gout), self._bitmap_array(step_rows), _ptr(out), int(K),
-                                                         int(bool(include_layer0)), d, int(bool(accumulate)), _ptr(param),
+                                                         int(bool(include_layer0)), d, int(bool(accumulate)) | (native.IDG_ADAM_DISCARD_GRAD if discard_grad else 0), _ptr(param),
                                                          _ptr(exp_avg), _ptr(exp_avg_sq), float(lr), float(beta1),
                                                          float(beta2), float(eps), int(step), _ptr(ws), _stream()),
               "idg_propagate_mean_bwd_adam_fields_f32")
         return out
 
     def propagate_mean_bwd_adam_raw(self, gout, K, include_layer0, out, accumulate, mask, param, exp_avg, exp_avg_sq, lr,
-                                    step, beta1=0.9, beta2=0.999, eps=1e-8):
+                                    step, beta1=0.9, beta2=0.999, eps=1e-8, discard_grad=False):
         """idg_propagate_mean_bwd_adam_f32: the backward above with the dense Adam step on `param` applied in the
-        epilogue of its last product (bit-identical to propagate_mean_bwd_raw + adam_step_raw)."""
+        epilogue of its last product (bit-identical to propagate_mean_bwd_raw + adam_step_raw).  discard_grad: the
+        finished gradient is not written back to `out` (IDG_ADAM_DISCARD_GRAD)."""
         _require_device(gout, out, mask, param, exp_avg, exp_avg_sq)
         gout = _f32c(gout, "gout")
         d = gout.shape[1]
@@ -405,7 +406,8 @@ class Graph:
                 raise TypeError("propagate_mean_bwd_adam_raw needs contiguous float32 panels shaped like gout")
         ws = self._workspace("prop", d)
         check(lib.idg_propagate_mean_bwd_adam_f32(self._h, _ptr(gout), _ptr(mask), _ptr(out), int(K), int(bool(include_layer0)),
-                                                  d, int(bool(accumulate)), _ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                                  d, int(bool(accumulate)) | (native.IDG_ADAM_DISCARD_GRAD if discard_grad else 0),
+                                                  _ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq),
                                                   float(lr), float(beta1), float(beta2), float(eps), int(step), _ptr(ws),
                                                   _stream()), "idg_propagate_mean_bwd_adam_f32")
         return out

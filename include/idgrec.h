@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 137 /* 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 138 /* 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -395,6 +395,8 @@ int idg_propagate_mean_bwd_f32(const idg_graph* g, const float* gout, const uint
  * of being re-read by a second kernel.  gE0 still receives the gradient.  Bit-identical to
  * idg_propagate_mean_bwd_f32 + idg_adam_step_f32 (which is what runs when K < 2 or d is not a tiled
  * width).  Hyper-parameters as idg_adam_step_f32. */
+#define IDG_ADAM_DISCARD_GRAD 2 /* OR-ed into `accumulate` of the two calls below: the finished gradient feeds the update and is
+                                * NOT written back to gE0 (17.8 MB per step less to store on the yelp2018 shape) */
 int idg_propagate_mean_bwd_adam_f32(const idg_graph* g, const float* gout, const uint32_t* gout_mask,
                                     float* gE0, int K, int include_layer0, int64_t d, int accumulate,
                                     float* param, float* exp_avg, float* exp_avg_sq, double lr,

@@ -169,9 +169,13 @@ def test_fused_train_step_equals_grad_then_optimizer_step(mname, tmp_path, golde
     tri = torch.from_numpy(g["sample1"][:5 * 256]).cuda()
     bt = [tuple(tri[i * 256:(i + 1) * 256, c].contiguous() for c in range(3)) for i in range(5)]
     res = []
-    for plan in ("TTTTT", "FFFFF", "FTTFT"):
+    for plan in ("TTTTT", "FFFFF", "FTTFT", "ttttt"):
         tools.set_seed(2024)
         model = (LightGCN if mname == "lgcn" else MFBPR)(cfg, data, torch.device("cuda")).to("cuda")
+        # upper case: the fused step also writes the gradient panel out (.grad readable afterwards); lower case: the
+        # trainer's default — the update consumes the gradient in the epilogue, .grad is None after the step
+        model.keep_fused_grad = plan.isupper()
+        plan = plan.upper()
         opt = ops.Adam(model.parameters(), lr=0.001)
         loss = torch.zeros((5, 2), device="cuda")
         for i, one_chain in enumerate(plan):
@@ -182,11 +186,13 @@ def test_fused_train_step_equals_grad_then_optimizer_step(mname, tmp_path, golde
                 opt.step()
         st = opt.state[model.item_embedding.weight]
         assert st["step"] == 5 and opt.state[model.user_embedding.weight]["step"] == 5
+        gr = model.user_embedding.weight.grad
+        assert (gr is not None) == model.keep_fused_grad, "gradient panel: readable exactly when asked for"
         res.append((model._storage.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), loss.clone(),
-                    model.user_embedding.weight.grad.clone()))
+                    None if gr is None else gr.clone()))
     for other in res[1:]:
         for a, b in zip(res[0], other):
-            assert torch.equal(a, b)
+            assert b is None or torch.equal(a, b)
     # a foreign optimizer is left to the two-call form
     assert not model.fused_train_step(*bt[0], loss[0], torch.optim.Adam(model.parameters(), lr=0.001))
 
@@ -315,6 +321,7 @@ def test_xsimgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
         ops.reset_noise_stream()
         model = XSimGCL(cfg, data, torch.device("cuda")).to("cuda")
         assert model.supports_fused_step
+        model.keep_fused_grad = True  # (.grad is compared below: by default a fused step does not write the panel out)
         opt = ops.Adam(model.parameters(), lr=0.001)
         loss = torch.zeros((3, 3), device="cuda")
         for i in range(3):
@@ -350,6 +357,7 @@ def test_simgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
         tools.set_seed(2024)
         ops.reset_noise_stream()
         model = SimGCL(cfg, data, torch.device("cuda")).to("cuda")
+        model.keep_fused_grad = True  # (.grad is compared below)
         opt = ops.Adam(model.parameters(), lr=0.001)
         loss = torch.zeros((3, 3), device="cuda")
         for i in range(3):
@@ -608,6 +616,7 @@ def test_sgl_fused_step_equals_autograd_step(tmp_path, golden_small, golden_next
     for fused in (True, False):
         tools.set_seed(2024)
         m = SGL(cfg, data, torch.device("cuda")).to("cuda")
+        m.keep_fused_grad = True  # (.grad is compared below)
         subs = [tools.convert_sp_mat_to_graph(sp.csr_matrix((nx[k + "_data"], nx[k + "_indices"], nx[k + "_indptr"]), shape=(n, n)),
                                               torch.device("cuda")) for k in ("sgl_sub1", "sgl_sub2")]
         opt = ops.Adam(m.parameters(), lr=0.001)
