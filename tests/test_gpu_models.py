@@ -904,11 +904,13 @@ def test_egcf_trainer_loop_runs(tmp_path, golden_small):
     assert len(losses_) == 2 and losses_[1] < losses_[0]
 
 
-@pytest.mark.parametrize("mname", ["EGCF", "NGCF"])
+@pytest.mark.parametrize("mname", ["EGCF", "NGCF", "LightGCN", "SimGCL", "XSimGCL", "MFBPR"])
 def test_batch_lookahead_changes_nothing(mname, tmp_path, golden_small):
-    """The side-stream preparation of the NEXT batch (engine.BatchPrep: row bitmap, live units, scatter plan — called by the
-    trainer through prefetch_batch) is index-only work: four steps over four different batches with the lookahead equal,
-    bit for bit, the same steps without it — losses and every parameter."""
+    """The side-stream preparation of the NEXT batch (engine.BatchPrep / PropagationEngine._prepare: row bitmap, live units,
+    scatter plan, the id lists of the step's InfoNCE calls — called by the trainer through prefetch_batch) is index-only
+    work: four steps over four different batches with the lookahead equal, bit for bit, the same steps without it — losses
+    and every parameter.  (With the lookahead the step's stream takes no event wait at all once the host can see the
+    preparation complete; without it the batch is prepared inside the step and waited for: both orders of the two streams.)"""
     import importlib
 
     import utility.utility_function.tools as tools
