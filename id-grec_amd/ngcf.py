@@ -13,8 +13,8 @@ Backward, l = K..1, with gN_l = layer l's slot of d loss / d final (stored at th
     g_side, g_ego = transform'(gT);  gE_{l-1} = G . g_side + g_ego    (G symmetric)
 and for l = 1 the batch's rows of slot 0 and of the regulariser's gradient join g_ego, and the product's epilogue applies
 Adam to the embedding panel.  The 4K small tensors live in ONE flat buffer (views handed back to the nn.Parameters): one
-Adam launch for all of them.  Node dropout (off in configure/NGCF.txt) is not part of this chain: the model then trains
-through the differentiable operators.
+Adam launch for all of them.  Node dropout (off in configure/NGCF.txt): the step's products run on a masked copy of the
+handle redrawn in place per step (forward) and on its transposed copy (backward).
 
 d = 64 (round 4): the three launches of a layer's forward and the four of its backward are ONE kernel each
 (idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32, csrc/idg_ngcf.hip): 64-row tiles staged once in LDS, S, ego * side and gT
@@ -32,11 +32,17 @@ lib, check = native.lib, native.check
 
 class NgcfEngine:
     def __init__(self, graph, num_users, num_items, params, small, slope=0.2, mess_dropout=(0.1, 0.1, 0.1), reg_lambda=1e-4,
-                 lr=1e-4, betas=(0.9, 0.999), eps=1e-8, store_grad=False):
+                 lr=1e-4, betas=(0.9, 0.999), eps=1e-8, store_grad=False, node_keep_prob=None):
         """params: the packed [n, d] embedding panel (users first; updated in place).  small: K tuples (W_gcn [d, d],
         b_gcn [1, d], W_bi [d, d], b_bi [1, d]) of tensors — copied into this engine's flat buffer; small_views() returns
         the views to re-point the nn.Parameters at."""
         self.G = graph
+        # node dropout (models/NGCF.py:56-65, 73-79): ONE edge mask per training forward, shared by the layers — a masked
+        # copy of the handle redrawn in place per step (Graph.dropout_copy); the masked operator is not symmetric, so the
+        # backward products run on its transposed copy.  None: off (configure/NGCF.txt).
+        self.node_keep = None if node_keep_prob is None else float(node_keep_prob)
+        self._dropped = None
+        self._Gf = self._Gb = graph  # the step's forward / backward operators
         self.U, self.I = int(num_users), int(num_items)
         self.n, self.d = int(params.shape[0]), int(params.shape[1])
         self.K = len(small)
@@ -102,15 +108,20 @@ class NgcfEngine:
 
     # ---- forward (every row); returns the [n, (K+1) d] final panel
     @torch.no_grad()
-    def forward(self, streams=None):
+    def forward(self, streams=None, train=False):
         n, d, D, K, p_ = self.n, self.d, self.D, self.K, self._p
         st = ops._stream()
+        self._Gf = self._Gb = self.G
+        if train and self.node_keep is not None:
+            # (drawn BEFORE the layers' dropout streams, as models.NGCF.aggregate() does: same sequence of draws)
+            self._dropped = self.G.dropout_copy(self.node_keep, reuse=self._dropped)
+            self._Gf, self._Gb = self._dropped, self._dropped._T
         self._streams = streams if streams is not None else [ops._next_noise_stream() for _ in range(K)]
         check(lib.idg_copy_cols_f32(p_(self.FINAL), D, p_(self.P), d, n, d, st), "idg_copy_cols_f32")
         ego = self.P
         for l in range(K):
             wg, bg, wb, bb = self._views[l]
-            self.G.spmm_raw(ego, out=self.SIDE[l])
+            self._Gf.spmm_raw(ego, out=self.SIDE[l])
             seed, sid = self._streams[l]
             slot = self.FINAL.data_ptr() + 4 * (l + 1) * d
             if self.fused_layer:
@@ -134,7 +145,7 @@ class NgcfEngine:
         loss = self.loss if loss_out is None else loss_out
         slot = self.prep.take(users, pos, neg)
         bitmap = slot.bitmap
-        self.forward(streams)
+        self.forward(streams, train=True)
         check(lib.idg_bpr_fused_ex_f32(p_(self.FINAL), D, p_(self.P), d, U, n, p_(users), p_(pos), p_(neg), B, self.reg_lambda, 0,
                                        p_(loss), p_(self.GFIN), p_(self.GE), native.IDG_BPR_PLANNED | native.IDG_BPR_TOUCHED_PRESET,
                                        p_(bitmap), p_(slot.ws), st), "idg_bpr_fused_ex_f32")
@@ -164,13 +175,13 @@ class NgcfEngine:
                                                      p_(self.g_side), p_(g_ego), st), "idg_ngcf_transform_bwd_f32")
             if l > 0:
                 nxt = self.g_ego[(l & 1) ^ 1]
-                self.G.spmm_raw(self.g_side, addend=g_ego, out=nxt)   # G symmetric: the backward of side = G . ego
+                self._Gb.spmm_raw(self.g_side, addend=g_ego, out=nxt)   # the backward of side = G . ego: G^T . g_side (G symmetric; a dropped copy: its transposed one)
                 gE = nxt
             else:
                 # the batch's rows of slot 0 (ego_0 is itself part of the final rows) and of the regulariser's gradient
                 check(lib.idg_rows_add2_f32(p_(g_ego), d, p_(self.GFIN), D, p_(self.GE), d, p_(bitmap), n, d, st),
                       "idg_rows_add2_f32")
-                ops.spmm_epi_raw(self.G, self.g_side, addend=g_ego, sum_out=self.GRAD,
+                ops.spmm_epi_raw(self._Gb, self.g_side, addend=g_ego, sum_out=self.GRAD,
                                  adam=(self.P, self.M, self.V, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps),
                                  adam_discard_grad=not self.store_grad)
         ops.adam_step_raw(self.SW, self.SG, self.SM, self.SV, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps)

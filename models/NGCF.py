@@ -16,8 +16,8 @@ from idgrec_amd.ngcf import NgcfEngine
 
 
 class NGCF(PackedRecommender):
-    #: trains through a fused, autograd-free chain of library calls (idgrec_amd/ngcf.py) when every layer maps d -> d and
-    #: node dropout is off (configure/NGCF.txt); otherwise through the differentiable operators below
+    #: trains through a fused, autograd-free chain of library calls (idgrec_amd/ngcf.py) when every layer maps d -> d (with or
+    #: without node dropout); otherwise through the differentiable operators below
     supports_fused_step = True
     n_fused_losses = 2
 
@@ -40,7 +40,7 @@ class NGCF(PackedRecommender):
     # ------------------------------------------------------------------ fused path (trainer protocol)
     def fused_step_available(self):
         st = self._storage
-        if st is None or not st.is_cuda or self.node_dropout or not hasattr(self, "mess_dropout"):
+        if st is None or not st.is_cuda or not hasattr(self, "mess_dropout"):
             return False
         d = int(st.shape[1])
         return d % 64 == 0 and d in self.FUSED_WIDTHS and all(
@@ -58,7 +58,8 @@ class NGCF(PackedRecommender):
                 or w['W_gcn_0'].data_ptr() != eng.small_views()[0][0].data_ptr():
             small = [tuple(w[nm % l].data for nm in names[l]) for l in range(self.n_layers)]
             eng = self._ngcf_engine = NgcfEngine(self.Graph, self.dataset.num_users, self.dataset.num_items, self._storage, small,
-                                                 slope=0.2, mess_dropout=self.mess_dropout, reg_lambda=self.reg_lambda)
+                                                 slope=0.2, mess_dropout=self.mess_dropout, reg_lambda=self.reg_lambda,
+                                                 node_keep_prob=self.node_keep_prob if self.node_dropout else None)
             for l in range(self.n_layers):
                 for nm, v in zip(names[l], eng.small_views()[l]):
                     w[nm % l].data = v

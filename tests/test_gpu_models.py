@@ -467,7 +467,7 @@ def test_ngcf_vs_reference(tmp_path, golden_small, golden_next):
     assert idx.shape == (32, 10)
 
 
-@pytest.mark.parametrize("drop", ["[0.0, 0.0, 0.0]", "[0.1, 0.1, 0.1]"])
+@pytest.mark.parametrize("drop", ["[0.0, 0.0, 0.0]", "[0.1, 0.1, 0.1]", "node"])
 def test_ngcf_fused_step_vs_reference_and_autograd(drop, tmp_path, golden_small, golden_next):
     """The fused, autograd-free NGCF step (idgrec_amd/ngcf.py: products, fp32-MFMA transforms, layer tails writing into the
     concatenated final rows, BPR over (K+1)d-wide rows with the item-only regulariser, the whole backward chain, Adam in
@@ -479,7 +479,12 @@ def test_ngcf_fused_step_vs_reference_and_autograd(drop, tmp_path, golden_small,
     from models.NGCF import NGCF
 
     g, nx = golden_small, golden_next
-    cfg = _cfg("NGCF", mess_drop_prob=drop)
+    if drop == "node":
+        # node dropout too (a masked copy of the graph redrawn per step, its transposed copy for the backward products):
+        # the fused chain against the differentiable operators on the same sequence of draws
+        cfg = _cfg("NGCF", mess_drop_prob="[0.1, 0.1, 0.1]", node_dropout=True, node_keep_prob=0.2)
+    else:
+        cfg = _cfg("NGCF", mess_drop_prob=drop)
     data = _data_with(tmp_path, g, cfg)
     b = torch.from_numpy(nx["batch"]).cuda()
     bu, bp, bn = b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous()
