@@ -1,4 +1,5 @@
-"""Fused, autograd-free training step of EGCF's `parallel` encoder (reference: models/EGCF.py:64-111 +
+"""Fused, autograd-free training steps of EGCF's two encoders — `parallel` (EgcfEngine, described here) and `alternating`
+(EgcfAltEngine, at the end of the file) — (reference: models/EGCF.py:46-111 +
 utility/utility_train/trainer.py:42-56) as a fixed chain of C-ABI calls on preallocated panels — what engine.py is for the
 LightGCN family (61 % of an EGCF epoch was stock ATen kernels: tanh, cat, gathers, three InfoNCE terms and
 their autograd mirrors).
@@ -104,7 +105,12 @@ class EgcfEngine:
                               grad_scale=self.ssl_lambda, ws=slot.ssl_ws[1], planned=True)
         torch.sum(self._ssl[:3], dim=0, keepdim=True, out=loss[2:3])
         loss[2:3].mul_(self.ssl_lambda)
-        # backward
+        self._backward(slot, bitmap)
+        self.prep.release(slot)
+        return loss
+
+    def _backward(self, slot, bitmap):
+        U, K, X = self.U, self.K, self.X
         Za, Zb = self.Z
         ops.rows_tanh_bwd_raw(self.GT, X[K], bitmap, Za)                           # Z_K at the batch's rows
         x_rows = bitmap
@@ -119,8 +125,6 @@ class EgcfEngine:
                          adam=(self.EGO[U:], self.M, self.V, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps),
                          adam_discard_grad=not self.store_grad)
         self._grad_items = Za[U:] if self.store_grad else None
-        self.prep.release(slot)
-        return loss
 
     def _plan_ssl(self, slot, users, pos, neg, stream):
         """BatchPrep's hook: the id-list stages of the step's two InfoNCE calls (raw user / item lists; the cross form), each
@@ -135,3 +139,92 @@ class EgcfEngine:
     def prefetch(self, users, pos, neg):
         """One-batch lookahead of the index-only work of the NEXT step (side stream)."""
         self.prep.prefetch(users, pos, neg)
+
+
+class EgcfAltEngine(EgcfEngine):
+    """The `alternating` encoder (models/EGCF.py:46-62) as the same kind of chain.  Forward, l = 1..K, i_0 = E:
+        u_l = tanh(R . i_{l-1}),   i_l = tanh(R^T . u_l);      TOT = [u_1 + .. + u_K ; i_1 + .. + i_K]
+    (rectangular operator and its transposed handle; layer sums in the last products' epilogues; in a training step the last
+    item product and the item sum are produced at the batch's item rows only).  Backward with g = d loss / d TOT at the
+    batch's rows, Zi_K = g_I . (1 - i_K^2):
+        Zu_l = (R . Zi_l + g_U) . (1 - u_l^2),    Zi_{l-1} = (R^T . Zu_l + g_I) . (1 - i_{l-1}^2),   l = K..1
+        dE = R^T . Zu_1 (+ the regulariser's rows)  -> Adam in that product's epilogue."""
+
+    def __init__(self, user_graph, num_users, num_items, dim, n_layers, item_weight, reg_lambda, ssl_lambda, temperature,
+                 lr=1e-3, betas=(0.9, 0.999), eps=1e-8, store_grad=False):
+        self._alt_graph = user_graph
+        super().__init__(user_graph, user_graph, num_users, num_items, dim, n_layers, item_weight, reg_lambda, ssl_lambda,
+                         temperature, lr=lr, betas=betas, eps=eps, store_grad=store_grad)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        # (no symmetric [n, n] operator here: the unit lists BatchPrep would build for one are not used)
+        self.prep = BatchPrep(self.U, self.n, self.d, self.device, units_graph=None, extra=self._plan_alt)
+        self.ZU = torch.empty((self.U, self.d), **f32)
+        self.ZI = [torch.empty((self.I, self.d), **f32) for _ in range(2)]
+        self.GI = torch.empty((self.I, self.d), **f32)  # d loss / d E when it is kept
+
+    def _plan_alt(self, slot, users, pos, neg, stream):
+        """BatchPrep's hook: the InfoNCE id lists, and the bitmap of the batch's ITEM rows in the item block's own numbering
+        (the rectangular operators' item-side rows / columns)."""
+        self._plan_ssl(slot, users, pos, neg, stream)
+        if getattr(slot, "items_bitmap", None) is None:
+            slot.items_bitmap = torch.zeros((self.I + 31) // 32, dtype=torch.int32, device=self.device)
+        ops.bpr_touch_rows_raw(pos, pos, neg, 0, slot.items_bitmap, stream=stream, clear_bits=self.I)
+
+    @torch.no_grad()
+    def propagate(self, out_rows=None, item_rows=None):
+        U, K, X = self.U, self.K, self.X
+        R, Rt = self.R, self.R.T
+        prev = self.EGO[U:]
+        for l in range(1, K + 1):
+            last = l == K
+            tu = [X[j][:U] for j in range(1, K)] + [None, None, None]
+            ti = [X[j][U:] for j in range(1, K)] + [None, None, None]
+            ops.spmm_epi_raw(R, prev, Y=X[l][:U], act=native.ACT_TANH,
+                             **(dict(sum_in=tu[0], sum_in2=tu[1] if tu[0] is not None else None,
+                                     sum_in3=tu[2] if tu[1] is not None else None, sum_out=self.TOT[:U]) if last else {}))
+            ops.spmm_epi_raw(Rt, X[l][:U], Y=X[l][U:], act=native.ACT_TANH,
+                             **(dict(sum_in=ti[0], sum_in2=ti[1] if ti[0] is not None else None,
+                                     sum_in3=ti[2] if ti[1] is not None else None, sum_out=self.TOT[U:],
+                                     out_rows=item_rows) if last else {}))
+            prev = X[l][U:]
+        return self.TOT[:U], self.TOT[U:]
+
+    @torch.no_grad()
+    def train_step(self, users, pos, neg, loss_out=None):
+        U = self.U
+        loss = self.loss if loss_out is None else loss_out
+        slot = self.prep.take(users, pos, neg)
+        bitmap = slot.bitmap
+        self.propagate(item_rows=slot.items_bitmap)
+        ops.bpr_fused_raw(self.TOT, self.EGO, users, pos, neg, U, self.reg_lambda, self.GT, self.GE, loss=loss[:2],
+                          deterministic=2 | native.IDG_BPR_TOUCHED_PRESET, touched=bitmap, ws=slot.ws)
+        ops.infonce_pair_raw(self.TOT, self.TOT, users, pos, U, self.temperature, g1=self.GT, g2=self.GT, loss=self._ssl[:2],
+                             dedup=False, grad_scale=self.ssl_lambda, accumulate=True, ws=slot.ssl_ws[0], planned=True)
+        ops.infonce_cross_raw(self.TOT, users, pos, U, self.temperature, g=self.GT, loss=self._ssl[2:4],
+                              grad_scale=self.ssl_lambda, ws=slot.ssl_ws[1], planned=True)
+        torch.sum(self._ssl[:3], dim=0, keepdim=True, out=loss[2:3])
+        loss[2:3].mul_(self.ssl_lambda)
+        self._backward(slot, bitmap)
+        self.prep.release(slot)
+        return loss
+
+    def _backward(self, slot, bitmap):
+        U, K, X = self.U, self.K, self.X
+        R, Rt = self.R, self.R.T
+        BI = slot.items_bitmap
+        gU, gI = self.GT[:U], self.GT[U:]
+        Zi, Zn = self.ZI
+        ops.rows_tanh_bwd_raw(gI, X[K][U:], BI, Zi)                                  # Zi_K at the batch's item rows
+        x_rows = BI
+        for l in range(K, 0, -1):
+            # Zu_l = (R . Zi_l + g_U) . (1 - u_l^2); g_U lives on the batch's user rows (the first U bits of the bitmap)
+            ops.spmm_epi_raw(R, Zi, Y=self.ZU, addend=gU, mask=bitmap, act=native.ACT_TANH_BWD, act_src=X[l][:U], x_rows=x_rows)
+            x_rows = None
+            if l > 1:
+                ops.spmm_epi_raw(Rt, self.ZU, Y=Zn, addend=gI, mask=BI, act=native.ACT_TANH_BWD, act_src=X[l - 1][U:])
+                Zi, Zn = Zn, Zi
+        self.step_count += 1
+        ops.spmm_epi_raw(Rt, self.ZU, addend=self.GE[U:], mask=BI, sum_out=self.GI,
+                         adam=(self.EGO[U:], self.M, self.V, self.lr, self.step_count, self.betas[0], self.betas[1], self.eps),
+                         adam_discard_grad=not self.store_grad)
+        self._grad_items = self.GI if self.store_grad else None

@@ -19,12 +19,12 @@ import utility.utility_function.losses as losses
 import utility.utility_function.tools as tools
 import utility.utility_train.trainer as trainer
 from idgrec_amd import ops
-from idgrec_amd.egcf import EgcfEngine
+from idgrec_amd.egcf import EgcfAltEngine, EgcfEngine
 
 
 class EGCF(nn.Module):
-    #: the `parallel` encoder trains through a fused, autograd-free chain of library calls (idgrec_amd/egcf.py); the
-    #: `alternating` one through the differentiable operators below
+    #: both encoders train through fused, autograd-free chains of library calls (idgrec_amd/egcf.py: EgcfEngine for
+    #: `parallel`, EgcfAltEngine for `alternating`); the differentiable operators below serve foreign optimizers
     supports_fused_step = True
     n_fused_losses = 3
     FUSED_WIDTHS = (32, 64, 128, 256, 512)
@@ -60,17 +60,20 @@ class EGCF(nn.Module):
     # ------------------------------------------------------------------ fused path (trainer protocol)
     def fused_step_available(self):
         w = self.item_embedding.weight
-        return (self.aggregate_mode == 'parallel' and w.is_cuda and w.dtype == torch.float32
-                and int(w.shape[1]) in self.FUSED_WIDTHS and 1 <= self.n_layers <= 4)
+        return (w.is_cuda and w.dtype == torch.float32 and int(w.shape[1]) in self.FUSED_WIDTHS and 1 <= self.n_layers <= 4)
 
     def engine(self):
         """The fused engine; the item table lives in ITS storage (nn.Embedding.weight is re-pointed at it), so that the
         regulariser's [n, d] view of the parameters and the table are one buffer."""
         w = self.item_embedding.weight
         if self._engine is None or w.data_ptr() != self._engine.item_table().data_ptr():
-            self._engine = EgcfEngine(self.Graph, self.user_Graph, self.dataset.num_users, self.dataset.num_items,
-                                      int(w.shape[1]), self.n_layers, w.data, self.reg_lambda, self.ssl_lambda,
-                                      self.temperature)
+            if self.aggregate_mode == 'parallel':
+                self._engine = EgcfEngine(self.Graph, self.user_Graph, self.dataset.num_users, self.dataset.num_items,
+                                          int(w.shape[1]), self.n_layers, w.data, self.reg_lambda, self.ssl_lambda,
+                                          self.temperature)
+            else:
+                self._engine = EgcfAltEngine(self.user_Graph, self.dataset.num_users, self.dataset.num_items, int(w.shape[1]),
+                                             self.n_layers, w.data, self.reg_lambda, self.ssl_lambda, self.temperature)
             w.data = self._engine.item_table()
         return self._engine
 

@@ -16,6 +16,9 @@ shape = sys.argv[3] if len(sys.argv) > 3 else "yelp2018"
 root = tempfile.mkdtemp(prefix="idg_e2e_")
 t0 = time.time(); S.make_dataset(root, shape, n_test=8); t_gen = time.time() - t0
 cfg = tools.read_configuration("./configure/%s.txt" % model, model)
+for kv in os.environ.get("E2E_CONFIG", "").split(","):  # e.g. E2E_CONFIG=mode=alternating
+    if "=" in kv:
+        cfg[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
 cfg.update(dataset=shape, dataset_path=root + "/", training_epochs=str(epochs), interval="1")
 logger = logging.getLogger("e2e"); logger.setLevel(logging.INFO); logger.addHandler(logging.StreamHandler(sys.stdout))
 tools.set_seed(2024)

@@ -892,11 +892,72 @@ def test_egcf_fused_step_vs_reference(tmp_path):
     np.testing.assert_allclose(r_fused.cpu().numpy(), m2.get_rating_for_test(users).cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
-def test_egcf_trainer_loop_runs(tmp_path, golden_small):
+def test_egcf_alternating_fused_step_vs_reference(tmp_path):
+    """The fused step of the `alternating` encoder (EgcfAltEngine: 2K rectangular products with tanh / tanh' epilogues, the
+    last item product at the batch's item rows only, Adam in the last epilogue) against the reference's own numbers
+    (egcf_small.npz): encoder outputs, the three losses, d loss / d item table, the table after one Adam step; then the
+    model's fused_train_step under the trainer's optimizer gives the same losses and table."""
+    import os
+
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+    from idgrec_amd.egcf import EgcfAltEngine
+    from models.EGCF import EGCF
+
+    eg = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "egcf_small.npz")))
+    cfg = dict(zip(eg["config_keys"].tolist(), eg["config_values"].tolist()))
+    cfg["mode"] = "alternating"
+    data = _data_with(tmp_path, eg, cfg)
+    tools.set_seed(2024)
+    m = EGCF(cfg, data, torch.device("cuda")).to("cuda")
+    W0 = m.item_embedding.weight.detach().clone()
+    np.testing.assert_array_equal(W0.cpu().numpy(), eg["alternating_init_item"])
+    U, I, d = data.num_users, data.num_items, W0.shape[1]
+    eng = EgcfAltEngine(m.user_Graph, U, I, d, m.n_layers, W0, m.reg_lambda, m.ssl_lambda, m.temperature, lr=1e-3, store_grad=True)
+    u, i = eng.propagate()
+    np.testing.assert_allclose(u.cpu().numpy(), eg["alternating_user"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(i.cpu().numpy(), eg["alternating_item"], rtol=1e-5, atol=1e-7)
+    full = eng.TOT.clone()
+    b = torch.from_numpy(eg["batch"]).cuda()
+    bu, bp, bn = b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous()
+    eng.TOT[U:].fill_(float("nan"))  # the step produces the item rows of the batch only, and reads no other
+    loss = eng.train_step(bu, bp, bn).cpu().numpy()
+    rows = torch.unique(torch.cat([bu, U + bp, U + bn]))
+    assert torch.equal(eng.TOT[rows], full[rows]), "row-restricted last item layer differs from the full one"
+    np.testing.assert_allclose(loss, eg["alternating_loss"], rtol=RTOL)
+    ref = eg["alternating_grad_item"]
+    np.testing.assert_allclose(eng.grad_items().cpu().numpy(), ref, rtol=1e-3, atol=3e-4 * np.abs(ref).max())
+    w = torch.nn.Parameter(W0.cpu().clone())
+    opt = torch.optim.Adam([w], lr=1e-3)
+    w.grad = torch.from_numpy(ref.copy())
+    opt.step()
+    moved = (w.detach() - W0.cpu()).abs() > 5e-4
+    got = eng.item_table().cpu()
+    assert torch.allclose(got[moved], w.detach()[moved], rtol=0, atol=2e-5)
+    assert float((got - w.detach()).abs().max()) <= 2.1e-3
+    # the model under the trainer's optimizer: the same chain
+    tools.set_seed(2024)
+    m2 = EGCF(cfg, data, torch.device("cuda")).to("cuda")
+    assert m2.fused_step_available()
+    opt2 = ops.Adam(list(m2.parameters()), lr=1e-3)
+    out = torch.zeros(3, device="cuda")
+    assert m2.fused_train_step(bu, bp, bn, out, opt2)
+    np.testing.assert_allclose(out.cpu().numpy(), loss, rtol=1e-6)
+    assert torch.equal(m2.item_embedding.weight.detach().cpu(), got) and int(opt2.state[m2.item_embedding.weight]["step"]) == 1
+    m2.eval()
+    users = torch.from_numpy(eg["rating_users"]).cuda()
+    r_fused = m2.get_rating_for_test(users)
+    m2._engine = None  # the same table through the differentiable operators
+    m2._eval_cache = None
+    np.testing.assert_allclose(r_fused.cpu().numpy(), m2.get_rating_for_test(users).cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["parallel", "alternating"])
+def test_egcf_trainer_loop_runs(mode, tmp_path, golden_small):
     import utility.utility_function.tools as tools
     from models.EGCF import Trainer
 
-    cfg = _cfg("EGCF", training_epochs=2, batch_size=256, test_batch_size=64, top_K="[5, 10]")
+    cfg = _cfg("EGCF", training_epochs=2, batch_size=256, test_batch_size=64, top_K="[5, 10]", mode=mode)
     data = _data_with(tmp_path, golden_small, cfg)
     stream = io.StringIO()
     logger = logging.getLogger("egcf_loop")
@@ -909,7 +970,7 @@ def test_egcf_trainer_loop_runs(tmp_path, golden_small):
     assert len(losses_) == 2 and losses_[1] < losses_[0]
 
 
-@pytest.mark.parametrize("mname", ["EGCF", "NGCF", "LightGCN", "SimGCL", "XSimGCL", "MFBPR"])
+@pytest.mark.parametrize("mname", ["EGCF", "EGCF:alternating", "NGCF", "LightGCN", "SimGCL", "XSimGCL", "MFBPR"])
 def test_batch_lookahead_changes_nothing(mname, tmp_path, golden_small):
     """The side-stream preparation of the NEXT batch (engine.BatchPrep / PropagationEngine._prepare: row bitmap, live units,
     scatter plan, the id lists of the step's InfoNCE calls — called by the trainer through prefetch_batch) is index-only
@@ -921,8 +982,9 @@ def test_batch_lookahead_changes_nothing(mname, tmp_path, golden_small):
     import utility.utility_function.tools as tools
     from idgrec_amd import ops
 
+    mname, _, mode = mname.partition(":")
     cls = getattr(importlib.import_module("models." + mname), mname)
-    cfg = _cfg(mname)
+    cfg = _cfg(mname, **({"mode": mode} if mode else {}))
     data = _data_with(tmp_path, golden_small, cfg)
     gen = torch.Generator().manual_seed(7)
     B, steps = 192, 4
