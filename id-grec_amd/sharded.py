@@ -322,11 +322,12 @@ class ShardedEngine:
                    mask=None if (add is None or mask is None) else k.bits_from(mask, r0),
                    out_rows=None if out_bits is None else k.bits_from(out_bits, r0), x_rows=x_rows)
             if reduce == "all":
-                self.comm.tag = tag
+                self.comm.tag, self.comm.slice = tag, j
                 works.append(self.comm.all_reduce_async(y))
             elif reduce == "scatter":
-                self.comm.tag = tag
+                self.comm.tag, self.comm.slice = tag, j
                 works.append(self.comm.reduce_scatter_async(self._slice_rows(Y_i, j, padded=True)))
+        self.comm.slice = None
         return works
 
     def _sum_rows(self, panel, rows, tag="rows"):
@@ -519,8 +520,9 @@ class ShardedEngine:
             if c > 0:
                 k.item_tail(blocks[0], blocks[1], blocks[2], items_bits, o0, c0, cnt, self.store_grad, blocks[3],
                             blocks[4], blocks[5], self.lr, adam_step)
-            self.comm.tag = "item_table.all_gather"
+            self.comm.tag, self.comm.slice = "item_table.all_gather", j
             self._ag.append(self.comm.all_gather_async(self._slice_rows(P_i, j, padded=True), blocks[3]))
+        self.comm.slice = None
         return self.G
 
     def _own_blocks(self, j, t_i):
@@ -678,6 +680,159 @@ class StepTimeline:
                         "bus_gbs = bytes x 2(N-1)/N (all-reduce) or (N-1)/N (reduce-scatter, all-gather) / collective_ms"}
 
 
+class IssueOrder:
+    """The ORDER in which one rank's host enqueues a step's products and collectives — DESIGN.md §7's overlap model as a
+    checked property: the projection for 8 GPUs assumes that each slice's collective is issued before the
+    next slice's product, that a panel exchange is only waited for after later products have been launched, and that the
+    end-of-step all-gather of the updated item rows is still in flight under the NEXT step's first item-side products.
+    None of this needs hardware: it is a property of the launch sequence, so the world-8 CPU tests and the
+    8-ranks-on-one-GPU rehearsal assert it, and the first real 8-GPU run can then only disappoint on link rate.
+
+        order = IssueOrder(); order.attach(engine)      # wraps engine.comm and engine.k
+        order.begin_step(); engine.train_step(gb); ...
+        assert not order.violations()
+
+    events: ("step", i) | ("product", "user") | ("product", "item", j) | ("issue", tag, j) | ("wait", tag, j)."""
+
+    SLICED = ("panel", "reduce_scatter")  # tags of collectives issued slice by slice from _item_side
+
+    def __init__(self):
+        self.events, self.n_steps, self.n_slices = [], 0, 1
+
+    def attach(self, eng):
+        self.n_slices = len(eng.slices)
+        names = {id(eng.G_ui): ("user",)}
+        names.update({id(sl[0]): ("item", j) for j, sl in enumerate(eng.slices)})
+        if isinstance(eng.comm, TimelineComm):
+            eng.comm.order = self
+        else:
+            eng.comm = OrderComm(eng.comm, self)
+        eng.k = OrderKernels(eng.k, self, names)
+        return self
+
+    def begin_step(self):
+        self.events.append(("step", self.n_steps))
+        self.n_steps += 1
+
+    def end_steps(self):
+        """What follows (the caller draining the last all-gather, evaluation) is not part of a step."""
+        self.events.append(("end",))
+
+    def steps(self):
+        out, live = [], False
+        for e in self.events:
+            if e[0] == "step":
+                out.append([])
+                live = True
+            elif e[0] == "end":
+                live = False
+            elif live:
+                out[-1].append(e)
+        return out
+
+    def violations(self):
+        """Every way the recorded sequence departs from the overlap model, as strings (empty list = as designed)."""
+        bad, S = [], self.n_slices
+        steps = self.steps()
+        for si, ev in enumerate(steps):
+            tags = []
+            for i, e in enumerate(ev):
+                if e[0] == "issue" and e[2] is not None and e[1].endswith(self.SLICED):
+                    if e[1] not in tags:
+                        tags.append(e[1])
+                    # (1) a slice's collective goes out right behind that slice's product, before the next slice's
+                    if i == 0 or ev[i - 1] != ("product", "item", e[2]):
+                        bad.append("step %d: %s slice %d issued after %r, not right behind its own product" % (si, e[1], e[2], ev[i - 1] if i else None))
+            for tag in tags:
+                issued = [i for i, e in enumerate(ev) if e[0] == "issue" and e[1] == tag]
+                waits = [i for i, e in enumerate(ev) if e[0] == "wait" and e[1] == tag]
+                if len(issued) != S:
+                    bad.append("step %d: %s issued for %d slices of %d" % (si, tag, len(issued), S))
+                if not waits:
+                    bad.append("step %d: %s never waited for inside the step" % (si, tag))
+                    continue
+                # (2) nobody waits for a sliced exchange before later products have been launched behind its last slice
+                if not any(e[0] == "product" for e in ev[issued[-1] + 1: waits[0]]):
+                    bad.append("step %d: %s waited for with no product launched behind it" % (si, tag))
+            # (3) the updated item rows go round slice by slice: slice j's all-gather is out before slice j + 1's
+            #     reduce-scatter is waited for
+            ag = {e[2]: i for i, e in enumerate(ev) if e[0] == "issue" and e[1] == "item_table.all_gather"}
+            rs = {e[2]: i for i, e in enumerate(ev) if e[0] == "wait" and e[1].endswith("reduce_scatter")}
+            if len(ag) != S:
+                bad.append("step %d: %d all-gathers of the updated item rows for %d slices" % (si, len(ag), S))
+            for j in range(S - 1):
+                if j in ag and j + 1 in rs and not ag[j] < rs[j + 1]:
+                    bad.append("step %d: all-gather of slice %d issued after the wait for slice %d's reduce-scatter" % (si, j, j + 1))
+            if any(e[0] == "wait" and e[1] == "item_table.all_gather" for e in ev[(ag[0] if 0 in ag else len(ev)):]):
+                bad.append("step %d: the end-of-step all-gather is waited for inside its own step" % si)
+            # (4) ... and is still in flight under the next step's first item-side products (which read local user rows only)
+            if si > 0:
+                w = [i for i, e in enumerate(ev) if e[0] == "wait" and e[1] == "item_table.all_gather"]
+                first_user = next((i for i, e in enumerate(ev) if e == ("product", "user")), len(ev))
+                n_before = sum(1 for e in ev[: (w[0] if w else 0)] if e[0] == "product" and e[1] == "item")
+                if len(w) != S:
+                    bad.append("step %d: %d waits for the previous step's %d all-gathers" % (si, len(w), S))
+                elif n_before < S:
+                    bad.append("step %d: the previous step's all-gather is waited for after %d of %d first-layer item-side "
+                               "products" % (si, n_before, S))
+                elif w[-1] > first_user:
+                    bad.append("step %d: a user-side product (reads the item table) launched before the table was whole" % si)
+        return bad
+
+    def summary(self):
+        return {"steps": self.n_steps, "slices": self.n_slices, "events": len(self.events), "violations": self.violations(),
+                "what": "host issue order of the instrumented steps' products and collectives on this rank, checked against "
+                        "DESIGN.md §7's overlap model (IssueOrder.violations): slice j's collective right behind slice j's "
+                        "product; sliced exchanges waited for only after later products were launched; the end-of-step "
+                        "all-gather waited for in the NEXT step, behind its first-layer item-side products"}
+
+
+class OrderComm:
+    """A comm wrapper that only records issue / wait order (IssueOrder); no events, no timing: CPU tests use it."""
+
+    def __init__(self, inner, order):
+        self.inner, self.order = inner, order
+        self.world, self.rank = inner.world, inner.rank
+        self.averages = getattr(inner, "averages", False)
+        self.tag, self.slice = "untagged", None
+
+    def all_reduce_async(self, t, average=False):
+        self.order.events.append(("issue", self.tag, self.slice))
+        return (self.inner.all_reduce_async(t, average), self.tag, self.slice)
+
+    def all_gather_async(self, out, t):
+        self.order.events.append(("issue", self.tag, self.slice))
+        return (self.inner.all_gather_async(out, t), self.tag, self.slice)
+
+    def reduce_scatter_async(self, t):
+        self.order.events.append(("issue", self.tag, self.slice))
+        return (self.inner.reduce_scatter_async(t), self.tag, self.slice)
+
+    def wait(self, handle):
+        if handle is None:
+            return
+        work, tag, sl = handle
+        self.order.events.append(("wait", tag, sl))
+        self.inner.wait(work)
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+
+class OrderKernels:
+    """A `kernels` wrapper that records every product launch (which operator: the user-side block or item slice j)."""
+
+    def __init__(self, inner, order, names):
+        self._inner, self._order, self._names = inner, order, names
+
+    def spmm(self, graph, X, **kw):
+        self._order.events.append(("product",) + self._names.get(id(graph), ("other",)))
+        return self._inner.spmm(graph, X, **kw)
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+
 class TimelineComm:
     """Wraps a comm (NativeComm / TorchComm / test comms) and fills a StepTimeline.  The collective's own duration is
     measured on the stream it runs on when the inner comm says which (NativeComm.timed_stream); otherwise between two
@@ -688,10 +843,13 @@ class TimelineComm:
         self.inner, self.tl = inner, timeline
         self.world, self.rank = inner.world, inner.rank
         self.averages = getattr(inner, "averages", False)
-        self.tag = "untagged"
+        self.tag, self.slice = "untagged", None
+        self.order = None  # an IssueOrder: the same instrumented steps also record their issue order
 
     def _issue(self, kind, nbytes, call):
         torch, tl = self.tl.torch, self.tl
+        if self.order is not None:
+            self.order.events.append(("issue", self.tag, self.slice))
         e0, e1 = tl.event(), tl.event()
         own = getattr(self.inner, "timed_stream", None)
         stream = own(nbytes) if own is not None else None  # the torch stream the inner comm will run this one on
@@ -701,7 +859,7 @@ class TimelineComm:
             e1.record()
             rec = [self.tag, kind, nbytes, e0, e1]
             self.tl.records.append(rec)
-            return (work, rec if work is not None else None, self.tag)
+            return (work, rec if work is not None else None, self.tag, self.slice)
         issued = torch.cuda.Event()
         issued.record()
         stream.wait_event(issued)   # (what the inner comm does next: the start event sits behind the same dependency)
@@ -709,7 +867,7 @@ class TimelineComm:
         work = call()
         e1.record(stream)
         self.tl.records.append([self.tag, kind, nbytes, e0, e1])
-        return (work, None, self.tag)
+        return (work, None, self.tag, self.slice)
 
     def all_reduce_async(self, t, average=False):
         return self._issue("all_reduce", t.numel() * 4, lambda: self.inner.all_reduce_async(t, average))
@@ -723,7 +881,9 @@ class TimelineComm:
     def wait(self, handle):
         if handle is None:
             return
-        work, rec, tag = handle
+        work, rec, tag, sl = handle
+        if self.order is not None:
+            self.order.events.append(("wait", tag, sl))
         a, b = self.tl.event(), self.tl.event()
         a.record()
         self.inner.wait(work)

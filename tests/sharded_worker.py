@@ -311,6 +311,7 @@ def run(rank, world, port, mode, path, steps):
         assert ("libidgrec" in comm_name) == (mode == "nccl-native"), comm_name
         if mode == "nccl-native":
             comm.overlap_bytes = 1 << 16  # the second-stream route (>= 64 MB in production) on this small problem too
+            comm._force = True            # at world size 1 a collective is the identity and would not be enqueued: go through RCCL
     eng = sh.ShardedEngine(kern, comm, ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
                            batch_sparsity=mode not in ("gpu-dense", "cpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
                            live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None,
@@ -321,6 +322,7 @@ def run(rank, world, port, mode, path, steps):
         tl = sh.StepTimeline(torch, world)
         eng.comm = sh.TimelineComm(eng.comm, tl)
         eng.timeline = tl
+    order = sh.IssueOrder().attach(eng)  # the launch sequence of every step, checked against DESIGN.md §7's overlap model
     Ug = hi - lo
     if mode.startswith("cpu"):
         eng.P[:Ug] = W0[lo:hi]
@@ -342,6 +344,7 @@ def run(rank, world, port, mode, path, steps):
         if tl is not None:
             ev = (tl.event(), tl.event())
             ev[0].record()
+        order.begin_step()
         loss = eng.train_step(cur[0])
         if tl is not None:
             ev[1].record()
@@ -350,6 +353,7 @@ def run(rank, world, port, mode, path, steps):
     mine = cur[1][(cur[1][:, 0] >= lo) & (cur[1][:, 0] < hi)]
     touched = np.unique(mine[:, 0] - lo)  # local user rows of the LAST batch: the only FIN user rows guaranteed fresh
 
+    order.end_steps()
     eng._wait_item_table()  # the last step's all-gathers of the updated item rows
 
     def strip(a):  # (drop the guest rows and the padding: users, then items)
@@ -363,7 +367,9 @@ def run(rank, world, port, mode, path, steps):
     fin_items = np.unique(np.concatenate([cur[1][:, 1], cur[1][:, 2]]))
     out = dict(P=strip(eng.P), FIN=strip(eng.FIN), G=strip(eng.G), losses=np.stack(losses), lo=lo, hi=hi, fin_rows=touched,
                fin_items=fin_items, own_items=own_items,
-               touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1])
+               touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1],
+               n_slices=len(eng.slices), order_violations=np.array("\n".join(order.violations())),
+               order_events=np.array(repr(order.steps()[-1])))
     if tl is not None:
         import json
 

@@ -72,6 +72,8 @@ def _check(p, outs, steps, rtol, atol, sparse=False):
     W, fin, grad, losses = _single_device_reference(p, steps)
     U = p["U"]
     for o in outs:
+        # the launch order of every step follows the overlap model of DESIGN.md §7 (sharded.IssueOrder)
+        assert str(o["order_violations"]) == "", str(o["order_violations"])
         lo, hi = int(o["lo"]), int(o["hi"])
         np.testing.assert_allclose(o["losses"], losses, rtol=rtol)                  # identical on every rank
         # a training step's forward is exact where its loss reads it: the batch's users (layer K - 1 reaches them through
@@ -339,6 +341,88 @@ def test_three_ranks_gloo_cpu_match_single_device(tmp_path, golden_small):
     outs = _launch("cpu", path, 3, world=3)
     assert len({(int(o["lo"]), int(o["hi"])) for o in outs}) == 3
     _check(p, outs, 3, rtol=1e-4, atol=2e-7)
+
+
+def _wide_problem(K, include0, B, steps, thin, d=64, n_slices=8, seed=9):
+    """A graph with enough item rows that EIGHT ranks cut them into EIGHT slices (inner cuts fall on multiples of 32 x world
+    = 256 rows: I >= 2048), as run_sharded_bench picks from four ranks on (n_slices = 8): 1,700 users x 2,400 items; thin
+    (6 k interactions: the touched items / near users of a small batch are strict subsets) or dense (40 k)."""
+    p = _sparse_problem(K, include0, B, steps, d=d, n_slices=n_slices, U=1700, I=2400, E=6000 if thin else 40000, seed=seed)
+    p["thin"] = thin
+    return p
+
+
+@pytest.mark.parametrize("world,mode,thin,K,include0", [(8, "cpu", False, 3, True), (8, "cpu-deferred", True, 3, True),
+                                                       (4, "cpu-deferred", False, 3, False), (4, "cpu", True, 2, True),
+                                                       (8, "cpu-deferred", False, 4, True)])
+def test_four_and_eight_ranks_eight_slices(world, mode, thin, K, include0, tmp_path):
+    """The HEADLINE multi-GPU configuration's code path: world 4 and 8 with the item panel in EIGHT slices —
+    the owner-slice arithmetic (every slice's share of the padded panel divided by the world size, each rank the Adam
+    state of its 1/N of every slice), the reduce-scatter / owner tail / all-gather hand-over from one step to the next
+    and the touched-item bound (global user degrees, device-style id list) at eight ranks — over gloo against the
+    single-device oracle; plain and with the communicator whose collectives take effect only in wait().  The launch
+    order of every step is checked against DESIGN.md §7's overlap model on every rank (_check)."""
+    steps = 3
+    p = _wide_problem(K, include0, B=24 if thin else 96, steps=steps, thin=thin)
+    if thin:
+        p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch(mode, path, steps, world=world)
+    assert all(int(o["n_slices"]) == 8 for o in outs)
+    assert len({(int(o["lo"]), int(o["hi"])) for o in outs}) == world
+    # every rank owns 1/world of every slice: 8 blocks per rank, the ranks' blocks tile the items (_check asserts the tiling)
+    if thin:
+        assert all(0 < int(o["touched_n"]) < p["I"] and int(o["touched_n"]) % 256 == 0 for o in outs)
+    _check(p, outs, steps, rtol=1e-4, atol=2e-7)
+
+
+def test_issue_order_checker_flags_what_it_is_there_for():
+    """sharded.IssueOrder.violations on hand-made launch sequences: the designed order passes; a collective issued after
+    the NEXT slice's product, a panel exchange waited for before anything was launched behind it, and an all-gather
+    drained inside its own step (or before the next step's first item-side products) are each reported."""
+    import idgrec_amd.sharded as sh
+
+    def step(S=2, drain_first=False, late_issue=False, early_wait=False, own_step_wait=False, first=False):
+        ev = []
+        items = [("product", "item", j) for j in range(S)]
+        if not first and drain_first:
+            ev += [("wait", "item_table.all_gather", j) for j in range(S)]
+        if late_issue:
+            ev += items + [("issue", "F1.panel", j) for j in range(S)]
+        else:
+            for j in range(S):
+                ev += [items[j], ("issue", "F1.panel", j)]
+        if not first and not drain_first:
+            ev += [("wait", "item_table.all_gather", j) for j in range(S)]
+        if early_wait:
+            ev += [("wait", "F1.panel", j) for j in range(S)] + [("product", "user")]
+        else:
+            ev += [("product", "user")] + items + [("wait", "F1.panel", j) for j in range(S)]
+        for j in range(S):
+            ev += [items[j], ("issue", "B3.reduce_scatter", j)]
+        ev += [("product", "user")]
+        for j in range(S):
+            ev += [("wait", "B3.reduce_scatter", j), ("issue", "item_table.all_gather", j)]
+        if own_step_wait:
+            ev += [("wait", "item_table.all_gather", j) for j in range(S)]
+        return ev
+
+    def run(**kw):
+        o = sh.IssueOrder()
+        o.n_slices = 2
+        for i in range(2):
+            o.begin_step()
+            o.events += step(first=(i == 0), **kw)
+        o.end_steps()
+        o.events += [("wait", "item_table.all_gather", 0)]  # the caller draining the table after the last step: not a step
+        return o.violations()
+
+    assert run() == []
+    assert any("not right behind its own product" in v for v in run(late_issue=True))
+    assert any("no product launched behind it" in v for v in run(early_wait=True))
+    assert any("inside its own step" in v for v in run(own_step_wait=True))
+    assert any("first-layer item-side" in v for v in run(drain_first=True))
 
 
 @pytest.mark.gpu
