@@ -82,6 +82,9 @@ def parse():
                    help="the multi-GPU lines' workload (synth-10M, d=256: BASELINE configs[4]) measured unsharded on ONE GPU in "
                         "this run: as `scale_point` of the default 1-GPU line (auto: only there) and as `single_gpu_reference` "
                         "/ `speedup_vs_1gpu` of a sharded line (auto: when the shape fits one GPU)")
+    p.add_argument("--item-slices", type=int, default=0,
+                   help="sharded form: row slices of the item panel whose collectives overlap the following slices' products "
+                        "(0 = auto: 8 from four ranks on, 4 below, 1 while the panel is under 256 MB)")
     p.add_argument("--worker", action="store_true",
                    help="(internal) this process is a rank's WORKER: started by the rank's supervisor — the process the "
                         "launcher started, which never touches the GPU — so that a hung collective can be ended from outside "
@@ -204,33 +207,56 @@ def self_launch(args):
     form that is always safe.)  The launcher runs in its own process group and under a deadline (the ranks' supervisors
     keep their own, shorter ones): if it is still there after IDG_BENCH_TIMEOUT + 120 s the whole group is ended and a
     JSON line with "error" is printed instead of nothing."""
+    import shutil
     import signal
-    import socket
     import subprocess
+    import tempfile
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    # the ranks' status files live in a directory of THIS run's own, made here and removed on the way out (ADVICE r04: a
+    # name built from pid and port can meet a stale directory of an earlier run)
+    sdir = tempfile.mkdtemp(prefix="idg_bench_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               IDG_BENCH_STATUS_DIR=sdir)
+    rc = 1
     try:
-        stdout, _ = proc.communicate(timeout=BENCH_TIMEOUT_S + 120)
-    except subprocess.TimeoutExpired:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
         try:
-            os.killpg(proc.pid, signal.SIGKILL)  # the group this call created: launcher, supervisors, workers
-        except ProcessLookupError:
-            pass
-        stdout, _ = proc.communicate()
+            stdout, _ = proc.communicate(timeout=BENCH_TIMEOUT_S + 120)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)  # the group this call created: launcher, supervisors, workers
+            except ProcessLookupError:
+                pass
+            stdout, _ = proc.communicate()
+            lines = [ln for ln in stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+            print(lines[-1] if lines else json.dumps(_error_line(args, args.gpus, "launcher still running after %.0f s: ended"
+                                                                 % (BENCH_TIMEOUT_S + 120))), flush=True)
+            sys.exit(1)
         lines = [ln for ln in stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
-        print(lines[-1] if lines else json.dumps(_error_line(args, args.gpus, "launcher still running after %.0f s: ended"
-                                                             % (BENCH_TIMEOUT_S + 120))), flush=True)
-        sys.exit(1)
-    lines = [ln for ln in stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
-    if lines:
-        print(lines[-1], flush=True)
-    sys.exit(proc.returncode if proc.returncode or lines else 1)
+        if lines:
+            print(lines[-1], flush=True)
+        rc = proc.returncode if proc.returncode or lines else 1
+    finally:
+        shutil.rmtree(sdir, ignore_errors=True)
+    sys.exit(rc)
+
+
+def _free_port(preferred=None):
+    """A TCP port nobody listens on right now: `preferred` if it can be bound, else one the kernel picks."""
+    import socket
+
+    for want in ([preferred] if preferred else []) + [0]:
+        try:
+            with socket.socket() as sk:
+                sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                sk.bind(("127.0.0.1", int(want)))
+                return sk.getsockname()[1]
+        except OSError:
+            continue
+    raise RuntimeError("no free TCP port on 127.0.0.1")
 
 
 # ---- multi-GPU ranks: a supervisor per rank (the process the launcher started) and its worker (the process that runs)
@@ -290,6 +316,15 @@ def supervise_rank(args):
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     sdir = _status_dir()
+    if "IDG_BENCH_STATUS_DIR" not in os.environ:
+        # a foreign launcher (the driver's torch.distributed.run): the directory's name is built from its pid and port and
+        # may have served an earlier run — this rank's own files of that run must not be read as this run's verdicts
+        for name in os.listdir(sdir):
+            if name.endswith("_r%d" % rank) and name.split("_")[0] in ("status", "phase", "stdout", "port"):
+                try:
+                    os.remove(os.path.join(sdir, name))
+                except OSError:
+                    pass
     t_start = time.time()
     child = [None]
 
@@ -308,8 +343,15 @@ def supervise_rank(args):
         env = dict(os.environ, IDG_BENCH_STATUS_DIR=sdir)
         extra = ["--worker", "--attempt", str(attempt)]
         if attempt == 2:
-            # a rendezvous of its own: the first attempt's keys stay in the launcher's store
-            env["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1 + (os.getuid() + int(os.environ["MASTER_PORT"])) % 89)
+            # a rendezvous of its own: the first attempt's keys stay in the launcher's store.  Rank 0 picks a port that is
+            # free NOW (the computed one if nobody listens there) and publishes it; the others read it
+            port_file = os.path.join(sdir, "port_a2_r0")
+            if rank == 0:
+                _write(port_file, str(_free_port(int(os.environ["MASTER_PORT"]) + 1 + (os.getuid() + int(os.environ["MASTER_PORT"])) % 89)))
+            t_port = time.time() + 30
+            while _read(port_file) is None and time.time() < t_port:
+                time.sleep(0.1)
+            env["MASTER_PORT"] = _read(port_file) or str(int(os.environ["MASTER_PORT"]) + 1)
             env["TORCHELASTIC_USE_AGENT_STORE"] = "False"  # rank 0's worker hosts the store
             extra += ["--comm", "torch"]
         mine = os.path.join(sdir, "status_a%d_r%d" % (attempt, rank))

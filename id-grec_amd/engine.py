@@ -120,7 +120,7 @@ class PropagationEngine:
             self.use_fields = False
             self.ids = None
             self.ws = None
-            self.ssl_ws, self.ssl_key = None, None  # InfoNCE workspace holding this batch's id lists (ops.infonce_plan_raw)
+            self.ssl_ws, self.ssl_key, self.ssl_B = None, None, -1  # InfoNCE workspace holding this batch's id lists (ops.infonce_plan_raw)
             self.key = None
             self.rows_done = self.plan_done = None
             self.free = None  # = free_ev once recorded on the main stream: the step that used this slot is done
@@ -130,6 +130,13 @@ class PropagationEngine:
     def _prepare(self, slot, users, pos, neg):
         main = torch.cuda.current_stream()
         B = users.shape[0]
+        slot.ssl_key = None  # a plan is honoured for the batch it was built for only: set again below
+        # Workspaces come from torch's caching allocator on the MAIN stream but are first written by the SIDE stream: a block
+        # recycled from a tensor whose last reader is still queued on main must not be overwritten early — any
+        # (re)allocation (a new batch size: the short last batch of an epoch) orders the side stream behind main once
+        ssl_form = self.graph is not None and (self.ssl is not None or self.xssl is not None or self.sgl is not None)
+        fresh = (slot.ws is None or slot.ws_B != B or (self.graph is not None and slot.units_B != B)
+                 or (ssl_form and (slot.ssl_ws is None or slot.ssl_B != B)))
         if slot.ws is None or slot.ws_B != B:
             slot.ws, slot.ws_B = ops.bpr_workspace(B, self.d, self.device), B
             slot.rows_done, slot.plan_done, slot.free_ev = ops.LocalEvent(), ops.LocalEvent(), ops.LocalEvent()
@@ -139,7 +146,7 @@ class PropagationEngine:
         # one epoch-long tensor: ordering after the main stream once per storage is enough (doing it per batch would
         # also queue this batch's index work behind the previous step's kernels: measured +6 us/step).
         src = (users.untyped_storage().data_ptr(), pos.untyped_storage().data_ptr(), neg.untyped_storage().data_ptr())
-        if slot.free is None or src != self._id_storage:
+        if slot.free is None or src != self._id_storage or fresh:
             self._id_storage = src
             self._fork.record(main.cuda_stream)
             self._fork.wait(self._side_raw)
@@ -168,8 +175,8 @@ class PropagationEngine:
             # the id-list stage of the step's InfoNCE call (unique rows of the batch; SGL: raw lists, their repeat flags
             # and positions) is index-only too: ~19 us of small launches per call off the main stream
             mode = ops.SSL_RAW if self.sgl is not None else ops.SSL_UNIQUE
-            if slot.ssl_ws is None or slot.ssl_key is None or slot.ssl_key[0] != B:
-                slot.ssl_ws = ops.infonce_workspace(self.n, B, self.d, self.device)
+            if slot.ssl_ws is None or slot.ssl_B != B:
+                slot.ssl_ws, slot.ssl_B = ops.infonce_workspace(self.n, B, self.d, self.device), B
             ops.infonce_plan_raw(users, pos, self.U, self.n, self.d, mode, slot.ssl_ws, stream=self._side_raw)
             slot.ssl_key = (B, mode)
         slot.plan_done.record(self._side_raw)  # needed by the gradient scatter (and by the InfoNCE call behind it)
@@ -260,7 +267,7 @@ class PropagationEngine:
         # need the wait: a barrier packet costs 4.5 us between two kernels whether or not its event has fired.
         if self._paced and len(self._ends) >= 2:
             self._ends[-2].synchronize()
-            del self._ends[:-2]
+        del self._ends[:-2]  # (also when not paced: the list must not grow by an entry per step)
         ready = ahead and self._paced and slot.plan_done.query()
         if not ready:
             (slot.plan_done if ahead else slot.rows_done).wait(main.cuda_stream)
@@ -478,14 +485,15 @@ class BatchPrep:
     def _prepare(self, slot, users, pos, neg):
         main = torch.cuda.current_stream()
         B = int(users.shape[0])
-        if slot.B != B:
+        fresh = slot.B != B  # workspaces (re)allocated on main, first written on the side stream: order it behind main once
+        if fresh:
             slot.ws, slot.units, slot.B = ops.bpr_workspace(B, self.d, self.device), None, B
         if slot.free is not None:
             slot.free.wait(self._side_raw)  # the step that last used this slot has consumed it
         # the side stream must not read the ids before the main stream has produced them: once per storage (batches are
         # slices of one epoch-long tensor), as PropagationEngine._prepare does
         src = (users.untyped_storage().data_ptr(), pos.untyped_storage().data_ptr(), neg.untyped_storage().data_ptr())
-        if slot.free is None or src != self._id_storage:
+        if slot.free is None or src != self._id_storage or fresh:
             self._id_storage = src
             self._fork.record(main.cuda_stream)
             self._fork.wait(self._side_raw)
@@ -521,7 +529,7 @@ class BatchPrep:
         # step is enqueued, and the step's stream needs no wait (PropagationEngine.loss_and_grad: 4.5 us per barrier packet)
         if self._paced and len(self._ends) >= 2:
             self._ends[-2].synchronize()
-            del self._ends[:-2]
+        del self._ends[:-2]  # (also when not paced)
         if not (ahead and self._paced and slot.done.query()):
             slot.done.wait(torch.cuda.current_stream().cuda_stream)
         return slot

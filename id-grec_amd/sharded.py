@@ -1536,7 +1536,7 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     nnz_global, n_edges = 2 * len(users), len(users)
     # slices of the item panel: what a collective moves at a time.  From 4 ranks on the communicator's stream is the
     # critical path and a collective can start when its first slice exists: finer slices there
-    n_slices = (8 if world >= 4 else 4) if I * d * 4 >= (256 << 20) else 1
+    n_slices = int(getattr(args, "item_slices", 0) or 0) or ((8 if world >= 4 else 4) if I * d * 4 >= (256 << 20) else 1)
     cuts = partition_users_by_nnz(np.bincount(items, minlength=I), n_slices)  # same cuts on every rank: global item degrees
     n_timeline = 3 if world > 1 or os.environ.get("IDG_BENCH_TIMELINE") == "1" else 0  # instrumented steps, after the timed ones
     need = (args.steps + args.warmup + n_timeline) * B
@@ -1622,17 +1622,24 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         phase("timeline")
         tl = StepTimeline(torch, world)
         eng._wait_item_table()
-        inner, eng.comm, eng.timeline = eng.comm, TimelineComm(eng.comm, tl), tl
+        inner, inner_k, eng.comm, eng.timeline = eng.comm, eng.k, TimelineComm(eng.comm, tl), tl
+        order = IssueOrder().attach(eng)  # the same steps' launch ORDER, checked against DESIGN.md §7's overlap model
         for i in range(last + 1, last + 1 + n_timeline):
             ev = (tl.event(), tl.event())
             ev[0].record()
+            order.begin_step()
             eng.train_step(batches[i])
             ev[1].record()
             tl.steps.append(ev)
+        order.end_steps()
         eng._wait_item_table()
         torch.cuda.synchronize()
-        eng.comm, eng.timeline = inner, None
+        eng.comm, eng.k, eng.timeline = inner, inner_k, None
         timeline = tl.summary()
+        # every rank checked its own sequence: the line carries rank 0's and the number of ranks that found a violation
+        bad = torch.tensor([1.0 if order.violations() else 0.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(bad)
+        timeline["issue_order"] = dict(order.summary(), ranks_with_violations=int(bad.item()))
         timeline["touched_item_rows_exchanged"] = eng.touched_items[1] if eng.touched_items is not None else 0
         timeline["touched_item_agreement"] = ("device-built id list sized by a host-side bound: no host synchronisation"
                                               if eng.user_degree is not None else "length read back: one host synchronisation")

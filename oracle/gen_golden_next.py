@@ -18,6 +18,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from models.NGCF import NGCF as RefNGCF  # noqa: E402
 from models.SGL import SGL as RefSGL  # noqa: E402
+from models.SimGCL import SimGCL as RefSimGCL  # noqa: E402
 from models.XSimGCL import XSimGCL as RefXSimGCL  # noqa: E402
 
 ref_tools, ref_loader = G.ref_tools, G.ref_loader
@@ -87,6 +88,35 @@ def main():
         with torch.no_grad():
             xu, xi = x.aggregate(perturbed=False)
         out["xsimgcl_user"], out["xsimgcl_item"] = xu.numpy().copy(), xi.numpy().copy()
+
+        # ---- SimGCL / XSimGCL with epsilon = 0: the perturbation is sign(X) * normalize(noise) * 0, so the
+        # step is deterministic although the reference draws its noise from the device RNG — forward() losses, .grad of
+        # both tables (the InfoNCE gradient path of models/SimGCL.py:62-90 / XSimGCL.py:69-95 through autograd) and the
+        # tables after three torch.optim.Adam steps on three batches (utility/utility_train/trainer.py:42-56)
+        tri3 = torch.from_numpy(s1[:3 * 256].copy())
+        out["eps0_batches"] = tri3.numpy()
+        for tag, Ref, name in (("simgcl0", RefSimGCL, "SimGCL"), ("xsimgcl0", RefXSimGCL, "XSimGCL")):
+            cfg_e = G.base_config(name, dataset=gname, dataset_path=tmp + "/", epsilon="0.0")
+            ref_tools.set_seed(G.SEED)
+            m = Ref(cfg_e, data, G.CPU)
+            m.zero_grad()
+            ll = m(bu, bp, bn)
+            sum(ll).backward()
+            out[tag + "_loss"] = np.array([x.item() for x in ll])
+            out[tag + "_grad_user"] = m.user_embedding.weight.grad.numpy().copy()
+            out[tag + "_grad_item"] = m.item_embedding.weight.grad.numpy().copy()
+            opt = torch.optim.Adam(m.parameters(), lr=float(cfg_e["learn_rate"]))
+            traj = []
+            for i in range(3):
+                b = tri3[i * 256:(i + 1) * 256]
+                ll = m(b[:, 0], b[:, 1], b[:, 2])
+                opt.zero_grad()
+                sum(ll).backward()
+                opt.step()
+                traj.append([x.item() for x in ll])
+            out[tag + "_traj_loss"] = np.array(traj)
+            out[tag + "_traj_user"] = m.user_embedding.weight.detach().numpy().copy()
+            out[tag + "_traj_item"] = m.item_embedding.weight.detach().numpy().copy()
         G.golden_io.save_npz(os.path.join(G.OUT, "next_small.npz"), **out)
         print("wrote next_small.npz (%d arrays)" % len(out))
     finally:

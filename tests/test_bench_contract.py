@@ -69,6 +69,35 @@ def test_two_rank_line():
     assert abs(d["speedup_vs_1gpu"] - d["single_gpu_reference"]["ms_per_step"] / d["ms_per_step"]) < 1e-9
 
 
+TIMELINE_TAGS = {"F1.panel", "flags", "F2.touched", "F3.items", "guest_rows", "B1.touched", "B2.panel", "B3.reduce_scatter",
+                 "item_table.all_gather"}
+
+
+@pytest.mark.gpu
+def test_eight_rank_line():
+    """The HEADLINE multi-GPU launch — eight ranks, the item panel in eight slices, as `bench.py --gpus 8` runs on a real
+    node — rehearsed with the eight ranks SHARING the one GPU over gloo (host-staged collectives: the structure, not the
+    numbers): one JSON line with n_gpus 8, every collective of the step under its timeline tag, the launch order of the
+    instrumented steps as DESIGN.md §7's overlap model assumes on every rank, the item table coherent — inside the
+    watchdog's deadline (the 8-rank configuration had never executed a step in any form)."""
+    env = dict(_env(), IDG_BENCH_TIMEOUT="900")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--parallel", "shard", "--workload",
+                        "synth-1M", "--dim", "64", "--item-slices", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--scale-point", "off"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["scaling"] == "strong" and d["item_table_coherent"] is True
+    assert "retried" not in d and d["config"]["parallelism"] == "user-row shard x8" and d["config"]["item_panel_slices"] == 8
+    t = d["timeline"]
+    assert t["instrumented_steps"] == 3 and TIMELINE_TAGS <= set(t["collectives"]), sorted(t["collectives"])
+    assert t["host_sync_ms"] == 0.0
+    assert t["collectives"]["F1.panel"]["calls_per_step"] == 8 and t["collectives"]["item_table.all_gather"]["calls_per_step"] == 8
+    o = t["issue_order"]
+    assert o["steps"] == 3 and o["slices"] == 8 and o["violations"] == [] and o["ranks_with_violations"] == 0
+
+
 @pytest.mark.gpu
 def test_gpus_flag_launches_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT a launcher (the form of the driver's N = 1 command with another N): the ranks are

@@ -303,16 +303,20 @@ def test_simgcl_runs_and_clean_view_matches_reference(tmp_path, golden_small):
     assert float(sum(ll)) < first  # five steps on one batch reduce its loss
 
 
-def test_xsimgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
+@pytest.mark.parametrize("keep_grad", [True, False])
+@pytest.mark.parametrize("layers", [2, 3, 4])
+def test_xsimgcl_fused_step_equals_autograd_step(layers, keep_grad, tmp_path, golden_small):
     """XSimGCL's fused trainer step (cl_layer = 1) against forward() under autograd + optimizer.step(), same noise
-    streams: three loss terms, gradients and weights over 3 steps."""
+    streams: three loss terms, gradients and weights over 3 steps.  keep_grad False is what the trainer and the bench run
+    (the Horner chain whose last product applies Adam and writes no gradient panel: weights and moments are compared);
+    GCN_layer = 2 has an empty inner loop, 4 two inner products."""
     import utility.utility_function.tools as tools
     from idgrec_amd import ops
     from models.XSimGCL import XSimGCL
 
     g = golden_small
     data, cfg = _dataset(tmp_path, g, "small", learn_rate=0.001, ssl_lambda=0.2, temperature=0.15, epsilon=0.2, cl_layer=1,
-                         **BASE)
+                         **dict(BASE, GCN_layer=layers))
     tri = torch.from_numpy(g["sample1"][:3 * 256]).cuda()
     bt = [tuple(tri[i * 256:(i + 1) * 256, c].contiguous() for c in range(3)) for i in range(3)]
     res = []
@@ -321,7 +325,7 @@ def test_xsimgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
         ops.reset_noise_stream()
         model = XSimGCL(cfg, data, torch.device("cuda")).to("cuda")
         assert model.supports_fused_step
-        model.keep_fused_grad = True  # (.grad is compared below: by default a fused step does not write the panel out)
+        model.keep_fused_grad = keep_grad  # (by default a fused step does not write the gradient panel out)
         opt = ops.Adam(model.parameters(), lr=0.001)
         loss = torch.zeros((3, 3), device="cuda")
         for i in range(3):
@@ -333,11 +337,20 @@ def test_xsimgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
                 opt.zero_grad()
                 sum(ll).backward()
                 opt.step()
-        res.append((loss.cpu().numpy(), model.user_embedding.weight.grad.cpu().numpy(), model._storage.cpu().numpy()))
-    (l_f, g_f, w_f), (l_a, g_a, w_a) = res
+        grad = model.user_embedding.weight.grad
+        assert fused and not keep_grad or grad is not None
+        res.append((loss.cpu().numpy(), None if grad is None else grad.cpu().numpy(), model._storage.cpu().numpy(),
+                    opt.state[model.item_embedding.weight]["exp_avg"].cpu().numpy(),
+                    opt.state[model.user_embedding.weight]["exp_avg_sq"].cpu().numpy()))
+    (l_f, g_f, w_f, m_f, v_f), (l_a, g_a, w_a, m_a, v_a) = res
     np.testing.assert_allclose(l_f, l_a, rtol=2e-5)
-    np.testing.assert_allclose(g_f, g_a, rtol=1e-3, atol=1e-5 * np.abs(g_a).max())
+    if keep_grad:
+        np.testing.assert_allclose(g_f, g_a, rtol=1e-3, atol=1e-5 * np.abs(g_a).max())
+    else:
+        assert g_f is None
     np.testing.assert_allclose(w_f, w_a, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m_f, m_a, rtol=1e-3, atol=1e-5 * np.abs(m_a).max())
+    np.testing.assert_allclose(v_f, v_a, rtol=2e-3, atol=1e-6 * np.abs(v_a).max())
 
 
 def test_simgcl_fused_step_equals_autograd_step(tmp_path, golden_small):
@@ -727,6 +740,51 @@ def test_xsimgcl_encoder_and_training(tmp_path, golden_small, golden_next):
         opt.step()
         vals.append(float(sum(ll).detach()))
     assert vals[-1] < vals[0]
+
+
+@pytest.mark.parametrize("keep_grad", [True, False])
+@pytest.mark.parametrize("name", ["SimGCL", "XSimGCL"])
+def test_ssl_step_with_epsilon_zero_vs_reference(name, keep_grad, tmp_path, golden_small, golden_next):
+    """SimGCL / XSimGCL pinned to the REFERENCE itself beyond their clean encoders: with epsilon = 0 the
+    reference's step is deterministic (the perturbation is noise * 0), so its forward() losses, the .grad of both tables
+    through its InfoNCE (models/SimGCL.py:62-90, XSimGCL.py:69-95, losses.py:24-35) and the tables after three
+    torch.optim.Adam steps are goldens (oracle/gen_golden_next.py: simgcl0_* / xsimgcl0_*).  Against them: forward() under
+    autograd, and the fused trainer step — with the gradient panel written out and, as the trainer runs it, consumed by
+    the Adam epilogue (keep_grad False: the XSimGCL Horner chain that folds the view's gradient into the penultimate
+    product)."""
+    import importlib
+
+    import utility.utility_function.tools as tools
+    from idgrec_amd import ops
+
+    g, nx = golden_small, golden_next
+    tag = name.lower() + "0"
+    cfg = _cfg(name, epsilon=0.0)
+    data = _data_with(tmp_path, g, cfg)
+    Model = getattr(importlib.import_module("models." + name), name)
+    tools.set_seed(2024)
+    m = Model(cfg, data, torch.device("cuda")).to("cuda")
+    b = torch.from_numpy(nx["batch"]).cuda()
+    ll = m(b[:, 0], b[:, 1], b[:, 2])
+    np.testing.assert_allclose([x.item() for x in ll], nx[tag + "_loss"], rtol=RTOL)
+    sum(ll).backward()
+    for mine, ref in ((m.user_embedding.weight.grad, nx[tag + "_grad_user"]), (m.item_embedding.weight.grad, nx[tag + "_grad_item"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), ref, rtol=1e-3, atol=3e-4 * np.abs(ref).max())
+    # the fused step, three batches, against the reference's own Adam trajectory
+    tri = torch.from_numpy(nx["eps0_batches"]).cuda()
+    tools.set_seed(2024)
+    ops.reset_noise_stream()
+    m = Model(cfg, data, torch.device("cuda")).to("cuda")
+    m.keep_fused_grad = keep_grad
+    opt = ops.Adam(m.parameters(), lr=float(cfg["learn_rate"]))
+    loss = torch.zeros((3, 3), device="cuda")
+    for i in range(3):
+        bt = tuple(tri[i * 256:(i + 1) * 256, c].contiguous() for c in range(3))
+        assert m.fused_train_step(*bt, loss[i], opt)
+        assert (m.user_embedding.weight.grad is not None) == keep_grad
+    np.testing.assert_allclose(loss.cpu().numpy(), nx[tag + "_traj_loss"], rtol=RTOL)
+    np.testing.assert_allclose(m.user_embedding.weight.detach().cpu().numpy(), nx[tag + "_traj_user"], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(m.item_embedding.weight.detach().cpu().numpy(), nx[tag + "_traj_item"], rtol=RTOL, atol=1e-6)
 
 
 def test_training_is_bit_reproducible_run_to_run(tmp_path, golden_small):
