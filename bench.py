@@ -591,16 +591,20 @@ def main():
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
     losses = torch.zeros((args.steps + args.warmup, 3 if args.model == "SimGCL" else 2), dtype=torch.float32, device="cuda")
 
+    # the mini-batches as views of the epoch's id tensors, made once (as the trainer does: list(tools.mini_batch(...)),
+    # utility/utility_function/tools.py:55-64), and one row of the loss record per step
+    batches = [(tu[i * B:(i + 1) * B], tp[i * B:(i + 1) * B], tn[i * B:(i + 1) * B]) for i in range(args.steps + args.warmup)]
+    loss_rows = list(losses.unbind(0))
+
     def batch(i):
-        s = slice(i * B, (i + 1) * B)
-        return tu[s], tp[s], tn[s]
+        return batches[i]
 
     last = args.warmup + args.steps - 1
 
     def step(i):
         if i < last:
-            eng.prefetch(*batch(i + 1))  # one-batch lookahead of the index-only work (as the trainer does)
-        eng.train_step(*batch(i), loss_out=losses[i])
+            eng.prefetch(*batches[i + 1])  # one-batch lookahead of the index-only work (as the trainer does)
+        eng.train_step(*batches[i], loss_out=loss_rows[i])
 
     # (the ramp's panel has a different width than the bench's, so its launches are another instantiation of the kernel
     #  and stay out of the measured kernel's row in a per-kernel trace of this command)
@@ -613,6 +617,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
 
+    plan0 = eng._plan.stats() if getattr(eng, "_plan", None) is not None else None
     # timed region: exactly --steps steps, nothing else (no events, no instrumented launches)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
@@ -620,6 +625,7 @@ def main():
     t_issue = time.perf_counter() - t0  # host time to issue the steps; < dt means the GPU, not the host, is the limit
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    plan1 = eng._plan.stats() if getattr(eng, "_plan", None) is not None else None
 
     ms_per_step = dt / args.steps * 1e3
     value = B * args.steps / dt
@@ -639,6 +645,19 @@ def main():
         "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[-1].sum().item())],
         "host_issue_ms_per_step": t_issue / args.steps * 1e3,
     }
+    if plan0 is not None and plan1 is not None and plan1["steps"] - plan0["steps"] == args.steps:
+        # the step is ONE library call (idg_step_run_f32): the host keeps at most two steps queued and BLOCKS in the call
+        # until the step before the previous one has finished, so host_issue_ms_per_step follows the device; what the host
+        # actually spends per step is the issue time minus that blocked time
+        blocked = plan1["ms_blocked"] - plan0["ms_blocked"]
+        out["host_busy_ms_per_step"] = max(t_issue * 1e3 - blocked, 0.0) / args.steps
+        out["step_call"] = {"library_calls_per_step": 1, "entry_point": "idg_step_run_f32",
+                            "ms_in_call_per_step": (plan1["ms_in_calls"] - plan0["ms_in_calls"]) / args.steps,
+                            "ms_blocked_in_pacing_per_step": blocked / args.steps,
+                            "steps_without_a_stream_wait": plan1["waits_skipped"] - plan0["waits_skipped"],
+                            "what": "host_busy = (issue time of the timed loop - time blocked in the pacing wait) / steps: "
+                                    "Python loop + the one call's own work (the next batch's preparation on the side stream, "
+                                    "K forward products, fused BPR, backward chain with the Adam epilogue, end-of-step event)"}
     hbm_leg = False
     if graph is not None:
         out["roofline"] = roofline(args, eng, graph, n, nnz, d, K, args.workload, in_step_form=(args.model == "LightGCN"),

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libidgrec.so")
-SOURCES = ["idg_host.cpp", "idg_comm.cpp", "idg_stream.cpp", "idg_graph.hip", "idg_bpr.hip", "idg_score.hip", "idg_ssl.hip", "idg_dense.hip",
+SOURCES = ["idg_host.cpp", "idg_comm.cpp", "idg_stream.cpp", "idg_step.cpp", "idg_graph.hip", "idg_bpr.hip", "idg_score.hip", "idg_ssl.hip", "idg_dense.hip",
            "idg_ngcf.hip", "idg_shard.hip"]
 ARCH = "gfx950"
 

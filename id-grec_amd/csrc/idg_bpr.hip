@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "idg_common.h"
 
@@ -18,6 +19,11 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;
 constexpr int LDS_SORT_MAX = 8192;  // (key,slot) pairs one workgroup sorts in LDS
+// IDG_SORT_SINGLE_BLOCK=1: lists of 1025..8192 pairs sorted by ONE workgroup as before round 5 (A/B runs; same result)
+static const bool g_single_block_sort = [] {
+  const char* e = std::getenv("IDG_SORT_SINGLE_BLOCK");
+  return e && e[0] == '1';
+}();
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -109,12 +115,19 @@ __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
 // (row, slot) keys of the 3B gradient contributions of a batch: depends on the indices only.
 __global__ __launch_bounds__(BLOCK) void bpr_keys_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
                                                          const int64_t* __restrict__ neg, int64_t B, int64_t num_users,
-                                                         int32_t* __restrict__ keys, int32_t* __restrict__ slots) {
+                                                         int32_t* __restrict__ keys, int32_t* __restrict__ slots,
+                                                         uint32_t* __restrict__ bitmap) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= B) return;
-  keys[3 * i + 0] = (int32_t)users[i];
-  keys[3 * i + 1] = (int32_t)(num_users + pos[i]);
-  keys[3 * i + 2] = (int32_t)(num_users + neg[i]);
+  const int64_t r0 = users[i], r1 = num_users + pos[i], r2 = num_users + neg[i];
+  keys[3 * i + 0] = (int32_t)r0;
+  keys[3 * i + 1] = (int32_t)r1;
+  keys[3 * i + 2] = (int32_t)r2;
+  if (bitmap) {  // (idg_bpr_plan_rows_f32: the batch's row bitmap on the way — what bpr_touch_kernel sets)
+    atomicOr(bitmap + (r0 >> 5), 1u << (r0 & 31));
+    atomicOr(bitmap + (r1 >> 5), 1u << (r1 & 31));
+    atomicOr(bitmap + (r2 >> 5), 1u << (r2 & 31));
+  }
   slots[3 * i + 0] = (int32_t)(3 * i + 0);
   slots[3 * i + 1] = (int32_t)(3 * i + 1);
   slots[3 * i + 2] = (int32_t)(3 * i + 2);
@@ -309,6 +322,51 @@ static void launch_lds_sort(const int32_t* keys, const int32_t* slots, int n3, i
   }
 }
 
+// 1024 < n3 <= LDS_SORT_MAX pairs, two launches on SEVERAL compute units (round 5).  One 1024-thread workgroup sorting the
+// whole list is bound by its CU's LDS pipe (every cross-lane exchange of 16 waves goes through it): 45 us for the 6144
+// pairs of a B = 2048 batch — the longest thing on the side stream, and for a step without propagation (MFBPR) longer
+// than the step itself.  Instead: runs of 1024 keys sorted by one workgroup each (lds_sort_kernel<KeyT, 1>, packed keys
+// out), then every key finds its final position on its own: the keys are unique, so rank = position in its run + the
+// number of smaller keys in every other run (a binary search per run, all runs staged in LDS).  Same sorted list.
+constexpr int RANK_RUN = 1024, RANK_BLOCK = 256;
+template <typename KeyT>
+__global__ __launch_bounds__(RANK_BLOCK) void rank_merge_kernel(const KeyT* __restrict__ runs, int n, int slot_bits,
+                                                                int32_t* __restrict__ keys_out,
+                                                                int32_t* __restrict__ slots_out) {
+  __shared__ KeyT s_k[LDS_SORT_MAX];
+  for (int i = threadIdx.x; i < n; i += RANK_BLOCK) s_k[i] = runs[i];
+  __syncthreads();
+  const int g = blockIdx.x * RANK_BLOCK + threadIdx.x;
+  if (g >= n) return;
+  const KeyT key = s_k[g];
+  const int own = g / RANK_RUN;
+  int rank = g - own * RANK_RUN;
+  const int n_runs = (n + RANK_RUN - 1) / RANK_RUN;
+  for (int q = 0; q < n_runs; ++q) {
+    if (q == own) continue;
+    const KeyT* r = s_k + q * RANK_RUN;
+    int lo = 0, hi = n - q * RANK_RUN < RANK_RUN ? n - q * RANK_RUN : RANK_RUN;
+    while (lo < hi) {  // number of keys of run q below `key`
+      const int mid = (lo + hi) >> 1;
+      if (r[mid] < key) lo = mid + 1;
+      else hi = mid;
+    }
+    rank += lo;
+  }
+  keys_out[rank] = (int32_t)(key >> slot_bits);
+  slots_out[rank] = (int32_t)(key & (KeyT)(((KeyT)1 << slot_bits) - 1));
+}
+
+template <typename KeyT>
+static void launch_rank_sort(const int32_t* keys, const int32_t* slots, int n3, int slot_bits, int32_t* skeys, int32_t* sslots,
+                             void* temp, hipStream_t st) {
+  KeyT* runs = reinterpret_cast<KeyT*>(temp);
+  hipLaunchKernelGGL((lds_sort_kernel<KeyT, 1>), dim3((unsigned)((n3 + RANK_RUN - 1) / RANK_RUN)), dim3(1024), 0, st, keys, slots, n3,
+                     RANK_RUN, slot_bits, skeys, sslots, runs);
+  hipLaunchKernelGGL((rank_merge_kernel<KeyT>), dim3((unsigned)((n3 + RANK_BLOCK - 1) / RANK_BLOCK)), dim3(RANK_BLOCK), 0, st, runs,
+                     n3, slot_bits, skeys, sslots);
+}
+
 // n3 > LDS_SORT_MAX pairs: runs of LDS_SORT_MAX sorted in LDS (one workgroup each), then merge passes between the two
 // halves of `temp` (2 x n3 packed 64-bit keys); the last pass unpacks into skeys / sslots.
 static void launch_merge_sort(const int32_t* keys, const int32_t* slots, int64_t n3, int slot_bits, int32_t* skeys,
@@ -412,7 +470,9 @@ __global__ __launch_bounds__(BLOCK) void bpr_scatter_kernel(BprArgs a, const int
       continue;
     }
     if (a.g_final && a.g_final == a.g_ego) {
-      a.g_final[o] += acc + reg;
+      // (MFBPR: one panel receives both gradients; with a bitmap the row is stored — what adding to a zero-filled row gives)
+      if (a.touched) a.g_final[o] = acc + reg;
+      else a.g_final[o] += acc + reg;
     } else {
       if (a.g_final) {
         if (a.touched) a.g_final[o] = acc;  // one wave owns a row: a plain store, no zero-fill needed
@@ -511,6 +571,36 @@ __global__ __launch_bounds__(BLOCK) void adam_kernel(float* __restrict__ p, cons
     }
   }
 #undef IDG_ADAM1
+}
+
+// adam_kernel with the gradient read at the rows flagged in `rows` only (zero elsewhere).  One thread per float4 column
+// of a row (d4 = d / 4 columns, BLOCK / d4 rows per workgroup pass when d4 divides BLOCK; else rows are walked by the
+// first d4-multiple of the block's threads): the row index costs one 32-bit division per THREAD, not one per element
+__global__ __launch_bounds__(BLOCK) void adam_rows_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          const uint32_t* __restrict__ rows, float* __restrict__ m,
+                                                          float* __restrict__ v, int64_t n, int d4, float w1, float beta2,
+                                                          float w2, float step_size, float bc2_sqrt, float eps) {
+  const int rpb = BLOCK / d4;  // rows per workgroup pass (>= 1: the caller guarantees d4 <= BLOCK)
+  const int r_in = (int)threadIdx.x / d4, c = (int)threadIdx.x - r_in * d4;
+  if (r_in >= rpb) return;
+  for (int64_t row = (int64_t)blockIdx.x * rpb + r_in; row < n; row += (int64_t)gridDim.x * rpb) {
+    const int64_t i = row * d4 + c;
+    const bool live = (rows[row >> 5] >> (row & 31)) & 1u;
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+#define IDG_ADAM1(c)                                                 \
+  M.c = __builtin_fmaf(w1, G.c - M.c, M.c);                          \
+  V.c = __builtin_fmaf(w2 * G.c, G.c, V.c * beta2);                  \
+  P.c = P.c - step_size * (M.c / (sqrtf(V.c) / bc2_sqrt + eps));
+    IDG_ADAM1(x) IDG_ADAM1(y) IDG_ADAM1(z) IDG_ADAM1(w)
+#undef IDG_ADAM1
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
 }
 
 // dst[t] = idx[t] >= 0 ? src[idx[t]] : 0   (rows of d floats; one wave per row)
@@ -704,9 +794,11 @@ BprWs bpr_layout(int64_t B, size_t sort_temp) {
   return w;
 }
 
-// Scratch of the merge sort of n3 > LDS_SORT_MAX (row, slot) pairs: two buffers of n3 packed 64-bit keys.
+// Scratch of the sort of the (row, slot) pairs: none up to one run of 1024; the packed runs (n3 keys of up to 64 bits) up
+// to LDS_SORT_MAX; two buffers of n3 packed 64-bit keys for the merge sort beyond.
 size_t sort_temp_bytes(int64_t n3) {
-  if (n3 <= LDS_SORT_MAX) return 0;
+  if (n3 <= RANK_RUN) return 0;
+  if (n3 <= LDS_SORT_MAX) return (size_t)n3 * 8;
   return (size_t)n3 * 16;
 }
 
@@ -775,7 +867,7 @@ int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_
 }
 
 static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
-                         int64_t n, void* ws, hipStream_t st, const char* who) {
+                         int64_t n, void* ws, hipStream_t st, const char* who, uint32_t* bitmap = nullptr) {
   if (!(users && pos && neg && ws)) return idg::fail(IDG_E_INVALID, "%s: NULL argument", who);
   if (!(B > 0 && num_users >= 0 && n >= num_users)) return idg::fail(IDG_E_INVALID, "%s: bad sizes", who);
   if (n >= ((int64_t)1 << 31) || 3 * B >= ((int64_t)1 << 31)) return idg::fail(IDG_E_INVALID, "%s: sizes exceed int32 keys", who);
@@ -785,8 +877,9 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
   int32_t* slots = reinterpret_cast<int32_t*>(base + w.slots);
   int32_t* skeys = reinterpret_cast<int32_t*>(base + w.skeys);
   int32_t* sslots = reinterpret_cast<int32_t*>(base + w.sslots);
+  if (bitmap) idg::rows_changed(bitmap);
   hipLaunchKernelGGL(bpr_keys_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, pos, neg, B,
-                     num_users, keys, slots);
+                     num_users, keys, slots, bitmap);
   const int64_t n3 = 3 * B;
   if (n3 <= LDS_SORT_MAX) {
     int p2 = 1;
@@ -794,10 +887,14 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
     int slot_bits = 1, row_bits = 1;
     while (((int64_t)1 << slot_bits) < n3) ++slot_bits;
     while (((int64_t)1 << row_bits) < n) ++row_bits;
-    if (slot_bits + row_bits <= 31)  // top bit kept clear so the all-ones padding key sorts last
-      launch_lds_sort<uint32_t>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);
-    else
-      launch_lds_sort<unsigned long long>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);
+    const bool rank_sort = n3 > RANK_RUN && !g_single_block_sort;
+    if (slot_bits + row_bits <= 31) {  // top bit kept clear so the all-ones padding key sorts last
+      if (rank_sort) launch_rank_sort<uint32_t>(keys, slots, (int)n3, slot_bits, skeys, sslots, base + w.temp, st);
+      else launch_lds_sort<uint32_t>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);
+    } else {
+      if (rank_sort) launch_rank_sort<unsigned long long>(keys, slots, (int)n3, slot_bits, skeys, sslots, base + w.temp, st);
+      else launch_lds_sort<unsigned long long>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);
+    }
   } else {
     int slot_bits = 1;
     while (((int64_t)1 << slot_bits) < n3) ++slot_bits;
@@ -830,6 +927,12 @@ int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* ne
   return bpr_sort_plan(users, pos, neg, B, num_users, n, ws, (hipStream_t)stream, "idg_bpr_plan_f32");
 }
 
+int idg_bpr_plan_rows_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
+                          int64_t n, void* ws, uint32_t* bitmap, void* stream) {
+  IDG_REQUIRE(bitmap, "idg_bpr_plan_rows_f32: NULL bitmap");
+  return bpr_sort_plan(users, pos, neg, B, num_users, n, ws, (hipStream_t)stream, "idg_bpr_plan_rows_f32", bitmap);
+}
+
 // loss_out != NULL (deterministic scatter only): the scatter launch also reduces the loss terms the forward left
 // in the workspace (the forward was then run without its own reduction)
 static int bpr_backward_impl(const float* final_panel, const float* ego_panel, int64_t num_users, int64_t n,
@@ -837,8 +940,9 @@ static int bpr_backward_impl(const float* final_panel, const float* ego_panel, i
                              float reg_lambda, const float* upstream, float* g_final, float* g_ego, int deterministic,
                              uint32_t* touched, void* ws, void* stream, float* loss_out, int64_t de = 0, int reg_users = 1) {
   hipStream_t st = (hipStream_t)stream;
-  IDG_REQUIRE(!touched || (deterministic && g_final != g_ego),
-              "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter and g_final distinct from g_ego");
+  IDG_REQUIRE(!touched || (deterministic && (g_final != g_ego || (de <= 0 || de == d) && reg_users)),
+              "idg_bpr_backward_f32: a touched-row bitmap needs a deterministic scatter (and, for ego rows of another width or an "
+              "item-only regulariser, g_final distinct from g_ego)");
   const BprWs w = bpr_layout(B > 0 ? B : 1, sort_temp_bytes(3 * B));
   BprArgs a{};
   int rc = bpr_args(a, w, final_panel, ego_panel, num_users, n, users, pos, neg, B, d, reg_lambda, ws,
@@ -1002,6 +1106,25 @@ int idg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* ex
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, n4, count, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size,
                      bc2_sqrt, (float)eps);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
+int idg_adam_rows_f32(float* param, const float* grad, const uint32_t* rows, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      int64_t d, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
+  IDG_REQUIRE(param && grad && rows && exp_avg && exp_avg_sq, "idg_adam_rows_f32: NULL argument");
+  IDG_REQUIRE(n >= 0 && d > 0 && d % 4 == 0 && step >= 1, "idg_adam_rows_f32: bad sizes (d must be a multiple of 4) / step");
+  if (n == 0) return IDG_OK;
+  IDG_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+              "idg_adam_rows_f32: pointers must be 16-byte aligned");
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  IDG_REQUIRE(d / 4 <= BLOCK, "idg_adam_rows_f32: rows of up to %d floats", 4 * BLOCK);
+  const int d4 = (int)(d / 4), rpb = BLOCK / d4;
+  int64_t nb = std::max<int64_t>(1, std::min<int64_t>((n + rpb - 1) / rpb, 256 * 8));
+  hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, param, grad, rows, exp_avg,
+                     exp_avg_sq, n, d4, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
+                     (float)std::sqrt(bc2), (float)eps);
   IDG_HIP(hipGetLastError());
   return IDG_OK;
 }

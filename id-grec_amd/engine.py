@@ -17,6 +17,76 @@ import torch
 from . import native, ops
 
 
+class StepPlan:
+    """idg_step (include/idgrec.h): the plain LightGCN / MFBPR training step as ONE library call.  Owns the three slots'
+    buffers (row bitmap, live-unit list, scatter workspace) and the plan handle; everything else belongs to the engine."""
+
+    def __init__(self, eng, batch_capacity):
+        import ctypes as C
+
+        g, dev = eng.graph, eng.device
+        self.B_cap = int(batch_capacity)
+        words = (eng.n + 31) // 32
+        self.bitmaps = [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(native.IDG_STEP_SLOTS)]
+        self.bpr_ws = [ops.bpr_workspace(self.B_cap, eng.d, dev) for _ in range(native.IDG_STEP_SLOTS)]
+        self.units = [None] * native.IDG_STEP_SLOTS
+        desc = native.StepDesc()
+        if g is not None:
+            nbytes = int(native.lib.idg_graph_live_units_bytes(g._h, 3 * self.B_cap))
+            self.units = [torch.empty(nbytes // 4 + 1, dtype=torch.int32, device=dev) for _ in range(native.IDG_STEP_SLOTS)]
+            self.prop_ws = g._workspace("prop", eng.d)
+            desc.graph, desc.prop_ws = g._h, self.prop_ws.data_ptr()
+            desc.final_panel, desc.g_final = eng.final.data_ptr(), eng.g_final.data_ptr()
+        desc.num_users, desc.n, desc.d = eng.U, eng.n, eng.d
+        desc.n_layers, desc.include_layer0, desc.reg_lambda = eng.K, int(eng.inc), eng.reg_lambda
+        desc.params, desc.grad = eng.params.data_ptr(), eng.grad.data_ptr()
+        desc.exp_avg, desc.exp_avg_sq = eng.exp_avg.data_ptr(), eng.exp_avg_sq.data_ptr()
+        desc.batch_capacity = self.B_cap
+        for i in range(native.IDG_STEP_SLOTS):
+            desc.slot_bitmap[i] = self.bitmaps[i].data_ptr()
+            desc.slot_units[i] = None if self.units[i] is None else self.units[i].data_ptr()
+            desc.slot_bpr_ws[i] = self.bpr_ws[i].data_ptr()
+        desc.side_stream = eng._side_raw
+        desc.flags = native.IDG_STEP_PACED if eng._paced else 0
+        self.key = self.key_of(eng)
+        self._graph = g  # (the plan names the handle: keep it alive)
+        self._h = C.c_void_p()
+        native.check(native.lib.idg_step_create(C.byref(desc), C.byref(self._h)), "idg_step_create")
+        self._by_ptr = {b.data_ptr(): b for b in self.bitmaps}
+        self._bm = C.c_void_p()
+
+    @staticmethod
+    def key_of(eng):
+        return (eng.params.data_ptr(), eng.grad.data_ptr(), eng.exp_avg.data_ptr(), eng.exp_avg_sq.data_ptr(),
+                None if eng.final is None else eng.final.data_ptr(), eng.K, eng.inc, eng.reg_lambda, eng._paced)
+
+    def last_bitmap(self):
+        import ctypes as C
+
+        native.check(native.lib.idg_step_last_bitmap(self._h, C.byref(self._bm)), "idg_step_last_bitmap")
+        return self._by_ptr[self._bm.value]
+
+    def stats(self):
+        """{steps, ms_in_calls, ms_blocked, waits_skipped} since the plan was made (idg_step_stats)."""
+        import ctypes as C
+
+        out = (C.c_int64 * 4)()
+        native.check(native.lib.idg_step_stats(self._h, out), "idg_step_stats")
+        return {"steps": int(out[0]), "ms_in_calls": out[1] / 1e6, "ms_blocked": out[2] / 1e6, "waits_skipped": int(out[3])}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            native.lib.idg_step_synchronize(self._h)
+            native.lib.idg_step_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class PropagationEngine:
     def __init__(self, graph, num_users, num_items, dim, n_layers, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
                  betas=(0.9, 0.999), eps=1e-8, deterministic=True, params=None):
@@ -46,7 +116,7 @@ class PropagationEngine:
         self._slots = [self._Slot(words if graph is not None else 1, dev) for _ in range(3)] if self.deterministic else None
         self._ends = []  # end-of-step events of the last steps, oldest first
         self._paced = os.environ.get("IDG_PACE", "1") != "0"
-        self.touched = None
+        self._touched = None
         self._stamp = 0
         self._loss3 = torch.zeros(3, **f32)  # [bpr, reg_lambda * reg, ssl_lambda * InfoNCE]
         self.loss = self._loss3[:2]
@@ -77,6 +147,11 @@ class PropagationEngine:
         self.xssl = None       # the same triple for XSimGCL (one perturbed pass, cl_layer = 1)
         self.sgl = None        # (temperature, ssl_lambda, sub_graph_1, sub_graph_2): SGL's two edge-dropped views
         self._views = self._ssl_loss = None
+        # one library call per step (StepPlan / idg_step_run_f32) for the plain LightGCN / MFBPR step; IDG_STEP_PLAN=0: the
+        # call-by-call chain below (same kernels, same bits)
+        self._plan, self._plan_on = None, os.environ.get("IDG_STEP_PLAN", "1") != "0"
+        self._next = None      # the batch prefetch() named: handed to the step call as its next_* arguments
+        self._alive = []       # id tensors of the last few batches (the side stream may still be reading them)
         self.exchange = None   # replicas (replicated.py): hook(slot, loss) -> bitmap, swaps this batch's gradient rows for
         #                        the average over all ranks' batches before the (linear) backward propagation
 
@@ -207,7 +282,58 @@ class PropagationEngine:
         they are ready long before its step starts (otherwise the step prepares them itself and the
         main stream waits a few microseconds for the side stream)."""
         if self.deterministic:
-            self._prepare(self._take_slot(), users, pos, neg)
+            if self._plan_eligible(int(users.shape[0])):
+                self._next = (users, pos, neg)  # prepared by the NEXT train_step() call, inside the library
+            else:
+                self._prepare(self._take_slot(), users, pos, neg)
+
+    def _plan_eligible(self, B):
+        """The one-call step covers the plain form: deterministic scatter, Adam in the epilogue, no SSL views, no gradient
+        exchange, no receptive-field restriction (graphs >= 4 M rows), a tiled width."""
+        if not (self._plan_on and self.deterministic and self.fuse_adam and self.ssl is None and self.xssl is None
+                and self.sgl is None and self.exchange is None and not self._compact):
+            return False
+        if self.graph is None:
+            return self.d % 4 == 0
+        return not (self._fields and 3 * B * 256 <= self.n) and self.K >= 2 and self.d in (32, 64, 128, 256, 512)
+
+    def _run_plan(self, users, pos, neg, loss_out):
+        B = int(users.shape[0])
+        plan = self._plan
+        if plan is None or plan.key != StepPlan.key_of(self) or B > plan.B_cap:
+            if plan is not None:
+                plan.close()
+            plan = self._plan = StepPlan(self, max(B, plan.B_cap if plan is not None else 0))
+        loss = self.loss if loss_out is None else loss_out
+        nxt = self._next
+        self._next = None
+        if nxt is not None and (nxt[0].data_ptr() == users.data_ptr() or int(nxt[0].shape[0]) > plan.B_cap):
+            nxt = None
+        tok = (users.untyped_storage().data_ptr() ^ (pos.untyped_storage().data_ptr() << 1)
+               ^ (neg.untyped_storage().data_ptr() << 2)) & 0xFFFFFFFFFFFFFFFF | 1
+        self._alive.append((users, pos, neg, nxt))
+        del self._alive[:-4]
+        self.step_count += 1
+        rc = native.lib.idg_step_run_f32(plan._h, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B,
+                                         None if nxt is None else nxt[0].data_ptr(), None if nxt is None else nxt[1].data_ptr(),
+                                         None if nxt is None else nxt[2].data_ptr(), 0 if nxt is None else int(nxt[0].shape[0]),
+                                         tok, loss.data_ptr(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         native.IDG_STEP_STORE_GRAD if self.store_grad else 0, ops._stream())
+        if rc:
+            native.check(rc, "idg_step_run_f32")
+        self._final_version = -1
+        return loss
+
+    @property
+    def touched(self):
+        """Bitmap of the panel rows the last step touched."""
+        if self._plan is not None and self._touched is None:
+            return self._plan.last_bitmap()
+        return self._touched
+
+    @touched.setter
+    def touched(self, value):
+        self._touched = value
 
     # ---- forward + backward: losses [bpr, reg_lambda*reg] and d(sum)/dE0 into self.grad
     @torch.no_grad()
@@ -418,6 +544,15 @@ class PropagationEngine:
     def train_step(self, users, pos, neg, loss_out=None):
         if self.exp_avg is None:
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        if self._plan_eligible(int(users.shape[0])):
+            for t, dt in ((users, torch.int64), (pos, torch.int64), (neg, torch.int64), (loss_out, torch.float32)):
+                if t is not None and not (t.is_cuda and t.is_contiguous() and t.dtype == dt):
+                    raise TypeError("train_step needs contiguous device tensors: int64 ids, a float32 loss vector")
+            self._touched = None
+            return self._run_plan(users, pos, neg, loss_out)
+        if self._next is not None:  # named for the one-call step, which does not apply after all: prepare it the other way
+            nxt, self._next = self._next, None
+            self._prepare(self._take_slot(), *nxt)
         if self.graph is not None and self.deterministic and self.fuse_adam:
             self.step_count += 1
             return self.loss_and_grad(users, pos, neg, loss_out, _adam_step=self.step_count)

@@ -156,6 +156,7 @@ PROTOTYPES = {
     "idg_bpr_unpack_rows_f32": (C.c_int, [c_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, c_vp, C.c_float, c_vp, c_vp,
                                           c_vp, C.c_int, c_vp, c_vp]),
     "idg_bpr_plan_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp]),
+    "idg_bpr_plan_rows_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, c_vp]),
     "idg_bpr_forward_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
                                       C.c_float, c_vp, c_vp, c_vp]),
     "idg_bpr_backward_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_int64,
@@ -166,6 +167,16 @@ PROTOTYPES = {
     "idg_score_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "idg_score_topk_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int,
                                      C.c_int, c_vp, c_vp, c_vp, c_vp]),
+    "idg_step_create": (C.c_int, [c_vp, C.POINTER(c_vp)]),
+    "idg_step_destroy": (C.c_int, [c_vp]),
+    "idg_step_prefetch": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_uint64, c_vp]),
+    "idg_step_run_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_uint64, c_vp, C.c_int64,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_vp]),
+    "idg_step_last_bitmap": (C.c_int, [c_vp, C.POINTER(c_vp)]),
+    "idg_step_synchronize": (C.c_int, [c_vp]),
+    "idg_step_stats": (C.c_int, [c_vp, C.POINTER(C.c_int64)]),
+    "idg_adam_rows_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_int64, c_vp]),
 }
 
 IDG_ADAM_DISCARD_GRAD = 2  # OR-ed into `accumulate` of idg_propagate_mean_bwd_adam(_fields)_f32: do not write the gradient back
@@ -174,6 +185,18 @@ IDG_BPR_TOUCHED_PRESET = 4  # OR-ed into `deterministic`: the touched bitmap alr
 IDG_BPR_PLANNED = 2  # `deterministic` value: the sorted scatter plan is already in the workspace (idg_bpr_plan_f32)
 IDG_GRAPH_SYMMETRIC = 1
 IDG_GRAPH_EXACT_ORDER = 2
+
+
+IDG_STEP_SLOTS, IDG_STEP_STORE_GRAD, IDG_STEP_PACED = 3, 1, 2
+
+
+class StepDesc(C.Structure):
+    """idg_step_desc (include/idgrec.h): every buffer of the one-call training step."""
+    _fields_ = [("graph", c_vp), ("num_users", C.c_int64), ("n", C.c_int64), ("d", C.c_int64), ("n_layers", C.c_int),
+                ("include_layer0", C.c_int), ("reg_lambda", C.c_float), ("params", c_vp), ("grad", c_vp), ("final_panel", c_vp),
+                ("g_final", c_vp), ("exp_avg", c_vp), ("exp_avg_sq", c_vp), ("prop_ws", c_vp), ("batch_capacity", C.c_int64),
+                ("slot_bitmap", c_vp * 3), ("slot_units", c_vp * 3), ("slot_bpr_ws", c_vp * 3), ("side_stream", c_vp),
+                ("flags", C.c_int)]
 
 
 class ShardPrep(C.Structure):
@@ -209,7 +232,7 @@ except ImportError:  # host-only use (sampler / parser / adjacency) works withou
     _torch = None
 
 ACT_TANH, ACT_TANH_BWD = 1, 2  # idg_epilogue.act
-ABI_VERSION = 138  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 139  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

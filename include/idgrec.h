@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 138 /* 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 139 /* 0.5.0: idg_step_* (one library call per training step), idg_adam_rows_f32; 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -476,6 +476,10 @@ int idg_bpr_unpack_rows_f32(const float* messages, int world, int64_t B, int64_t
 #define IDG_BPR_TOUCHED_PRESET 4
 int idg_bpr_plan_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      int64_t num_users, int64_t n, void* ws, void* stream);
+/* idg_bpr_plan_f32 + idg_bpr_touch_rows in one pass over the ids: the plan's first kernel also sets the batch's bits in
+ * `bitmap` (ceil(n / 32) words, zeroed by the caller) — one launch less per step. */
+int idg_bpr_plan_rows_f32(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
+                          int64_t n, void* ws, uint32_t* bitmap, void* stream);
 int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_t num_users,
                         int64_t n, const int64_t* users, const int64_t* pos, const int64_t* neg,
                         int64_t B, int64_t d, float reg_lambda, float* loss, void* ws,
@@ -698,6 +702,77 @@ typedef struct idg_shard_prep {
   void* ev_fork; void* ev_rows; void* ev_plan;
 } idg_shard_prep;
 int idg_shard_prepare(const idg_shard_prep* prep);
+
+/* ------------------------------------------------------------------------------------
+ * DEVICE: ONE library call per training step
+ * (the body of the reference's batch loop, utility/utility_train/trainer.py:42-56 — model(batch) ->
+ *  [bpr, reg] (models/LightGCN.py:54-72 / models/MFBPR.py:29-42), backward(), Adam.step() — which this
+ *  library's host previously drove as ~8 calls + Python slicing per step: the host was within 10 % of
+ *  being the limit of a 0.26 ms step)
+ * ---------------------------------------------------------------------------------- */
+/* A step plan is built once per model: it names every buffer a step touches (all caller-owned — the library
+ * still allocates no device memory) and owns only its events.  idg_step_run_f32 then enqueues, in order:
+ *   - on `side_stream`, the index-only preparation of the NEXT batch (row bitmap, live work units, sorted scatter
+ *     plan: idg_bpr_touch_rows, idg_graph_live_units, idg_bpr_plan_f32) into one of IDG_STEP_SLOTS slots;
+ *   - on `stream`, this batch's step: K forward products with the layer mean at the batch's rows
+ *     (idg_propagate_mean_f32 with out_rows), fused BPR + regulariser storing its gradient rows
+ *     (idg_bpr_fused_f32, IDG_BPR_PLANNED | IDG_BPR_TOUCHED_PRESET), the backward chain with the Adam update in
+ *     its last product's epilogue (idg_propagate_mean_bwd_adam_f32) and the end-of-step event;
+ *   graph == NULL (MFBPR: no propagation): fused BPR on the raw tables with stored gradient rows, then
+ *     idg_adam_rows_f32 (the dense Adam step reading the gradient at the batch's rows only).
+ * Bit-identical to the same chain issued call by call.  IDG_STEP_PACED: the host blocks until the step before the
+ * previous one has finished (two steps stay queued), after which a batch prepared a step ahead is complete when its
+ * own step is enqueued and the step's stream does not wait for the side stream at all (a barrier packet costs ~4.5 us
+ * whether or not its event has fired).
+ * ids_token: any value that changes whenever the id arrays' STORAGE changes (a new epoch's triples): the side stream is
+ * ordered behind `stream` once per token — the arrays may have been produced there — and 0 means "every call". */
+#define IDG_STEP_SLOTS 3
+#define IDG_STEP_STORE_GRAD 1 /* the finished gradient is also written to `grad` (parity tests read it) */
+#define IDG_STEP_PACED 2
+typedef struct idg_step idg_step;
+typedef struct idg_step_desc {
+  const idg_graph* graph;      /* symmetric [n, n] handle, or NULL: no propagation */
+  int64_t num_users, n, d;
+  int n_layers, include_layer0;
+  float reg_lambda;
+  float* params;               /* [n, d] E0: users then items */
+  float* grad;                 /* [n, d] d loss / d E0 (graph: rows outside the batch's receptive field are overwritten) */
+  float* final_panel;          /* [n, d] layer mean (graph != NULL) */
+  float* g_final;              /* [n, d] d loss / d final (graph != NULL) */
+  float* exp_avg; float* exp_avg_sq;   /* [n, d] Adam moments */
+  void* prop_ws;               /* idg_propagate_workspace_bytes(graph, d) (graph != NULL) */
+  int64_t batch_capacity;      /* largest B of any call */
+  uint32_t* slot_bitmap[IDG_STEP_SLOTS];  /* ceil(n / 32) words each, zeroed once */
+  void* slot_units[IDG_STEP_SLOTS];       /* idg_graph_live_units_bytes(graph, 3 * batch_capacity) each (graph != NULL) */
+  void* slot_bpr_ws[IDG_STEP_SLOTS];      /* idg_bpr_workspace_bytes(batch_capacity, d) each */
+  void* side_stream;
+  int flags;
+} idg_step_desc;
+int idg_step_create(const idg_step_desc* desc, idg_step** out);
+int idg_step_destroy(idg_step* plan);
+/* Prepare a batch a step ahead without running a step (the first batch of an epoch). */
+int idg_step_prefetch(idg_step* plan, const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
+                      uint64_t ids_token, void* stream);
+/* next_* (nullable, next_B = 0: none): the batch the NEXT call will run.  loss: 2 floats [bpr, reg_lambda * reg].
+ * adam_step: 1-based step count of this update; lr / betas / eps as idg_adam_step_f32.  flags: IDG_STEP_STORE_GRAD. */
+int idg_step_run_f32(idg_step* plan, const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
+                     const int64_t* next_users, const int64_t* next_pos, const int64_t* next_neg, int64_t next_B,
+                     uint64_t ids_token, float* loss, int64_t adam_step, double lr, double beta1, double beta2, double eps,
+                     int flags, void* stream);
+/* The bitmap of the panel rows the LAST idg_step_run_f32 touched (its slot's; valid until that slot is reused two calls on). */
+int idg_step_last_bitmap(const idg_step* plan, const uint32_t** out_bitmap);
+/* Block the host until every step enqueued through the plan has finished. */
+int idg_step_synchronize(idg_step* plan);
+/* Host-side accounting since the plan was made: out[0] = steps run, out[1] = nanoseconds spent inside idg_step_run_f32,
+ * out[2] = of those, nanoseconds BLOCKED in the pacing wait (the device was the limit, not the host), out[3] = steps whose
+ * stream did not have to wait for the side stream (the prepared batch was seen complete). */
+int idg_step_stats(const idg_step* plan, int64_t out[4]);
+/* Dense Adam (idg_adam_step_f32) whose gradient is read at the rows flagged in `rows` only and taken as ZERO elsewhere:
+ * the update of a table whose step's gradient lives on the batch's <= 3B rows (MFBPR: no propagation spreads it) —
+ * neither a zero-fill of the gradient panel nor its read.  Same arithmetic per element, so bit-identical to
+ * idg_adam_step_f32 on a zero-filled panel. */
+int idg_adam_rows_f32(float* param, const float* grad, const uint32_t* rows, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      int64_t d, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DEVICE: full-rank scoring, train-positive masking, top-K

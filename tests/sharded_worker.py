@@ -383,8 +383,10 @@ def run(rank, world, port, mode, path, steps):
 
         def reduce_sums(a):
             t = torch.from_numpy(a)
+            if rccl:  # (the nccl backend moves device tensors only)
+                t = t.cuda()
             dist.all_reduce(t)
-            return t.numpy()
+            return t.cpu().numpy()
 
         res = eng.evaluate([u for u, _ in own], [t for _, t in own], ex_ptr, ex_items, [5, 10], reduce_sums)
         out.update(ev_recall=res["recall"], ev_precision=res["precision"], ev_ndcg=res["ndcg"])

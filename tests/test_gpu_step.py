@@ -1,0 +1,75 @@
+"""The one-call training step (idg_step_run_f32, id-grec_amd/csrc/idg_step.cpp) against the same chain issued call by call
+from Python (PropagationEngine with the plan switched off): bit-identical weights, moments, losses and gradient over 50
+steps — LightGCN and MFBPR, with and without the one-batch lookahead, a short last batch included."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _setup(g, model, d=64, seed=0):
+    import idgrec_amd.ops as ops
+
+    U, I = int(g["num_users"]), int(g["num_items"])
+    n = U + I
+    rng = np.random.default_rng(seed)
+    W0 = torch.from_numpy((rng.standard_normal((n, d)) * 0.1).astype(np.float32)).cuda()
+    graph = ops.Graph(g["adj_indptr"], g["adj_indices"], g["adj_data"], n, n) if model == "lgcn" else None
+    return U, I, W0, graph
+
+
+def _run(g, model, plan, lookahead, store_grad, steps=50, B=96, K=3):
+    from idgrec_amd.engine import PropagationEngine
+
+    U, I, W0, graph = _setup(g, model)
+    eng = PropagationEngine(graph, U, I, W0.shape[1], K, include_layer0=True, reg_lambda=1e-4, lr=1e-3, params=W0.clone())
+    eng._plan_on = plan
+    eng.store_grad = store_grad
+    tri = torch.from_numpy(np.concatenate([g["sample1"], g["sample2"]])[: steps * B - 37]).cuda()  # the last batch is short
+    cols = [tri[:, c].contiguous() for c in range(3)]
+    losses = torch.zeros((steps, 2), device="cuda")
+    batch = lambda i: tuple(c[i * B:(i + 1) * B] for c in cols)  # noqa: E731
+    for i in range(steps):
+        if lookahead and i + 1 < steps and i % 5 != 3:  # (every fifth batch is NOT announced: prepared inside its own step)
+            eng.prefetch(*batch(i + 1))
+        eng.train_step(*batch(i), loss_out=losses[i])
+    torch.cuda.synchronize()
+    assert (eng._plan is not None) == plan
+    return (eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), losses.clone(),
+            eng.grad.clone() if store_grad else None, eng.touched.clone() if graph is not None else None)
+
+
+@pytest.mark.parametrize("model", ["lgcn", "mf"])
+@pytest.mark.parametrize("lookahead", [True, False])
+@pytest.mark.parametrize("store_grad", [True, False])
+def test_one_call_step_is_the_call_by_call_chain(model, lookahead, store_grad, golden_small):
+    a = _run(golden_small, model, True, lookahead, store_grad)
+    b = _run(golden_small, model, False, lookahead, store_grad)
+    for x, y, name in zip(a[:4], b[:4], ("params", "exp_avg", "exp_avg_sq", "losses")):
+        assert torch.equal(x, y), name
+    if store_grad:
+        assert torch.equal(a[4], b[4]), "grad"
+    if model == "lgcn":
+        assert torch.equal(a[5], b[5]), "touched bitmap of the last step"
+    assert float(a[3][-1].sum()) < float(a[3][0].sum())
+
+
+def test_one_call_step_checks_its_arguments(golden_small):
+    from idgrec_amd.engine import PropagationEngine
+
+    U, I, W0, graph = _setup(golden_small, "lgcn")
+    eng = PropagationEngine(graph, U, I, 64, 3, params=W0.clone())
+    tri = torch.from_numpy(golden_small["sample1"][:64]).cuda()
+    u, p, n = (tri[:, c].contiguous() for c in range(3))
+    eng.train_step(u, p, n)
+    with pytest.raises(TypeError):
+        eng.train_step(tri[:, 0], p, n)  # a strided column
+    with pytest.raises(TypeError):
+        eng.train_step(u.int(), p, n)
+    # a larger batch than the plan was built for: the plan is rebuilt, not overrun
+    tri2 = torch.from_numpy(golden_small["sample1"][:200]).cuda()
+    eng.train_step(*(tri2[:, c].contiguous() for c in range(3)))
+    assert eng._plan.B_cap >= 200
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.params).all()

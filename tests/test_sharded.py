@@ -544,6 +544,26 @@ def test_ranks_on_distinct_devices_over_rccl(K, include0, d, thin, kind, tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["native", "torch"])
+@pytest.mark.parametrize("K,include0,d,thin", [(3, True, 64, False), (3, False, 256, True)])
+def test_rccl_communicators_at_world_one(K, include0, d, thin, kind, tmp_path, golden_small):
+    """The same worker modes as test_ranks_on_distinct_devices_over_rccl on ONE device: backend nccl at
+    world size 1, where RCCL itself runs on every box of the pool — TorchComm's nccl branches (reduce_scatter_tensor into
+    a scratch block copied at wait(), all_gather_into_tensor with the input aliasing its block of the output, the process
+    group called directly) and NativeComm's second-stream route (forced through RCCL: at world size 1 a collective is
+    otherwise not enqueued at all), six steps against the single-device oracle.  What this cannot show is RCCL BETWEEN
+    devices; that stays with the test above."""
+    p = _sparse_problem(K, include0, B=6, steps=6, d=d) if thin else _problem(golden_small, K, include0, B=160, steps=6, d=d, n_slices=3)
+    if thin:
+        p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("nccl-" + kind, path, 6, world=1)
+    assert bool(outs[0]["coherent"])
+    _check(p, outs, 6, rtol=1e-4, atol=2e-7, sparse=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K,include0,d", [(3, True, 64), (2, False, 64), (3, False, 256)])
 def test_one_rank_hip_kernels_match_single_device(K, include0, d, tmp_path):
     """World size 1 (what `bench.py --force-sharded` runs): nothing is agreed or exchanged as rows, but the touched-item
