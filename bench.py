@@ -85,6 +85,20 @@ def parse():
     p.add_argument("--item-slices", type=int, default=0,
                    help="sharded form: row slices of the item panel whose collectives overlap the following slices' products "
                         "(0 = auto: 8 from four ranks on, 4 below, 1 while the panel is under 256 MB)")
+    p.add_argument("--configs-leg", default="auto", choices=["auto", "on", "off"],
+                   help="after the headline, one short measured leg for each of the other single-GPU BASELINE configs — [0] MFBPR "
+                        "B=2048 yelp2018, [2] LightGCN amazon-book, [3] SimGCL amazon-book B=2048 — as the `configs` array of the "
+                        "line (auto: only beside the default headline)")
+    p.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
+                   help="measure roofline.traffic IN THIS RUN: after every other leg, child processes `rocprofv3 --kernel-trace "
+                        "--pmc <counters> -- python3 bench.py --roofline-only ...` (one counter set per pass) re-run the dense "
+                        "launches of the roofline legs' graphs; auto: beside the default headline, when rocprofv3 is on PATH")
+    p.add_argument("--roofline-only", default=None, metavar="GRAPHS",
+                   help="(internal, the child of --pmc) comma-separated graphs: run only the dominant dense launch on each, a few "
+                        "times, and print one JSON line of launch times and tile counts")
+    p.add_argument("--steady-steps", type=int, default=-1,
+                   help="after the timed region, this many further steps in 50-step windows between HIP events -> "
+                        "`steady_state` {min, median, max} (default: 500 beside the default headline, else 0)")
     p.add_argument("--worker", action="store_true",
                    help="(internal) this process is a rank's WORKER: started by the rank's supervisor — the process the "
                         "launcher started, which never touches the GPU — so that a hung collective can be ended from outside "
@@ -111,13 +125,13 @@ def build_workload(args, rank, world):
     t0 = time.time()
     users, items = S.generate(U, I, E, seed=0)
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
-    need = (args.steps + args.warmup) * args.batch
+    need = (args.steps + args.warmup + max(getattr(args, "steady_steps", 0), 0)) * args.batch
     tri, sampler_rate, pos_ptr, items32 = S.draw_triples(args.seed, users, items, U, I, need)  # native sampler, one host core
     return dict(U=U, I=I, E=len(users), indptr=ip, indices=ix, values=dv, triples=tri, prep_s=time.time() - t0,
-                sampler_rate=sampler_rate, pos_ptr=pos_ptr, items32=items32)
+                sampler_rate=sampler_rate, pos_ptr=pos_ptr, items32=items32, users=users, items=items)
 
 
-def cpu_baseline(args, wl, W0):
+def cpu_baseline(args, wl, W0, threads=None, warm=True):
     """The reference's step restated on stock PyTorch CPU ops (oracle/torch_ref.py), timed on
     this box's host cores on a bounded number of steps of the same workload."""
     from oracle.torch_ref import RefStep
@@ -144,23 +158,31 @@ def cpu_baseline(args, wl, W0):
     # 32 on the 2 x 64-core host): probe a few thread counts for one step each, keep the fastest
     ncpu = os.cpu_count() or 1
     best_t, best_dt, i = 1, None, 0
-    for t in sorted({min(ncpu, c) for c in (16, 32, 64)}):
-        torch.set_num_threads(t)
-        one(i)          # warm-up at this thread count
-        dt = one(i + 1)
-        i += 2
-        if best_dt is None or dt < best_dt:
-            best_t, best_dt = t, dt
-    torch.set_num_threads(best_t)
+    if threads:  # a short leg beside the headline: the thread count the headline's probe chose, no warm-up beyond one step
+        best_t = int(threads)
+        torch.set_num_threads(best_t)
+        if warm:
+            one(i)
+            i += 1
+    else:
+        for t in sorted({min(ncpu, c) for c in (16, 32, 64)}):
+            torch.set_num_threads(t)
+            one(i)          # warm-up at this thread count
+            dt = one(i + 1)
+            i += 2
+            if best_dt is None or dt < best_dt:
+                best_t, best_dt = t, dt
+        torch.set_num_threads(best_t)
     done, t_used = 0, 0.0
-    while t_used < args.cpu_seconds and (i + 1) * B <= len(tri):
+    while (t_used < args.cpu_seconds or done == 0) and (i + 1) * B <= len(tri):
         t_used += one(i)
         i += 1
         done += 1
     return {"value": done * B / t_used, "unit": "triples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d steps of the same %s B=%d workload, torch %s CPU ops (oracle/torch_ref.py), %.1f s, "
-                      "fastest of 16/32/64 threads on %d hardware threads"
-                      % (done, args.model, B, torch.__version__, t_used, ncpu)}
+            "sample": "%d steps of the same %s B=%d workload, torch %s CPU ops (oracle/torch_ref.py), %.1f s, %s on %d hardware "
+                      "threads" % (done, args.model, B, torch.__version__, t_used,
+                                   ("%d threads (the headline leg's choice)%s" % (best_t, "" if warm else ", no warm-up step"))
+                                   if threads else "fastest of 16/32/64 threads", ncpu)}
 
 
 def cpu_baseline_scaled(args):
@@ -429,6 +451,8 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
     n, nnz, n_edges = U + I, len(ix), len(users)
     tri = torch.from_numpy(S.draw_triples(args.seed, users, items, U, I, (steps + warmup) * B)[0]).cuda()
     del users, items
+    if before_engine is not None:
+        _save_csr(args, workload, ip, ix, dv, U, I, 64)  # (the d=64 HBM-bound leg's graph: for the traffic children)
     graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
     del ip, ix, dv
     extra = None
@@ -475,6 +499,8 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
 
 def main():
     args = parse()
+    if args.roofline_only:
+        return roofline_only(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         self_launch(args)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.worker and os.environ.get("IDG_BENCH_SUPERVISE", "1") != "0":
@@ -567,12 +593,17 @@ def main():
         worker_phase(args, "done")
         return
 
+    default_headline = args.workload == "yelp2018" and args.dim == 64 and args.model == "LightGCN" and args.layers == 3
+    if args.steady_steps < 0:
+        args.steady_steps = 500 if default_headline else 0
     wl = build_workload(args, rank, world)
     U, I, d, K, B = wl["U"], wl["I"], args.dim, args.layers, args.batch
     n, nnz = U + I, len(wl["indices"])
     graph = None
     if args.model in ("LightGCN", "SimGCL"):
         graph = ops.Graph(wl["indptr"], wl["indices"], wl["values"], n, n, split_threshold=args.split)
+        if default_headline:
+            _save_csr(args, args.workload, wl["indptr"], wl["indices"], wl["values"], U, I, d)
     W0 = S.xavier_uniform_panel(U, I, d, args.seed)
     eng = PropagationEngine(graph, U, I, d, K, include_layer0=(args.model != "SimGCL"), reg_lambda=1e-4, lr=1e-3,
                             deterministic=not args.atomic, params=W0.cuda())
@@ -589,17 +620,18 @@ def main():
     eng.store_grad = os.environ.get("IDG_BENCH_STORE_GRAD") == "1"  # (A/B knob: "1" = the panel is written out as well)
     tri = torch.from_numpy(wl["triples"]).cuda()
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
-    losses = torch.zeros((args.steps + args.warmup, 3 if args.model == "SimGCL" else 2), dtype=torch.float32, device="cuda")
+    n_all = args.steps + args.warmup + args.steady_steps
+    losses = torch.zeros((n_all, 3 if args.model == "SimGCL" else 2), dtype=torch.float32, device="cuda")
 
     # the mini-batches as views of the epoch's id tensors, made once (as the trainer does: list(tools.mini_batch(...)),
     # utility/utility_function/tools.py:55-64), and one row of the loss record per step
-    batches = [(tu[i * B:(i + 1) * B], tp[i * B:(i + 1) * B], tn[i * B:(i + 1) * B]) for i in range(args.steps + args.warmup)]
+    batches = [(tu[i * B:(i + 1) * B], tp[i * B:(i + 1) * B], tn[i * B:(i + 1) * B]) for i in range(n_all)]
     loss_rows = list(losses.unbind(0))
 
     def batch(i):
         return batches[i]
 
-    last = args.warmup + args.steps - 1
+    last = n_all - 1
 
     def step(i):
         if i < last:
@@ -627,6 +659,26 @@ def main():
     dt = time.perf_counter() - t0
     plan1 = eng._plan.stats() if getattr(eng, "_plan", None) is not None else None
 
+    steady = None
+    if args.steady_steps >= 100:
+        # the driver times 20 steps (5 ms): a 2 % round-to-round delta cannot be told from box noise there.  500 further
+        # steps of the same loop, in 50-step windows between HIP events on the step's stream (no host synchronisation in
+        # between: the pipeline stays full), give the spread
+        win = 50
+        n_win = args.steady_steps // win
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
+        i0 = args.warmup + args.steps
+        evs[0].record()
+        for w in range(n_win):
+            for i in range(i0 + w * win, i0 + (w + 1) * win):
+                step(i)
+            evs[w + 1].record()
+        torch.cuda.synchronize()
+        per = sorted(evs[w].elapsed_time(evs[w + 1]) / win for w in range(n_win))
+        steady = {"ms_per_step_min": per[0], "ms_per_step_median": per[len(per) // 2], "ms_per_step_max": per[-1],
+                  "windows": n_win, "steps_per_window": win,
+                  "what": "%d further steps of the same loop right after the timed region, %d-step windows between HIP events "
+                          "on the step's stream: the spread a %d-step timed region cannot show" % (n_win * win, win, args.steps)}
     ms_per_step = dt / args.steps * 1e3
     value = B * args.steps / dt
     out = {
@@ -642,7 +694,7 @@ def main():
                    "batch": B, "dim": d, "layers": K, "scatter": "atomic" if args.atomic else "deterministic",
                    "gradient_panel": "consumed by the Adam update in the last backward product's epilogue, not written out "
                                      "(the trainer path's setting; weights, moments and losses are those of the stored form)"},
-        "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[-1].sum().item())],
+        "loss_first_last": [float(x) for x in (losses[args.warmup].sum().item(), losses[args.warmup + args.steps - 1].sum().item())],
         "host_issue_ms_per_step": t_issue / args.steps * 1e3,
     }
     if plan0 is not None and plan1 is not None and plan1["steps"] - plan0["steps"] == args.steps:
@@ -658,6 +710,8 @@ def main():
                             "what": "host_busy = (issue time of the timed loop - time blocked in the pacing wait) / steps: "
                                     "Python loop + the one call's own work (the next batch's preparation on the side stream, "
                                     "K forward products, fused BPR, backward chain with the Adam epilogue, end-of-step event)"}
+    if steady is not None:
+        out["steady_state"] = steady
     hbm_leg = False
     if graph is not None:
         out["roofline"] = roofline(args, eng, graph, n, nnz, d, K, args.workload, in_step_form=(args.model == "LightGCN"),
@@ -689,8 +743,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, wl, W0.numpy())
     scale_point = args.scale_point == "on" or (args.scale_point == "auto" and args.workload == "yelp2018" and d == 64
                                                and args.model == "LightGCN")
-    del eng, graph, tri, tu, tp, tn, losses
+    del eng, graph, tri, tu, tp, tn, losses, batches, loss_rows
     torch.cuda.empty_cache()
+    if args.configs_leg == "on" or (args.configs_leg == "auto" and default_headline):
+        threads = (out.get("cpu_baseline") or {}).get("cores")
+        out["configs"] = other_configs(args, wl, threads)
     if hbm_leg:
         try:
             out["roofline"]["cache_boundary"] = cache_boundary_leg(args)
@@ -715,7 +772,316 @@ def main():
             out["roofline"]["hbm_bound"] = hbm_bound_leg(args)
         except Exception as exc:  # noqa: BLE001
             out["roofline"]["hbm_bound"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    if hbm_leg:
+        try:
+            out["roofline"]["hbm_reuse_free"] = reuse_free_leg(args)
+        except Exception as exc:  # noqa: BLE001
+            out["roofline"]["hbm_reuse_free"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    if args.pmc == "on" or (args.pmc == "auto" and default_headline and hbm_leg):
+        torch.cuda.empty_cache()
+        try:
+            attach_measured_traffic(args, out)
+        except Exception as exc:  # noqa: BLE001 - the file-based traffic figures stay
+            out["roofline"]["traffic_in_run_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
     args.emit(out)
+
+# ---- graphs handed to the --pmc children: the CSR adjacency a leg built, left in a directory of this run's own
+def _pmc_dir(args, create=False):
+    d = getattr(args, "_pmc_dir_path", None)
+    if d is None and create:
+        import tempfile
+
+        d = args._pmc_dir_path = tempfile.mkdtemp(prefix="idg_bench_pmc_")
+    return d
+
+
+def _pmc_wanted(args):
+    import shutil
+
+    if args.pmc == "off" or getattr(args, "roofline_only", None):
+        return False
+    default_headline = args.workload == "yelp2018" and args.dim == 64 and args.model == "LightGCN" and args.layers == 3
+    return (args.pmc == "on" or default_headline) and shutil.which("rocprofv3") is not None
+
+
+def _save_csr(args, name, ip, ix, dv, U, I, d):
+    """Leave a leg's adjacency for the traffic children (uncompressed .npy files: written and read at memory speed)."""
+    if not _pmc_wanted(args):
+        return
+    root = os.path.join(_pmc_dir(args, create=True), name)
+    os.makedirs(root, exist_ok=True)
+    np.save(os.path.join(root, "indptr.npy"), np.asarray(ip))
+    np.save(os.path.join(root, "indices.npy"), np.asarray(ix))
+    np.save(os.path.join(root, "values.npy"), np.asarray(dv))
+    json.dump({"U": int(U), "I": int(I), "d": int(d)}, open(os.path.join(root, "shape.json"), "w"))
+
+
+def roofline_only(args):
+    """The child of --pmc, run under `rocprofv3 --kernel-trace --pmc ...`: for every graph directory named, the dominant
+    dense launch in the step's form (layers 1..K-1 of the forward), a few times, nothing else.  Prints one JSON line:
+    per graph the tile count (= grid size / 256: how the parent tells the graphs' dispatches apart) and the launch time
+    seen here (under counter collection: not a performance figure)."""
+    import idgrec_amd.ops as ops
+    from idgrec_amd.engine import PropagationEngine
+
+    torch.cuda.set_device(0)
+    res = {}
+    for root in args.roofline_only.split(","):
+        name = os.path.basename(root.rstrip("/"))
+        try:
+            shape = json.load(open(os.path.join(root, "shape.json")))
+            ip, ix, dv = (np.load(os.path.join(root, f + ".npy")) for f in ("indptr", "indices", "values"))
+            U, I, d = shape["U"], shape["I"], shape["d"]
+            n, nnz = U + I, len(ix)
+            graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
+            del ip, ix, dv
+            g = torch.Generator(device="cuda").manual_seed(args.seed)
+            params = (torch.rand((n, d), device="cuda", generator=g) * 2 - 1) * (6.0 / (U + d)) ** 0.5
+            eng = PropagationEngine(graph, U, I, d, 3, include_layer0=True, deterministic=False, params=params)
+            reps = 3 if nnz * d > 4e9 else 20
+
+            def fwd():
+                for k in (1, 2):
+                    eng.forward_layer(k)
+
+            t = _time_launches(fwd, 2, reps, warm=1)
+            res[name] = {"tiles": graph.info()["n_tiles"], "launches": 2 * (reps + 1), "us_per_launch_under_counters": t * 1e6,
+                         "n": n, "nnz": nnz, "d": d}
+            del eng, params, graph
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 - the other graphs still count
+            res[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    print(json.dumps({"roofline_only": res}), flush=True)
+
+
+def attach_measured_traffic(args, out):
+    """roofline.traffic MEASURED IN THIS RUN: after every other leg, two child processes
+
+        rocprofv3 --kernel-trace --pmc <counters> --output-format csv -d <tmp> -o p -- python3 bench.py --roofline-only <graphs>
+
+    (the interpreter directly after `--`; one counter set per pass as MI355X_MICROARCH.md prescribes: FETCH_SIZE alone —
+    it takes 3 of the 4 TCC slots — then WRITE_SIZE with the L2 hit / miss counters) re-run the dense launch on the CSR
+    files the legs left behind.  Per graph: traffic = 2 x FETCH_SIZE + WRITE_SIZE per dispatch (KB units; gfx950 tallies
+    its 128-byte read requests at 64 B), averaged over the dispatches whose grid is that graph's tile count.  Children,
+    never an exec: this process has initialised the GPU."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+
+    exe = shutil.which("rocprofv3")
+    root = _pmc_dir(args)
+    if exe is None or root is None:
+        out["roofline"]["traffic_in_run_error"] = "rocprofv3 not on PATH" if exe is None else "no graph was saved for the children"
+        return
+    graphs = sorted(os.path.join(root, g) for g in os.listdir(root) if os.path.isdir(os.path.join(root, g)) and g != "_prof")
+    t_all = time.perf_counter()
+    counters, child_info, errors = {}, None, []
+    try:
+        for cset in (["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"], ["WRITE_SIZE"]):
+            if cset == ["WRITE_SIZE"] and "WRITE_SIZE" in {c for v in counters.values() for c in v}:
+                break  # (the combined pass worked)
+            pdir = os.path.join(root, "_prof", "_".join(cset))
+            cmd = [exe, "--kernel-trace", "--pmc"] + cset + ["--output-format", "csv", "-d", pdir, "-o", "p", "--",
+                                                           sys.executable, os.path.abspath(__file__), "--roofline-only",
+                                                           ",".join(graphs), "--seed", str(args.seed), "--split", str(args.split)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=float(os.environ.get("IDG_BENCH_PMC_TIMEOUT", "240")))
+            except subprocess.TimeoutExpired:
+                errors.append("pass %s: no result after the timeout" % "+".join(cset))
+                continue
+            lines = [ln for ln in r.stdout.decode("utf-8", "replace").splitlines() if ln.startswith('{"roofline_only"')]
+            if r.returncode != 0 or not lines:
+                errors.append("pass %s: exit status %d: %s" % ("+".join(cset), r.returncode, r.stderr.decode("utf-8", "replace")[-200:]))
+                continue
+            child_info = json.loads(lines[-1])["roofline_only"]
+            grid_of = {v["tiles"] * 256: k for k, v in child_info.items() if "tiles" in v}
+            for f in glob.glob(os.path.join(pdir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    # the plain dense instantiation: spmm_tile_kernel<LPR, 1, 8, true, MINW, EPI = 0, fused>
+                    if not re.search(r"spmm_tile_kernel<\d+, 1, 8, true, \d+, 0, (true|false)>", row["Kernel_Name"]):
+                        continue
+                    g = grid_of.get(int(row["Grid_Size"]))
+                    if g is not None:
+                        counters.setdefault(g, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    took = time.perf_counter() - t_all
+    legs = {"yelp2018": out["roofline"], "synth-10M": out["roofline"].get("hbm_bound"),
+            "regular-15M": out["roofline"].get("hbm_reuse_free"), "synth-1M": out["roofline"].get("cache_boundary")}
+    legs = {k: [v] for k, v in legs.items() if isinstance(v, dict)}
+    for c in out.get("configs") or []:
+        if isinstance(c.get("roofline"), dict) and c.get("graph") and "bytes_gather" in c["roofline"]:
+            legs.setdefault(c["graph"], []).append(c["roofline"])
+    attached = []
+    for name, ctr in counters.items():
+        for leg in legs.get(name, []):
+            if not isinstance(leg, dict) or "FETCH_SIZE" not in ctr or "WRITE_SIZE" not in ctr or "us_per_launch" not in leg:
+                continue
+            fetch = sum(ctr["FETCH_SIZE"]) / len(ctr["FETCH_SIZE"]) * 1024.0
+            write = sum(ctr["WRITE_SIZE"]) / len(ctr["WRITE_SIZE"]) * 1024.0
+            traffic = 2.0 * fetch + write
+            hit = None
+            if "TCC_HIT_sum" in ctr and "TCC_MISS_sum" in ctr:
+                h, m = sum(ctr["TCC_HIT_sum"]), sum(ctr["TCC_MISS_sum"])
+                hit = h / (h + m) if h + m > 0 else None
+            sec = leg["us_per_launch"] * 1e-6
+            leg["traffic_from_file"] = {"traffic": leg.get("traffic"), "source": leg.get("traffic_source")}
+            leg.update(traffic=traffic, traffic_gbs=traffic / sec / 1e9, frac_traffic=traffic / sec / 1e9 / HBM_PEAK_GBS,
+                       traffic_over_bytes_gather=traffic / leg["bytes_gather"] if leg.get("bytes_gather") else None,
+                       traffic_l2_hit_rate=hit,
+                       traffic_source="measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes, "
+                                      "child processes after every other leg), 2 x FETCH_SIZE + WRITE_SIZE (KB units) averaged over %d / "
+                                      "%d dispatches of this graph's dense launch; bytes at the L2s' memory side (Infinity-Cache hits "
+                                      "included); divided by the launch time measured WITHOUT counters in this run"
+                                      % (len(ctr["FETCH_SIZE"]), len(ctr["WRITE_SIZE"])))
+            if name not in attached:
+                attached.append(name)
+    out["roofline"]["traffic_in_run"] = {"graphs": attached, "seconds": took, "errors": errors,
+                                         "child": child_info}
+
+
+def reuse_free_leg(args, d=64):
+    """The dense launch where NOTHING can be reused (synth-10M's Zipf(0.8) item popularity keeps hub rows in
+    the 256 MiB Infinity Cache, so its bytes at the L2s' memory side are an upper bound of DRAM bytes): a regular
+    bipartite graph — 10 M users x 5 M items, every user exactly 20 items, every item exactly 40 users, neighbours
+    scattered over the whole id range (idgrec_amd.synth.regular_adjacency) — 15 M rows, 4e8 entries, gathered panel
+    3.84 GB = 14 x the Infinity Cache.  Every gathered row comes from DRAM, so here fabric bytes ~ DRAM bytes ~ SURVEY §8d's
+    gather bytes and `frac` is a fraction of the HBM peak in the plain sense."""
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+
+    U, I, D = 10_000_000, 5_000_000, 20
+    t0 = time.perf_counter()
+    ip, ix, dv = S.regular_adjacency(U, I, D)
+    t_gen = time.perf_counter() - t0
+    n, nnz = U + I, len(ix)
+    _save_csr(args, "regular-15M", ip, ix, dv, U, I, d)
+    graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
+    del ip, ix, dv
+    r = dense_launch_leg(args, "regular-15M", d=d, K=3, graph=graph, shape=(U, I, n, nnz, nnz // 2), reps=5)
+    r["workload"] = "regular bipartite graph, no reuse: %d users x %d items, every user %d items, every item %d users, neighbours " \
+                    "scattered over the id range; nnz(A)=%d, d=%d (gathered panel %.0f MB = %.1f x the Infinity Cache); drawn in " \
+                    "%.1f s" % (U, I, D, U * D // I, nnz, d, 4 * n * d / 1e6, 4 * n * d / INFINITY_CACHE_BYTES, t_gen)
+    r["bound"] = "hbm (no row is re-read while it could still be cached: fabric bytes ~ DRAM bytes)"
+    del graph
+    torch.cuda.empty_cache()
+    return r
+
+
+def other_configs(args, wl_yelp, cpu_threads):
+    """One short measured leg for each of the other single-GPU BASELINE configs (the driver's line covered one
+    config): [0] MFBPR d=64 yelp2018 B=2048 (configure/MFBPR.txt), [2] LightGCN-3 d=64 amazon-book B=1024
+    (configure/LightGCN.txt), [3] SimGCL-3 d=64 amazon-book B=2048 (configure/SimGCL.txt; models/SimGCL.py:62-90).  Each:
+    100 timed steps after 20 warm-up steps through the same engine path as the headline, the dominant kernel's launch
+    time and roofline fractions, and a CPU leg of a few seconds (the headline's thread count, no probing)."""
+    import argparse
+
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+
+    res = []
+    steps, warm = 100, 20
+    amazon = {}
+
+    def leg(index, model, workload, batch):
+        a = argparse.Namespace(**vars(args))
+        a.model, a.workload, a.batch, a.steps, a.warmup, a.steady_steps, a.cpu_seconds = model, workload, batch, steps, warm, 0, 3.0
+        t0 = time.perf_counter()
+        if workload == "yelp2018":
+            wl = dict(wl_yelp)
+            wl["triples"] = S.draw_triples(a.seed, wl["users"], wl["items"], wl["U"], wl["I"], (steps + warm) * batch)[0]
+        else:
+            if "wl" not in amazon:
+                a.batch = 2048  # (triples for the larger of the two amazon-book legs)
+                amazon["wl"] = build_workload(a, 0, 1)
+                a.batch = batch
+            wl = amazon["wl"]
+        U, I, d, K, B = wl["U"], wl["I"], a.dim, a.layers, batch
+        n, nnz = U + I, len(wl["indices"])
+        graph = None
+        if model != "MFBPR":
+            if "graph" not in amazon:
+                amazon["graph"] = ops.Graph(wl["indptr"], wl["indices"], wl["values"], n, n, split_threshold=a.split)
+                _save_csr(args, workload, wl["indptr"], wl["indices"], wl["values"], U, I, d)
+            graph = amazon["graph"]
+        W0 = S.xavier_uniform_panel(U, I, d, a.seed)
+        eng = PropagationEngine(graph, U, I, d, K, include_layer0=(model != "SimGCL"), reg_lambda=1e-4, lr=1e-3, params=W0.cuda())
+        if model == "SimGCL":
+            import utility.utility_function.tools as tools
+
+            torch.cuda.manual_seed(a.seed)
+            c = tools.read_configuration(os.path.join(ROOT, "configure", "SimGCL.txt"), "SimGCL")
+            eng.ssl = (float(c["epsilon"]), float(c["temperature"]), float(c["ssl_lambda"]))
+        eng.store_grad = False
+        tri = torch.from_numpy(wl["triples"][: (steps + warm) * B]).cuda()
+        cols = [tri[:, c].contiguous() for c in range(3)]
+        batches = [tuple(c[i * B:(i + 1) * B] for c in cols) for i in range(steps + warm)]
+        losses = torch.zeros((steps + warm, 3 if model == "SimGCL" else 2), dtype=torch.float32, device="cuda")
+        rows = list(losses.unbind(0))
+
+        def step(i):
+            if i + 1 < steps + warm:
+                eng.prefetch(*batches[i + 1])
+            eng.train_step(*batches[i], loss_out=rows[i])
+
+        for i in range(warm):
+            step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(warm, warm + steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        one = {"baseline_config": index, "metric": "BPR triples/sec, %s%s dim=%d" % (model, "" if model == "MFBPR" else "-%d" % K, d),
+               "workload": "%s-shape graph: %d users x %d items, %d train edges; %s d=%d B=%d" % (workload, U, I, wl["E"], model, d, B),
+               "graph": workload, "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "triples/s", "steps": steps,
+               "warmup": warm, "loss_first_last": [float(losses[warm].sum().item()), float(losses[-1].sum().item())]}
+        if graph is not None:
+            r = roofline(a, eng, graph, n, nnz, d, K, workload, in_step_form=(model == "LightGCN"),
+                         bitmap=eng.touched if model == "LightGCN" else None, reps=10)
+            one["dominant_kernel_us"] = r["us_per_launch"]
+            one["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                   "frac_traffic", "us_per_launch", "bytes_gather", "bytes_min", "frac_bytes_min",
+                                                   "cache_resident", "tiles")}
+        else:
+            # no propagation: the step is the fused BPR (latency-bound gathers of 3B rows) and the dense Adam update, which
+            # streams the three [n, d] panels in and out: 24 B per element
+            import ctypes as C
+
+            from idgrec_amd import native
+
+            bm = eng.touched
+            call = lambda: native.check(native.lib.idg_adam_rows_f32(  # noqa: E731
+                eng.params.data_ptr(), eng.grad.data_ptr(), bm.data_ptr(), eng.exp_avg.data_ptr(), eng.exp_avg_sq.data_ptr(), n, d,
+                C.c_double(0.0), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), 1, ops._stream()), "idg_adam_rows_f32")
+            sec = _time_launches(call, 1, 20)
+            nbytes = 24 * n * d
+            one["dominant_kernel_us"] = sec * 1e6
+            one["roofline"] = {"bound": "l2+infinity-cache streaming (three %.0f MB panels: cache resident)" % (4 * n * d / 1e6),
+                               "kernel": "adam_rows_kernel (dense Adam, gradient read at the batch's rows only)", "achieved": nbytes / sec / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "us_per_launch": sec * 1e6, "bytes": nbytes, "cache_resident": True}
+        if not args.no_cpu_baseline:
+            one["cpu_baseline"] = cpu_baseline(a, wl, W0.numpy(), threads=cpu_threads or 32, warm=(model != "SimGCL"))
+        one["seconds"] = time.perf_counter() - t0
+        del eng, tri, cols, batches, losses, rows
+        torch.cuda.empty_cache()
+        return one
+
+    for index, model, workload, batch in ((0, "MFBPR", "yelp2018", 2048), (2, "LightGCN", "amazon-book", 1024),
+                                          (3, "SimGCL", "amazon-book", 2048)):
+        try:
+            res.append(leg(index, model, workload, batch))
+        except Exception as exc:  # noqa: BLE001 - the headline stands without it
+            res.append({"baseline_config": index, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])})
+    amazon.clear()
+    torch.cuda.empty_cache()
+    return res
 
 
 def _time_launches(fn, launches_per_call, reps, warm=2):
@@ -822,6 +1188,7 @@ def dense_launch_leg(args, workload, d=64, K=3, graph=None, shape=None, reps=5):
         ip, ix, dv = H.build_norm_adj(U, I, users, items)
         n, nnz, n_edges = U + I, len(ix), len(users)
         del users, items
+        _save_csr(args, workload, ip, ix, dv, U, I, d)
         graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
         del ip, ix, dv
     else:

@@ -79,6 +79,56 @@ def generate(num_users, num_items, num_edges, seed=0, zipf_a=0.8, match_edges=Tr
     return users, items
 
 
+def regular_adjacency(num_users, num_items, user_degree, multiplier=None):
+    """The normalised adjacency (CSR: indptr int64, indices int32, values float32) of a REGULAR bipartite graph with no
+    reuse to exploit: every user has exactly `user_degree` items, every item exactly U * user_degree / I users (which must
+    be whole), and neighbours are scattered over the whole id range — interaction t = u * D + j (j < D) joins user u with
+    item (t * P) mod I for a multiplier P coprime to I.  Uniform item popularity, constant degree: what bench.py's
+    `hbm_reuse_free` leg gathers from, so that the bytes at the L2s' memory side are DRAM bytes and not Infinity-Cache
+    hits on hub rows.  Built directly, without an edge list or a sort of 2e8 keys: a user's items are D
+    values sorted per row; an item's users are ((t0 + m I) // D, m = 0 .. U D / I - 1) with t0 = i P^-1 mod I, ascending
+    as they come.  Every value is 1 / sqrt(D * D_item) (the reference's D^-1/2 A D^-1/2, data_graph.py:46-51, on a graph
+    whose degrees are constant)."""
+    U, I, D = int(num_users), int(num_items), int(user_degree)
+    if U * D % I or D >= I:
+        raise ValueError("regular_adjacency: U * D must be a multiple of I and D < I")
+    Di = U * D // I
+    P = int(multiplier) if multiplier else 2654435761 % I
+    import math
+
+    while math.gcd(P, I) != 1:
+        P += 1
+    Pinv = pow(P, -1, I)
+    n = U + I
+    indptr = np.empty(n + 1, dtype=np.int64)
+    indptr[: U + 1] = np.arange(U + 1, dtype=np.int64) * D
+    indptr[U:] = U * D + np.arange(I + 1, dtype=np.int64) * Di
+    indices = np.empty(U * D + I * Di, dtype=np.int32)
+    # user rows, in blocks of whole users on a few threads (the modular products and the per-row sort release the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def user_block(b):
+        u0, u1 = b
+        t = np.arange(u0 * D, u1 * D, dtype=np.int64)
+        it = ((t % I) * P % I).astype(np.int32).reshape(u1 - u0, D)
+        it.sort(axis=1)
+        indices[u0 * D: u1 * D] = (it + U).reshape(-1)  # columns of the [n, n] adjacency: items start at U
+
+    def item_block(b):
+        i0, i1 = b
+        t0 = (np.arange(i0, i1, dtype=np.int64) * Pinv) % I
+        us = (t0[:, None] + np.arange(Di, dtype=np.int64)[None, :] * I) // D
+        indices[U * D + i0 * Di: U * D + i1 * Di] = us.astype(np.int32).reshape(-1)
+
+    step_u, step_i = max(1, (1 << 22) // D), max(1, (1 << 22) // Di)
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        list(ex.map(user_block, [(a, min(a + step_u, U)) for a in range(0, U, step_u)]))
+        list(ex.map(item_block, [(a, min(a + step_i, I)) for a in range(0, I, step_i)]))
+    val = np.float32(np.power(np.float32(D), np.float32(-0.5)) * np.float32(1.0) * np.power(np.float32(Di), np.float32(-0.5)))
+    values = np.full(len(indices), val, dtype=np.float32)
+    return indptr, indices, values
+
+
 GENERATOR_VERSION = 2  # part of generate_shared's cache file name: bump when generate()'s output changes
 
 

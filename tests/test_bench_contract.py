@@ -48,6 +48,41 @@ def test_single_gpu_line():
 
 
 @pytest.mark.gpu
+def test_headline_carries_the_other_configs_steady_state_and_in_run_traffic():
+    """The default headline's extra fields on a cut-down run (no synth-10M legs): `configs` = one measured leg for each of
+    BASELINE configs[0], [2], [3] with its own roofline object and CPU leg; `steady_state` (50-step windows); the step as
+    ONE library call with the host's busy time; and `roofline.traffic` MEASURED IN THIS RUN by rocprofv3 children (when the
+    profiler is on PATH), the file-based figure kept beside it."""
+    import shutil
+
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1", "--hbm-leg", "off",
+                        "--scale-point", "off", "--epoch-leg", "off", "--configs-leg", "on", "--pmc", "on", "--steady-steps", "200"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and "yelp2018" in d["config"]["workload"]
+    assert d["step_call"]["library_calls_per_step"] == 1 and 0 < d["host_busy_ms_per_step"] <= d["host_issue_ms_per_step"] + 1e-9
+    st = d["steady_state"]
+    assert st["windows"] == 4 and 0 < st["ms_per_step_min"] <= st["ms_per_step_median"] <= st["ms_per_step_max"]
+    cfg = {c["baseline_config"]: c for c in d["configs"]}
+    assert sorted(cfg) == [0, 2, 3], d["configs"]
+    for i, model in ((0, "MFBPR"), (2, "LightGCN"), (3, "SimGCL")):
+        c = cfg[i]
+        assert "error" not in c, c
+        assert model in c["metric"] and c["ms_per_step"] > 0 and c["dominant_kernel_us"] > 0 and c["cpu_baseline"]["value"] > 0
+        assert abs(c["value"] - (2048 if i != 2 else 1024) * 1e3 / c["ms_per_step"]) <= 1e-6 * c["value"]
+        assert c["roofline"]["frac"] > 0 and c["loss_first_last"][1] < c["loss_first_last"][0]
+    assert "amazon-book" in cfg[2]["workload"] and "amazon-book" in cfg[3]["workload"] and "yelp2018" in cfg[0]["workload"]
+    if shutil.which("rocprofv3"):
+        t = d["roofline"]["traffic_in_run"]
+        assert "yelp2018" in t["graphs"] and "amazon-book" in t["graphs"], t
+        assert d["roofline"]["traffic_source"].startswith("measured in this run")
+        # bytes at the L2s' memory side of a cache-resident gather: between the compulsory bytes and the gather bytes
+        assert d["roofline"]["bytes_min"] * 0.5 < d["roofline"]["traffic"] < d["roofline"]["bytes_gather"]
+        assert cfg[2]["roofline"]["traffic_source"].startswith("measured in this run")
+
+
+@pytest.mark.gpu
 def test_two_rank_line():
     """The launch the driver uses for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks on
     one GPU over gloo: the user-row-sharded step, exchanged row counts reported, item table coherent across ranks."""
