@@ -406,6 +406,182 @@ __device__ __forceinline__ void flag_candidates(const f32x16& acc0, const f32x16
   }
 }
 
+// The consumer half of the producer / consumer kernels (score_topk_spec_kernel: exact fp32 scores; score_topk_bf16_kernel:
+// split-bf16 approximations of them): wave `wave` (0..3) owns users 16 wave .. 16 wave + 15 of the block's 64.
+template <bool SIGMOID, bool MAXONLY>
+__device__ __forceinline__ void topk_consume(float (*s_buf)[FT_USERS * FT_LD], float* s_floor, uint32_t (*s_flag)[FT_USERS],
+                                             const int wave, const int lane, const int64_t* __restrict__ users, int64_t Bt,
+                                             const int64_t b0, const int64_t c_lo, const int64_t c_hi, const int n_chunks,
+                                             const int n_slabs, const int64_t* __restrict__ excl_indptr,
+                                             const int32_t* __restrict__ excl_items, int k,
+                                             unsigned long long* __restrict__ partial,
+                                             const unsigned long long* __restrict__ bound, float* __restrict__ chunk_max,
+                                             const float* __restrict__ floor0) {
+  // ================= consumers: wave w owns users 16w .. 16w+15 of the block
+#ifndef IDG_TOPK_CONS_PRIO
+#define IDG_TOPK_CONS_PRIO 2
+#endif
+  // Vector issue on a SIMD is arbitrated by priority, then age: the consumers are the younger half of the workgroup
+  // and would get what the producers' MFMA stream leaves over.  Their chains of short dependent instructions are what
+  // the slab time hangs on, and an MFMA that issues a few cycles late costs the paced matrix pipe nothing.
+  __builtin_amdgcn_s_setprio(IDG_TOPK_CONS_PRIO);
+  // Train-item masking (batch_test.py:62-65).  Exclusion lists are ascending.  Lane (mu, mj) = (lane / 4, lane % 4)
+  // holds entry mj of a 4-entry window into the list of user mu of this wave, starting at the user's cursor (parked at
+  // the first train item >= c_lo).  Per slab ONE compare pair finds the window entries inside the slab (their LDS
+  // scores are overwritten before selection), one ballot counts how many entries each user has passed (a prefix of
+  // its window: ascending), cursors advance and the windows of users that advanced are re-read — a load whose result
+  // is first needed at the next slab.  A user that used up all four entries may have more inside this slab: rare, the
+  // loop then goes round again.  (The alternating kernel's 32-entry windows per user PAIR cost 8 dependent
+  // compare / ballot / branch rounds per slab: 6,500 of this wave's ~16,000 cycles per slab, measured.)
+  const int mu = lane >> 2, mj = lane & 3;
+  int64_t m_cur = 0, m_end = 0;
+  if (excl_indptr && b0 + FT_UPW * wave + mu < Bt) {
+    const int64_t uid = users[b0 + FT_UPW * wave + mu];  // (the exclusion lists are indexed by user id)
+    int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
+    m_end = hi;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
+      else hi = mid;
+    }
+    m_cur = lo;
+  }
+  int32_t m_win = (excl_indptr && m_cur + mj < m_end) ? excl_items[m_cur + mj] : 0x7fffffff;
+  // Per user of this wave: the list (lane = rank).  Its k-th key is wave-uniform, but it is fetched where needed with
+  // ds_bpermute into VECTOR registers on purpose: an fp32 MFMA runs on the SIMD's own FMA lanes (the fp32 matrix and
+  // vector peaks are the same number), so while the producers' MFMAs execute no other vector instruction of this SIMD
+  // does — every vector-class instruction of the select waits for an MFMA boundary (measured: halving the MFMAs takes
+  // exactly their pipe time off the kernel; ~2,800 cycles for the ~85 vector instructions of one (user, slab) pair).
+  // Scalar and LDS-class instructions do not wait, so the select is written to use them: thresholds broadcast with
+  // ds_bpermute instead of v_readlane pairs, no scalar-register spills (v_readlane / v_writelane are vector-class),
+  // keys built in three vector instructions.
+  unsigned long long best[FT_UPW];
+#pragma unroll
+  for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull;
+  unsigned long long my_bound = ~0ull;
+  if (bound && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_bound = bound[b0 + FT_UPW * wave + lane];
+  float my_floor = -__builtin_inff();  // lane uu: the floor user uu of this wave starts every chunk with (floor0)
+  if (!MAXONLY && floor0 && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_floor = floor0[b0 + FT_UPW * wave + lane];
+  auto key_of = [](float sc, uint32_t not_item) {  // make_key with the item id already complemented
+    const uint32_t ub = __float_as_uint(sc);
+    const uint32_t hi = ub ^ ((uint32_t)((int32_t)ub >> 31) | 0x80000000u);
+    return ((unsigned long long)hi << 32) | not_item;
+  };
+  auto floor_of = [](unsigned long long tk) { return tk ? key_score(tk) : -__builtin_inff(); };
+  // feed the keys of this wave's lanes (0 = none) that beat the k-th key into the list; true if the list changed
+  auto offer = [&](unsigned long long& list, unsigned long long& tk, unsigned long long key) {
+    unsigned long long m = __ballot(key > tk);
+    const bool any = m != 0ull;
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      list_insert(list, readlane_u64(key, src), lane);
+      tk = shfl_u64(list, k - 1);
+      m = (m & (m - 1)) & __ballot(key > tk);
+    }
+    return any;
+  };
+
+  for (int t = 0; t < n_slabs; ++t) {
+    const int64_t slab = c_lo + (int64_t)t * FT_SLAB;
+    __syncthreads();  // barrier t: slab t is complete in buffer t & 1
+    float* s_score = s_buf[t & 1];
+    const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
+    if (excl_indptr) {
+      const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
+      while (true) {
+        const bool passed = m_win < (int32_t)slab_end;
+        if (passed && m_win >= (int32_t)slab) s_score[(FT_UPW * wave + mu) * FT_LD + (m_win - (int32_t)slab)] = masked;
+        const unsigned long long pm = __ballot(passed);
+        if (pm == 0ull) break;  // nobody has a train item up to the end of this slab
+        const int adv = __popc((uint32_t)(pm >> (4 * mu)) & 0xFu);  // entries user mu has passed
+        m_cur += adv;
+        const bool again = __ballot(adv == 4) != 0ull;  // a whole window used up: that user may have more in this slab
+        if (adv > 0) m_win = m_cur + mj < m_end ? excl_items[m_cur + mj] : 0x7fffffff;
+        if (!again) break;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const bool in0 = slab + lane < c_hi, in1 = slab + 64 + lane < c_hi;
+    const uint32_t not_item0 = ~(uint32_t)(slab + lane), not_item1 = ~(uint32_t)(slab + 64 + lane);
+    if (MAXONLY) {
+      // phase one of a many-chunk call: the best score per user over the chunk's first FLOOR_SLABS slabs, nothing else
+      // (lane uu keeps user uu's running maximum)
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        const int u = FT_UPW * wave + uu;
+        float m = fmaxf(in0 ? s_score[u * FT_LD + lane] : -__builtin_inff(), in1 ? s_score[u * FT_LD + 64 + lane] : -__builtin_inff());
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+        if (lane == uu) my_floor = fmaxf(my_floor, m);
+      }
+      if (t + 1 == n_slabs && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt)
+        chunk_max[(b0 + FT_UPW * wave + lane) * n_chunks + blockIdx.x] = my_floor;
+      continue;
+    }
+    if (t == 0 && !floor0) {
+      // first slab of the chunk: one 128-key sorting network per user fills its list
+      for (int uu = 0; uu < FT_UPW; ++uu) {
+        const int u = FT_UPW * wave + uu;
+        unsigned long long k0 = in0 ? key_of(s_score[u * FT_LD + lane], not_item0) : 0ull;
+        unsigned long long k1 = in1 ? key_of(s_score[u * FT_LD + 64 + lane], not_item1) : 0ull;
+        if (bound) {
+          const unsigned long long bd = shfl_u64(my_bound, uu);
+          k0 = k0 < bd ? k0 : 0ull;
+          k1 = k1 < bd ? k1 : 0ull;
+        }
+        wave_sort128_desc(k0, k1, lane);
+        const unsigned long long tk = shfl_u64(k0, k - 1);
+        if (lane == 0) s_floor[u] = floor_of(tk);
+#pragma unroll
+        for (int q = 0; q < FT_UPW; ++q) best[q] = q == uu ? k0 : best[q];
+      }
+      if (lane < FT_UPW) s_flag[0][FT_UPW * wave + lane] = 0u;  // (slab 0 flagged everybody: floors were -inf)
+      continue;
+    }
+    // the producers have flagged the users that may have a candidate in this slab (flag_candidates): one LDS read for
+    // the wave's users; the flags are cleared for the slab after next, which reuses this buffer
+    uint32_t fl_ = 0u;
+    if (lane < FT_UPW) {
+      fl_ = s_flag[t & 1][FT_UPW * wave + lane];
+      s_flag[t & 1][FT_UPW * wave + lane] = 0u;
+    }
+    const uint32_t cand = (uint32_t)__ballot(fl_ != 0u);
+#if defined(IDG_TOPK_PROBE) && IDG_TOPK_PROBE == 1  // (timing probe 1, wrong results: the producers on their own)
+    continue;
+#endif
+    if (cand == 0) continue;
+#pragma unroll
+    for (int uu = 0; uu < FT_UPW; ++uu) {
+      if (!((cand >> uu) & 1u)) continue;
+      const int u = FT_UPW * wave + uu;
+      const float s0 = s_score[u * FT_LD + lane], s1 = s_score[u * FT_LD + 64 + lane];
+      // columns past the chunk hold scores of a clamped item: in0 / in1 drop them.  No float pre-filter: the keys
+      // are three vector instructions each and the offer's own first compare is the filter
+      unsigned long long c0 = in0 ? key_of(s0, not_item0) : 0ull;
+      unsigned long long c1 = in1 ? key_of(s1, not_item1) : 0ull;
+      if (bound) {
+        const unsigned long long bd = shfl_u64(my_bound, uu);
+        c0 = c0 < bd ? c0 : 0ull;
+        c1 = c1 < bd ? c1 : 0ull;
+      }
+      float fl0 = -__builtin_inff();
+      if (floor0) {  // nothing below the user's starting floor can reach the final list (the chunk's list may stay short)
+        fl0 = __shfl(my_floor, uu, WAVE);
+        c0 = s0 >= fl0 ? c0 : 0ull;
+        c1 = s1 >= fl0 ? c1 : 0ull;
+      }
+      unsigned long long tk = shfl_u64(best[uu], k - 1);
+      const bool ch0 = offer(best[uu], tk, c0);
+      const bool ch1 = offer(best[uu], tk, c1);
+      if ((ch0 || ch1) && lane == 0) s_floor[u] = fmaxf(fl0, floor_of(tk));
+    }
+  }
+#pragma unroll
+  for (int uu = 0; uu < FT_UPW; ++uu) {
+    const int64_t b = b0 + FT_UPW * wave + uu;
+    if (b < Bt) partial[(b * n_chunks + blockIdx.x) * 64 + lane] = best[uu];
+  }
+}
+
 // Calls with few user tiles cut the catalogue into many short chunks (to fill the chip), and a chunk's list starts
 // empty: while it is young nearly every (user, slab) pair holds a candidate and pays the ~2,800-cycle select — at 1024
 // users per call (the reference's test_batch_size shape, batch_test.py:52-68) that was 190 of a launch's 240 us.  So
@@ -588,169 +764,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
   }
 
   // ================= consumers: wave w owns users 16w .. 16w+15 of the block
-  const int wave = wave8 - BLOCK / WAVE;
-#ifndef IDG_TOPK_CONS_PRIO
-#define IDG_TOPK_CONS_PRIO 2
-#endif
-  // Vector issue on a SIMD is arbitrated by priority, then age: the consumers are the younger half of the workgroup
-  // and would get what the producers' MFMA stream leaves over.  Their chains of short dependent instructions are what
-  // the slab time hangs on, and an MFMA that issues a few cycles late costs the paced matrix pipe nothing.
-  __builtin_amdgcn_s_setprio(IDG_TOPK_CONS_PRIO);
-  // Train-item masking (batch_test.py:62-65).  Exclusion lists are ascending.  Lane (mu, mj) = (lane / 4, lane % 4)
-  // holds entry mj of a 4-entry window into the list of user mu of this wave, starting at the user's cursor (parked at
-  // the first train item >= c_lo).  Per slab ONE compare pair finds the window entries inside the slab (their LDS
-  // scores are overwritten before selection), one ballot counts how many entries each user has passed (a prefix of
-  // its window: ascending), cursors advance and the windows of users that advanced are re-read — a load whose result
-  // is first needed at the next slab.  A user that used up all four entries may have more inside this slab: rare, the
-  // loop then goes round again.  (The alternating kernel's 32-entry windows per user PAIR cost 8 dependent
-  // compare / ballot / branch rounds per slab: 6,500 of this wave's ~16,000 cycles per slab, measured.)
-  const int mu = lane >> 2, mj = lane & 3;
-  int64_t m_cur = 0, m_end = 0;
-  if (excl_indptr && b0 + FT_UPW * wave + mu < Bt) {
-    const int64_t uid = users[b0 + FT_UPW * wave + mu];
-    int64_t lo = excl_indptr[uid], hi = excl_indptr[uid + 1];
-    m_end = hi;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (excl_items[mid] < (int32_t)c_lo) lo = mid + 1;
-      else hi = mid;
-    }
-    m_cur = lo;
-  }
-  int32_t m_win = (excl_indptr && m_cur + mj < m_end) ? excl_items[m_cur + mj] : 0x7fffffff;
-  // Per user of this wave: the list (lane = rank).  Its k-th key is wave-uniform, but it is fetched where needed with
-  // ds_bpermute into VECTOR registers on purpose: an fp32 MFMA runs on the SIMD's own FMA lanes (the fp32 matrix and
-  // vector peaks are the same number), so while the producers' MFMAs execute no other vector instruction of this SIMD
-  // does — every vector-class instruction of the select waits for an MFMA boundary (measured: halving the MFMAs takes
-  // exactly their pipe time off the kernel; ~2,800 cycles for the ~85 vector instructions of one (user, slab) pair).
-  // Scalar and LDS-class instructions do not wait, so the select is written to use them: thresholds broadcast with
-  // ds_bpermute instead of v_readlane pairs, no scalar-register spills (v_readlane / v_writelane are vector-class),
-  // keys built in three vector instructions.
-  unsigned long long best[FT_UPW];
-#pragma unroll
-  for (int uu = 0; uu < FT_UPW; ++uu) best[uu] = 0ull;
-  unsigned long long my_bound = ~0ull;
-  if (bound && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_bound = bound[b0 + FT_UPW * wave + lane];
-  float my_floor = -__builtin_inff();  // lane uu: the floor user uu of this wave starts every chunk with (floor0)
-  if (!MAXONLY && floor0 && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt) my_floor = floor0[b0 + FT_UPW * wave + lane];
-  auto key_of = [](float sc, uint32_t not_item) {  // make_key with the item id already complemented
-    const uint32_t ub = __float_as_uint(sc);
-    const uint32_t hi = ub ^ ((uint32_t)((int32_t)ub >> 31) | 0x80000000u);
-    return ((unsigned long long)hi << 32) | not_item;
-  };
-  auto floor_of = [](unsigned long long tk) { return tk ? key_score(tk) : -__builtin_inff(); };
-  // feed the keys of this wave's lanes (0 = none) that beat the k-th key into the list; true if the list changed
-  auto offer = [&](unsigned long long& list, unsigned long long& tk, unsigned long long key) {
-    unsigned long long m = __ballot(key > tk);
-    const bool any = m != 0ull;
-    while (m) {
-      const int src = __builtin_ctzll(m);
-      list_insert(list, readlane_u64(key, src), lane);
-      tk = shfl_u64(list, k - 1);
-      m = (m & (m - 1)) & __ballot(key > tk);
-    }
-    return any;
-  };
-
-  for (int t = 0; t < n_slabs; ++t) {
-    const int64_t slab = c_lo + (int64_t)t * FT_SLAB;
-    __syncthreads();  // barrier t: slab t is complete in buffer t & 1
-    float* s_score = s_buf[t & 1];
-    const int64_t slab_end = slab + FT_SLAB < c_hi ? slab + FT_SLAB : c_hi;
-    if (excl_indptr) {
-      const float masked = SIGMOID ? -__builtin_inff() : -1.0f;  // ranks as the value -1 in either domain
-      while (true) {
-        const bool passed = m_win < (int32_t)slab_end;
-        if (passed && m_win >= (int32_t)slab) s_score[(FT_UPW * wave + mu) * FT_LD + (m_win - (int32_t)slab)] = masked;
-        const unsigned long long pm = __ballot(passed);
-        if (pm == 0ull) break;  // nobody has a train item up to the end of this slab
-        const int adv = __popc((uint32_t)(pm >> (4 * mu)) & 0xFu);  // entries user mu has passed
-        m_cur += adv;
-        const bool again = __ballot(adv == 4) != 0ull;  // a whole window used up: that user may have more in this slab
-        if (adv > 0) m_win = m_cur + mj < m_end ? excl_items[m_cur + mj] : 0x7fffffff;
-        if (!again) break;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    const bool in0 = slab + lane < c_hi, in1 = slab + 64 + lane < c_hi;
-    const uint32_t not_item0 = ~(uint32_t)(slab + lane), not_item1 = ~(uint32_t)(slab + 64 + lane);
-    if (MAXONLY) {
-      // phase one of a many-chunk call: the best score per user over the chunk's first FLOOR_SLABS slabs, nothing else
-      // (lane uu keeps user uu's running maximum)
-      for (int uu = 0; uu < FT_UPW; ++uu) {
-        const int u = FT_UPW * wave + uu;
-        float m = fmaxf(in0 ? s_score[u * FT_LD + lane] : -__builtin_inff(), in1 ? s_score[u * FT_LD + 64 + lane] : -__builtin_inff());
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
-        if (lane == uu) my_floor = fmaxf(my_floor, m);
-      }
-      if (t + 1 == n_slabs && lane < FT_UPW && b0 + FT_UPW * wave + lane < Bt)
-        chunk_max[(b0 + FT_UPW * wave + lane) * n_chunks + blockIdx.x] = my_floor;
-      continue;
-    }
-    if (t == 0 && !floor0) {
-      // first slab of the chunk: one 128-key sorting network per user fills its list
-      for (int uu = 0; uu < FT_UPW; ++uu) {
-        const int u = FT_UPW * wave + uu;
-        unsigned long long k0 = in0 ? key_of(s_score[u * FT_LD + lane], not_item0) : 0ull;
-        unsigned long long k1 = in1 ? key_of(s_score[u * FT_LD + 64 + lane], not_item1) : 0ull;
-        if (bound) {
-          const unsigned long long bd = shfl_u64(my_bound, uu);
-          k0 = k0 < bd ? k0 : 0ull;
-          k1 = k1 < bd ? k1 : 0ull;
-        }
-        wave_sort128_desc(k0, k1, lane);
-        const unsigned long long tk = shfl_u64(k0, k - 1);
-        if (lane == 0) s_floor[u] = floor_of(tk);
-#pragma unroll
-        for (int q = 0; q < FT_UPW; ++q) best[q] = q == uu ? k0 : best[q];
-      }
-      if (lane < FT_UPW) s_flag[0][FT_UPW * wave + lane] = 0u;  // (slab 0 flagged everybody: floors were -inf)
-      continue;
-    }
-    // the producers have flagged the users that may have a candidate in this slab (flag_candidates): one LDS read for
-    // the wave's users; the flags are cleared for the slab after next, which reuses this buffer
-    uint32_t fl_ = 0u;
-    if (lane < FT_UPW) {
-      fl_ = s_flag[t & 1][FT_UPW * wave + lane];
-      s_flag[t & 1][FT_UPW * wave + lane] = 0u;
-    }
-    const uint32_t cand = (uint32_t)__ballot(fl_ != 0u);
-#if defined(IDG_TOPK_PROBE) && IDG_TOPK_PROBE == 1  // (timing probe 1, wrong results: the producers on their own)
-    continue;
-#endif
-    if (cand == 0) continue;
-#pragma unroll
-    for (int uu = 0; uu < FT_UPW; ++uu) {
-      if (!((cand >> uu) & 1u)) continue;
-      const int u = FT_UPW * wave + uu;
-      const float s0 = s_score[u * FT_LD + lane], s1 = s_score[u * FT_LD + 64 + lane];
-      // columns past the chunk hold scores of a clamped item: in0 / in1 drop them.  No float pre-filter: the keys
-      // are three vector instructions each and the offer's own first compare is the filter
-      unsigned long long c0 = in0 ? key_of(s0, not_item0) : 0ull;
-      unsigned long long c1 = in1 ? key_of(s1, not_item1) : 0ull;
-      if (bound) {
-        const unsigned long long bd = shfl_u64(my_bound, uu);
-        c0 = c0 < bd ? c0 : 0ull;
-        c1 = c1 < bd ? c1 : 0ull;
-      }
-      float fl0 = -__builtin_inff();
-      if (floor0) {  // nothing below the user's starting floor can reach the final list (the chunk's list may stay short)
-        fl0 = __shfl(my_floor, uu, WAVE);
-        c0 = s0 >= fl0 ? c0 : 0ull;
-        c1 = s1 >= fl0 ? c1 : 0ull;
-      }
-      unsigned long long tk = shfl_u64(best[uu], k - 1);
-      const bool ch0 = offer(best[uu], tk, c0);
-      const bool ch1 = offer(best[uu], tk, c1);
-      if ((ch0 || ch1) && lane == 0) s_floor[u] = fmaxf(fl0, floor_of(tk));
-    }
-  }
-#pragma unroll
-  for (int uu = 0; uu < FT_UPW; ++uu) {
-    const int64_t b = b0 + FT_UPW * wave + uu;
-    if (b < Bt) partial[(b * n_chunks + blockIdx.x) * 64 + lane] = best[uu];
-  }
+  topk_consume<SIGMOID, MAXONLY>(s_buf, s_floor, s_flag, wave8 - BLOCK / WAVE, lane, users, Bt, b0, c_lo, c_hi, n_chunks, n_slabs,
+                                 excl_indptr, excl_items, k, partial, bound, chunk_max, floor0);
 }
 
 // one wave per batch row: fold the per-chunk lists (each holds its chunk's true top-k in lanes < k),
@@ -759,7 +774,8 @@ template <bool SIGMOID>
 __global__ __launch_bounds__(BLOCK) void topk_merge_kernel(const unsigned long long* __restrict__ partial, int64_t Bt,
                                                            int n_chunks, int k, int64_t* __restrict__ out_idx,
                                                            float* __restrict__ out_val, int64_t ld_out, int64_t col0,
-                                                           unsigned long long* __restrict__ bound_out) {
+                                                           unsigned long long* __restrict__ bound_out,
+                                                           unsigned long long* __restrict__ keys_out) {
   const int lane = threadIdx.x % WAVE;
   const int64_t b = (int64_t)blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
   if (b >= Bt) return;
@@ -774,6 +790,10 @@ __global__ __launch_bounds__(BLOCK) void topk_merge_kernel(const unsigned long l
     for (int q = 0; q < 8; ++q) a[q] = (lane < k && c0 + q < n_chunks) ? partial[(b * n_chunks + c0 + q) * 64 + lane] : 0ull;
 #pragma unroll
     for (int q = 0; q < 8; ++q) list_offer(best, tau, a[q], k, lane);
+  }
+  if (keys_out) {  // (the candidate list of the split-bf16 pre-filter: raw keys, 0 = no candidate)
+    keys_out[b * 64 + lane] = lane < k ? best : 0ull;
+    return;
   }
   if (lane < k) {
     out_idx[b * ld_out + col0 + lane] = (int64_t)key_item(best);
@@ -810,6 +830,8 @@ __global__ __launch_bounds__(BLOCK) void chunk_floor_kernel(const float* __restr
   if (lane == 0) floor0[b] = found;
 }
 
+#include "idg_score_bf16.inc"
+
 }  // namespace
 
 extern "C" {
@@ -845,13 +867,29 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 // for 317 calls) and the alternating kernel, with its ~1024 short workgroups, is kept.
 static inline bool floor_phase(int form, int nc, int64_t ci, int k);
 
-static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr, int k = 0) {
+// form 2 (round 5, OPT-IN: IDG_TOPK_BF16=1): the producer / consumer kernel on split-bf16 operands + exact re-scoring of 64
+// candidates per user (idg_score_bf16.inc): d = 64, one pass, k small enough that the 64-key list leaves a margin; one
+// workgroup per CU.  Exact (bit-identical lists and values, tests/test_gpu_parity.py) and MEASURED SLOWER than form 1
+// (yelp2018 size, one call: 3.36 ms vs 1.95; profiles/r05/topk_bf16_probe.txt): with the matrix time cut five-fold the
+// streaming select is what a slab costs, and the 64-key list the guarantee needs makes the select dearer (at a 20-key
+// list — no guarantee, timing probe IDG_TOPK_BF16_LIST=20 — the main kernel takes 1.73 ms).  Kept as the record of
+// VERDICT r04's experiment; the next step it points to is a select without insertions.
+static inline bool bf16_prefilter_applies(int64_t user_tiles, int64_t d, int k) {
+  const char* v = std::getenv("IDG_TOPK_BF16");
+  if (!(v && *v && std::atoi(v) == 1)) return false;
+  return user_tiles >= 16 && d == 64 && k <= 48;
+}
+
+static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr, int k = 0,
+                                  int64_t d = 0) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
-  const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 forces a kernel
+  const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 / 2 forces a kernel
   const int forced = fv && *fv ? std::atoi(fv) : -1;
-  const int form = forced >= 0 ? forced : (user_tiles >= 16 ? 1 : 0);
+  int form = forced >= 0 ? forced : (user_tiles >= 16 ? 1 : 0);
+  if (forced < 0 && form == 1 && k > 0 && bf16_prefilter_applies(user_tiles, d, k)) form = 2;
+  if (form == 2 && !(d == 64 && k >= 1 && k <= 64)) form = 1;  // (a forced form 2 outside its domain)
   if (form_out) *form_out = form;
-  const int64_t tuned = form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
+  const int64_t tuned = form == 2 ? 256 / user_tiles : form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
   const int64_t max_nc = (I + 1023) / 1024;
   auto finish = [&](int64_t nc, int64_t* ci_out) {
     if (const char* v = std::getenv("IDG_TOPK_WGS"))
@@ -871,7 +909,7 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
   // partial-list workspace grows with the chunk count: calls of 17..256 user tiles at k + 2 chunks up to ~16x).
   // Measured where it pays: calls of 1024 users (16 tiles) at yelp2018 / amazon-book size; beyond 64 user tiles the
   // tuned count is already <= 8 chunks and the start-up the floor saves is a small share of a launch.
-  if (form == 1 && tuned > 1 && tuned < k + 2 && k <= 64 && user_tiles <= 64) {
+  if (form >= 1 && tuned > 1 && tuned < k + 2 && k <= 64 && user_tiles <= 64) {
     int64_t ci2;
     const int64_t nc2 = finish(k + 2, &ci2);
     if (floor_phase(form, (int)nc2, ci2, k)) nc = nc2, ci = ci2;
@@ -886,19 +924,55 @@ static_assert(FLOOR_SLABS >= 1, "IDG_TOPK_FLOOR_SLABS must be >= 1: chunk_floor_
 static inline bool floor_phase(int form, int nc, int64_t ci, int k) {
   const char* v = std::getenv("IDG_TOPK_FLOOR");
   if (v && *v && std::atoi(v) == 0) return false;
-  return form == 1 && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
+  return form >= 1 && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
+}
+
+// extra scratch of form 2, behind the partial lists (+ chunk maxima / floors): offsets in bytes, 256-byte aligned
+struct Bf16Ws {
+  size_t vs, us, vnorm, unorm, cand, scalars, total;
+};
+static inline Bf16Ws bf16_layout(int64_t Bt, int64_t I, int64_t d, size_t base) {
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  Bf16Ws w{};
+  size_t o = up(base);
+  w.vs = o, o = up(o + (size_t)I * d * 4);
+  w.us = o, o = up(o + (size_t)Bt * d * 4);
+  w.vnorm = o, o = up(o + (size_t)I * 4);
+  w.unorm = o, o = up(o + (size_t)Bt * 4);
+  w.cand = o, o = up(o + (size_t)Bt * 64 * 8);
+  w.scalars = o, o = up(o + 16);  // [0] max item norm (float bits), [1] users redone by brute force
+  w.total = o;
+  return w;
 }
 
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
-  (void)d;
   if (Bt <= 0 || I <= 0) return 0;
   int nc, form;
   int64_t ci;
-  fused_geometry(Bt, I, &nc, &ci, &form, k);
+  fused_geometry(Bt, I, &nc, &ci, &form, k, d);
   // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes + (two-phase form) one
-  // maximum per (user, chunk) and one starting floor per user
-  return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
-         (floor_phase(form, nc, ci, k) ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
+  // maximum per (user, chunk) and one starting floor per user + (form 2) the split tables, norms and candidate lists
+  const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
+                      (floor_phase(form, nc, ci, k) ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
+  return form == 2 ? bf16_layout(Bt, I, d, base).total : base;
+}
+
+int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int64_t info[4], void* stream) {
+  IDG_REQUIRE(info && Bt > 0 && I > 0 && d > 0 && k >= 1, "idg_score_topk_info: bad argument");
+  int nc, form;
+  int64_t ci;
+  fused_geometry(Bt, I, &nc, &ci, &form, k, d);
+  info[0] = form, info[1] = nc, info[2] = floor_phase(form, nc, ci, k) ? 1 : 0, info[3] = -1;
+  if (form == 2 && ws) {
+    const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) +
+                        (info[2] ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
+    const Bf16Ws w = bf16_layout(Bt, I, d, base);
+    uint32_t redone = 0;
+    IDG_HIP(hipMemcpyAsync(&redone, reinterpret_cast<const char*>(ws) + w.scalars + 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    IDG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    info[3] = redone;
+  }
+  return IDG_OK;
 }
 
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users, int64_t Bt,
@@ -913,10 +987,64 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   hipStream_t st = (hipStream_t)stream;
   int nc, form;
   int64_t ci;
-  fused_geometry(Bt, I, &nc, &ci, &form, k);
+  fused_geometry(Bt, I, &nc, &ci, &form, k, d);
   unsigned long long* partial = reinterpret_cast<unsigned long long*>(ws);
   const dim3 grid((unsigned)nc, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
   const unsigned nbm = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  if (form == 2) {
+    // split-bf16 pre-filter: candidates by approximate score, exact re-scoring, brute force where the guarantee fails
+    IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_score_topk_f32: workspace must be 16-byte aligned");
+    const bool fl = floor_phase(form, nc, ci, k);
+    const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) +
+                        (fl ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
+    const Bf16Ws w = bf16_layout(Bt, I, d, base);
+    char* wb = reinterpret_cast<char*>(ws);
+    __bf16* Vs = reinterpret_cast<__bf16*>(wb + w.vs);
+    __bf16* Us = reinterpret_cast<__bf16*>(wb + w.us);
+    float* vnorm = reinterpret_cast<float*>(wb + w.vnorm);
+    float* unorm = reinterpret_cast<float*>(wb + w.unorm);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(wb + w.cand);
+    uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
+    IDG_HIP(hipMemsetAsync(scal, 0, 16, st));
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
+                       (const int64_t*)nullptr, I, d, Vs, vnorm, scal);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((Bt * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
+                       d, Us, unorm, (uint32_t*)nullptr);
+    float* chunk_max = nullptr;
+    float* floor0 = nullptr;
+    if (fl) {
+      chunk_max = reinterpret_cast<float*>(partial + (size_t)Bt * (size_t)nc * 64);
+      floor0 = chunk_max + (size_t)Bt * (size_t)nc;
+      const int slabs_per_chunk = (int)(ci / FT_SLAB);
+      const int floor_slabs = slabs_per_chunk / 2 < FLOOR_SLABS ? slabs_per_chunk / 2 : FLOOR_SLABS;
+      if (apply_sigmoid)
+        hipLaunchKernelGGL((score_topk_bf16_kernel<true, true>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
+                           excl_items, floor_slabs, partial, chunk_max, (const float*)nullptr);
+      else
+        hipLaunchKernelGGL((score_topk_bf16_kernel<false, true>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
+                           excl_items, floor_slabs, partial, chunk_max, (const float*)nullptr);
+      hipLaunchKernelGGL(chunk_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, chunk_max, Bt, nc, k, floor0);
+      hipLaunchKernelGGL(floor_margin_kernel, dim3((unsigned)((Bt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, floor0, unorm, scal, Bt);
+    }
+    int kl = 64;
+    if (const char* v = std::getenv("IDG_TOPK_BF16_LIST")) kl = std::atoi(v);  // TIMING PROBE ONLY (wrong guarantee below 64)
+    if (apply_sigmoid)
+      hipLaunchKernelGGL((score_topk_bf16_kernel<true, false>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
+                         excl_items, kl, partial, (float*)nullptr, (const float*)floor0);
+    else
+      hipLaunchKernelGGL((score_topk_bf16_kernel<false, false>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
+                         excl_items, kl, partial, (float*)nullptr, (const float*)floor0);
+    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kl, out_idx, (float*)nullptr,
+                       (int64_t)k, (int64_t)0, (unsigned long long*)nullptr, cand);
+    if (apply_sigmoid)
+      hipLaunchKernelGGL(topk_rescore_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
+                         excl_items, k, cand, unorm, scal, (const float*)floor0, out_idx, out_val, scal + 1);
+    else
+      hipLaunchKernelGGL(topk_rescore_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
+                         excl_items, k, cand, unorm, scal, (const float*)floor0, out_idx, out_val, scal + 1);
+    IDG_HIP(hipGetLastError());
+    return IDG_OK;
+  }
   // k <= 64: one pass.  Larger k (the reference's torch.topk takes any k <= I, batch_test.py:68): one pass per 64
   // ranks; pass p only admits keys strictly below the last key pass p - 1 emitted (keys are unique per item, so
   // "below the 64p-th best" is exactly "not among the best 64p"), and its winners fill columns [64p, 64p + kk).
@@ -962,10 +1090,10 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
                          Bt, I, d, ci, excl_indptr, excl_items, kk, partial, bd_in);
     if (apply_sigmoid)
       hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kk, out_idx, out_val,
-                         (int64_t)k, (int64_t)done, bd_out);
+                         (int64_t)k, (int64_t)done, bd_out, (unsigned long long*)nullptr);
     else
       hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kk, out_idx, out_val,
-                         (int64_t)k, (int64_t)done, bd_out);
+                         (int64_t)k, (int64_t)done, bd_out, (unsigned long long*)nullptr);
   }
   IDG_HIP(hipGetLastError());
   return IDG_OK;

@@ -1251,9 +1251,10 @@ def score_dense(user_panel, item_panel, users, apply_sigmoid=True):
 
 
 def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=None, apply_sigmoid=True,
-               return_values=False):
+               return_values=False, info=None):
     """Top-k item ids per batch user, train positives masked to -1 (batch_test.py:59-68).
-    excl_indptr int64[num_users+1] / excl_items int32: DEVICE CSR of the train matrix."""
+    excl_indptr int64[num_users+1] / excl_items int32: DEVICE CSR of the train matrix.
+    info: a dict to fill with idg_score_topk_info's answer for this call (form, chunks, floor, users redone; synchronises)."""
     _require_device(user_panel, item_panel, users, excl_indptr, excl_items)
     U, V = _f32c(user_panel, "user_panel"), _f32c(item_panel, "item_panel")
     users = _i64c(users, "users")
@@ -1267,4 +1268,8 @@ def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=No
     check(lib.idg_score_topk_f32(_ptr(U), _ptr(V), _ptr(users), Bt, I, d, _ptr(excl_indptr), _ptr(excl_items), int(k),
                                  int(bool(apply_sigmoid)), _ptr(idx), _ptr(val), _ptr(ws), _stream()),
           "idg_score_topk_f32")
+    if info is not None:
+        out = (C.c_int64 * 4)()
+        check(lib.idg_score_topk_info(Bt, I, d, int(k), _ptr(ws), out, _stream()), "idg_score_topk_info")
+        info.update(form=int(out[0]), chunks=int(out[1]), floor=bool(out[2]), users_redone=int(out[3]))
     return (idx, val) if return_values else idx

@@ -24,7 +24,9 @@ Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
 ip, ix = torch.from_numpy(pos_ptr).cuda(), torch.from_numpy(items.astype(np.int32)).cuda()
 all_users = torch.arange(U, device="cuda")
 args = (None, None) if nomask else (ip, ix)
-ops.score_topk(Ue, Ie, all_users, k, *args)
+info = {}
+ops.score_topk(Ue, Ie, all_users, k, *args, info=info)
+print("form / chunks / floor / users redone:", info)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):

@@ -753,11 +753,13 @@ def test_score_dense_widths_and_ragged_shapes(ops, d):
         np.testing.assert_allclose(R, oracle.score(Uu, Vv, users, sig), rtol=2e-5, atol=2e-5)
 
 
-@pytest.fixture(params=["alternating", "producer-consumer"])
+@pytest.fixture(params=["alternating", "producer-consumer", "bf16-prefilter"])
 def topk_form(request, monkeypatch):
-    """The fused top-K has two kernels (every wave alternating between scoring and selecting; producer and consumer
-    waves) chosen by the number of user tiles: every contract test runs on both (IDG_TOPK_FORM forces one)."""
-    monkeypatch.setenv("IDG_TOPK_FORM", "0" if request.param == "alternating" else "1")
+    """The fused top-K has three forms (every wave alternating between scoring and selecting; producer and consumer
+    waves on exact scores; round 5: candidates by split-bf16 approximate scores + exact re-scoring, d = 64 — other widths
+    and k > 64 run the exact producer / consumer form under this name) chosen by the call's geometry: every contract test
+    runs on all of them (IDG_TOPK_FORM forces one)."""
+    monkeypatch.setenv("IDG_TOPK_FORM", {"alternating": "0", "producer-consumer": "1", "bf16-prefilter": "2"}[request.param])
     return request.param
 
 
@@ -1089,6 +1091,47 @@ def test_topk_calls_of_1024_users_start_from_a_floor(ops, d, sig):
             os.environ.pop("IDG_TOPK_FLOOR", None)
         else:
             os.environ["IDG_TOPK_FLOOR"] = old
+
+
+@pytest.mark.parametrize("sig", [True, False])
+@pytest.mark.parametrize("per_call", [31668, 1024])
+def test_topk_bf16_prefilter_is_the_exact_answer(ops, per_call, sig, monkeypatch):
+    """Round 5 (opt-in form, IDG_TOPK_BF16=1; measured slower than the exact form, kept as the record of the experiment):
+    calls of >= 16 user tiles at d = 64, k <= 48 choose candidates by a split-bf16 APPROXIMATE score (64 per user), re-score
+    them exactly and prove the list complete — or redo the user by brute force.  At yelp2018 size, one call and calls of
+    1024 users (chunks starting from a lowered floor), with train items masked and duplicated item rows (exact ties): ids
+    AND values equal, bit for bit, what the exact fp32 producer / consumer form returns; the form is the one taken, and on
+    such embeddings (almost) nobody needs the brute-force path: the error bound is tight enough."""
+    import idgrec_amd.synth as S
+
+    U, I, d, k = 31668, 38048, 64, 20
+    users, items = S.generate(U, I, 600000, seed=21)
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    ip, ix = dev(ptr), dev(items.astype(np.int32))
+    g = torch.Generator(device="cuda").manual_seed(per_call)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
+    Ie[::101] = Ie[3]  # duplicate rows: exact ties
+    Ue[5] = 0.0        # a user whose every score is 0: all items tie (the brute-force path must give the id order)
+    calls = [torch.arange(s0, min(s0 + per_call, U), device="cuda") for s0 in range(0, U, per_call)]
+    info, redone = {}, 0
+    got = []
+    monkeypatch.setenv("IDG_TOPK_BF16", "1")
+    for b in calls:
+        got.append(ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info))
+        if len(b) < 1024:  # (the ragged last call: fewer than 16 user tiles, an exact form)
+            assert info["form"] == 0, info
+            continue
+        assert info["form"] == 2, info
+        assert info["floor"] == (per_call == 1024), info
+        redone += info["users_redone"]
+    monkeypatch.setenv("IDG_TOPK_BF16", "0")
+    want = [ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info) for b in calls]
+    assert info["form"] == 1
+    assert torch.equal(torch.cat([x[0] for x in got]), torch.cat([x[0] for x in want])), "ids differ from the exact form"
+    assert torch.equal(torch.cat([x[1] for x in got]), torch.cat([x[1] for x in want])), "values differ from the exact form"
+    assert 1 <= redone <= 32, redone  # user 5 (all ties) certainly; hardly anybody else
 
 
 @pytest.mark.parametrize("per_call", [2048, 4096, 8192])

@@ -9,6 +9,8 @@
 * config 4 (SimGCL-3 d=64, amazon-book shape): the shared-first-product / multi-panel row-restricted encoder passes
   against the single-purpose kernels, and the fused step against the autograd composition.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -259,6 +261,50 @@ def test_simgcl_encoder_passes_and_fused_step_at_amazon_book_size():
     gmax = float(g_a.abs().max())
     assert float((g_f - g_a).abs().max()) <= 1e-3 * gmax
     assert torch.allclose(w_f, w_a, rtol=1e-4, atol=1e-6)
+
+
+def test_simgcl_fused_step_at_amazon_book_size_vs_the_cpu_port():
+    """BASELINE configs[3] at full size against the ORACLE, not against this library: the fused SimGCL step
+    (clean + two view passes, fused BPR, MFMA InfoNCE forward / backward at B = 2048 with the batch's real duplicate
+    structure, ONE shared backward propagation, Adam in its epilogue) with epsilon = 0 — where the reference's step is
+    deterministic — against oracle/torch_ref.RefStep(simgcl=(0, 0.2, 0.5)), the CPU port of models/SimGCL.py:62-90 that
+    tests/test_torch_ref.py pins to the imported reference's own epsilon-0 trajectory.  Three steps: every loss term and
+    both tables within 1e-4."""
+    import idgrec_amd.host as H
+    import idgrec_amd.ops as ops
+    import idgrec_amd.synth as S
+    from idgrec_amd.engine import PropagationEngine
+    from oracle.torch_ref import RefStep
+
+    U, I, E = S.SHAPES["amazon-book"]
+    d, K, B, temperature, ssl_lambda = 64, 3, 2048, 0.2, 0.5
+    users, items = S.generate(U, I, E, seed=0)
+    ip, ix, dv = H.build_norm_adj(U, I, users, items)
+    n = U + I
+    W0 = S.xavier_uniform_panel(U, I, d, 2024)
+    tri = S.draw_triples(2024, users, items, U, I, 3 * B)[0][: 3 * B]
+    ref = RefStep(ip, ix, dv, U, I, W0[:U], W0[U:], n_layers=K, lr=1e-3, simgcl=(0.0, temperature, ssl_lambda))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    want = [ref.step(*(torch.from_numpy(tri[i * B:(i + 1) * B, c].copy()) for c in range(3))) for i in range(3)]
+    G = ops.Graph(ip, ix, dv, n, n)
+    eng = PropagationEngine(G, U, I, d, K, include_layer0=False, reg_lambda=1e-4, lr=1e-3, params=W0.cuda())
+    eng.ssl = (0.0, temperature, ssl_lambda)
+    eng.store_grad = False  # (as the trainer runs it)
+    loss = torch.zeros((3, 3), device="cuda")
+    bt = [tuple(dev(tri[i * B:(i + 1) * B, c]) for c in range(3)) for i in range(3)]
+    for i in range(3):
+        if i + 1 < 3:
+            eng.prefetch(*bt[i + 1])
+        eng.train_step(*bt[i], loss_out=loss[i])
+    np.testing.assert_allclose(loss.cpu().numpy(), np.array(want), rtol=1e-4)
+    assert len(np.unique(tri[:B, 0])) < B and len(np.unique(tri[:B, 1])) < B  # the batch does repeat users and items
+    W = eng.params.cpu().numpy()
+    for mine, ref_w in ((W[:U], ref.user_w.detach().numpy()), (W[U:], ref.item_w.detach().numpy())):
+        # (Adam's quotient m / (sqrt(v) + 1e-8) amplifies last-place differences of gradient elements that are themselves of
+        #  the order of rounding noise: all but a handful of elements within 1e-4, none further than a tenth of lr x steps)
+        off = ~np.isclose(mine, ref_w, rtol=1e-4, atol=1e-6)
+        assert off.mean() < 1e-3, off.mean()
+        assert np.abs(mine - ref_w).max() < 3e-4, np.abs(mine - ref_w).max()
 
 
 def test_topk_at_full_catalogue_geometry(monkeypatch):

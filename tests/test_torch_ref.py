@@ -57,3 +57,25 @@ def test_port_simgcl_pieces_match_reference(golden_small, golden_misc):
     b = torch.arange(64)
     losses = ref.step(b % U, b % I, (b * 7) % I)
     assert len(losses) == 3 and all(np.isfinite(losses))
+
+
+def test_port_simgcl_step_with_epsilon_zero_is_the_references(golden_small):
+    """With epsilon = 0 SimGCL's step is deterministic (the perturbation is noise * 0): the port's three losses and its
+    tables after three Adam steps equal the imported reference's (oracle/gen_golden_next.py: simgcl0_traj_*) — which makes
+    RefStep(simgcl=(0, tau, lambda)) a pinned checker for the fused SimGCL step at full size (tests/test_gpu_scale.py)."""
+    import os
+
+    g = golden_small
+    nx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "next_small.npz")))
+    torch.set_num_threads(1)
+    U, I = int(g["num_users"]), int(g["num_items"])
+    # (the golden model was built under set_seed(2024): its initial tables are the d64_init_* of graph_small.npz)
+    ref = RefStep(g["adj_indptr"], g["adj_indices"], g["adj_data"], U, I, g["d64_init_user"], g["d64_init_item"], lr=1e-3,
+                  simgcl=(0.0, 0.2, 0.5))
+    tri = torch.from_numpy(nx["eps0_batches"])
+    for i in range(3):
+        b = tri[i * 256:(i + 1) * 256]
+        vals = ref.step(b[:, 0], b[:, 1], b[:, 2])
+        np.testing.assert_allclose(vals, nx["simgcl0_traj_loss"][i], rtol=1e-6)
+    np.testing.assert_allclose(ref.user_w.detach().numpy(), nx["simgcl0_traj_user"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(ref.item_w.detach().numpy(), nx["simgcl0_traj_item"], rtol=1e-5, atol=1e-8)
