@@ -712,6 +712,8 @@ def main():
                                     "K forward products, fused BPR, backward chain with the Adam epilogue, end-of-step event)"}
     if steady is not None:
         out["steady_state"] = steady
+    if graph is not None and args.model == "LightGCN" and K >= 2:
+        out["step_bytes"] = step_bytes(wl, n, nnz, d, K, B, ms_per_step)
     hbm_leg = False
     if graph is not None:
         out["roofline"] = roofline(args, eng, graph, n, nnz, d, K, args.workload, in_step_form=(args.model == "LightGCN"),
@@ -1082,6 +1084,40 @@ def other_configs(args, wl_yelp, cpu_threads):
     amazon.clear()
     torch.cuda.empty_cache()
     return res
+
+
+def step_bytes(wl, n, nnz, d, K, B, ms_per_step):
+    """Bytes of one training step: SURVEY.md §8(d)'s per-step formula (2K dense products + Adam + the mean's write and the
+    gradient's read) beside what the step EXECUTES: K - 1 dense forward products, the last forward layer at
+    the batch's <= 3B rows only, a first backward product whose input lives on those rows (the whole entry list is read,
+    panel rows only where the column is live), K - 2 dense backward products and a last one with the Adam update in its
+    epilogue (p, m, v in and out; the finished gradient is not stored).  The restricted products' entries are counted on
+    the host for the first timed batch.  Gather-equivalent bytes in both cases: the panel is cache resident, so neither
+    figure over the step time is an HBM rate — the line's `roofline` says what the memory side moved."""
+    gather, _ = spmm_bytes(n, nnz, d)
+    formula = 2 * K * gather + 28 * n * d + 8 * n * d
+    U = wl["U"]
+    b = wl["triples"][:B]
+    rows = np.unique(np.concatenate([b[:, 0], U + b[:, 1], U + b[:, 2]]))
+    deg = np.diff(wl["indptr"])
+    e_rows = int(deg[rows].sum())                     # entries of the requested output rows (last forward layer)
+    live = np.zeros(n, dtype=bool)
+    live[rows] = True
+    e_live = int(live[wl["indices"]].sum())           # entries whose INPUT row is live (first backward product)
+    restricted_fwd = 8 * e_rows + 4 * d * e_rows + 4 * d * len(rows)
+    sparse_bwd = 4 * (n + 1) + 8 * nnz + 4 * d * e_live + 4 * n * d
+    adam_epilogue = gather - 4 * n * d + 24 * n * d   # the product's gathers; p, m, v in and out instead of the gradient's store
+    dense = (K - 1) + max(K - 2, 0)
+    executed = dense * gather + restricted_fwd + sparse_bwd + adam_epilogue
+    return {"formula_8d": formula, "executed": executed,
+            "executed_breakdown": {"dense_products": dense, "bytes_per_dense_product": gather, "row_restricted_last_forward_layer": restricted_fwd,
+                                   "sparse_input_first_backward_product": sparse_bwd, "last_backward_product_with_adam_epilogue": adam_epilogue,
+                                   "batch_rows": int(len(rows)), "entries_of_batch_rows": e_rows, "entries_with_live_input": e_live},
+            "formula_8d_over_step_time_gbs": formula / (ms_per_step * 1e-3) / 1e9,
+            "executed_over_step_time_gbs": executed / (ms_per_step * 1e-3) / 1e9,
+            "what": "gather-equivalent bytes (a panel row counted once per stored entry that reads it): SURVEY 8(d)'s per-step formula "
+                    "assumes 2K dense products; the step runs %d dense ones, two restricted to the batch's rows (exact) and one with "
+                    "the Adam update in its epilogue" % dense}
 
 
 def _time_launches(fn, launches_per_call, reps, warm=2):
