@@ -602,8 +602,7 @@ def main():
     graph = None
     if args.model in ("LightGCN", "SimGCL"):
         graph = ops.Graph(wl["indptr"], wl["indices"], wl["values"], n, n, split_threshold=args.split)
-        if default_headline:
-            _save_csr(args, args.workload, wl["indptr"], wl["indices"], wl["values"], U, I, d)
+        _save_csr(args, args.workload, wl["indptr"], wl["indices"], wl["values"], U, I, d)  # (kept only when --pmc will run)
     W0 = S.xavier_uniform_panel(U, I, d, args.seed)
     eng = PropagationEngine(graph, U, I, d, K, include_layer0=(args.model != "SimGCL"), reg_lambda=1e-4, lr=1e-3,
                             deterministic=not args.atomic, params=W0.cuda())
@@ -903,8 +902,8 @@ def attach_measured_traffic(args, out):
             grid_of = {v["tiles"] * 256: k for k, v in child_info.items() if "tiles" in v}
             for f in glob.glob(os.path.join(pdir, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    # the plain dense instantiation: spmm_tile_kernel<LPR, 1, 8, true, MINW, EPI = 0, fused>
-                    if not re.search(r"spmm_tile_kernel<\d+, 1, 8, true, \d+, 0, (true|false)>", row["Kernel_Name"]):
+                    # the plain dense instantiation: spmm_tile_kernel<LPR, NB, 8, true, MINW, EPI = 0, fused>
+                    if not re.search(r"spmm_tile_kernel<\d+, \d+, 8, true, \d+, 0, (true|false)>", row["Kernel_Name"]):
                         continue
                     g = grid_of.get(int(row["Grid_Size"]))
                     if g is not None:
@@ -912,8 +911,9 @@ def attach_measured_traffic(args, out):
     finally:
         shutil.rmtree(root, ignore_errors=True)
     took = time.perf_counter() - t_all
-    legs = {"yelp2018": out["roofline"], "synth-10M": out["roofline"].get("hbm_bound"),
-            "regular-15M": out["roofline"].get("hbm_reuse_free"), "synth-1M": out["roofline"].get("cache_boundary")}
+    legs = {"synth-10M": out["roofline"].get("hbm_bound"), "regular-15M": out["roofline"].get("hbm_reuse_free"),
+            "synth-1M": out["roofline"].get("cache_boundary")}
+    legs[args.workload] = out["roofline"]  # (the headline's own graph)
     legs = {k: [v] for k, v in legs.items() if isinstance(v, dict)}
     for c in out.get("configs") or []:
         if isinstance(c.get("roofline"), dict) and c.get("graph") and "bytes_gather" in c["roofline"]:
