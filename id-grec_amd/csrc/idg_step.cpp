@@ -170,7 +170,9 @@ int idg_step_run_f32(idg_step* p, const int64_t* users, const int64_t* pos, cons
     IDG_TRY(prepare(p, si, users, pos, neg, B, ids_token, stream));
   }
   idg_step::Slot& s = p->slots[si];
-  s.has_key = false;
+  // A prepared batch is honoured by the NEXT step only: whatever else was prepared and not run (a lookahead nobody came
+  // for) is dropped now — its id arrays may be gone, and the same addresses may come back holding other ids
+  for (int i = 0; i < IDG_STEP_SLOTS; ++i) p->slots[i].has_key = false;
   // the next batch's index-only work goes out first: it runs on the side stream under this step's products
   if (next_B > 0) IDG_TRY(idg_step_prefetch(p, next_users, next_pos, next_neg, next_B, ids_token, stream));
   // pacing: at most two steps queued.  A batch prepared ahead started its preparation when ITS slot's last step, three

@@ -750,7 +750,9 @@ typedef struct idg_step_desc {
 } idg_step_desc;
 int idg_step_create(const idg_step_desc* desc, idg_step** out);
 int idg_step_destroy(idg_step* plan);
-/* Prepare a batch a step ahead without running a step (the first batch of an epoch). */
+/* Prepare a batch a step ahead without running a step (the first batch of an epoch).  A prepared batch is identified by its
+ * three pointers and B and is honoured by the NEXT idg_step_run_f32 only (any other prepared batch is dropped there): keep
+ * the id arrays alive and unchanged until that call. */
 int idg_step_prefetch(idg_step* plan, const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                       uint64_t ids_token, void* stream);
 /* next_* (nullable, next_B = 0: none): the batch the NEXT call will run.  loss: 2 floats [bpr, reg_lambda * reg].

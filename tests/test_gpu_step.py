@@ -73,3 +73,34 @@ def test_one_call_step_checks_its_arguments(golden_small):
     assert eng._plan.B_cap >= 200
     torch.cuda.synchronize()
     assert torch.isfinite(eng.params).all()
+
+
+def test_a_lookahead_nobody_came_for_is_dropped(golden_small):
+    """A batch announced with prefetch() but never run must not be mistaken for a later batch at the same addresses: the
+    plan honours a prepared slot in the NEXT step only.  Here the announced batch's id tensors are rewritten in place after
+    another batch ran in between (what a recycled allocation looks like to the library); the step on them must use the
+    new ids — the same bits as the call-by-call chain run on the three batches without any lookahead."""
+    from idgrec_amd.engine import PropagationEngine
+
+    tri = torch.from_numpy(golden_small["sample1"][:64 * 4]).cuda()
+    bt = [tuple(tri[i * 64:(i + 1) * 64, c].contiguous() for c in range(3)) for i in range(4)]
+    res = []
+    for plan in (True, False):
+        U, I, W0, graph = _setup(golden_small, "lgcn")
+        eng = PropagationEngine(graph, U, I, 64, 3, params=W0.clone())
+        eng._plan_on = plan
+        if plan:
+            scratch = tuple(t.clone() for t in bt[1])
+            eng.prefetch(*scratch)
+            eng.train_step(*bt[0])      # prepares `scratch` ahead ...
+            eng.train_step(*bt[2])      # ... but another batch runs
+            for t, src in zip(scratch, bt[3]):
+                t.copy_(src)            # the announced batch's storage now holds other ids
+            eng.train_step(*scratch)
+        else:
+            for i in (0, 2, 3):
+                eng.train_step(*bt[i])
+        torch.cuda.synchronize()
+        res.append((eng.params.clone(), eng.exp_avg_sq.clone(), eng.loss.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
