@@ -116,9 +116,10 @@ __global__ __launch_bounds__(BLOCK) void bpr_triple_kernel(BprArgs a) {
 __global__ __launch_bounds__(BLOCK) void bpr_keys_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
                                                          const int64_t* __restrict__ neg, int64_t B, int64_t num_users,
                                                          int32_t* __restrict__ keys, int32_t* __restrict__ slots,
-                                                         uint32_t* __restrict__ bitmap) {
+                                                         uint32_t* __restrict__ bitmap, uint32_t* __restrict__ zero2) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= B) return;
+  if (zero2 && i == 0) zero2[0] = 0u, zero2[1] = 0u;  // (idg::bpr_plan_rows: the header of a unit list built right after)
   const int64_t r0 = users[i], r1 = num_users + pos[i], r2 = num_users + neg[i];
   keys[3 * i + 0] = (int32_t)r0;
   keys[3 * i + 1] = (int32_t)r1;
@@ -804,6 +805,15 @@ size_t sort_temp_bytes(int64_t n3) {
 
 }  // namespace
 
+static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users, int64_t n,
+                         void* ws, hipStream_t st, const char* who, uint32_t* bitmap, uint32_t* zero2, bool one_launch_sort);
+int idg::bpr_plan_rows(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users, int64_t n,
+                       void* ws, uint32_t* bitmap, uint32_t* zero2, bool one_launch_sort, void* stream) {
+  if (!bitmap) return idg::fail(IDG_E_INVALID, "bpr_plan_rows: NULL bitmap");
+  return bpr_sort_plan(users, pos, neg, B, num_users, n, ws, (hipStream_t)stream, "idg_step_run_f32 (plan)", bitmap, zero2,
+                       one_launch_sort);
+}
+
 extern "C" {
 
 size_t idg_bpr_workspace_bytes(int64_t B, int64_t d) {
@@ -867,7 +877,8 @@ int idg_bpr_forward_f32(const float* final_panel, const float* ego_panel, int64_
 }
 
 static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users,
-                         int64_t n, void* ws, hipStream_t st, const char* who, uint32_t* bitmap = nullptr) {
+                         int64_t n, void* ws, hipStream_t st, const char* who, uint32_t* bitmap = nullptr,
+                         uint32_t* zero2 = nullptr, bool one_launch_sort = false) {
   if (!(users && pos && neg && ws)) return idg::fail(IDG_E_INVALID, "%s: NULL argument", who);
   if (!(B > 0 && num_users >= 0 && n >= num_users)) return idg::fail(IDG_E_INVALID, "%s: bad sizes", who);
   if (n >= ((int64_t)1 << 31) || 3 * B >= ((int64_t)1 << 31)) return idg::fail(IDG_E_INVALID, "%s: sizes exceed int32 keys", who);
@@ -879,7 +890,7 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
   int32_t* sslots = reinterpret_cast<int32_t*>(base + w.sslots);
   if (bitmap) idg::rows_changed(bitmap);
   hipLaunchKernelGGL(bpr_keys_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, users, pos, neg, B,
-                     num_users, keys, slots, bitmap);
+                     num_users, keys, slots, bitmap, zero2);
   const int64_t n3 = 3 * B;
   if (n3 <= LDS_SORT_MAX) {
     int p2 = 1;
@@ -887,7 +898,7 @@ static int bpr_sort_plan(const int64_t* users, const int64_t* pos, const int64_t
     int slot_bits = 1, row_bits = 1;
     while (((int64_t)1 << slot_bits) < n3) ++slot_bits;
     while (((int64_t)1 << row_bits) < n) ++row_bits;
-    const bool rank_sort = n3 > RANK_RUN && !g_single_block_sort;
+    const bool rank_sort = n3 > RANK_RUN && !g_single_block_sort && !(one_launch_sort && n3 <= 4096);
     if (slot_bits + row_bits <= 31) {  // top bit kept clear so the all-ones padding key sorts last
       if (rank_sort) launch_rank_sort<uint32_t>(keys, slots, (int)n3, slot_bits, skeys, sslots, base + w.temp, st);
       else launch_lds_sort<uint32_t>(keys, slots, (int)n3, p2, slot_bits, skeys, sslots, st);

@@ -29,6 +29,14 @@ inline int fail(int code, const char* fmt, ...) {
 // registered for a sub-range starting inside it go too); 0 = lists registered at `bitmap` itself.
 void rows_changed(const void* bitmap, size_t bytes = 0);
 
+// Library-internal forms of two entry points, for idg_step.cpp's one-call step (fewer launches per step on the host):
+// idg_bpr_plan_rows_f32 whose first kernel also zeroes two words (`zero2`, nullable: the header of the unit list about to
+// be built) and which may sort up to 4096 pairs with ONE workgroup (`one_launch_sort`: a launch less where the side stream
+// has slack); idg_graph_live_units without its own clearing of that header.
+int bpr_plan_rows(const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B, int64_t num_users, int64_t n, void* ws,
+                  uint32_t* bitmap, uint32_t* zero2, bool one_launch_sort, void* stream);
+int live_units_prezeroed(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream);
+
 }  // namespace idg
 
 #define IDG_REQUIRE(cond, ...)                                   \

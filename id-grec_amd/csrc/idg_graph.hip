@@ -2433,17 +2433,21 @@ int idg_graph_forget_live_units(const idg_graph* g, const uint32_t* bitmap) {
   return IDG_OK;
 }
 
-int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream) {
+static int live_units_impl(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream, bool clear) {
   IDG_REQUIRE(g && bitmap && units_ws && max_rows >= 0, "idg_graph_live_units: bad argument");
   IDG_REQUIRE(g->d_row_unit || g->n_rows == 0, "idg_graph_live_units: handle without a row -> unit table");
   hipStream_t st = (hipStream_t)stream;
-  IDG_HIP(hipMemsetAsync(units_ws, 0, UNITS_HEADER * sizeof(int32_t), st));
+  if (clear) IDG_HIP(hipMemsetAsync(units_ws, 0, UNITS_HEADER * sizeof(int32_t), st));
   const int64_t words = (g->n_rows + 31) / 32;
   if (words > 0)
     hipLaunchKernelGGL(live_units_kernel, dim3((unsigned)((words + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, bitmap, g->n_rows,
                        g->d_row_unit, g->d_long, g->d_slot_unit, reinterpret_cast<int32_t*>(units_ws), max_rows + g->n_slots);
   IDG_HIP(hipGetLastError());
   return idg_graph_bind_live_units(g, bitmap, units_ws, max_rows);
+}
+
+int idg_graph_live_units(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream) {
+  return live_units_impl(g, bitmap, units_ws, max_rows, stream, true);
 }
 
 size_t idg_graph_compact_inputs_bytes(const idg_graph* g) {
@@ -2950,3 +2954,7 @@ static int bwd_adam_impl(const idg_graph* g, const float* gout, const uint32_t* 
 }
 
 }  // extern "C"
+
+int idg::live_units_prezeroed(const idg_graph* g, const uint32_t* bitmap, void* units_ws, int64_t max_rows, void* stream) {
+  return live_units_impl(g, bitmap, units_ws, max_rows, stream, false);
+}

@@ -70,10 +70,13 @@ int prepare(idg_step* p, int si, const int64_t* users, const int64_t* pos, const
     IDG_TRY(idg_stream_wait_event(side, p->fork));
   }
   // the row bitmap is set by the plan's first kernel (idg_bpr_plan_rows_f32); with a graph its live work units follow
+  // (with a graph the side stream has slack and the host does not: up to 4096 pairs are sorted by one launch, and the
+  //  plan's first kernel also clears the header of the unit list built next — two launches less per step)
   IDG_TRY(idg_bitmap_clear(d.slot_bitmap[si], d.n, side));
-  IDG_TRY(idg_bpr_plan_rows_f32(users, pos, neg, B, d.num_users, d.n, d.slot_bpr_ws[si], d.slot_bitmap[si], side));
+  IDG_TRY(idg::bpr_plan_rows(users, pos, neg, B, d.num_users, d.n, d.slot_bpr_ws[si], d.slot_bitmap[si],
+                             d.graph ? reinterpret_cast<uint32_t*>(d.slot_units[si]) : nullptr, d.graph != nullptr, side));
   if (d.graph) {
-    IDG_TRY(idg_graph_live_units(d.graph, d.slot_bitmap[si], d.slot_units[si], 3 * B, side));
+    IDG_TRY(idg::live_units_prezeroed(d.graph, d.slot_bitmap[si], d.slot_units[si], 3 * B, side));
     IDG_TRY(idg_event_record(s.rows_done, side));
   }
   IDG_TRY(idg_event_record(s.plan_done, side));
