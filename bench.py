@@ -855,6 +855,25 @@ def roofline_only(args):
     print(json.dumps({"roofline_only": res}), flush=True)
 
 
+def collect_dense_counters(pdir, grid_of, counters):
+    """rocprofv3's *counter_collection.csv files under pdir -> counters[graph][counter name] = values per dispatch, for
+    the dispatches of the PLAIN dense product (spmm_tile_kernel<LPR, NB, 8, true, MINW, EPI = 0, fused>: what the
+    --roofline-only child launches) whose grid size names a graph (grid_of: tiles x 256 threads -> graph)."""
+    import csv
+    import glob
+    import re
+
+    for f in glob.glob(os.path.join(pdir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if not re.search(r"spmm_tile_kernel<\d+, \d+, 8, true, \d+, 0, (true|false)>", row["Kernel_Name"]):
+                    continue
+                g = grid_of.get(int(row["Grid_Size"]))
+                if g is not None:
+                    counters.setdefault(g, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return counters
+
+
 def attach_measured_traffic(args, out):
     """roofline.traffic MEASURED IN THIS RUN: after every other leg, two child processes
 
@@ -865,9 +884,6 @@ def attach_measured_traffic(args, out):
     files the legs left behind.  Per graph: traffic = 2 x FETCH_SIZE + WRITE_SIZE per dispatch (KB units; gfx950 tallies
     its 128-byte read requests at 64 B), averaged over the dispatches whose grid is that graph's tile count.  Children,
     never an exec: this process has initialised the GPU."""
-    import csv
-    import glob
-    import re
     import shutil
     import subprocess
 
@@ -900,14 +916,7 @@ def attach_measured_traffic(args, out):
                 continue
             child_info = json.loads(lines[-1])["roofline_only"]
             grid_of = {v["tiles"] * 256: k for k, v in child_info.items() if "tiles" in v}
-            for f in glob.glob(os.path.join(pdir, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    # the plain dense instantiation: spmm_tile_kernel<LPR, NB, 8, true, MINW, EPI = 0, fused>
-                    if not re.search(r"spmm_tile_kernel<\d+, \d+, 8, true, \d+, 0, (true|false)>", row["Kernel_Name"]):
-                        continue
-                    g = grid_of.get(int(row["Grid_Size"]))
-                    if g is not None:
-                        counters.setdefault(g, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            collect_dense_counters(pdir, grid_of, counters)
     finally:
         shutil.rmtree(root, ignore_errors=True)
     took = time.perf_counter() - t_all

@@ -183,3 +183,33 @@ def test_a_hung_first_attempt_is_retried_over_torch_distributed():
     assert why["attempt"] == 1 and why["phase_reached"]["1"] == "warmup" and any("deadline" in v for v in why["verdicts"])
     t = d["timeline"]
     assert t["instrumented_steps"] == 3 and "F1.panel" in t["collectives"] and t["host_sync_ms"] == 0.0
+
+
+def test_counter_csv_parsing_tells_the_graphs_apart(tmp_path):
+    """bench.py --pmc reads rocprofv3's counter_collection.csv: only dispatches of the plain dense product count, and the
+    grid size (tiles x 256) says which graph a dispatch belongs to (the same kernel instantiation serves every graph)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("idg_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = tmp_path / "FETCH_SIZE" / "host"
+    d.mkdir(parents=True)
+    head = '"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",' \
+           '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name",' \
+           '"Counter_Value","Start_Timestamp","End_Timestamp"\n'
+    dense = "void (anonymous namespace)::spmm_tile_kernel<16, 1, 8, true, 1, 0, true>((anonymous namespace)::Tile const*, long const*)"
+    adam = "void (anonymous namespace)::spmm_tile_kernel<16, 1, 8, true, 1, 2, true>((anonymous namespace)::Tile const*, long const*)"
+    wide = "void (anonymous namespace)::spmm_tile_kernel<64, 2, 8, true, 8, 0, false>((anonymous namespace)::Tile const*, long const*)"
+
+    def row(grid, name, ctr, val):
+        return '1,1,"Agent 2",1,10,10,%d,8,"%s",256,0,0,64,0,32,"%s",%f,1,2\n' % (grid, name, ctr, val)
+
+    (d / "p_counter_collection.csv").write_text(head + row(5321 * 256, dense, "FETCH_SIZE", 100.0) + row(5321 * 256, dense, "FETCH_SIZE", 102.0)
+                                                + row(5321 * 256, adam, "FETCH_SIZE", 999.0)        # another epilogue: not the plain product
+                                                + row(10242 * 256, dense, "FETCH_SIZE", 300.0)
+                                                + row(836557 * 256, wide, "FETCH_SIZE", 7.0)          # the d = 256 instantiation counts too
+                                                + row(777 * 256, dense, "FETCH_SIZE", 1.0)            # a grid nobody named (the clock ramp)
+                                                + row(512, "__amd_rocclr_copyBuffer", "FETCH_SIZE", 5.0))
+    got = bench.collect_dense_counters(str(tmp_path), {5321 * 256: "yelp2018", 10242 * 256: "amazon-book", 836557 * 256: "synth-10M"}, {})
+    assert got == {"yelp2018": {"FETCH_SIZE": [100.0, 102.0]}, "amazon-book": {"FETCH_SIZE": [300.0]}, "synth-10M": {"FETCH_SIZE": [7.0]}}
