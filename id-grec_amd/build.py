@@ -39,7 +39,9 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(ROOT, "include", "idgrec.h"), os.path.join(CSRC, "idg_common.h"), os.path.join(CSRC, "idg_dropout.h")]
+    # every header and include file of csrc/ is a dependency of every object (idg_score.hip includes its *.inc kernels)
+    headers = [os.path.join(ROOT, "include", "idgrec.h")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                                                                   if f.endswith((".h", ".inc")))
     # -ffp-contract=off: the kernels spell out every fused multiply-add they want (fmaf); left to itself the compiler
     # contracts a*b+c differently in different instantiations of the same source, and paths that must agree bit for
     # bit (single- vs multi-panel kernels, epilogue vs stand-alone perturbation) then differ in the last place

@@ -831,6 +831,7 @@ __global__ __launch_bounds__(BLOCK) void chunk_floor_kernel(const float* __restr
 }
 
 #include "idg_score_bf16.inc"
+#include "idg_score_collect.inc"
 
 }  // namespace
 
@@ -880,6 +881,19 @@ static inline bool bf16_prefilter_applies(int64_t user_tiles, int64_t d, int k) 
   return user_tiles >= 16 && d == 64 && k <= 48;
 }
 
+// form 3 (round 5): threshold + collect + exact finish (idg_score_collect.inc): d = 64, one pass, ONE catalogue chunk (more
+// than 256 user tiles: every CU has its own), a catalogue of at least two slabs per sampled group.
+static inline bool collect_domain(int64_t user_tiles, int64_t I, int64_t d, int k) {
+  // (k <= a third of the sampled groups: the floor is the k-th largest of 64 / 128 half-slab maxima — at k = 20 of 64 about
+  //  220 items pass it; as k approaches the group count it falls to the smallest maximum and the candidate lists overflow)
+  return user_tiles > 256 && d == 64 && k >= 1 && 3 * k <= COLLECT_GROUPS_MAX + 2 && I >= (int64_t)2 * COLLECT_GROUPS_MAX * FT_SLAB;
+}
+static inline bool collect_applies(int64_t user_tiles, int64_t I, int64_t d, int k) {
+  const char* v = std::getenv("IDG_TOPK_COLLECT");  // "0": the exact producer / consumer form instead
+  if (v && *v && std::atoi(v) == 0) return false;
+  return collect_domain(user_tiles, I, d, k);
+}
+
 static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr, int k = 0,
                                   int64_t d = 0) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
@@ -887,9 +901,11 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
   const int forced = fv && *fv ? std::atoi(fv) : -1;
   int form = forced >= 0 ? forced : (user_tiles >= 16 ? 1 : 0);
   if (forced < 0 && form == 1 && k > 0 && bf16_prefilter_applies(user_tiles, d, k)) form = 2;
+  if (forced < 0 && form == 1 && k > 0 && collect_applies(user_tiles, I, d, k)) form = 3;
   if (form == 2 && !(d == 64 && k >= 1 && k <= 64)) form = 1;  // (a forced form 2 outside its domain)
+  if (form == 3 && !collect_domain(user_tiles, I, d, k)) form = 1;
   if (form_out) *form_out = form;
-  const int64_t tuned = form == 2 ? 256 / user_tiles : form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
+  const int64_t tuned = form == 3 ? 1 : form == 2 ? 256 / user_tiles : form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
   const int64_t max_nc = (I + 1023) / 1024;
   auto finish = [&](int64_t nc, int64_t* ci_out) {
     if (const char* v = std::getenv("IDG_TOPK_WGS"))
@@ -935,7 +951,7 @@ static inline Bf16Ws bf16_layout(int64_t Bt, int64_t I, int64_t d, size_t base) 
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   Bf16Ws w{};
   size_t o = up(base);
-  w.vs = o, o = up(o + (size_t)I * d * 4);
+  w.vs = o, o = up(o + (size_t)((I + 31) / 32 * 32) * d * 4);  // (tiles of 32 items)
   w.us = o, o = up(o + (size_t)Bt * d * 4);
   w.vnorm = o, o = up(o + (size_t)I * 4);
   w.unorm = o, o = up(o + (size_t)Bt * 4);
@@ -945,11 +961,27 @@ static inline Bf16Ws bf16_layout(int64_t Bt, int64_t I, int64_t d, size_t base) 
   return w;
 }
 
+struct CollectWs {
+  size_t group_max, floor0, count, cand, tail;
+};
+static inline CollectWs collect_layout(int64_t Bt) {
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  CollectWs w{};
+  size_t o = 0;
+  w.group_max = o, o = up(o + (size_t)Bt * COLLECT_GROUPS_MAX * 4);
+  w.floor0 = o, o = up(o + (size_t)Bt * 4);
+  w.count = o, o = up(o + (size_t)Bt * 4);
+  w.cand = o, o = up(o + (size_t)Bt * COLLECT_CAP * 8);
+  w.tail = o;
+  return w;
+}
+
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   if (Bt <= 0 || I <= 0) return 0;
   int nc, form;
   int64_t ci;
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
+  if (form == 3) return bf16_layout(Bt, I, d, collect_layout(Bt).tail).total;
   // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes + (two-phase form) one
   // maximum per (user, chunk) and one starting floor per user + (form 2) the split tables, norms and candidate lists
   const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
@@ -963,9 +995,10 @@ int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws,
   int64_t ci;
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
   info[0] = form, info[1] = nc, info[2] = floor_phase(form, nc, ci, k) ? 1 : 0, info[3] = -1;
-  if (form == 2 && ws) {
-    const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) +
-                        (info[2] ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
+  if ((form == 2 || form == 3) && ws) {
+    const size_t base = form == 3 ? collect_layout(Bt).tail
+                                  : (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) +
+                                        (info[2] ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
     const Bf16Ws w = bf16_layout(Bt, I, d, base);
     uint32_t redone = 0;
     IDG_HIP(hipMemcpyAsync(&redone, reinterpret_cast<const char*>(ws) + w.scalars + 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -991,6 +1024,54 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   unsigned long long* partial = reinterpret_cast<unsigned long long*>(ws);
   const dim3 grid((unsigned)nc, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
   const unsigned nbm = (unsigned)((Bt + (BLOCK / WAVE) - 1) / (BLOCK / WAVE));
+  if (form == 3) {
+    // threshold + collect + exact finish (idg_score_collect.inc)
+    IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_score_topk_f32: workspace must be 16-byte aligned");
+    const CollectWs cw = collect_layout(Bt);
+    const Bf16Ws w = bf16_layout(Bt, I, d, cw.tail);
+    char* wb = reinterpret_cast<char*>(ws);
+    float* group_max = reinterpret_cast<float*>(wb + cw.group_max);
+    float* floor0 = reinterpret_cast<float*>(wb + cw.floor0);
+    unsigned int* count = reinterpret_cast<unsigned int*>(wb + cw.count);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(wb + cw.cand);
+    __bf16* Vs = reinterpret_cast<__bf16*>(wb + w.vs);
+    __bf16* Us = reinterpret_cast<__bf16*>(wb + w.us);
+    float* vnorm = reinterpret_cast<float*>(wb + w.vnorm);
+    float* unorm = reinterpret_cast<float*>(wb + w.unorm);
+    uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
+    IDG_HIP(hipMemsetAsync(scal, 0, 16, st));
+    const int64_t I_pad = (I + 31) / 32 * 32;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
+                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((Bt * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
+                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr);
+    const int n_slabs_all = (int)((I + FT_SLAB - 1) / FT_SLAB);
+    // the floor pass samples about a tenth of the catalogue whatever its size: `groups` / 2 x gs slabs, evenly spaced, a group =
+    // the same half of gs consecutive sampled slabs (yelp2018 size: gs = 1, 32 or 64 slabs of 298)
+    const int groups = collect_groups(k);
+    const int gs = std::max(1, n_slabs_all / 300);
+    const int walk = (groups / 2) * gs;
+    const int stride = std::max(1, n_slabs_all / walk);  // (the last sampled slab lies inside the catalogue)
+    const dim3 g1(1u, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
+#define IDG_COLLECT(SIG, GM, WALK, STRIDE, GS)                                                                                  \
+  hipLaunchKernelGGL((score_topk_collect_kernel<SIG, GM>), g1, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, WALK, STRIDE, GS, \
+                     excl_indptr, excl_items, group_max, (const float*)floor0, count, cand)
+    if (apply_sigmoid) IDG_COLLECT(true, true, walk, stride, gs);
+    else IDG_COLLECT(false, true, walk, stride, gs);
+    hipLaunchKernelGGL(group_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, group_max, Bt, groups, k, floor0);
+    hipLaunchKernelGGL(floor_margin_kernel, dim3((unsigned)((Bt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, floor0, unorm, scal, Bt);
+    if (apply_sigmoid) IDG_COLLECT(true, false, n_slabs_all, 1, 1);
+    else IDG_COLLECT(false, false, n_slabs_all, 1, 1);
+#undef IDG_COLLECT
+    if (apply_sigmoid)
+      hipLaunchKernelGGL(topk_finish_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
+                         excl_items, k, count, cand, unorm, scal, out_idx, out_val, scal + 1);
+    else
+      hipLaunchKernelGGL(topk_finish_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
+                         excl_items, k, count, cand, unorm, scal, out_idx, out_val, scal + 1);
+    IDG_HIP(hipGetLastError());
+    return IDG_OK;
+  }
   if (form == 2) {
     // split-bf16 pre-filter: candidates by approximate score, exact re-scoring, brute force where the guarantee fails
     IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_score_topk_f32: workspace must be 16-byte aligned");
@@ -1006,10 +1087,11 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(wb + w.cand);
     uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
     IDG_HIP(hipMemsetAsync(scal, 0, 16, st));
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
-                       (const int64_t*)nullptr, I, d, Vs, vnorm, scal);
+    const int64_t I_pad = (I + 31) / 32 * 32;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
+                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal);
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((Bt * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
-                       d, Us, unorm, (uint32_t*)nullptr);
+                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr);
     float* chunk_max = nullptr;
     float* floor0 = nullptr;
     if (fl) {

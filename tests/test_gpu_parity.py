@@ -1127,6 +1127,7 @@ def test_topk_bf16_prefilter_is_the_exact_answer(ops, per_call, sig, monkeypatch
         assert info["floor"] == (per_call == 1024), info
         redone += info["users_redone"]
     monkeypatch.setenv("IDG_TOPK_BF16", "0")
+    monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
     want = []
     for b in calls:
         want.append(ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info))
@@ -1134,6 +1135,42 @@ def test_topk_bf16_prefilter_is_the_exact_answer(ops, per_call, sig, monkeypatch
     assert torch.equal(torch.cat([x[0] for x in got]), torch.cat([x[0] for x in want])), "ids differ from the exact form"
     assert torch.equal(torch.cat([x[1] for x in got]), torch.cat([x[1] for x in want])), "values differ from the exact form"
     assert 1 <= redone <= 32, redone  # user 5 (all ties) certainly; hardly anybody else
+
+
+@pytest.mark.parametrize("sig", [True, False])
+@pytest.mark.parametrize("k", [20, 22, 1, 40])
+def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatch):
+    """Round 5, form 3 (the default for calls of more than 256 user tiles at d = 64, k <= 42; IDG_TOPK_COLLECT=0 turns it off): a floor per user from the maxima
+    of a strided sample of the catalogue (split-bf16 scores, lowered by twice their error bound), ONE pass that appends
+    every item at or above the floor to the user's candidate list — no list insertions in the scoring pass — and an exact
+    finish: the candidates' fp32 scores as the fmaf chain the fp32 matrix cores evaluate, masked, through the streaming
+    select.  At yelp2018 size, all users in one call, train items masked, duplicated item rows (exact ties), a user whose
+    every score ties (its candidate list overflows: redone over the whole catalogue): ids AND values bit for bit what the
+    exact producer / consumer form returns."""
+    import idgrec_amd.synth as S
+
+    U, I, d = 31668, 38048, 64
+    users, items = S.generate(U, I, 600000, seed=23)
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    ip, ix = dev(ptr), dev(items.astype(np.int32))
+    g = torch.Generator(device="cuda").manual_seed(k)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
+    Ie[::101] = Ie[3]
+    Ue[5] = 0.0
+    every = torch.arange(U, device="cuda")
+    info = {}
+    monkeypatch.delenv("IDG_TOPK_COLLECT", raising=False)
+    got = ops.score_topk(Ue, Ie, every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
+    assert info["form"] == 3 and info["chunks"] == 1, info
+    # user 5 (every score ties: its candidate list overflows) certainly; the 377 identical item rows overflow a few more
+    assert 1 <= info["users_redone"] <= U // 200, info
+    monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
+    want = ops.score_topk(Ue, Ie, every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
+    assert info["form"] == 1
+    assert torch.equal(got[0], want[0]), "ids differ from the exact form"
+    assert torch.equal(got[1], want[1]), "values differ from the exact form"
 
 
 @pytest.mark.parametrize("per_call", [2048, 4096, 8192])
