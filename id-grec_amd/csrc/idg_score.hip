@@ -1058,8 +1058,8 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
                      excl_indptr, excl_items, group_max, (const float*)floor0, count, cand)
     if (apply_sigmoid) IDG_COLLECT(true, true, walk, stride, gs);
     else IDG_COLLECT(false, true, walk, stride, gs);
-    hipLaunchKernelGGL(group_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, group_max, Bt, groups, k, floor0);
-    hipLaunchKernelGGL(floor_margin_kernel, dim3((unsigned)((Bt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, floor0, unorm, scal, Bt);
+    hipLaunchKernelGGL(group_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, group_max, Bt, groups, k, (const float*)unorm,
+                       (const uint32_t*)scal, floor0);
     if (apply_sigmoid) IDG_COLLECT(true, false, n_slabs_all, 1, 1);
     else IDG_COLLECT(false, false, n_slabs_all, 1, 1);
 #undef IDG_COLLECT
