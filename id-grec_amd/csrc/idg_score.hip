@@ -203,6 +203,14 @@ __device__ __forceinline__ void list_offer(unsigned long long& list, unsigned lo
   }
 }
 __device__ __forceinline__ float tau_floor(unsigned long long tau) { return tau ? key_score(tau) : -__builtin_inff(); }
+// The floor a consumer PUBLISHES to the producers' flagging (flag_candidates compares raw accumulators, before masking).
+// On raw scores a train item ranks as the value -1 whatever its raw score is, so while a user's floor is not above -1 a
+// slab may hold a candidate the producers cannot see: publish -inf (every slab of that user is looked at) until the
+// floor has passed -1.  After the sigmoid a masked entry ranks below every score and never is a candidate.
+template <bool SIGMOID>
+__device__ __forceinline__ float floor_published(float f) {
+  return (!SIGMOID && f <= -1.0f) ? -__builtin_inff() : f;
+}
 
 template <bool SIGMOID>
 __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float* __restrict__ U,
@@ -530,7 +538,7 @@ __device__ __forceinline__ void topk_consume(float (*s_buf)[FT_USERS * FT_LD], f
         }
         wave_sort128_desc(k0, k1, lane);
         const unsigned long long tk = shfl_u64(k0, k - 1);
-        if (lane == 0) s_floor[u] = floor_of(tk);
+        if (lane == 0) s_floor[u] = floor_published<SIGMOID>(floor_of(tk));
 #pragma unroll
         for (int q = 0; q < FT_UPW; ++q) best[q] = q == uu ? k0 : best[q];
       }
@@ -572,7 +580,7 @@ __device__ __forceinline__ void topk_consume(float (*s_buf)[FT_USERS * FT_LD], f
       unsigned long long tk = shfl_u64(best[uu], k - 1);
       const bool ch0 = offer(best[uu], tk, c0);
       const bool ch1 = offer(best[uu], tk, c1);
-      if ((ch0 || ch1) && lane == 0) s_floor[u] = fmaxf(fl0, floor_of(tk));
+      if ((ch0 || ch1) && lane == 0) s_floor[u] = floor_published<SIGMOID>(fmaxf(fl0, floor_of(tk)));
     }
   }
 #pragma unroll
@@ -609,7 +617,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void score_topk_spec_kernel(const floa
   const int wave8 = __builtin_amdgcn_readfirstlane(tid / WAVE);  // scalar: the role branch below is wave-uniform
   const int64_t b0 = (int64_t)blockIdx.y * FT_USERS;
   if (tid < FT_USERS) {
-    s_floor[tid] = (!MAXONLY && floor0 && b0 + tid < Bt) ? floor0[b0 + tid] : -__builtin_inff();
+    s_floor[tid] = (!MAXONLY && floor0 && b0 + tid < Bt) ? floor_published<SIGMOID>(floor0[b0 + tid]) : -__builtin_inff();
     s_flag[0][tid] = 0u, s_flag[1][tid] = 0u;
   }
   __syncthreads();

@@ -1171,6 +1171,20 @@ def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatc
     assert info["form"] == 1
     assert torch.equal(got[0], want[0]), "ids differ from the exact form"
     assert torch.equal(got[1], want[1]), "values differ from the exact form"
+    if k == 20:
+        # every score far below -1: in raw-score mode the masked train items, ranking as the VALUE -1 (batch_test.py:65), are
+        # then the BEST items of a user and must head its list (the collect pass masks in this mode for exactly that); in
+        # sigmoid mode they rank below everything and never appear
+        Un, In = -Ue.abs() - 0.1, Ie.abs() + 0.1
+        monkeypatch.delenv("IDG_TOPK_COLLECT", raising=False)
+        got = ops.score_topk(Un, In, every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
+        assert info["form"] == 3, info
+        monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
+        want = ops.score_topk(Un, In, every, k, ip, ix, apply_sigmoid=sig, return_values=True)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), "all-negative scores: differs from the exact form"
+        deg = torch.from_numpy(np.diff(ptr)).cuda()
+        head_is_train = (got[1][:, 0] == -1.0)
+        assert bool((head_is_train == ((deg > 0) & (not sig))).all())
 
 
 @pytest.mark.parametrize("per_call", [2048, 4096, 8192])
@@ -1239,6 +1253,51 @@ def test_topk_exact_order_on_integer_embeddings(ops, per_call, d):
         want_s = np.lexsort((np.broadcast_to(np.arange(I), M.shape), -M), axis=1)[:, :k]
         assert np.array_equal(sig_i[c0:c0 + 500], want_s), "sigmoid mode: ids differ from the float64 reference"
         np.testing.assert_allclose(sig_v[c0:c0 + 500], 1.0 / (1.0 + np.exp(-np.take_along_axis(M, want_s, 1))), rtol=3e-7, atol=0)
+
+
+@pytest.mark.parametrize("per_call", [100, 1024, 5000, 20000])
+def test_topk_raw_scores_below_minus_one_put_the_masked_items_first(ops, per_call):
+    """Raw-score mode (apply_sigmoid = 0) ranks a masked train item as the VALUE -1 (batch_test.py:65 writes -1 into the
+    rating matrix; after the sigmoid that is below every score, on raw scores it is not).  When every score of a user is
+    below -1 its train items are its best items: they head the list, in item order, whatever their raw scores are.  The
+    producer / consumer kernels flag (user, slab) pairs on raw accumulators, before masking — round 5 found them dropping
+    these entries; a consumer now publishes no floor until it has passed -1.  Integer embeddings (users <= -1, items >= 1:
+    every dot product an exact integer <= -64), float64 NumPy reference, call sizes that take the one-kernel, the
+    starting-floor and the many-tile geometries (20000 users: form 3 when it applies)."""
+    import idgrec_amd.synth as S
+
+    U, I, d, k = 20000, 33001, 64, 20
+    users, items = S.generate(U, I, 300000, seed=per_call)
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    order = np.lexsort((items, users))
+    items_sorted = items[order].astype(np.int32)
+    rng = np.random.default_rng(per_call)
+    Ue = -rng.integers(1, 4, (U, d)).astype(np.float32)
+    Ie = rng.integers(1, 4, (I, d)).astype(np.float32)
+    ip, ix = dev(ptr), dev(items_sorted)
+    Ud, Id = dev(Ue), dev(Ie)
+    got_i, got_v = [], []
+    for s0 in range(0, U, per_call):
+        b = torch.arange(s0, min(s0 + per_call, U), device="cuda")
+        i_, v_ = ops.score_topk(Ud, Id, b, k, ip, ix, apply_sigmoid=False, return_values=True)
+        got_i.append(i_.cpu().numpy())
+        got_v.append(v_.cpu().numpy())
+    got_i, got_v = np.concatenate(got_i), np.concatenate(got_v)
+    deg = np.diff(ptr)
+    assert (deg >= k).any() and ((deg > 0) & (deg < k)).any()
+    for u in np.nonzero(deg > 0)[0]:  # every user: its train items first, ascending, as -1
+        n = min(int(deg[u]), k)
+        assert np.array_equal(got_i[u, :n], items_sorted[ptr[u]:ptr[u] + n]), "user %d: train items do not head the list" % u
+        assert (got_v[u, :n] == -1.0).all()
+    for c0 in range(0, U, 4000):  # and the whole list against float64, 500 users out of every 4000
+        R = Ue[c0:c0 + 500].astype(np.float64) @ Ie.astype(np.float64).T
+        assert R.max() <= -64.0
+        for r, u in enumerate(range(c0, min(c0 + 500, U))):
+            R[r, items_sorted[ptr[u]:ptr[u + 1]]] = -1.0
+        want = np.lexsort((np.broadcast_to(np.arange(I), R.shape), -R), axis=1)[:, :k]
+        assert np.array_equal(got_i[c0:c0 + 500], want), "ids differ from the float64 reference"
+        assert np.array_equal(got_v[c0:c0 + 500].astype(np.float64), np.take_along_axis(R, want, 1))
 
 
 @pytest.mark.parametrize("mode", ["unique", "raw", "cross"])
