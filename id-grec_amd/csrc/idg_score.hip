@@ -889,13 +889,28 @@ static inline bool bf16_prefilter_applies(int64_t user_tiles, int64_t d, int k) 
   return user_tiles >= 16 && d == 64 && k <= 48;
 }
 
-// form 3 (round 5): threshold + collect + exact finish (idg_score_collect.inc): d = 64, one pass, ONE catalogue chunk (more
-// than 256 user tiles: every CU has its own), a catalogue of at least two slabs per sampled group.
+// form 3 (round 5): threshold + collect + exact finish (idg_score_collect.inc): d = 64, one pass, a catalogue of at least
+// two slabs per sampled group, calls of at least COLLECT_MIN_TILES user tiles (more than 256 tiles: ONE catalogue chunk,
+// every CU has its own tiles; fewer: the catalogue is cut so that the grid fills the chip, collect_chunks).
+constexpr int COLLECT_MIN_TILES = 8;  // (512 / 8 = 64 chunks: the finish reads one count per lane)
 static inline bool collect_domain(int64_t user_tiles, int64_t I, int64_t d, int k) {
   // (k <= a third of the sampled groups: the floor is the k-th largest of 64 / 128 half-slab maxima — at k = 20 of 64 about
   //  220 items pass it; as k approaches the group count it falls to the smallest maximum and the candidate lists overflow)
-  return user_tiles > 256 && d == 64 && k >= 1 && 3 * k <= COLLECT_GROUPS_MAX + 2 && I >= (int64_t)2 * COLLECT_GROUPS_MAX * FT_SLAB;
+  return user_tiles >= COLLECT_MIN_TILES && d == 64 && k >= 1 && 3 * k <= COLLECT_GROUPS_MAX + 2 &&
+         I >= (int64_t)2 * COLLECT_GROUPS_MAX * FT_SLAB;
 }
+// chunks of a form-3 call: two workgroups per CU's worth of them, a multiple of 8 where there are that many (workgroup ->
+// XCD goes round robin over the linear id, chunk fastest: the tiles of one chunk then share an L2), chunks of >= 8 slabs
+static inline int64_t collect_chunks(int64_t user_tiles, int64_t I) {
+  int64_t nc = user_tiles > 256 ? 1 : 512 / user_tiles;
+  const int64_t most = ((I + FT_SLAB - 1) / FT_SLAB) / 8;
+  nc = nc > most ? most : nc;
+  nc = nc > 64 ? 64 : nc;
+  if (nc >= 8) nc = nc / 8 * 8;
+  return nc < 1 ? 1 : nc;
+}
+// candidate keys a (user, chunk) segment holds: the whole list when there is one chunk, else a share with room for skew
+static inline int collect_cap_chunk(int nc) { return nc == 1 ? COLLECT_CAP : std::max(128, 2 * COLLECT_CAP / nc); }
 static inline bool collect_applies(int64_t user_tiles, int64_t I, int64_t d, int k) {
   const char* v = std::getenv("IDG_TOPK_COLLECT");  // "0": the exact producer / consumer form instead
   if (v && *v && std::atoi(v) == 0) return false;
@@ -913,7 +928,7 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
   if (form == 2 && !(d == 64 && k >= 1 && k <= 64)) form = 1;  // (a forced form 2 outside its domain)
   if (form == 3 && !collect_domain(user_tiles, I, d, k)) form = 1;
   if (form_out) *form_out = form;
-  const int64_t tuned = form == 3 ? 1 : form == 2 ? 256 / user_tiles : form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
+  const int64_t tuned = form == 3 ? collect_chunks(user_tiles, I) : form == 2 ? 256 / user_tiles : form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
   const int64_t max_nc = (I + 1023) / 1024;
   auto finish = [&](int64_t nc, int64_t* ci_out) {
     if (const char* v = std::getenv("IDG_TOPK_WGS"))
@@ -933,7 +948,7 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
   // partial-list workspace grows with the chunk count: calls of 17..256 user tiles at k + 2 chunks up to ~16x).
   // Measured where it pays: calls of 1024 users (16 tiles) at yelp2018 / amazon-book size; beyond 64 user tiles the
   // tuned count is already <= 8 chunks and the start-up the floor saves is a small share of a launch.
-  if (form >= 1 && tuned > 1 && tuned < k + 2 && k <= 64 && user_tiles <= 64) {
+  if ((form == 1 || form == 2) && tuned > 1 && tuned < k + 2 && k <= 64 && user_tiles <= 64) {
     int64_t ci2;
     const int64_t nc2 = finish(k + 2, &ci2);
     if (floor_phase(form, (int)nc2, ci2, k)) nc = nc2, ci = ci2;
@@ -948,7 +963,7 @@ static_assert(FLOOR_SLABS >= 1, "IDG_TOPK_FLOOR_SLABS must be >= 1: chunk_floor_
 static inline bool floor_phase(int form, int nc, int64_t ci, int k) {
   const char* v = std::getenv("IDG_TOPK_FLOOR");
   if (v && *v && std::atoi(v) == 0) return false;
-  return form >= 1 && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
+  return (form == 1 || form == 2) && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
 }
 
 // extra scratch of form 2, behind the partial lists (+ chunk maxima / floors): offsets in bytes, 256-byte aligned
@@ -972,14 +987,14 @@ static inline Bf16Ws bf16_layout(int64_t Bt, int64_t I, int64_t d, size_t base) 
 struct CollectWs {
   size_t group_max, floor0, count, cand, tail;
 };
-static inline CollectWs collect_layout(int64_t Bt) {
+static inline CollectWs collect_layout(int64_t Bt, int nc) {
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   CollectWs w{};
   size_t o = 0;
   w.group_max = o, o = up(o + (size_t)Bt * COLLECT_GROUPS_MAX * 4);
   w.floor0 = o, o = up(o + (size_t)Bt * 4);
-  w.count = o, o = up(o + (size_t)Bt * 4);
-  w.cand = o, o = up(o + (size_t)Bt * COLLECT_CAP * 8);
+  w.count = o, o = up(o + (size_t)Bt * (size_t)nc * 4);
+  w.cand = o, o = up(o + (size_t)Bt * (size_t)nc * (size_t)collect_cap_chunk(nc) * 8);
   w.tail = o;
   return w;
 }
@@ -989,7 +1004,7 @@ size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   int nc, form;
   int64_t ci;
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
-  if (form == 3) return bf16_layout(Bt, I, d, collect_layout(Bt).tail).total;
+  if (form == 3) return bf16_layout(Bt, I, d, collect_layout(Bt, nc).tail).total;
   // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes + (two-phase form) one
   // maximum per (user, chunk) and one starting floor per user + (form 2) the split tables, norms and candidate lists
   const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
@@ -1004,7 +1019,7 @@ int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws,
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
   info[0] = form, info[1] = nc, info[2] = floor_phase(form, nc, ci, k) ? 1 : 0, info[3] = -1;
   if ((form == 2 || form == 3) && ws) {
-    const size_t base = form == 3 ? collect_layout(Bt).tail
+    const size_t base = form == 3 ? collect_layout(Bt, nc).tail
                                   : (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) +
                                         (info[2] ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
     const Bf16Ws w = bf16_layout(Bt, I, d, base);
@@ -1035,7 +1050,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   if (form == 3) {
     // threshold + collect + exact finish (idg_score_collect.inc)
     IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_score_topk_f32: workspace must be 16-byte aligned");
-    const CollectWs cw = collect_layout(Bt);
+    const CollectWs cw = collect_layout(Bt, nc);
     const Bf16Ws w = bf16_layout(Bt, I, d, cw.tail);
     char* wb = reinterpret_cast<char*>(ws);
     float* group_max = reinterpret_cast<float*>(wb + cw.group_max);
@@ -1047,12 +1062,12 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     float* vnorm = reinterpret_cast<float*>(wb + w.vnorm);
     float* unorm = reinterpret_cast<float*>(wb + w.unorm);
     uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
-    IDG_HIP(hipMemsetAsync(scal, 0, 16, st));
     const int64_t I_pad = (I + 31) / 32 * 32;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
-                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal);
+    // (the users' launch goes first and zeroes the call's scalars: the items' launch takes its maximum into scal[0])
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((Bt * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
-                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr);
+                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr, scal);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
+                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal, (uint32_t*)nullptr);
     const int n_slabs_all = (int)((I + FT_SLAB - 1) / FT_SLAB);
     // the floor pass samples about a tenth of the catalogue whatever its size: `groups` / 2 x gs slabs, evenly spaced, a group =
     // the same half of gs consecutive sampled slabs (yelp2018 size: gs = 1, 32 or 64 slabs of 298)
@@ -1060,23 +1075,29 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     const int gs = std::max(1, n_slabs_all / 300);
     const int walk = (groups / 2) * gs;
     const int stride = std::max(1, n_slabs_all / walk);  // (the last sampled slab lies inside the catalogue)
-    const dim3 g1(1u, (unsigned)((Bt + FT_USERS - 1) / FT_USERS));
-#define IDG_COLLECT(SIG, GM, WALK, STRIDE, GS)                                                                                  \
-  hipLaunchKernelGGL((score_topk_collect_kernel<SIG, GM>), g1, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, WALK, STRIDE, GS, \
-                     excl_indptr, excl_items, group_max, (const float*)floor0, count, cand)
-    if (apply_sigmoid) IDG_COLLECT(true, true, walk, stride, gs);
-    else IDG_COLLECT(false, true, walk, stride, gs);
+    // the floor pass is cut by slab groups (a power of two of them per workgroup), the collect pass by fused_geometry's chunks
+    int fc = 1;
+    while (2 * fc <= groups / 2 && (int64_t)2 * fc <= nc) fc *= 2;
+    const int walk_c = walk / fc;
+    const int64_t ci_floor = (int64_t)walk_c * stride * FT_SLAB;
+    const int cap_chunk = collect_cap_chunk(nc);
+    const unsigned tiles = (unsigned)((Bt + FT_USERS - 1) / FT_USERS);
+#define IDG_COLLECT(SIG, GM, GRIDX, CI, WALK, STRIDE, GS)                                                                       \
+  hipLaunchKernelGGL((score_topk_collect_kernel<SIG, GM>), dim3((unsigned)(GRIDX), tiles), dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, \
+                     (int64_t)(CI), WALK, STRIDE, GS, excl_indptr, excl_items, group_max, (const float*)floor0, count, cand, cap_chunk)
+    if (apply_sigmoid) IDG_COLLECT(true, true, fc, ci_floor, walk_c, stride, gs);
+    else IDG_COLLECT(false, true, fc, ci_floor, walk_c, stride, gs);
     hipLaunchKernelGGL(group_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, group_max, Bt, groups, k, (const float*)unorm,
                        (const uint32_t*)scal, floor0);
-    if (apply_sigmoid) IDG_COLLECT(true, false, n_slabs_all, 1, 1);
-    else IDG_COLLECT(false, false, n_slabs_all, 1, 1);
+    if (apply_sigmoid) IDG_COLLECT(true, false, nc, ci, 0, 1, 1);
+    else IDG_COLLECT(false, false, nc, ci, 0, 1, 1);
 #undef IDG_COLLECT
     if (apply_sigmoid)
       hipLaunchKernelGGL(topk_finish_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, count, cand, unorm, scal, out_idx, out_val, scal + 1);
+                         excl_items, k, count, cand, nc, cap_chunk, unorm, scal, out_idx, out_val, scal + 1);
     else
       hipLaunchKernelGGL(topk_finish_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, count, cand, unorm, scal, out_idx, out_val, scal + 1);
+                         excl_items, k, count, cand, nc, cap_chunk, unorm, scal, out_idx, out_val, scal + 1);
     IDG_HIP(hipGetLastError());
     return IDG_OK;
   }
@@ -1094,12 +1115,12 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     float* unorm = reinterpret_cast<float*>(wb + w.unorm);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(wb + w.cand);
     uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
-    IDG_HIP(hipMemsetAsync(scal, 0, 16, st));
     const int64_t I_pad = (I + 31) / 32 * 32;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
-                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal);
+    // (the users' launch goes first and zeroes the call's scalars: the items' launch takes its maximum into scal[0])
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((Bt * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
-                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr);
+                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr, scal);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
+                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal, (uint32_t*)nullptr);
     float* chunk_max = nullptr;
     float* floor0 = nullptr;
     if (fl) {
