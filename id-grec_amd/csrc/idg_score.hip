@@ -936,7 +936,9 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
     if (const char* v = std::getenv("IDG_TOPK_CHUNKS"))
       if (*v && std::atoll(v) > 0) nc = std::atoll(v);  // testing knob
     nc = nc < 1 ? 1 : (nc > max_nc ? max_nc : nc);
-    const int64_t ci = ((I + nc - 1) / nc + FT_SLAB - 1) / FT_SLAB * FT_SLAB;
+    // (form 3's producers walk slabs in pairs: an even number per chunk leaves only the last chunk a phantom slab)
+    const int64_t unit = form == 3 ? 2 * FT_SLAB : FT_SLAB;
+    const int64_t ci = ((I + nc - 1) / nc + unit - 1) / unit * unit;
     *ci_out = ci;
     return (I + ci - 1) / ci;
   };
