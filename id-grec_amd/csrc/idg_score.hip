@@ -414,8 +414,8 @@ __device__ __forceinline__ void flag_candidates(const f32x16& acc0, const f32x16
   }
 }
 
-// The consumer half of the producer / consumer kernels (score_topk_spec_kernel: exact fp32 scores; score_topk_bf16_kernel:
-// split-bf16 approximations of them): wave `wave` (0..3) owns users 16 wave .. 16 wave + 15 of the block's 64.
+// The consumer half of the producer / consumer kernel (score_topk_spec_kernel: exact fp32 scores): wave `wave` (0..3)
+// owns users 16 wave .. 16 wave + 15 of the block's 64.
 template <bool SIGMOID, bool MAXONLY>
 __device__ __forceinline__ void topk_consume(float (*s_buf)[FT_USERS * FT_LD], float* s_floor, uint32_t (*s_flag)[FT_USERS],
                                              const int wave, const int lane, const int64_t* __restrict__ users, int64_t Bt,
@@ -876,27 +876,16 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 // for 317 calls) and the alternating kernel, with its ~1024 short workgroups, is kept.
 static inline bool floor_phase(int form, int nc, int64_t ci, int k);
 
-// form 2 (round 5, OPT-IN: IDG_TOPK_BF16=1): the producer / consumer kernel on split-bf16 operands + exact re-scoring of 64
-// candidates per user (idg_score_bf16.inc): d = 64, one pass, k small enough that the 64-key list leaves a margin; one
-// workgroup per CU.  Exact (bit-identical lists and values, tests/test_gpu_parity.py) and MEASURED SLOWER than form 1
-// (yelp2018 size, one call: 3.36 ms vs 1.95; profiles/r05/topk_bf16_probe.txt): with the matrix time cut five-fold the
-// streaming select is what a slab costs, and the 64-key list the guarantee needs makes the select dearer (at a 20-key
-// list — no guarantee, timing probe IDG_TOPK_BF16_LIST=20 — the main kernel takes 1.73 ms).  Kept as the record of
-// VERDICT r04's experiment; the next step it points to is a select without insertions.
-static inline bool bf16_prefilter_applies(int64_t user_tiles, int64_t d, int k) {
-  const char* v = std::getenv("IDG_TOPK_BF16");
-  if (!(v && *v && std::atoi(v) == 1)) return false;
-  return user_tiles >= 16 && d == 64 && k <= 48;
-}
-
-// form 3 (round 5): threshold + collect + exact finish (idg_score_collect.inc): d = 64, one pass, a catalogue of at least
-// two slabs per sampled group, calls of at least COLLECT_MIN_TILES user tiles (more than 256 tiles: ONE catalogue chunk,
-// every CU has its own tiles; fewer: the catalogue is cut so that the grid fills the chip, collect_chunks).
+// form 3 (round 5): threshold + collect + exact finish on bf16 bound scores (idg_score_collect.inc, idg_score_bf16.inc):
+// d = 64, 128 or 256, one pass, a catalogue of at least two slabs per sampled group, calls of at least COLLECT_MIN_TILES user
+// tiles (more than 256 tiles: ONE catalogue chunk, every CU has its own tiles; fewer: the catalogue is cut so that the grid
+// fills the chip, collect_chunks).  (VERDICT r04's split-bf16 pre-filter on the streaming select — "form 2" — was built,
+// measured slower than form 1 and removed: profiles/r05/topk_bf16_probe.txt, HISTORY.md.)
 constexpr int COLLECT_MIN_TILES = 8;  // (512 / 8 = 64 chunks: the finish reads one count per lane)
 static inline bool collect_domain(int64_t user_tiles, int64_t I, int64_t d, int k) {
   // (k <= a third of the sampled groups: the floor is the k-th largest of 64 / 128 half-slab maxima — at k = 20 of 64 about
   //  220 items pass it; as k approaches the group count it falls to the smallest maximum and the candidate lists overflow)
-  return user_tiles >= COLLECT_MIN_TILES && d == 64 && k >= 1 && 3 * k <= COLLECT_GROUPS_MAX + 2 &&
+  return user_tiles >= COLLECT_MIN_TILES && (d == 64 || d == 128 || d == 256) && k >= 1 && 3 * k <= COLLECT_GROUPS_MAX + 2 &&
          I >= (int64_t)2 * COLLECT_GROUPS_MAX * FT_SLAB;
 }
 // chunks of a form-3 call: two workgroups per CU's worth of them, a multiple of 8 where there are that many (workgroup ->
@@ -920,15 +909,14 @@ static inline bool collect_applies(int64_t user_tiles, int64_t I, int64_t d, int
 static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t* chunk_items, int* form_out = nullptr, int k = 0,
                                   int64_t d = 0) {
   const int64_t user_tiles = (Bt + FT_USERS - 1) / FT_USERS;
-  const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 / 2 forces a kernel
+  const char* fv = std::getenv("IDG_TOPK_FORM");  // testing knob: 0 / 1 / 3 forces a kernel (3: where its domain allows)
   const int forced = fv && *fv ? std::atoi(fv) : -1;
   int form = forced >= 0 ? forced : (user_tiles >= 16 ? 1 : 0);
-  if (forced < 0 && form == 1 && k > 0 && bf16_prefilter_applies(user_tiles, d, k)) form = 2;
-  if (forced < 0 && form == 1 && k > 0 && collect_applies(user_tiles, I, d, k)) form = 3;
-  if (form == 2 && !(d == 64 && k >= 1 && k <= 64)) form = 1;  // (a forced form 2 outside its domain)
+  if (forced < 0 && k > 0 && collect_applies(user_tiles, I, d, k)) form = 3;
+  if (form == 2) form = 1;  // (the removed pre-filter form)
   if (form == 3 && !collect_domain(user_tiles, I, d, k)) form = 1;
   if (form_out) *form_out = form;
-  const int64_t tuned = form == 3 ? collect_chunks(user_tiles, I) : form == 2 ? 256 / user_tiles : form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
+  const int64_t tuned = form == 3 ? collect_chunks(user_tiles, I) : form == 1 ? (2 * 256) / user_tiles : (TOPK_WGS + user_tiles - 1) / user_tiles;
   const int64_t max_nc = (I + 1023) / 1024;
   auto finish = [&](int64_t nc, int64_t* ci_out) {
     if (const char* v = std::getenv("IDG_TOPK_WGS"))
@@ -950,7 +938,7 @@ static inline void fused_geometry(int64_t Bt, int64_t I, int* n_chunks, int64_t*
   // partial-list workspace grows with the chunk count: calls of 17..256 user tiles at k + 2 chunks up to ~16x).
   // Measured where it pays: calls of 1024 users (16 tiles) at yelp2018 / amazon-book size; beyond 64 user tiles the
   // tuned count is already <= 8 chunks and the start-up the floor saves is a small share of a launch.
-  if ((form == 1 || form == 2) && tuned > 1 && tuned < k + 2 && k <= 64 && user_tiles <= 64) {
+  if (form == 1 && tuned > 1 && tuned < k + 2 && k <= 64 && user_tiles <= 64) {
     int64_t ci2;
     const int64_t nc2 = finish(k + 2, &ci2);
     if (floor_phase(form, (int)nc2, ci2, k)) nc = nc2, ci = ci2;
@@ -965,23 +953,23 @@ static_assert(FLOOR_SLABS >= 1, "IDG_TOPK_FLOOR_SLABS must be >= 1: chunk_floor_
 static inline bool floor_phase(int form, int nc, int64_t ci, int k) {
   const char* v = std::getenv("IDG_TOPK_FLOOR");
   if (v && *v && std::atoi(v) == 0) return false;
-  return (form == 1 || form == 2) && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
+  return form == 1 && k <= 64 && nc >= k && ci >= 4 * FT_SLAB;
 }
 
-// extra scratch of form 2, behind the partial lists (+ chunk maxima / floors): offsets in bytes, 256-byte aligned
-struct Bf16Ws {
-  size_t vs, us, vnorm, unorm, cand, scalars, total;
+// form 3's bound tables, behind its own scratch: offsets in bytes, 256-byte aligned
+struct BoundWs {
+  size_t vs, us, vbound, ubound, scalars, total;
 };
-static inline Bf16Ws bf16_layout(int64_t Bt, int64_t I, int64_t d, size_t base) {
+static inline BoundWs bound_layout(int64_t Bt, int64_t I, int64_t d, size_t base) {
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-  Bf16Ws w{};
+  const size_t ks = (size_t)d / 16;
+  BoundWs w{};
   size_t o = up(base);
-  w.vs = o, o = up(o + (size_t)((I + 31) / 32 * 32) * d * 4);  // (tiles of 32 items)
-  w.us = o, o = up(o + (size_t)Bt * d * 4);
-  w.vnorm = o, o = up(o + (size_t)I * 4);
-  w.unorm = o, o = up(o + (size_t)Bt * 4);
-  w.cand = o, o = up(o + (size_t)Bt * 64 * 8);
-  w.scalars = o, o = up(o + 16);  // [0] max item norm (float bits), [1] users redone by brute force
+  w.vs = o, o = up(o + (size_t)((I + 31) / 32) * (ks + 1) * 1024);  // (tiles of 32 items, KS + 1 blocks of 1 KiB)
+  w.us = o, o = up(o + (size_t)Bt * (ks + 2) * 32);
+  w.vbound = o, o = up(o + (size_t)I * 4);
+  w.ubound = o, o = up(o + (size_t)Bt * 4);
+  w.scalars = o, o = up(o + 16);  // [0] max item bound (float bits), [1] users redone by brute force
   w.total = o;
   return w;
 }
@@ -1006,12 +994,11 @@ size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   int nc, form;
   int64_t ci;
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
-  if (form == 3) return bf16_layout(Bt, I, d, collect_layout(Bt, nc).tail).total;
+  if (form == 3) return bound_layout(Bt, I, d, collect_layout(Bt, nc).tail).total;
   // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes + (two-phase form) one
-  // maximum per (user, chunk) and one starting floor per user + (form 2) the split tables, norms and candidate lists
-  const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
-                      (floor_phase(form, nc, ci, k) ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
-  return form == 2 ? bf16_layout(Bt, I, d, base).total : base;
+  // maximum per (user, chunk) and one starting floor per user
+  return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
+         (floor_phase(form, nc, ci, k) ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
 }
 
 int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int64_t info[4], void* stream) {
@@ -1020,11 +1007,8 @@ int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws,
   int64_t ci;
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
   info[0] = form, info[1] = nc, info[2] = floor_phase(form, nc, ci, k) ? 1 : 0, info[3] = -1;
-  if ((form == 2 || form == 3) && ws) {
-    const size_t base = form == 3 ? collect_layout(Bt, nc).tail
-                                  : (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) +
-                                        (info[2] ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
-    const Bf16Ws w = bf16_layout(Bt, I, d, base);
+  if (form == 3 && ws) {
+    const BoundWs w = bound_layout(Bt, I, d, collect_layout(Bt, nc).tail);
     uint32_t redone = 0;
     IDG_HIP(hipMemcpyAsync(&redone, reinterpret_cast<const char*>(ws) + w.scalars + 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     IDG_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -1053,7 +1037,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     // threshold + collect + exact finish (idg_score_collect.inc)
     IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_score_topk_f32: workspace must be 16-byte aligned");
     const CollectWs cw = collect_layout(Bt, nc);
-    const Bf16Ws w = bf16_layout(Bt, I, d, cw.tail);
+    const BoundWs w = bound_layout(Bt, I, d, cw.tail);
     char* wb = reinterpret_cast<char*>(ws);
     float* group_max = reinterpret_cast<float*>(wb + cw.group_max);
     float* floor0 = reinterpret_cast<float*>(wb + cw.floor0);
@@ -1061,15 +1045,17 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(wb + cw.cand);
     __bf16* Vs = reinterpret_cast<__bf16*>(wb + w.vs);
     __bf16* Us = reinterpret_cast<__bf16*>(wb + w.us);
-    float* vnorm = reinterpret_cast<float*>(wb + w.vnorm);
-    float* unorm = reinterpret_cast<float*>(wb + w.unorm);
+    float* vbound = reinterpret_cast<float*>(wb + w.vbound);
+    float* ubound = reinterpret_cast<float*>(wb + w.ubound);
     uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
     const int64_t I_pad = (I + 31) / 32 * 32;
+    const int lg = d == 64 ? 3 : d == 128 ? 4 : 5;  // 8-feature groups per row: d / 8
+    const int64_t gpr = d / 8;
     // (the users' launch goes first and zeroes the call's scalars: the items' launch takes its maximum into scal[0])
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((Bt * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
-                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr, scal);
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
-                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(bound_table_kernel, dim3((unsigned)((Bt * gpr + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
+                       Bt, d, lg, 0, bound_c(d), Us, ubound, (uint32_t*)nullptr, scal);
+    hipLaunchKernelGGL(bound_table_kernel, dim3((unsigned)((I_pad * gpr + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
+                       (const int64_t*)nullptr, I, I_pad, d, lg, 1, 0.f, Vs, vbound, scal, (uint32_t*)nullptr);
     const int n_slabs_all = (int)((I + FT_SLAB - 1) / FT_SLAB);
     // the floor pass samples about a tenth of the catalogue whatever its size: `groups` / 2 x gs slabs, evenly spaced, a group =
     // the same half of gs consecutive sampled slabs (yelp2018 size: gs = 1, 32 or 64 slabs of 298)
@@ -1084,77 +1070,29 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     const int64_t ci_floor = (int64_t)walk_c * stride * FT_SLAB;
     const int cap_chunk = collect_cap_chunk(nc);
     const unsigned tiles = (unsigned)((Bt + FT_USERS - 1) / FT_USERS);
+#define IDG_COLLECT_KS(SIG, GM, KS_, GRIDX, CI, WALK, STRIDE, GS)                                                                \
+  hipLaunchKernelGGL((score_topk_collect_kernel<SIG, GM, KS_>), dim3((unsigned)(GRIDX), tiles), dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, \
+                     I, (int64_t)(CI), WALK, STRIDE, GS, excl_indptr, excl_items, group_max, (const float*)floor0, count, cand,   \
+                     cap_chunk)
 #define IDG_COLLECT(SIG, GM, GRIDX, CI, WALK, STRIDE, GS)                                                                       \
-  hipLaunchKernelGGL((score_topk_collect_kernel<SIG, GM>), dim3((unsigned)(GRIDX), tiles), dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, \
-                     (int64_t)(CI), WALK, STRIDE, GS, excl_indptr, excl_items, group_max, (const float*)floor0, count, cand, cap_chunk)
-    if (apply_sigmoid) IDG_COLLECT(true, true, fc, ci_floor, walk_c, stride, gs);
-    else IDG_COLLECT(false, true, fc, ci_floor, walk_c, stride, gs);
-    hipLaunchKernelGGL(group_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, group_max, Bt, groups, k, (const float*)unorm,
-                       (const uint32_t*)scal, floor0);
-    if (apply_sigmoid) IDG_COLLECT(true, false, nc, ci, 0, 1, 1);
-    else IDG_COLLECT(false, false, nc, ci, 0, 1, 1);
+  {                                                                                                                             \
+    if (d == 64) IDG_COLLECT_KS(SIG, GM, 4, GRIDX, CI, WALK, STRIDE, GS);                                                       \
+    else if (d == 128) IDG_COLLECT_KS(SIG, GM, 8, GRIDX, CI, WALK, STRIDE, GS);                                                 \
+    else IDG_COLLECT_KS(SIG, GM, 16, GRIDX, CI, WALK, STRIDE, GS);                                                              \
+  }
+    if (apply_sigmoid) IDG_COLLECT(true, true, fc, ci_floor, walk_c, stride, gs)
+    else IDG_COLLECT(false, true, fc, ci_floor, walk_c, stride, gs)
+    hipLaunchKernelGGL(group_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, (const float*)group_max, Bt, groups, k, floor0);
+    if (apply_sigmoid) IDG_COLLECT(true, false, nc, ci, 0, 1, 1)
+    else IDG_COLLECT(false, false, nc, ci, 0, 1, 1)
 #undef IDG_COLLECT
+#undef IDG_COLLECT_KS
     if (apply_sigmoid)
       hipLaunchKernelGGL(topk_finish_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, count, cand, nc, cap_chunk, unorm, scal, out_idx, out_val, scal + 1);
+                         excl_items, k, count, cand, nc, cap_chunk, ubound, scal, out_idx, out_val, scal + 1);
     else
       hipLaunchKernelGGL(topk_finish_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, count, cand, nc, cap_chunk, unorm, scal, out_idx, out_val, scal + 1);
-    IDG_HIP(hipGetLastError());
-    return IDG_OK;
-  }
-  if (form == 2) {
-    // split-bf16 pre-filter: candidates by approximate score, exact re-scoring, brute force where the guarantee fails
-    IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_score_topk_f32: workspace must be 16-byte aligned");
-    const bool fl = floor_phase(form, nc, ci, k);
-    const size_t base = (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) +
-                        (fl ? ((size_t)Bt * (size_t)nc + (size_t)Bt) * sizeof(float) : 0);
-    const Bf16Ws w = bf16_layout(Bt, I, d, base);
-    char* wb = reinterpret_cast<char*>(ws);
-    __bf16* Vs = reinterpret_cast<__bf16*>(wb + w.vs);
-    __bf16* Us = reinterpret_cast<__bf16*>(wb + w.us);
-    float* vnorm = reinterpret_cast<float*>(wb + w.vnorm);
-    float* unorm = reinterpret_cast<float*>(wb + w.unorm);
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(wb + w.cand);
-    uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
-    const int64_t I_pad = (I + 31) / 32 * 32;
-    // (the users' launch goes first and zeroes the call's scalars: the items' launch takes its maximum into scal[0])
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((Bt * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
-                       Bt, d, 0, Us, unorm, (uint32_t*)nullptr, scal);
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((I_pad * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
-                       (const int64_t*)nullptr, I, I_pad, d, 1, Vs, vnorm, scal, (uint32_t*)nullptr);
-    float* chunk_max = nullptr;
-    float* floor0 = nullptr;
-    if (fl) {
-      chunk_max = reinterpret_cast<float*>(partial + (size_t)Bt * (size_t)nc * 64);
-      floor0 = chunk_max + (size_t)Bt * (size_t)nc;
-      const int slabs_per_chunk = (int)(ci / FT_SLAB);
-      const int floor_slabs = slabs_per_chunk / 2 < FLOOR_SLABS ? slabs_per_chunk / 2 : FLOOR_SLABS;
-      if (apply_sigmoid)
-        hipLaunchKernelGGL((score_topk_bf16_kernel<true, true>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
-                           excl_items, floor_slabs, partial, chunk_max, (const float*)nullptr);
-      else
-        hipLaunchKernelGGL((score_topk_bf16_kernel<false, true>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
-                           excl_items, floor_slabs, partial, chunk_max, (const float*)nullptr);
-      hipLaunchKernelGGL(chunk_floor_kernel, dim3(nbm), dim3(BLOCK), 0, st, chunk_max, Bt, nc, k, floor0);
-      hipLaunchKernelGGL(floor_margin_kernel, dim3((unsigned)((Bt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, floor0, unorm, scal, Bt);
-    }
-    int kl = 64;
-    if (const char* v = std::getenv("IDG_TOPK_BF16_LIST")) kl = std::atoi(v);  // TIMING PROBE ONLY (wrong guarantee below 64)
-    if (apply_sigmoid)
-      hipLaunchKernelGGL((score_topk_bf16_kernel<true, false>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
-                         excl_items, kl, partial, (float*)nullptr, (const float*)floor0);
-    else
-      hipLaunchKernelGGL((score_topk_bf16_kernel<false, false>), grid, dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, I, ci, excl_indptr,
-                         excl_items, kl, partial, (float*)nullptr, (const float*)floor0);
-    hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, partial, Bt, nc, kl, out_idx, (float*)nullptr,
-                       (int64_t)k, (int64_t)0, (unsigned long long*)nullptr, cand);
-    if (apply_sigmoid)
-      hipLaunchKernelGGL(topk_rescore_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, cand, unorm, scal, (const float*)floor0, out_idx, out_val, scal + 1);
-    else
-      hipLaunchKernelGGL(topk_rescore_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, cand, unorm, scal, (const float*)floor0, out_idx, out_val, scal + 1);
+                         excl_items, k, count, cand, nc, cap_chunk, ubound, scal, out_idx, out_val, scal + 1);
     IDG_HIP(hipGetLastError());
     return IDG_OK;
   }

@@ -753,13 +753,12 @@ def test_score_dense_widths_and_ragged_shapes(ops, d):
         np.testing.assert_allclose(R, oracle.score(Uu, Vv, users, sig), rtol=2e-5, atol=2e-5)
 
 
-@pytest.fixture(params=["alternating", "producer-consumer", "bf16-prefilter"])
+@pytest.fixture(params=["alternating", "producer-consumer"])
 def topk_form(request, monkeypatch):
-    """The fused top-K has three forms (every wave alternating between scoring and selecting; producer and consumer
-    waves on exact scores; round 5: candidates by split-bf16 approximate scores + exact re-scoring, d = 64 — other widths
-    and k > 64 run the exact producer / consumer form under this name) chosen by the call's geometry: every contract test
-    runs on all of them (IDG_TOPK_FORM forces one)."""
-    monkeypatch.setenv("IDG_TOPK_FORM", {"alternating": "0", "producer-consumer": "1", "bf16-prefilter": "2"}[request.param])
+    """The fused top-K has two exact-score forms (every wave alternating between scoring and selecting; producer and
+    consumer waves) chosen by the call's geometry — every contract test runs on both (IDG_TOPK_FORM forces one) — and the
+    threshold + collect form on bf16 bound scores for calls of >= 8 user tiles over >= 32,768 items (its own tests below)."""
+    monkeypatch.setenv("IDG_TOPK_FORM", {"alternating": "0", "producer-consumer": "1"}[request.param])
     return request.param
 
 
@@ -1094,59 +1093,15 @@ def test_topk_calls_of_1024_users_start_from_a_floor(ops, d, sig):
 
 
 @pytest.mark.parametrize("sig", [True, False])
-@pytest.mark.parametrize("per_call", [31668, 1024])
-def test_topk_bf16_prefilter_is_the_exact_answer(ops, per_call, sig, monkeypatch):
-    """Round 5 (opt-in form, IDG_TOPK_BF16=1; measured slower than the exact form, kept as the record of the experiment):
-    calls of >= 16 user tiles at d = 64, k <= 48 choose candidates by a split-bf16 APPROXIMATE score (64 per user), re-score
-    them exactly and prove the list complete — or redo the user by brute force.  At yelp2018 size, one call and calls of
-    1024 users (chunks starting from a lowered floor), with train items masked and duplicated item rows (exact ties): ids
-    AND values equal, bit for bit, what the exact fp32 producer / consumer form returns; the form is the one taken, and on
-    such embeddings (almost) nobody needs the brute-force path: the error bound is tight enough."""
-    import idgrec_amd.synth as S
-
-    U, I, d, k = 31668, 38048, 64, 20
-    users, items = S.generate(U, I, 600000, seed=21)
-    ptr = np.zeros(U + 1, dtype=np.int64)
-    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
-    ip, ix = dev(ptr), dev(items.astype(np.int32))
-    g = torch.Generator(device="cuda").manual_seed(per_call)
-    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
-    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
-    Ie[::101] = Ie[3]  # duplicate rows: exact ties
-    Ue[5] = 0.0        # a user whose every score is 0: all items tie (the brute-force path must give the id order)
-    calls = [torch.arange(s0, min(s0 + per_call, U), device="cuda") for s0 in range(0, U, per_call)]
-    info, redone = {}, 0
-    got = []
-    monkeypatch.setenv("IDG_TOPK_BF16", "1")
-    for b in calls:
-        got.append(ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info))
-        if len(b) < 1024:  # (the ragged last call: fewer than 16 user tiles, an exact form)
-            assert info["form"] == 0, info
-            continue
-        assert info["form"] == 2, info
-        assert info["floor"] == (per_call == 1024), info
-        redone += info["users_redone"]
-    monkeypatch.setenv("IDG_TOPK_BF16", "0")
-    monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
-    want = []
-    for b in calls:
-        want.append(ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info))
-        assert info["form"] == (1 if len(b) >= 1024 else 0), info
-    assert torch.equal(torch.cat([x[0] for x in got]), torch.cat([x[0] for x in want])), "ids differ from the exact form"
-    assert torch.equal(torch.cat([x[1] for x in got]), torch.cat([x[1] for x in want])), "values differ from the exact form"
-    assert 1 <= redone <= 32, redone  # user 5 (all ties) certainly; hardly anybody else
-
-
-@pytest.mark.parametrize("sig", [True, False])
 @pytest.mark.parametrize("k", [20, 22, 1, 40])
 def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatch):
-    """Round 5, form 3 (the default for calls of more than 256 user tiles at d = 64, k <= 42; IDG_TOPK_COLLECT=0 turns it off): a floor per user from the maxima
-    of a strided sample of the catalogue (split-bf16 scores, lowered by twice their error bound), ONE pass that appends
-    every item at or above the floor to the user's candidate list — no list insertions in the scoring pass — and an exact
-    finish: the candidates' fp32 scores as the fmaf chain the fp32 matrix cores evaluate, masked, through the streaming
-    select.  At yelp2018 size, all users in one call, train items masked, duplicated item rows (exact ties), a user whose
-    every score ties (its candidate list overflows: redone over the whole catalogue): ids AND values bit for bit what the
-    exact producer / consumer form returns."""
+    """Round 5, form 3 (the default for calls of >= 8 user tiles over >= 32,768 items at d = 64 / 128, k <= 42;
+    IDG_TOPK_COLLECT=0 turns it off): a floor per user from the maxima of a strided sample of the catalogue scored as bf16
+    LOWER bounds, ONE pass that appends every item whose bf16 UPPER bound reaches the floor to the user's candidate list —
+    no list insertions in the scoring pass — and an exact finish: the candidates' fp32 scores as the fmaf chain the fp32
+    matrix cores evaluate, masked, through the streaming select.  At yelp2018 size, all users in one call, train items
+    masked, duplicated item rows (exact ties), a user whose every score ties (its candidate list overflows: redone over
+    the whole catalogue): ids AND values bit for bit what the exact producer / consumer form returns."""
     import idgrec_amd.synth as S
 
     U, I, d = 31668, 38048, 64
@@ -1185,6 +1140,47 @@ def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatc
         deg = torch.from_numpy(np.diff(ptr)).cuda()
         head_is_train = (got[1][:, 0] == -1.0)
         assert bool((head_is_train == ((deg > 0) & (not sig))).all())
+
+
+@pytest.mark.parametrize("d,per_call", [(128, 20000), (128, 1024), (64, 3000), (256, 20000), (256, 2048)])
+def test_topk_collect_form_with_uneven_norms_and_at_d128(ops, d, per_call, monkeypatch):
+    """Form 3's bounds are per pair — UB - LB = 2 cu(u) vb(v) — so a catalogue whose row norms spread over two orders of
+    magnitude (trained tables: popular items grow long) costs candidates only where the long rows are, and the finish's
+    uniform cut (cu(u) max vb) stays correct whatever the spread.  Item rows scaled by 0.03 .. 3, a few users scaled up
+    100x and down 1e-3x, a zero user, a zero item block, d = 128 (nine k-steps), 256 (seventeen; user operands from LDS) and 64,
+    one call and chunked calls: ids and
+    values bit for bit those of the exact producer / consumer form."""
+    import idgrec_amd.synth as S
+
+    U, I, k = 20000, 40000, 20
+    users, items = S.generate(U, I, 400000, seed=d + per_call)
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    ip, ix = dev(ptr), dev(items.astype(np.int32))
+    g = torch.Generator(device="cuda").manual_seed(d + per_call)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
+    Ie *= torch.exp(torch.rand(I, 1, device="cuda", generator=g) * 4.6 - 3.5)  # row scale 0.03 .. 3
+    Ue[100:110] *= 100.0
+    Ue[200:210] *= 1e-3
+    Ue[7] = 0.0
+    Ie[5000:5200] = 0.0
+    every = torch.arange(U, device="cuda")
+    info = {}
+
+    def run():
+        out = [ops.score_topk(Ue, Ie, every[s0:s0 + per_call], k, ip, ix, return_values=True, info=info if s0 == 0 else None)
+               for s0 in range(0, U, per_call)]
+        return torch.cat([x[0] for x in out]), torch.cat([x[1] for x in out])
+
+    monkeypatch.delenv("IDG_TOPK_COLLECT", raising=False)
+    got = run()
+    assert info["form"] == 3, info
+    monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
+    want = run()
+    assert info["form"] == 1, info
+    assert torch.equal(got[0], want[0]), "ids differ from the exact form"
+    assert torch.equal(got[1], want[1]), "values differ from the exact form"
 
 
 @pytest.mark.parametrize("per_call", [2048, 4096, 8192])
