@@ -801,13 +801,13 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
  * bound): the catalogue is only cut into chunks when Bt/64 workgroups cannot fill the chip. */
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k);
 /* Which form a call of this geometry takes, for tests and diagnostics: info[0] = 0 every wave alternates between scoring and
- * selecting, 1 producer / consumer waves on exact fp32 scores, 3 (more than 256 user tiles, d = 64, k <= 42; IDG_TOPK_COLLECT=0
- * turns it off) threshold + collect + exact finish: a per-user floor from a strided sample of the catalogue (split-bf16
- * scores, lowered by twice their error bound), one pass that appends every item at or above the floor to the user's
- * candidate list, exact fp32 re-scoring of the candidates near the top — bit-identical to forms 0 / 1, about twice as fast;
- * 2 (opt-in, IDG_TOPK_BF16=1: exact, measured slower) the split-bf16 pre-filter with a 64-key list; info[1] = catalogue
- * chunks, info[2] = 1 when chunks start from a floor, info[3] = (forms 2 / 3, `ws` the workspace of a finished call on
- * `stream`; synchronises) users redone over the whole catalogue, else -1. */
+ * selecting, 1 producer / consumer waves on exact fp32 scores, 3 (calls of >= 8 user tiles over >= 32,768 items, d = 64 / 128 /
+ * 256, k <= 42; IDG_TOPK_COLLECT=0 turns it off) threshold + collect + exact finish on one-sided bf16 bounds of the exact
+ * score: a per-user floor from a strided sample of the catalogue scored as LOWER bounds, one pass that appends every item
+ * whose UPPER bound reaches the floor to the user's candidate list, exact fp32 re-scoring of the candidates near the top —
+ * bit-identical to forms 0 / 1, 2.5x (d = 64) to 10x (d = 256) as fast.  info[1] = catalogue chunks, info[2] = 1 when
+ * chunks start from a floor (form 1), info[3] = (form 3, `ws` the workspace of a finished call on `stream`; synchronises)
+ * users redone over the whole catalogue (their candidate lists overflowed), else -1. */
 int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int64_t info[4], void* stream);
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users,
                        int64_t Bt, int64_t I, int64_t d, const int64_t* excl_indptr,
