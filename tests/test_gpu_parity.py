@@ -1142,7 +1142,7 @@ def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatc
         assert bool((head_is_train == ((deg > 0) & (not sig))).all())
 
 
-@pytest.mark.parametrize("d,per_call", [(128, 20000), (128, 1024), (64, 3000), (256, 20000), (256, 2048)])
+@pytest.mark.parametrize("d,per_call", [(128, 20000), (128, 1024), (64, 3000), (64, 512), (64, 20000), (256, 20000), (256, 2048)])
 def test_topk_collect_form_with_uneven_norms_and_at_d128(ops, d, per_call, monkeypatch):
     """Form 3's bounds are per pair — UB - LB = 2 cu(u) vb(v) — so a catalogue whose row norms spread over two orders of
     magnitude (trained tables: popular items grow long) costs candidates only where the long rows are, and the finish's
@@ -1178,7 +1178,7 @@ def test_topk_collect_form_with_uneven_norms_and_at_d128(ops, d, per_call, monke
     assert info["form"] == 3, info
     monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
     want = run()
-    assert info["form"] == 1, info
+    assert info["form"] in (0, 1), info
     assert torch.equal(got[0], want[0]), "ids differ from the exact form"
     assert torch.equal(got[1], want[1]), "values differ from the exact form"
 
