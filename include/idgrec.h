@@ -805,7 +805,7 @@ size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k);
  * 256, k <= 42; IDG_TOPK_COLLECT=0 turns it off) threshold + collect + exact finish on one-sided bf16 bounds of the exact
  * score: a per-user floor from a strided sample of the catalogue scored as LOWER bounds, one pass that appends every item
  * whose UPPER bound reaches the floor to the user's candidate list, exact fp32 re-scoring of the candidates near the top —
- * bit-identical to forms 0 / 1, 2.5x (d = 64) to 10x (d = 256) as fast.  info[1] = catalogue chunks, info[2] = 1 when
+ * bit-identical to forms 0 / 1, 3x (d = 64) to 10x (d = 256) as fast.  info[1] = catalogue chunks, info[2] = 1 when
  * chunks start from a floor (form 1), info[3] = (form 3, `ws` the workspace of a finished call on `stream`; synchronises)
  * users redone over the whole catalogue (their candidate lists overflowed), else -1. */
 int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int64_t info[4], void* stream);
