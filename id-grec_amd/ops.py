@@ -10,6 +10,7 @@ reg_lambda*get_reg_loss of `forward()` (models/LightGCN.py:57-68); `score_topk` 
 get_rating_for_test + mask + torch.topk (utility/utility_train/batch_test.py:59-68).
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -1264,12 +1265,29 @@ def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=No
             raise TypeError("excl_indptr must be int64 and excl_items int32")
     idx = torch.empty((Bt, k), dtype=torch.int64, device=V.device)
     val = torch.empty((Bt, k), dtype=torch.float32, device=V.device) if return_values else None
-    ws = torch.empty(int(lib.idg_score_topk_workspace_bytes(Bt, I, d, int(k))), dtype=torch.uint8, device=V.device)
-    check(lib.idg_score_topk_f32(_ptr(U), _ptr(V), _ptr(users), Bt, I, d, _ptr(excl_indptr), _ptr(excl_items), int(k),
-                                 int(bool(apply_sigmoid)), _ptr(idx), _ptr(val), _ptr(ws), _stream()),
-          "idg_score_topk_f32")
-    if info is not None:
-        out = (C.c_int64 * 4)()
-        check(lib.idg_score_topk_info(Bt, I, d, int(k), _ptr(ws), out, _stream()), "idg_score_topk_info")
-        info.update(form=int(out[0]), chunks=int(out[1]), floor=bool(out[2]), users_redone=int(out[3]))
+    # One library call per `per_call` users.  A user's list does not depend on who shares its call, and every test user in
+    # one call is what the kernels want — but the workspace grows with the call (the threshold + collect form keeps up to
+    # 1024 candidate keys per user: 8-16 KB each), so a call whose workspace would exceed the budget (IDG_TOPK_WS_BYTES,
+    # default 8 GiB: ~500,000 users) is cut into calls of a multiple of 16,384 users (256 user tiles: every CU keeps its own).
+    budget = int(os.environ.get("IDG_TOPK_WS_BYTES", str(8 << 30)))
+    per_call = Bt
+    if Bt > 32768 and int(lib.idg_score_topk_workspace_bytes(Bt, I, d, int(k))) > budget:
+        per_call = 16384
+        while per_call * 2 < Bt and int(lib.idg_score_topk_workspace_bytes(per_call * 2, I, d, int(k))) <= budget:
+            per_call *= 2
+    redone = 0
+    for s0 in range(0, Bt, per_call):
+        n = min(per_call, Bt - s0)
+        ws = torch.empty(int(lib.idg_score_topk_workspace_bytes(n, I, d, int(k))), dtype=torch.uint8, device=V.device)
+        check(lib.idg_score_topk_f32(_ptr(U), _ptr(V), _ptr(users[s0:s0 + n]), n, I, d, _ptr(excl_indptr), _ptr(excl_items),
+                                     int(k), int(bool(apply_sigmoid)), _ptr(idx[s0:s0 + n]),
+                                     _ptr(val[s0:s0 + n]) if val is not None else None, _ptr(ws), _stream()),
+              "idg_score_topk_f32")
+        if info is not None:
+            out = (C.c_int64 * 4)()
+            check(lib.idg_score_topk_info(n, I, d, int(k), _ptr(ws), out, _stream()), "idg_score_topk_info")
+            redone += max(int(out[3]), 0)
+            if s0 == 0:  # (form / chunks / floor of the first call: later ones differ only in a shorter last call)
+                info.update(form=int(out[0]), chunks=int(out[1]), floor=bool(out[2]), calls=-(-Bt // per_call))
+            info["users_redone"] = redone if int(out[3]) >= 0 else int(out[3])
     return (idx, val) if return_values else idx

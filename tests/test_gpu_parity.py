@@ -1183,6 +1183,25 @@ def test_topk_collect_form_with_uneven_norms_and_at_d128(ops, d, per_call, monke
     assert torch.equal(got[1], want[1]), "values differ from the exact form"
 
 
+def test_topk_call_cut_by_the_workspace_budget(ops, monkeypatch):
+    """ops.score_topk hands over every user in ONE library call unless that call's workspace (form 3: up to 1024 candidate
+    keys per user) would exceed IDG_TOPK_WS_BYTES (default 8 GiB — half a million users); then it issues calls of a multiple
+    of 16,384 users.  Same lists and values, by construction and here: 40,000 users under a 280 MiB budget (three calls)."""
+    U, I, d, k = 40000, 33000, 64, 20
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
+    every = torch.arange(U, device="cuda")
+    info = {}
+    monkeypatch.delenv("IDG_TOPK_WS_BYTES", raising=False)
+    whole = ops.score_topk(Ue, Ie, every, k, return_values=True, info=info)
+    assert info["form"] == 3 and info["calls"] == 1, info
+    monkeypatch.setenv("IDG_TOPK_WS_BYTES", str(280 << 20))
+    cut = ops.score_topk(Ue, Ie, every, k, return_values=True, info=info)
+    assert info["calls"] == 3 and info["users_redone"] == 0, info
+    assert torch.equal(cut[0], whole[0]) and torch.equal(cut[1], whole[1])
+
+
 @pytest.mark.parametrize("per_call", [2048, 4096, 8192])
 def test_topk_calls_of_a_few_thousand_users(ops, per_call):
     """calls of 2048 / 4096 users (32 / 64 user tiles) still take the k + 2 chunk geometry with its starting
