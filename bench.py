@@ -768,6 +768,11 @@ def main():
                 out["roofline"]["hbm_bound"] = err
         except Exception as exc:  # noqa: BLE001 - the headline stands without it
             out["scale_point"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        # and the evaluation of that configuration: one fused score + mask + top-20 call at its geometry
+        try:
+            out["eval_scale_point"] = eval_scale_point()
+        except Exception as exc:  # noqa: BLE001 - the headline stands without it
+            out["eval_scale_point"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     elif hbm_leg:
         try:
             out["roofline"]["hbm_bound"] = hbm_bound_leg(args)
@@ -785,6 +790,51 @@ def main():
         except Exception as exc:  # noqa: BLE001 - the file-based traffic figures stay
             out["roofline"]["traffic_in_run_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
     args.emit(out)
+
+def eval_scale_point(users=16384, items=5_000_000, d=256, k=20, degree=50):
+    """BASELINE configs[4]'s evaluation (1e7 users x 5e6 items x d = 256: 25.6 PFLOP in fp32 per evaluation), one call of it:
+    `users` test users against the whole catalogue, `degree` train items each masked, random tables (a call's cost does not
+    depend on the values).  The threshold + collect form and, once, the exact producer / consumer form beside it."""
+    import idgrec_amd.ops as ops
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    Ue = torch.randn(users, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(items, d, device="cuda", generator=g) * 0.3
+    rng = np.random.default_rng(0)
+    ix = np.sort(rng.integers(0, items - degree, (users, degree)), axis=1) + np.arange(degree)[None, :]  # ascending, distinct
+    ip = torch.arange(0, (users + 1) * degree, degree, dtype=torch.int64, device="cuda")
+    ixd = torch.from_numpy(ix.reshape(-1).astype(np.int32)).cuda()
+    every = torch.arange(users, device="cuda")
+
+    def timed(reps):
+        ops.score_topk(Ue, Ie, every, k, ip, ixd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ops.score_topk(Ue, Ie, every, k, ip, ixd)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    info = {}
+    ops.score_topk(Ue, Ie, every, k, ip, ixd, info=info)
+    t = timed(3)
+    before = os.environ.get("IDG_TOPK_COLLECT")
+    os.environ["IDG_TOPK_COLLECT"] = "0"
+    try:
+        t_exact = timed(1)
+    finally:
+        if before is None:
+            del os.environ["IDG_TOPK_COLLECT"]
+        else:
+            os.environ["IDG_TOPK_COLLECT"] = before
+    flop = 2.0 * users * items * d
+    return {"what": "one fused score + mask + top-%d call at configs[4]'s geometry: %d users x %d items x d=%d, %d train items "
+                    "per user masked, random tables" % (k, users, items, d, degree),
+            "ms_per_call": t * 1e3, "fp32_equivalent_tflops": flop / t / 1e12, "form": info.get("form"),
+            "users_redone": info.get("users_redone"),
+            "exact_form_ms_per_call": t_exact * 1e3, "exact_form_tflops": flop / t_exact / 1e12,
+            "s_per_evaluation_of_1e7_users": 1e7 / users * t, "exact_form_s_per_evaluation_of_1e7_users": 1e7 / users * t_exact}
+
 
 # ---- graphs handed to the --pmc children: the CSR adjacency a leg built, left in a directory of this run's own
 def _pmc_dir(args, create=False):
