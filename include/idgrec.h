@@ -796,9 +796,12 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
  * out_idx int64 [Bt,k], out_val fp32 [Bt,k] (may be NULL).  1 <= k <= min(I, 1024): k <= 64 is one pass;
  * a larger k (torch.topk takes any k <= I, batch_test.py:68) runs one scoring pass per 64 ranks, each admitting only
  * keys strictly below the last one the previous pass emitted (same order, same values as one pass would give).
- * ws: idg_score_topk_workspace_bytes (one 64-key list per user and item chunk: 512 B x Bt x chunks).
+ * ws: idg_score_topk_workspace_bytes, 16-byte aligned (exact forms: one 64-key list per user and item chunk, 512 B x Bt x
+ * chunks; threshold + collect form: up to 1024 candidate keys per user — 8 to 16 KB x Bt — plus the bf16 operand tables,
+ * (d / 16 + 1) KiB per 32 items and (d / 16 + 2) x 32 B per user).
  * Throughput wants Bt large — hand over EVERY test user in one call (there is no [Bt, I] matrix to
- * bound): the catalogue is only cut into chunks when Bt/64 workgroups cannot fill the chip. */
+ * bound; what bounds a call is this workspace): the catalogue is only cut into chunks when Bt/64 workgroups cannot fill
+ * the chip. */
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k);
 /* Which form a call of this geometry takes, for tests and diagnostics: info[0] = 0 every wave alternates between scoring and
  * selecting, 1 producer / consumer waves on exact fp32 scores, 3 (calls of >= 8 user tiles over >= 32,768 items, d = 64 / 128 /
