@@ -899,7 +899,11 @@ static inline int64_t collect_chunks(int64_t user_tiles, int64_t I) {
   return nc < 1 ? 1 : nc;
 }
 // candidate keys a (user, chunk) segment holds: the whole list when there is one chunk, else a share with room for skew
-static inline int collect_cap_chunk(int nc) { return nc == 1 ? COLLECT_CAP : std::max(128, 2 * COLLECT_CAP / nc); }
+static inline int collect_cap(int64_t I) { return I >= 1000000 ? COLLECT_CAP_BIG : COLLECT_CAP; }
+static inline int collect_cap_chunk(int nc, int64_t I) {
+  const int cap = collect_cap(I);
+  return nc == 1 ? cap : std::max(cap / 8, 2 * cap / nc);
+}
 static inline bool collect_applies(int64_t user_tiles, int64_t I, int64_t d, int k) {
   const char* v = std::getenv("IDG_TOPK_COLLECT");  // "0": the exact producer / consumer form instead
   if (v && *v && std::atoi(v) == 0) return false;
@@ -977,14 +981,14 @@ static inline BoundWs bound_layout(int64_t Bt, int64_t I, int64_t d, size_t base
 struct CollectWs {
   size_t group_max, floor0, count, cand, tail;
 };
-static inline CollectWs collect_layout(int64_t Bt, int nc) {
+static inline CollectWs collect_layout(int64_t Bt, int nc, int64_t I) {
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   CollectWs w{};
   size_t o = 0;
   w.group_max = o, o = up(o + (size_t)Bt * COLLECT_GROUPS_MAX * 4);
   w.floor0 = o, o = up(o + (size_t)Bt * 4);
   w.count = o, o = up(o + (size_t)Bt * (size_t)nc * 4);
-  w.cand = o, o = up(o + (size_t)Bt * (size_t)nc * (size_t)collect_cap_chunk(nc) * 8);
+  w.cand = o, o = up(o + (size_t)Bt * (size_t)nc * (size_t)collect_cap_chunk(nc, I) * 8);
   w.tail = o;
   return w;
 }
@@ -994,7 +998,7 @@ size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k) {
   int nc, form;
   int64_t ci;
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
-  if (form == 3) return bound_layout(Bt, I, d, collect_layout(Bt, nc).tail).total;
+  if (form == 3) return bound_layout(Bt, I, d, collect_layout(Bt, nc, I).tail).total;
   // one best-64 list per (user, chunk) + (k > 64 only) one bound key per user between the passes + (two-phase form) one
   // maximum per (user, chunk) and one starting floor per user
   return (size_t)Bt * (size_t)nc * 64 * sizeof(unsigned long long) + (k > 64 ? (size_t)Bt * sizeof(unsigned long long) : 0) +
@@ -1008,7 +1012,7 @@ int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws,
   fused_geometry(Bt, I, &nc, &ci, &form, k, d);
   info[0] = form, info[1] = nc, info[2] = floor_phase(form, nc, ci, k) ? 1 : 0, info[3] = -1;
   if (form == 3 && ws) {
-    const BoundWs w = bound_layout(Bt, I, d, collect_layout(Bt, nc).tail);
+    const BoundWs w = bound_layout(Bt, I, d, collect_layout(Bt, nc, I).tail);
     uint32_t redone = 0;
     IDG_HIP(hipMemcpyAsync(&redone, reinterpret_cast<const char*>(ws) + w.scalars + 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     IDG_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -1036,7 +1040,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
   if (form == 3) {
     // threshold + collect + exact finish (idg_score_collect.inc)
     IDG_REQUIRE((uintptr_t)ws % 16 == 0, "idg_score_topk_f32: workspace must be 16-byte aligned");
-    const CollectWs cw = collect_layout(Bt, nc);
+    const CollectWs cw = collect_layout(Bt, nc, I);
     const BoundWs w = bound_layout(Bt, I, d, cw.tail);
     char* wb = reinterpret_cast<char*>(ws);
     float* group_max = reinterpret_cast<float*>(wb + cw.group_max);
@@ -1068,7 +1072,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     while (2 * fc <= groups / 2 && (int64_t)2 * fc <= nc) fc *= 2;
     const int walk_c = walk / fc;
     const int64_t ci_floor = (int64_t)walk_c * stride * FT_SLAB;
-    const int cap_chunk = collect_cap_chunk(nc);
+    const int cap_chunk = collect_cap_chunk(nc, I);
     const unsigned tiles = (unsigned)((Bt + FT_USERS - 1) / FT_USERS);
 #define IDG_COLLECT_KS(SIG, GM, KS_, GRIDX, CI, WALK, STRIDE, GS)                                                                \
   hipLaunchKernelGGL((score_topk_collect_kernel<SIG, GM, KS_>), dim3((unsigned)(GRIDX), tiles), dim3(SP_BLOCK), 0, st, Us, Vs, users, Bt, \
@@ -1087,12 +1091,17 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     else IDG_COLLECT(false, false, nc, ci, 0, 1, 1)
 #undef IDG_COLLECT
 #undef IDG_COLLECT_KS
-    if (apply_sigmoid)
-      hipLaunchKernelGGL(topk_finish_kernel<true>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, count, cand, nc, cap_chunk, ubound, scal, out_idx, out_val, scal + 1);
-    else
-      hipLaunchKernelGGL(topk_finish_kernel<false>, dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d, excl_indptr,
-                         excl_items, k, count, cand, nc, cap_chunk, ubound, scal, out_idx, out_val, scal + 1);
+#define IDG_FINISH(SIG, CAP_)                                                                                                   \
+  hipLaunchKernelGGL((topk_finish_kernel<SIG, CAP_>), dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d,     \
+                     excl_indptr, excl_items, k, count, cand, nc, cap_chunk, ubound, scal, out_idx, out_val, scal + 1)
+    if (collect_cap(I) == COLLECT_CAP) {
+      if (apply_sigmoid) IDG_FINISH(true, COLLECT_CAP);
+      else IDG_FINISH(false, COLLECT_CAP);
+    } else {
+      if (apply_sigmoid) IDG_FINISH(true, COLLECT_CAP_BIG);
+      else IDG_FINISH(false, COLLECT_CAP_BIG);
+    }
+#undef IDG_FINISH
     IDG_HIP(hipGetLastError());
     return IDG_OK;
   }
