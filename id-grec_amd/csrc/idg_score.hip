@@ -962,7 +962,7 @@ static inline bool floor_phase(int form, int nc, int64_t ci, int k) {
 
 // form 3's bound tables, behind its own scratch: offsets in bytes, 256-byte aligned
 struct BoundWs {
-  size_t vs, us, vbound, ubound, scalars, total;
+  size_t vs, us, vbound, ubound, scalars, redo, total;
 };
 static inline BoundWs bound_layout(int64_t Bt, int64_t I, int64_t d, size_t base) {
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -973,7 +973,8 @@ static inline BoundWs bound_layout(int64_t Bt, int64_t I, int64_t d, size_t base
   w.us = o, o = up(o + (size_t)Bt * (ks + 2) * 32);
   w.vbound = o, o = up(o + (size_t)I * 4);
   w.ubound = o, o = up(o + (size_t)Bt * 4);
-  w.scalars = o, o = up(o + 16);  // [0] max item bound (float bits), [1] users redone by brute force
+  w.scalars = o, o = up(o + 16);  // [0] max item bound (float bits), [1] users handed to topk_redo_kernel
+  w.redo = o, o = up(o + (size_t)Bt * 4);  // their batch indices
   w.total = o;
   return w;
 }
@@ -1052,6 +1053,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     float* vbound = reinterpret_cast<float*>(wb + w.vbound);
     float* ubound = reinterpret_cast<float*>(wb + w.ubound);
     uint32_t* scal = reinterpret_cast<uint32_t*>(wb + w.scalars);
+    uint32_t* redo_list = reinterpret_cast<uint32_t*>(wb + w.redo);
     const int64_t I_pad = (I + 31) / 32 * 32;
     const int lg = d == 64 ? 3 : d == 128 ? 4 : 5;  // 8-feature groups per row: d / 8
     const int64_t gpr = d / 8;
@@ -1093,7 +1095,7 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
 #undef IDG_COLLECT_KS
 #define IDG_FINISH(SIG, CAP_)                                                                                                   \
   hipLaunchKernelGGL((topk_finish_kernel<SIG, CAP_>), dim3(nbm), dim3(BLOCK), 0, st, user_panel, item_panel, users, Bt, I, d,     \
-                     excl_indptr, excl_items, k, count, cand, nc, cap_chunk, ubound, scal, out_idx, out_val, scal + 1)
+                     excl_indptr, excl_items, k, count, cand, nc, cap_chunk, ubound, scal, out_idx, out_val, scal + 1, redo_list)
     if (collect_cap(I) == COLLECT_CAP) {
       if (apply_sigmoid) IDG_FINISH(true, COLLECT_CAP);
       else IDG_FINISH(false, COLLECT_CAP);
@@ -1102,6 +1104,14 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
       else IDG_FINISH(false, COLLECT_CAP_BIG);
     }
 #undef IDG_FINISH
+    // whoever the finish could not serve (none, on tables that do not tie massively): the grid is fixed, the count on the device
+    const unsigned redo_grid = (unsigned)std::min<int64_t>((Bt + 3) / 4, 512);
+    if (apply_sigmoid)
+      hipLaunchKernelGGL(topk_redo_kernel<true>, dim3(redo_grid), dim3(REDO_WAVES * WAVE), 0, st, user_panel, item_panel, users, I, d,
+                         excl_indptr, excl_items, k, (const uint32_t*)redo_list, (const unsigned int*)(scal + 1), out_idx, out_val);
+    else
+      hipLaunchKernelGGL(topk_redo_kernel<false>, dim3(redo_grid), dim3(REDO_WAVES * WAVE), 0, st, user_panel, item_panel, users, I, d,
+                         excl_indptr, excl_items, k, (const uint32_t*)redo_list, (const unsigned int*)(scal + 1), out_idx, out_val);
     IDG_HIP(hipGetLastError());
     return IDG_OK;
   }
