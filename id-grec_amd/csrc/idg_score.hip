@@ -1060,8 +1060,13 @@ int idg_score_topk_f32(const float* user_panel, const float* item_panel, const i
     // (the users' launch goes first and zeroes the call's scalars: the items' launch takes its maximum into scal[0])
     hipLaunchKernelGGL(bound_table_kernel, dim3((unsigned)((Bt * gpr + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, user_panel, users, Bt,
                        Bt, d, lg, 0, bound_c(d), Us, ubound, (uint32_t*)nullptr, scal);
-    hipLaunchKernelGGL(bound_table_kernel, dim3((unsigned)((I_pad * gpr + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, item_panel,
-                       (const int64_t*)nullptr, I, I_pad, d, lg, 1, 0.f, Vs, vbound, scal, (uint32_t*)nullptr);
+    const unsigned n_tiles = (unsigned)(I_pad / 32);
+    if (d == 64)
+      hipLaunchKernelGGL(item_table_kernel<4>, dim3(n_tiles), dim3(64 * 4), 0, st, item_panel, I, Vs, vbound, scal);
+    else if (d == 128)
+      hipLaunchKernelGGL(item_table_kernel<8>, dim3(n_tiles), dim3(64 * 8), 0, st, item_panel, I, Vs, vbound, scal);
+    else
+      hipLaunchKernelGGL(item_table_kernel<16>, dim3(n_tiles), dim3(64 * 16), 0, st, item_panel, I, Vs, vbound, scal);
     const int n_slabs_all = (int)((I + FT_SLAB - 1) / FT_SLAB);
     // the floor pass samples about a tenth of the catalogue whatever its size: `groups` / 2 x gs slabs, evenly spaced, a group =
     // the same half of gs consecutive sampled slabs (yelp2018 size: gs = 1, 32 or 64 slabs of 298)
