@@ -1183,38 +1183,39 @@ def test_topk_collect_form_with_uneven_norms_and_at_d128(ops, d, per_call, monke
     assert torch.equal(got[1], want[1]), "values differ from the exact form"
 
 
-def test_topk_collect_form_on_adversarial_roundings(ops, monkeypatch):
+@pytest.mark.parametrize("d", [64, 256])
+def test_topk_collect_form_on_adversarial_roundings(ops, d, monkeypatch):
     """The bounds of form 3 must hold for the WORST rounding, not the typical one (random tables stay two orders of magnitude
     under it: a bound constant half its size passed every other test of this file for most of round 5).  Here every mantissa
-    sits just beside a bf16 rounding midpoint: on coordinates 0..31 the users and the ten best items A round DOWN (their
-    bf16 score is 0.78 % under the exact one), on coordinates 32..63 the users and a family of items C — one per 128 items,
+    sits just beside a bf16 rounding midpoint: on the first half of the coordinates the users and the ten best items A round DOWN
+    (their bf16 score is 0.78 % under the exact one), on the second half the users and a family of items C — one per 128 items,
     exact scores 0.2 % (most) to 2.9 % under A's — round UP (0.78 % over).  With bounds too narrow by a factor of two the floor made of
     C's lower bounds lies above A's upper bounds and the ten best items of every user are lost; with bound_c(d) the lists are
     the exact form's, ids and values."""
-    U, I, d, k = 8192, 33024, 64, 20
+    U, I, k, half = 8192, 33024, 20, d // 2
     w_dn = np.float32(1.0 + 2.0 ** -8 * (1.0 - 2.0 ** -12))  # rounds down to 1.0
     w_up = np.float32(1.0 + 2.0 ** -8 * (1.0 + 2.0 ** -12))  # rounds up to 1 + 2^-7
     rng = np.random.default_rng(7)
     Ue = np.empty((U, d), dtype=np.float32)
-    Ue[:, :32], Ue[:, 32:] = w_dn, w_up
+    Ue[:, :half], Ue[:, half:] = w_dn, w_up
     Ue *= (2.0 ** rng.integers(-3, 4, (U, 1))).astype(np.float32)  # (powers of two keep the mantissas)
     Ie = (rng.standard_normal((I, d)) * 0.01).astype(np.float32)  # background: far below
     a_items = rng.choice(np.arange(0, I, 128) + 5, 10, replace=False)
     Ie[a_items] = 0.0
-    Ie[a_items, :32] = w_dn  # exact score 32 w_dn^2 per unit of the user's scale
+    Ie[a_items, :half] = w_dn  # exact score (d / 2) w_dn^2 per unit of the user's scale
     c_items = np.setdiff1d(np.arange(0, I, 128) + 77, a_items)
     for j, it in enumerate(c_items):
-        # the 32 coordinates sum to 32 - m / 16 (m = 1 .. 15) in powers of two only, so that every mantissa stays w_up's:
-        # 27 ones, one 4, and the binary digits of (16 - m) / 16
+        # the d / 2 coordinates sum to d / 2 - m / 16 (m = 1 .. 15) in powers of two only, so that every mantissa stays w_up's:
+        # ones, one 4, and the binary digits of (16 - m) / 16
         # (m = 1 for nine items in ten — 0.2 % under A, the level whose lower bounds a too narrow bound lifts over A's upper
         #  bounds — in a random order of the coordinates: same real score, fp32 chains that differ in the last places)
         m = 1 if j % 10 else 1 + j % 15
-        row = np.ones(32)
-        row[27] = 4.0
-        row[28:32] = [((16 - m) >> b) & 1 for b in (3, 2, 1, 0)]
-        row[28:32] *= [0.5, 0.25, 0.125, 0.0625]
+        row = np.ones(half)
+        row[half - 5] = 4.0
+        row[half - 4:] = [((16 - m) >> b) & 1 for b in (3, 2, 1, 0)]
+        row[half - 4:] *= [0.5, 0.25, 0.125, 0.0625]
         Ie[it] = 0.0
-        Ie[it, 32:] = (rng.permutation(row) * w_up).astype(np.float32)
+        Ie[it, half:] = (rng.permutation(row) * w_up).astype(np.float32)
     Ud, Id = dev(Ue), dev(Ie)
     every = torch.arange(U, device="cuda")
     info = {}
