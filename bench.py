@@ -82,6 +82,11 @@ def parse():
                    help="the multi-GPU lines' workload (synth-10M, d=256: BASELINE configs[4]) measured unsharded on ONE GPU in "
                         "this run: as `scale_point` of the default 1-GPU line (auto: only there) and as `single_gpu_reference` "
                         "/ `speedup_vs_1gpu` of a sharded line (auto: when the shape fits one GPU)")
+    p.add_argument("--parity-steps", type=int, default=3,
+                   help="sharded form with a single-GPU reference in the run: this many training steps are taken on the N ranks "
+                        "BEFORE the warm-up, from the fresh tables, and repeated on ONE device (rank 0, the fused engine) from "
+                        "the same tables and batches; the line carries `parity_vs_1gpu` {loss_rel_err, final_rows_rel_err, "
+                        "table_rel_err, tol 1e-4, ok} and the run leaves with status 3 when ok is false (0 = no check)")
     p.add_argument("--item-slices", type=int, default=0,
                    help="sharded form: row slices of the item panel whose collectives overlap the following slices' products "
                         "(0 = auto: 8 from four ranks on, 4 below, 1 while the panel is under 256 MB)")
@@ -212,6 +217,24 @@ def cpu_baseline_scaled(args):
 BENCH_TIMEOUT_S = float(os.environ.get("IDG_BENCH_TIMEOUT", "1500"))  # both attempts of a multi-GPU run together
 
 
+PARITY_EXIT = 3  # exit status of a multi-GPU run whose result differs from the single-GPU result (the line says where)
+
+
+def _flag_parity_failure(line):
+    """A measured N-rank line whose `parity_vs_1gpu.ok` is False is not a measurement: it gets an "error" field and the
+    process that prints it leaves with PARITY_EXIT — no retry (a wrong result is not a hang).  ok = None (the reference
+    could not run) is reported, not failed."""
+    par = line.get("parity_vs_1gpu") or {}
+    if par.get("ok") is False:
+        line["error"] = ("parity_vs_1gpu FAILED: the %d-rank run differs from the single-GPU run of the same steps beyond %g "
+                         "(loss %.3g, final rows %.3g, tables %.3g)" % (line.get("n_gpus", 0), par.get("tol", 0),
+                                                                       par.get("loss_rel_err", float("nan")),
+                                                                       par.get("final_rows_rel_err", float("nan")),
+                                                                       par.get("table_rel_err", float("nan"))))
+        return True
+    return False
+
+
 def _error_line(args, world, message, **extra):
     """The ONE JSON line of a multi-GPU run that did not produce a measurement."""
     out = {"metric": "BPR triples/sec, LightGCN-%d dim=%s" % (args.layers, args.dim or 256), "value": None, "unit": "triples/s",
@@ -261,6 +284,11 @@ def self_launch(args):
         if lines:
             print(lines[-1], flush=True)
         rc = proc.returncode if proc.returncode or lines else 1
+        try:  # (the launcher answers 1 for any failed rank: a result that failed its parity check keeps its own status)
+            if lines and (json.loads(lines[-1]).get("parity_vs_1gpu") or {}).get("ok") is False:
+                rc = PARITY_EXIT
+        except ValueError:
+            pass
     finally:
         shutil.rmtree(sdir, ignore_errors=True)
     sys.exit(rc)
@@ -422,6 +450,8 @@ def supervise_rank(args):
                     line["retried"] = {"why": summary[0], "note": "first attempt ended by the watchdog; this line is the retry "
                                                                 "over torch.distributed's process group (--comm torch)"}
                 print(json.dumps(line), flush=True)
+                if (line.get("parity_vs_1gpu") or {}).get("ok") is False:
+                    sys.exit(PARITY_EXIT)  # the line is printed (with "error"); a wrong result is not retried
             sys.exit(0)
         print("[bench] rank %d: attempt %d failed: %s (phases %s)" % (rank, attempt, all_v, phases), file=sys.stderr, flush=True)
     if rank == 0:
@@ -432,7 +462,7 @@ def supervise_rank(args):
     sys.exit(1)
 
 
-def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None, before_engine=None):
+def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None, before_engine=None, parity=None):
     """The multi-GPU lines' workload on ONE GPU, unsharded, through the fused single-GPU engine (PropagationEngine): the
     1-GPU point the N-GPU speed-ups are quoted against, measured in the same run.  ~140 GB resident at synth-10M d=256.
     edges: the (users, items) arrays when the caller has drawn the graph already.  before_engine(graph, U, I, n, nnz,
@@ -468,6 +498,16 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
     eng = PropagationEngine(graph, U, I, dim, K, include_layer0=True, reg_lambda=1e-4, lr=1e-3,
                             params=S.xavier_uniform_panel(U, I, dim, args.seed).cuda())
     eng.store_grad = False  # (as the trainer path: see main())
+    parity_out = None
+    if parity is not None:
+        # the N ranks ran these batches from these tables before their warm-up (sharded.parity_capture): the same steps on
+        # this one device are the oracle of the N-rank run — before anything else touches the engine
+        from idgrec_amd.sharded import parity_compare
+
+        try:
+            parity_out = parity_compare(eng, parity)
+        except Exception as exc:  # noqa: BLE001 - reported in the line; the reference timing below still runs
+            parity_out = {"ok": None, "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     tu, tp, tn = tri[:, 0].contiguous(), tri[:, 1].contiguous(), tri[:, 2].contiguous()
 
     def step(i):
@@ -494,6 +534,8 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
     out["seconds_including_graph_build"] = time.perf_counter() - t_all
     if extra is not None:
         out["before_engine"] = extra
+    if parity_out is not None:
+        out["parity_vs_1gpu"] = parity_out
     return out
 
 
@@ -571,7 +613,7 @@ def main():
             fits = 9 * 4 * (U_ + I_) * args.dim + 24 * E_ < 250e9
             ref = None
             if args.scale_point == "on" or (args.scale_point == "auto" and world > 1 and fits):
-                ref = lambda a, edges=None: single_gpu_point(a, a.workload, a.dim, edges=edges)  # noqa: E731
+                ref = lambda a, edges=None, parity=None: single_gpu_point(a, a.workload, a.dim, edges=edges, parity=parity)  # noqa: E731
             out = run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_reference=ref)
             if args.parallel == "auto" and world > 1:
                 rep = run_replicated_bench(args, rank, world, dist, comm, comm_name, workload="yelp2018", dim=64)
@@ -584,13 +626,17 @@ def main():
         if rank == 0 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_scaled(args)
         dist.barrier()
+        parity_failed = False
         if rank == 0:
+            parity_failed = _flag_parity_failure(out)
             args.emit(out)
         worker_phase(args, "teardown")
         if hasattr(comm, "close"):
             comm.close()
         dist.destroy_process_group()
         worker_phase(args, "done")
+        if parity_failed and not args.worker:
+            sys.exit(PARITY_EXIT)  # (under a supervisor the worker ends cleanly and the SUPERVISOR leaves with this status)
         return
 
     default_headline = args.workload == "yelp2018" and args.dim == 64 and args.model == "LightGCN" and args.layers == 3
@@ -818,15 +864,8 @@ def eval_scale_point(users=16384, items=5_000_000, d=256, k=20, degree=50):
     info = {}
     ops.score_topk(Ue, Ie, every, k, ip, ixd, info=info)
     t = timed(3)
-    before = os.environ.get("IDG_TOPK_COLLECT")
-    os.environ["IDG_TOPK_COLLECT"] = "0"
-    try:
+    with ops.topk_options(collect=0):
         t_exact = timed(1)
-    finally:
-        if before is None:
-            del os.environ["IDG_TOPK_COLLECT"]
-        else:
-            os.environ["IDG_TOPK_COLLECT"] = before
     flop = 2.0 * users * items * d
     return {"what": "one fused score + mask + top-%d call at configs[4]'s geometry: %d users x %d items x d=%d, %d train items "
                     "per user masked, random tables" % (k, users, items, d, degree),

@@ -19,6 +19,7 @@ struct idg_step {
   struct Slot {
     hipEvent_t rows_done = nullptr, plan_done = nullptr, free_ev = nullptr;
     bool used = false;        // free_ev has been recorded at least once
+    bool prepared = false;    // plan_done has been recorded at least once (the side stream has written this slot's buffers)
     bool has_key = false;     // holds a prepared batch nobody has run yet
     const int64_t *users = nullptr, *pos = nullptr, *neg = nullptr;
     int64_t B = 0;
@@ -62,7 +63,9 @@ int prepare(idg_step* p, int si, const int64_t* users, const int64_t* pos, const
   void* side = d.side_stream;
   if (s.used) IDG_TRY(idg_stream_wait_event(side, s.free_ev));  // the step that last used this slot has consumed it
   // the side stream must not read the ids before the caller's stream has produced them: once per storage (batches are
-  // slices of one epoch-long tensor; per batch it would also queue this batch's index work behind the previous step)
+  // slices of one epoch-long tensor; per batch it would also queue this batch's index work behind the previous step).
+  // `token` names the storage of the batch BEING PREPARED — a lookahead batch brings its own (the step's
+  // token used for the next batch let a lookahead in a new storage through without the fork)
   if (!s.used || token == 0 || token != p->token || !p->forked_once) {
     p->token = token;
     p->forked_once = true;
@@ -80,6 +83,7 @@ int prepare(idg_step* p, int si, const int64_t* users, const int64_t* pos, const
     IDG_TRY(idg_event_record(s.rows_done, side));
   }
   IDG_TRY(idg_event_record(s.plan_done, side));
+  s.prepared = true;
   s.has_key = true;
   s.users = users, s.pos = pos, s.neg = neg, s.B = B;
   return IDG_OK;
@@ -155,8 +159,8 @@ int idg_step_prefetch(idg_step* p, const int64_t* users, const int64_t* pos, con
 
 int idg_step_run_f32(idg_step* p, const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      const int64_t* next_users, const int64_t* next_pos, const int64_t* next_neg, int64_t next_B,
-                     uint64_t ids_token, float* loss, int64_t adam_step, double lr, double beta1, double beta2, double eps,
-                     int flags, void* stream) {
+                     uint64_t ids_token, uint64_t next_ids_token, float* loss, int64_t adam_step, double lr, double beta1,
+                     double beta2, double eps, int flags, void* stream) {
   IDG_REQUIRE(p && loss && adam_step >= 1, "idg_step_run_f32: NULL plan / loss, or adam_step < 1");
   IDG_TRY(check_batch(p, users, pos, neg, B, "idg_step_run_f32"));
   const auto t_in = std::chrono::steady_clock::now();
@@ -177,7 +181,7 @@ int idg_step_run_f32(idg_step* p, const int64_t* users, const int64_t* pos, cons
   // for) is dropped now — its id arrays may be gone, and the same addresses may come back holding other ids
   for (int i = 0; i < IDG_STEP_SLOTS; ++i) p->slots[i].has_key = false;
   // the next batch's index-only work goes out first: it runs on the side stream under this step's products
-  if (next_B > 0) IDG_TRY(idg_step_prefetch(p, next_users, next_pos, next_neg, next_B, ids_token, stream));
+  if (next_B > 0) IDG_TRY(idg_step_prefetch(p, next_users, next_pos, next_neg, next_B, next_ids_token, stream));
   // pacing: at most two steps queued.  A batch prepared ahead started its preparation when ITS slot's last step, three
   // back, had finished — complete by now, which the host can see; the step's stream then needs no wait at all
   const bool paced = (d.flags & IDG_STEP_PACED) != 0;
@@ -236,6 +240,10 @@ int idg_step_last_bitmap(const idg_step* p, const uint32_t** out_bitmap) {
 int idg_step_synchronize(idg_step* p) {
   IDG_REQUIRE(p, "idg_step_synchronize: NULL plan");
   for (int i = 0; i < p->n_ends; ++i) IDG_TRY(idg_event_synchronize(p->ends[i]));
+  // ... and every preparation enqueued on the SIDE stream: a lookahead nobody ran may still be writing its slot's
+  // bitmap / unit list / plan workspace, which the caller is about to release
+  for (int i = 0; i < IDG_STEP_SLOTS; ++i)
+    if (p->slots[i].prepared) IDG_TRY(idg_event_synchronize(p->slots[i].plan_done));
   return IDG_OK;
 }
 

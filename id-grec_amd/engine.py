@@ -294,8 +294,14 @@ class PropagationEngine:
                 and self.sgl is None and self.exchange is None and not self._compact):
             return False
         if self.graph is None:
-            return self.d % 4 == 0
+            return self.d % 4 == 0 and self.d <= 1024  # idg_step_create / idg_adam_rows_f32's limits
         return not (self._fields and 3 * B * 256 <= self.n) and self.K >= 2 and self.d in (32, 64, 128, 256, 512)
+
+    @staticmethod
+    def _ids_token(users, pos, neg):
+        """idg_step_*'s ids_token of a batch: changes whenever the STORAGE of its id tensors does (never 0 = "every call")."""
+        return (users.untyped_storage().data_ptr() ^ (pos.untyped_storage().data_ptr() << 1)
+                ^ (neg.untyped_storage().data_ptr() << 2)) & 0xFFFFFFFFFFFFFFFF | 1
 
     def _run_plan(self, users, pos, neg, loss_out):
         B = int(users.shape[0])
@@ -309,15 +315,17 @@ class PropagationEngine:
         self._next = None
         if nxt is not None and (nxt[0].data_ptr() == users.data_ptr() or int(nxt[0].shape[0]) > plan.B_cap):
             nxt = None
-        tok = (users.untyped_storage().data_ptr() ^ (pos.untyped_storage().data_ptr() << 1)
-               ^ (neg.untyped_storage().data_ptr() << 2)) & 0xFFFFFFFFFFFFFFFF | 1
+        tok = self._ids_token(users, pos, neg)
+        # the lookahead batch may live in ANOTHER storage (a new epoch's tensor, a clone, a gather result): its own token
+        # orders the side stream behind this stream before it reads those ids
+        ntok = 0 if nxt is None else self._ids_token(*nxt)
         self._alive.append((users, pos, neg, nxt))
         del self._alive[:-4]
         self.step_count += 1
         rc = native.lib.idg_step_run_f32(plan._h, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B,
                                          None if nxt is None else nxt[0].data_ptr(), None if nxt is None else nxt[1].data_ptr(),
                                          None if nxt is None else nxt[2].data_ptr(), 0 if nxt is None else int(nxt[0].shape[0]),
-                                         tok, loss.data_ptr(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         tok, ntok, loss.data_ptr(), self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
                                          native.IDG_STEP_STORE_GRAD if self.store_grad else 0, ops._stream())
         if rc:
             native.check(rc, "idg_step_run_f32")

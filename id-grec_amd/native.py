@@ -166,12 +166,13 @@ PROTOTYPES = {
     "idg_score_dense_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp]),
     "idg_score_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "idg_score_topk_info": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, C.POINTER(C.c_int64), c_vp]),
+    "idg_score_topk_option": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_int64)]),
     "idg_score_topk_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int,
                                      C.c_int, c_vp, c_vp, c_vp, c_vp]),
     "idg_step_create": (C.c_int, [c_vp, C.POINTER(c_vp)]),
     "idg_step_destroy": (C.c_int, [c_vp]),
     "idg_step_prefetch": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_uint64, c_vp]),
-    "idg_step_run_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_uint64, c_vp, C.c_int64,
+    "idg_step_run_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp, C.c_int64, C.c_uint64, C.c_uint64, c_vp, C.c_int64,
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_vp]),
     "idg_step_last_bitmap": (C.c_int, [c_vp, C.POINTER(c_vp)]),
     "idg_step_synchronize": (C.c_int, [c_vp]),
@@ -189,6 +190,9 @@ IDG_GRAPH_EXACT_ORDER = 2
 
 
 IDG_STEP_SLOTS, IDG_STEP_STORE_GRAD, IDG_STEP_PACED = 3, 1, 2
+# idg_score_topk_option: which -> (index, default)
+IDG_TOPK_OPTS = {"form": (0, -1), "collect": (1, 1), "floor": (2, 1), "wgs": (3, 0), "chunks": (4, 0), "fallback_permille": (5, 20)}
+IDG_TOPK_OPT_RESET, IDG_TOPK_OPT_KEEP = -1, -(1 << 63)
 
 
 class StepDesc(C.Structure):
@@ -233,7 +237,7 @@ except ImportError:  # host-only use (sampler / parser / adjacency) works withou
     _torch = None
 
 ACT_TANH, ACT_TANH_BWD = 1, 2  # idg_epilogue.act
-ABI_VERSION = 139  # include/idgrec.h IDG_VERSION the prototype table above was written against
+ABI_VERSION = 140  # include/idgrec.h IDG_VERSION the prototype table above was written against
 
 lib = C.CDLL(LIB_PATH)
 lib.idg_version.restype = C.c_int

@@ -1251,11 +1251,53 @@ def score_dense(user_panel, item_panel, users, apply_sigmoid=True):
     return rating
 
 
+def topk_option(name, value=None):
+    """idg_score_topk_option: one of the process-wide knobs of score_topk's form choice — 'form' (-1 by geometry; 0 / 1 / 3),
+    'collect' (0: never the threshold + collect form), 'floor', 'wgs', 'chunks', 'fallback_permille' (form 3 hands a call
+    to the exact form beyond this share of users it cannot serve; < 0 never).  Returns the previous value; value None only
+    reads; name 'reset' restores every default.  The library reads IDG_TOPK_* from the environment once, at first use."""
+    from . import native
+
+    if name == "reset":
+        check(lib.idg_score_topk_option(native.IDG_TOPK_OPT_RESET, 0, None), "idg_score_topk_option")
+        return None
+    prev = C.c_int64()
+    check(lib.idg_score_topk_option(native.IDG_TOPK_OPTS[name][0], native.IDG_TOPK_OPT_KEEP if value is None else int(value),
+                                    C.byref(prev)), "idg_score_topk_option")
+    return int(prev.value)
+
+
+class topk_options:
+    """with ops.topk_options(collect=0): ... — knobs of score_topk's form choice for the duration of a block."""
+
+    def __init__(self, **values):
+        self.values, self.saved = values, {}
+
+    def __enter__(self):
+        for name, value in self.values.items():
+            self.saved[name] = topk_option(name, value)
+        return self
+
+    def __exit__(self, *exc):
+        for name, value in self.saved.items():
+            topk_option(name, value)
+        return False
+
+
+def score_topk_form(n_users, n_items, d, k):
+    """Which kernel a score_topk call of this geometry takes (idg_score_topk_info without a workspace):
+    {form: 0 alternating / 1 producer-consumer / 3 threshold + collect, chunks, floor}."""
+    out = (C.c_int64 * 8)()
+    check(lib.idg_score_topk_info(int(n_users), int(n_items), int(d), int(k), None, out, None), "idg_score_topk_info")
+    return {"form": int(out[0]), "chunks": int(out[1]), "floor": bool(out[2])}
+
+
 def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=None, apply_sigmoid=True,
                return_values=False, info=None):
     """Top-k item ids per batch user, train positives masked to -1 (batch_test.py:59-68).
     excl_indptr int64[num_users+1] / excl_items int32: DEVICE CSR of the train matrix.
-    info: a dict to fill with idg_score_topk_info's answer for this call (form, chunks, floor, users redone; synchronises)."""
+    info: a dict to fill with idg_score_topk_info's answer for this call (form, chunks, floor; form 3: users redone one by
+    one, users the finish could not serve, whether the call fell back to the exact form as a whole; synchronises)."""
     _require_device(user_panel, item_panel, users, excl_indptr, excl_items)
     U, V = _f32c(user_panel, "user_panel"), _f32c(item_panel, "item_panel")
     users = _i64c(users, "users")
@@ -1275,7 +1317,7 @@ def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=No
         per_call = 16384
         while per_call * 2 < Bt and int(lib.idg_score_topk_workspace_bytes(per_call * 2, I, d, int(k))) <= budget:
             per_call *= 2
-    redone = 0
+    redone = unserved = fell_back = 0
     for s0 in range(0, Bt, per_call):
         n = min(per_call, Bt - s0)
         ws = torch.empty(int(lib.idg_score_topk_workspace_bytes(n, I, d, int(k))), dtype=torch.uint8, device=V.device)
@@ -1284,10 +1326,14 @@ def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=No
                                      _ptr(val[s0:s0 + n]) if val is not None else None, _ptr(ws), _stream()),
               "idg_score_topk_f32")
         if info is not None:
-            out = (C.c_int64 * 4)()
+            out = (C.c_int64 * 8)()
             check(lib.idg_score_topk_info(n, I, d, int(k), _ptr(ws), out, _stream()), "idg_score_topk_info")
             redone += max(int(out[3]), 0)
+            unserved += max(int(out[4]), 0)
+            fell_back += max(int(out[5]), 0)
             if s0 == 0:  # (form / chunks / floor of the first call: later ones differ only in a shorter last call)
                 info.update(form=int(out[0]), chunks=int(out[1]), floor=bool(out[2]), calls=-(-Bt // per_call))
             info["users_redone"] = redone if int(out[3]) >= 0 else int(out[3])
+            if int(out[3]) >= 0:  # (form 3)
+                info.update(users_unserved=unserved, calls_fallen_back=fell_back, items_irregular=bool(out[6]))
     return (idx, val) if return_values else idx

@@ -619,6 +619,9 @@ class ShardedEngine:
 
 
 # --------------------------------------------------------------------------- per-collective timeline (instrumented steps)
+XGMI_PEAK_GBS = 7 * 153.0  # what one MI355X can send to its seven peers at once (MI355X_MICROARCH.md: 7 links x ~153 GB/s)
+
+
 class StepTimeline:
     """What a sub-6x multi-GPU line is diagnosed from: for a few INSTRUMENTED steps after the timed
     region, per collective tag (ShardedEngine sets comm.tag before every collective): how long the collective itself
@@ -664,12 +667,16 @@ class StepTimeline:
         for tag, r in per.items():
             ms = r["collective_ms"] / n
             factor = bus if r["kind"] == "all_reduce" else bus / 2.0  # reduce-scatter / all-gather: (N-1)/N of the buffer
+            gbs = (r["bytes"] / n * factor / (ms * 1e-3) / 1e9) if ms > 0 else None
             out[tag] = {"kind": r["kind"], "calls_per_step": r["calls"] / n, "bytes_per_step": r["bytes"] / n,
-                        "collective_ms": ms, "main_stream_stall_ms": r["stall_ms"] / n,
-                        "bus_gbs": (r["bytes"] / n * factor / (ms * 1e-3) / 1e9) if ms > 0 else None}
+                        "collective_ms": ms, "main_stream_stall_ms": r["stall_ms"] / n, "bus_gbs": gbs,
+                        # against what one GPU can send: 7 xGMI links x 153 GB/s (MI355X_MICROARCH.md); the 8-GPU
+                        # projection of DESIGN.md §7 needs >= 0.75 of it on the three panel-sized exchanges
+                        "bus_frac_of_xgmi_peak": (gbs / XGMI_PEAK_GBS) if gbs is not None else None}
         step_ms = sum(a.elapsed_time(b) for a, b in self.steps) / n
         stall = sum(v["main_stream_stall_ms"] for v in out.values())
         return {"instrumented_steps": len(self.steps), "step_gpu_ms": step_ms, "main_stream_stall_ms": stall,
+                "xgmi_peak_gbs": XGMI_PEAK_GBS,
                 "compute_ms": step_ms - stall,
                 "host_sync_ms": (sum(self.host_syncs) / n * 1e3) if self.host_syncs else 0.0,
                 "collectives": out,
@@ -1507,6 +1514,108 @@ class NoComm:
 
 
 # --------------------------------------------------------------------------- bench driver
+PARITY_TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 relative on fp32 embeddings and loss"
+
+
+def parity_capture(eng, batches, tri, dist, rank, lo, hi, num_users, num_items, seed=0, n_sample=1024):
+    """The N-rank half of `parity_vs_1gpu` (the only place RCCL between devices ever runs — the driver's
+    `bench.py --gpus N` — must carry its own correctness evidence).  Runs the steps `batches` (GlobalBatch list; `tri` their
+    global triples [n * B, 3]) on the freshly initialised sharded engine — every rank calls this — and returns on rank 0
+    what the single-device engine has to reproduce from the same tables and batches (the oracle of a k-GPU
+    run is the 1-GPU result):
+      loss [n, 2]; per step FIN at the batch's user rows (the guest rows: batch order) and at its distinct item rows;
+      after the last step, table rows of a sample of users (each from its owner, summed over the ranks: x + 0 + ...) and
+      items (replicated): the batch's own and `n_sample` random ones of each side.
+    Leaves the engine n steps into training (the timed region goes on from there)."""
+    import torch
+
+    B = eng.B
+    n = len(batches)
+    host = dist.get_backend() != "nccl"
+    rng = np.random.default_rng(seed + 12345)
+    user_ids = np.unique(np.concatenate([tri[:, 0], rng.integers(0, num_users, n_sample)])).astype(np.int64)
+    item_ids = np.unique(np.concatenate([tri[:, 1], tri[:, 2], rng.integers(0, num_items, n_sample)])).astype(np.int64)
+
+    def user_rows():
+        mine = (user_ids >= lo) & (user_ids < hi)
+        buf = torch.zeros((len(user_ids), eng.d), dtype=torch.float32, device=eng.P.device)
+        if mine.any():
+            buf[torch.from_numpy(np.nonzero(mine)[0]).to(buf.device)] = eng.P[torch.from_numpy(user_ids[mine] - lo).to(buf.device)]
+        buf = buf.cpu() if host else buf
+        dist.all_reduce(buf)
+        return buf.cpu()
+
+    eng._wait_item_table()
+    item_dev = torch.from_numpy(item_ids).to(eng.P.device)
+    out = {"triples": np.ascontiguousarray(tri), "user_ids": user_ids, "item_ids": item_ids, "user_rows_before": user_rows(),
+           "item_rows_before": eng.item_rows(eng.P)[item_dev].cpu(), "loss": [], "fin_users": [], "fin_items": [],
+           "fin_item_ids": []}
+    for i, gb in enumerate(batches):
+        eng.train_step(gb)
+        if i == 0 and rank == 1 and os.environ.get("IDG_BENCH_TEST_BREAK_PARITY") == "1":
+            eng._wait_item_table()
+            eng.P_u.mul_(1.001)  # tests only: stands in for a broken exchange (tests/test_bench_contract.py)
+        out["loss"].append(eng.loss.double().cpu().numpy().copy())
+        out["fin_users"].append(eng._guest(eng.FIN, gb.B).cpu())
+        out["fin_items"].append(eng.item_rows(eng.FIN)[gb.items].cpu())
+        out["fin_item_ids"].append(gb.items.cpu().numpy())
+    eng._wait_item_table()
+    out["user_rows"] = user_rows()
+    out["item_rows"] = eng.item_rows(eng.P)[item_dev].cpu()
+    out["loss"] = np.stack(out["loss"])
+    assert tri.shape[0] == n * B
+    return out if rank == 0 else None
+
+
+def parity_compare(single, captured, tol=PARITY_TOL):
+    """The 1-GPU half: `single` = a freshly initialised PropagationEngine on the WHOLE graph with the same initial tables;
+    runs the captured batches through it and returns the `parity_vs_1gpu` object of the bench line — relative errors
+    (Frobenius norms over the compared rows; the loss: largest over steps and terms) of the N-rank run against this one,
+    and `ok` = all three within tol.  `update_rel_err` (informational) measures the same table rows as UPDATES since the
+    initial tables: an N-rank step that left the tables alone would show there."""
+    import torch
+
+    tri = torch.from_numpy(captured["triples"]).to(single.params.device)
+    B = captured["fin_users"][0].shape[0]
+    U = single.U
+    dev = single.params.device
+    urows = torch.from_numpy(captured["user_ids"]).to(dev)
+    irows = torch.from_numpy(captured["item_ids"]).to(dev) + U
+    before = torch.cat([single.params[urows], single.params[irows]]).cpu()
+    init_n = torch.cat([captured["user_rows_before"], captured["item_rows_before"]])
+    init_equal = bool(torch.equal(before, init_n))
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+    loss_err, fin_err = 0.0, 0.0
+    loss_1 = []
+    for i in range(len(captured["fin_users"])):
+        u, p, n = (tri[i * B:(i + 1) * B, c].contiguous() for c in range(3))
+        loss = single.train_step(u, p, n).double().cpu().numpy().copy()
+        loss_1.append(loss)
+        loss_err = max(loss_err, float(np.max(np.abs(captured["loss"][i] - loss) / np.maximum(np.abs(loss), 1e-30))))
+        items = torch.from_numpy(captured["fin_item_ids"][i]).to(dev)
+        fin_1 = torch.cat([single.final[u], single.final[items + U]]).cpu()
+        fin_n = torch.cat([captured["fin_users"][i], captured["fin_items"][i]])
+        fin_err = max(fin_err, rel(fin_n, fin_1))
+    after_1 = torch.cat([single.params[urows], single.params[irows]]).cpu()
+    after_n = torch.cat([captured["user_rows"], captured["item_rows"]])
+    table_err = rel(after_n, after_1)
+    upd_err = rel(after_n - init_n, after_1 - before)
+    ok = bool(init_equal and loss_err <= tol and fin_err <= tol and table_err <= tol)
+    return {"what": "%d training steps from the same initial tables and the same global batches on the N ranks and on ONE "
+                    "device (the fused single-GPU engine, rank 0, same run): N-rank result against the 1-GPU result — loss: "
+                    "largest relative error over steps and terms; final_rows: FIN at every batch's user and item rows; table: "
+                    "%d sampled user + %d item rows after the last Adam step (each batch's own + random ones); relative "
+                    "Frobenius norms.  SURVEY.md 8e: the oracle of a k-GPU run is the 1-GPU result"
+                    % (len(loss_1), len(captured["user_ids"]), len(captured["item_ids"])),
+            "steps": len(loss_1), "loss_rel_err": loss_err, "final_rows_rel_err": fin_err, "table_rel_err": table_err,
+            "update_rel_err": upd_err, "table_max_abs_err": float((after_n - after_1).abs().max()),
+            "initial_tables_equal": init_equal, "loss_n_ranks": [[float(x) for x in row] for row in captured["loss"]],
+            "loss_1_gpu": [[float(x) for x in row] for row in loss_1], "tol": tol, "ok": ok}
+
+
 def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_reference=None):
     """bench.py --gpus N (N > 1), the north-star split: ONE graph of the named shape cut across the
     ranks by nnz-balanced user-row blocks, item table replicated, ONE global batch of B triples per step (the
@@ -1539,7 +1648,10 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     n_slices = int(getattr(args, "item_slices", 0) or 0) or ((8 if world >= 4 else 4) if I * d * 4 >= (256 << 20) else 1)
     cuts = partition_users_by_nnz(np.bincount(items, minlength=I), n_slices)  # same cuts on every rank: global item degrees
     n_timeline = 3 if world > 1 or os.environ.get("IDG_BENCH_TIMELINE") == "1" else 0  # instrumented steps, after the timed ones
-    need = (args.steps + args.warmup + n_timeline) * B
+    # parity_vs_1gpu: the first n_parity batches run BEFORE the warm-up, on the fresh tables, and rank 0's single-GPU
+    # reference repeats them after the timed region (no reference in this run -> nothing to compare with)
+    n_parity = max(int(getattr(args, "parity_steps", 3)), 0) if single_gpu_reference is not None else 0
+    need = (n_parity + args.steps + args.warmup + n_timeline) * B
     tri = S.draw_triples(args.seed, users, items, U, I, need)[0]  # the same global sequence on every rank
     edges = (users, items) if (rank == 0 and single_gpu_reference is not None) else None  # (rank 0 measures the 1-GPU point later)
     del users, items
@@ -1562,23 +1674,28 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         del blk
     eng.item_rows(eng.P).copy_((torch.rand(I, d, generator=g) * 2 - 1) * bi)
     batches = [eng.make_batch(tri[i * B:(i + 1) * B, 0], tri[i * B:(i + 1) * B, 1], tri[i * B:(i + 1) * B, 2])
-               for i in range(args.steps + args.warmup + n_timeline)]
-    last = args.warmup + args.steps - 1
+               for i in range(n_parity + args.steps + args.warmup + n_timeline)]
+    first = n_parity
+    last = first + args.warmup + args.steps - 1
 
     def step(i):
         if i < last:
             eng.prefetch(batches[i + 1])  # index-only work of the next batch, off the critical path
         return eng.train_step(batches[i])
 
+    captured = None
+    if n_parity:
+        phase("parity_steps")
+        captured = parity_capture(eng, batches[:n_parity], tri[:n_parity * B], dist, rank, lo, hi, U, I, seed=args.seed)
     S.ramp_clocks()
     phase("warmup")
-    for i in range(args.warmup):
+    for i in range(first, first + args.warmup):
         step(i)
     dist.barrier()
     torch.cuda.synchronize()
     phase("timed")
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(first + args.warmup, first + args.warmup + args.steps):
         step(i)
     t_enqueue = time.perf_counter() - t0  # host time to issue the steps (== wall time when the host is the bottleneck)
     eng._wait_item_table()                # (the last step's all-gathers of the updated item rows belong to it)
@@ -1707,10 +1824,14 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         ref = None
         if rank == 0:
             try:
-                ref = single_gpu_reference(args, edges)
+                ref = single_gpu_reference(args, edges, captured)
             except Exception as exc:  # noqa: BLE001 - the headline stands without it; the line says why it is missing
                 ref = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
             out["single_gpu_reference"] = ref
+            if n_parity:
+                # correctness of the N-rank run, in the line itself: ok = False makes bench.py leave with a non-zero status
+                out["parity_vs_1gpu"] = ref.pop("parity_vs_1gpu", None) or {
+                    "ok": None, "error": "the single-GPU reference did not run: " + str(ref.get("error", "no result"))}
             if ref.get("ms_per_step"):
                 out["speedup_vs_1gpu"] = ref["ms_per_step"] / out["ms_per_step"]
                 if world >= 8 and out["speedup_vs_1gpu"] < 6.0:

@@ -301,7 +301,7 @@ def ramp_clocks(seconds=0.5, graph=None, d=64):
     (5 x 0.3 ms at the driver's flags) are over before the clocks are up.  With a graph handle the work is that
     graph's own product on a scratch panel — what the steps will run, so the clocks settle where the steps hold them
     (measured, steps 5-24 after the ramp: 276 us; after a GEMM ramp or none at all 282 us; steady state 274 us;
-    scripts/step_trend.py) — otherwise a dense GEMM loop."""
+    scripts/probes/step_trend.py) — otherwise a dense GEMM loop."""
     import time
 
     import torch

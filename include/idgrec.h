@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 139 /* 0.5.0: idg_step_* (one library call per training step), idg_adam_rows_f32; 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 140 /* 0.5.1: idg_score_topk_option (the top-K knobs: environment read once), idg_score_topk_info fills info[8], form 3's whole-call fall-back; idg_step_run_f32 takes next_ids_token; idg_step_synchronize also drains the side stream's preparations; 0.5.0: idg_step_* (one library call per training step), idg_adam_rows_f32; 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -725,7 +725,9 @@ int idg_shard_prepare(const idg_shard_prep* prep);
  * own step is enqueued and the step's stream does not wait for the side stream at all (a barrier packet costs ~4.5 us
  * whether or not its event has fired).
  * ids_token: any value that changes whenever the id arrays' STORAGE changes (a new epoch's triples): the side stream is
- * ordered behind `stream` once per token — the arrays may have been produced there — and 0 means "every call". */
+ * ordered behind `stream` once per token — the arrays may have been produced there — and 0 means "every call".
+ * next_ids_token (idg_step_run_f32): the same for the storage of the NEXT batch's arrays, which need not be this
+ * batch's (the first batch of a new epoch, a clone, a gather result). */
 #define IDG_STEP_SLOTS 3
 #define IDG_STEP_STORE_GRAD 1 /* the finished gradient is also written to `grad` (parity tests read it) */
 #define IDG_STEP_PACED 2
@@ -759,11 +761,12 @@ int idg_step_prefetch(idg_step* plan, const int64_t* users, const int64_t* pos, 
  * adam_step: 1-based step count of this update; lr / betas / eps as idg_adam_step_f32.  flags: IDG_STEP_STORE_GRAD. */
 int idg_step_run_f32(idg_step* plan, const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
                      const int64_t* next_users, const int64_t* next_pos, const int64_t* next_neg, int64_t next_B,
-                     uint64_t ids_token, float* loss, int64_t adam_step, double lr, double beta1, double beta2, double eps,
-                     int flags, void* stream);
+                     uint64_t ids_token, uint64_t next_ids_token, float* loss, int64_t adam_step, double lr, double beta1,
+                     double beta2, double eps, int flags, void* stream);
 /* The bitmap of the panel rows the LAST idg_step_run_f32 touched (its slot's; valid until that slot is reused two calls on). */
 int idg_step_last_bitmap(const idg_step* plan, const uint32_t** out_bitmap);
-/* Block the host until every step enqueued through the plan has finished. */
+/* Block the host until every step enqueued through the plan has finished AND every batch preparation it put on the side
+ * stream has (a lookahead nobody ran still writes its slot's buffers): after this the plan's buffers may be released. */
 int idg_step_synchronize(idg_step* plan);
 /* Host-side accounting since the plan was made: out[0] = steps run, out[1] = nanoseconds spent inside idg_step_run_f32,
  * out[2] = of those, nanoseconds BLOCKED in the pacing wait (the device was the limit, not the host), out[3] = steps whose
@@ -805,13 +808,33 @@ int idg_score_dense_f32(const float* user_panel, const float* item_panel, const 
 size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k);
 /* Which form a call of this geometry takes, for tests and diagnostics: info[0] = 0 every wave alternates between scoring and
  * selecting, 1 producer / consumer waves on exact fp32 scores, 3 (calls of >= 8 user tiles over >= 32,768 items, d = 64 / 128 /
- * 256, k <= 42; IDG_TOPK_COLLECT=0 turns it off) threshold + collect + exact finish on one-sided bf16 bounds of the exact
+ * 256, k <= 42; IDG_TOPK_OPT_COLLECT = 0 turns it off) threshold + collect + exact finish on one-sided bf16 bounds of the exact
  * score: a per-user floor from a strided sample of the catalogue scored as LOWER bounds, one pass that appends every item
  * whose UPPER bound reaches the floor to the user's candidate list, exact fp32 re-scoring of the candidates near the top —
  * bit-identical to forms 0 / 1, 3x (d = 64) to 10x (d = 256) as fast.  info[1] = catalogue chunks, info[2] = 1 when
- * chunks start from a floor (form 1), info[3] = (form 3, `ws` the workspace of a finished call on `stream`; synchronises)
- * users redone over the whole catalogue (their candidate lists overflowed), else -1. */
-int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int64_t info[4], void* stream);
+ * chunks start from a floor (form 1).  Form 3 with `ws` the workspace of a FINISHED call on `stream` (synchronises), else -1:
+ * info[3] = users redone one by one, exactly, over the whole catalogue (candidate list overflowed or short; a NaN / infinity /
+ * a norm beyond 2^60 in the user's row), info[4] = users the finish could not serve (counted up to just past the fall-back
+ * threshold: a lower bound when info[5] = 1), info[5] = 1 when the call as a whole
+ * was answered by the exact form, whose launches follow every form-3 call and return at once otherwise (more than
+ * IDG_TOPK_OPT_FALLBACK_PERMILLE of the users unservable — tables that tie massively — or an irregular ITEM row: decided
+ * on the device, no host read; then info[3] = 0), info[6] = 1 when an item row was irregular.  info[7] = 0 (reserved). */
+int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int64_t info[8], void* stream);
+/* Knobs of the form choice, process-wide, for tests and tuning.  Their initial values are read from the environment ONCE,
+ * by the first call that needs them (IDG_TOPK_FORM, IDG_TOPK_COLLECT, IDG_TOPK_FLOOR, IDG_TOPK_WGS, IDG_TOPK_CHUNKS,
+ * IDG_TOPK_FALLBACK_PERMILLE).  *previous (nullable) receives the old value; value = IDG_TOPK_OPT_KEEP only reads;
+ * which = IDG_TOPK_OPT_RESET restores every default.  Not thread-safe against concurrent idg_score_topk_* calls. */
+#define IDG_TOPK_OPT_FORM 0               /* -1 (default): by geometry; 0 / 1 / 3: force a kernel (3 where its domain allows) */
+#define IDG_TOPK_OPT_COLLECT 1            /* 1; 0: never form 3 */
+#define IDG_TOPK_OPT_FLOOR 2              /* 1; 0: many-chunk calls of form 1 without their floor phase */
+#define IDG_TOPK_OPT_WGS 3                /* 0; > 0: workgroups wanted per launch */
+#define IDG_TOPK_OPT_CHUNKS 4             /* 0; > 0: catalogue chunks */
+#define IDG_TOPK_OPT_FALLBACK_PERMILLE 5  /* 20: form 3 hands the whole call to the exact form beyond this share of unservable
+                                             users (at least 4); < 0: never (every such user is redone one by one) */
+#define IDG_TOPK_OPT_COUNT 6
+#define IDG_TOPK_OPT_RESET (-1)
+#define IDG_TOPK_OPT_KEEP INT64_MIN
+int idg_score_topk_option(int which, int64_t value, int64_t* previous);
 int idg_score_topk_f32(const float* user_panel, const float* item_panel, const int64_t* users,
                        int64_t Bt, int64_t I, int64_t d, const int64_t* excl_indptr,
                        const int32_t* excl_items, int k, int apply_sigmoid, int64_t* out_idx,

@@ -23,7 +23,8 @@ import golden_io  # noqa: E402
 
 FAST = [("gen_golden.py", ["graph_tiny.npz", "graph_small.npz", "misc.npz"]),
         ("gen_golden_next.py", ["next_small.npz"]),
-        ("gen_golden_egcf.py", ["egcf_small.npz"])]
+        ("gen_golden_egcf.py", ["egcf_small.npz"]),
+        ("gen_golden_wide.py", ["wide_small.npz"])]
 SLOW = [("gen_golden_convergence.py", ["convergence_medium.npz"])]
 
 

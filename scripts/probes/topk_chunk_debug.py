@@ -13,7 +13,7 @@ users = torch.arange(Bt, device="cuda")
 info = {}
 got = ops.score_topk(Ue, Ie, users, k, None, None, return_values=True, info=info)
 print(info)
-os.environ["IDG_TOPK_COLLECT"] = "0"
+ops.topk_option("collect", 0)
 want = ops.score_topk(Ue, Ie, users, k, None, None, return_values=True)
 bad = (got[0] != want[0]).any(dim=1).nonzero().flatten()
 print("users differing:", len(bad), "of", Bt)

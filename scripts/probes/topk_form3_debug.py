@@ -16,7 +16,7 @@ every = torch.arange(U, device="cuda")
 info = {}
 got = ops.score_topk(Un, In, every, k, ip, ix, apply_sigmoid=False, return_values=True, info=info)
 print(info)
-os.environ["IDG_TOPK_COLLECT"] = "0"
+ops.topk_option("collect", 0)
 want = ops.score_topk(Un, In, every, k, ip, ix, apply_sigmoid=False, return_values=True)
 bad = (got[0] != want[0]).any(dim=1).nonzero().flatten()
 print("users differing:", len(bad), bad[:10].tolist())

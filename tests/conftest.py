@@ -52,3 +52,12 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(autouse=True)
+def _topk_options_reset():
+    """score_topk's knobs (idg_score_topk_option) are process-wide: a test's override does not outlive it."""
+    yield
+    mod = sys.modules.get("idgrec_amd.ops")
+    if mod is not None:
+        mod.topk_option("reset")

@@ -102,6 +102,18 @@ def test_two_rank_line():
     # the same workload on ONE GPU, measured in the same run (rank 0, after the timed region)
     assert d["single_gpu_reference"]["ms_per_step"] > 0
     assert abs(d["speedup_vs_1gpu"] - d["single_gpu_reference"]["ms_per_step"] / d["ms_per_step"]) < 1e-9
+    _assert_parity(d)
+
+
+def _assert_parity(d, steps=3):
+    """the N-rank line proves its own correctness — the first steps, from the fresh tables, repeated on one
+    device in the same run: loss, FIN at the batch rows and sampled table rows within 1e-4."""
+    par = d["parity_vs_1gpu"]
+    assert par["ok"] is True and par["tol"] == 1e-4 and par["steps"] == steps and par["initial_tables_equal"] is True, par
+    for key in ("loss_rel_err", "final_rows_rel_err", "table_rel_err"):
+        assert 0 <= par[key] <= 1e-4, (key, par[key])
+    assert par["update_rel_err"] <= 1e-2, par  # (the tables as UPDATES since the initial ones: the steps did move them alike)
+    assert len(par["loss_n_ranks"]) == steps and "error" not in d
 
 
 TIMELINE_TAGS = {"F1.panel", "flags", "F2.touched", "F3.items", "guest_rows", "B1.touched", "B2.panel", "B3.reduce_scatter",
@@ -118,7 +130,7 @@ def test_eight_rank_line():
     env = dict(_env(), IDG_BENCH_TIMEOUT="900")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--parallel", "shard", "--workload",
                         "synth-1M", "--dim", "64", "--item-slices", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--scale-point", "off"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+                        "--scale-point", "on"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_line(r.stdout)
     for k in KEYS:
@@ -131,6 +143,45 @@ def test_eight_rank_line():
     assert t["collectives"]["F1.panel"]["calls_per_step"] == 8 and t["collectives"]["item_table.all_gather"]["calls_per_step"] == 8
     o = t["issue_order"]
     assert o["steps"] == 3 and o["slices"] == 8 and o["violations"] == [] and o["ranks_with_violations"] == 0
+    # every collective's achieved bus rate against what one GPU can send over its seven xGMI links
+    assert t["xgmi_peak_gbs"] == 7 * 153.0
+    for tag in ("F1.panel", "B2.panel", "B3.reduce_scatter", "item_table.all_gather"):
+        c = t["collectives"][tag]
+        assert c["bus_gbs"] > 0 and abs(c["bus_frac_of_xgmi_peak"] - c["bus_gbs"] / (7 * 153.0)) < 1e-12, c
+    # ... and the line's own correctness evidence: the eight ranks' first steps against ONE device, in this run
+    _assert_parity(d)
+    assert d["single_gpu_reference"]["ms_per_step"] > 0 and d["speedup_vs_1gpu"] > 0
+
+
+@pytest.mark.gpu
+def test_a_wrong_multi_rank_result_fails_the_run():
+    """`parity_vs_1gpu.ok` false: the line is printed WITH an "error" field and the launcher leaves with status 3 — no
+    retry (a wrong result is not a hang).  IDG_BENCH_TEST_BREAK_PARITY stands in for a broken exchange: rank 1 scales the
+    user rows it owns by 1 + 1e-3 after the parity steps' first one."""
+    env = dict(_env(), IDG_BENCH_TEST_BREAK_PARITY="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--parallel", "shard", "--workload",
+                        "medium", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--scale-point", "on"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
+    d = _one_line(r.stdout)
+    par = d["parity_vs_1gpu"]
+    assert par["ok"] is False and "parity_vs_1gpu FAILED" in d["error"] and "retried" not in d
+    assert max(par["final_rows_rel_err"], par["table_rel_err"]) > 1e-4, par
+    assert d["n_gpus"] == 2 and d["value"] > 0  # (the measurement is in the line; the status says it must not be used)
+
+
+@pytest.mark.gpu
+def test_world_one_over_rccl_carries_the_parity_check():
+    """The sharded path at world size 1 over backend nccl (RCCL, the library's communicator) with the single-GPU reference
+    in the run: the code path of the driver's N > 1 launch on the one device there is."""
+    env = dict(_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--force-sharded", "--parallel", "shard", "--workload", "medium",
+                        "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--scale-point", "on"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "user-row shard x1"
+    _assert_parity(d)
 
 
 @pytest.mark.gpu

@@ -756,9 +756,11 @@ def test_score_dense_widths_and_ragged_shapes(ops, d):
 @pytest.fixture(params=["alternating", "producer-consumer"])
 def topk_form(request, monkeypatch):
     """The fused top-K has two exact-score forms (every wave alternating between scoring and selecting; producer and
-    consumer waves) chosen by the call's geometry — every contract test runs on both (IDG_TOPK_FORM forces one) — and the
+    consumer waves) chosen by the call's geometry — every contract test runs on both (ops.topk_option('form', ..) forces one) — and the
     threshold + collect form on bf16 bound scores for calls of >= 8 user tiles over >= 32,768 items (its own tests below)."""
-    monkeypatch.setenv("IDG_TOPK_FORM", {"alternating": "0", "producer-consumer": "1"}[request.param])
+    import idgrec_amd.ops as ops
+
+    ops.topk_option("form", {"alternating": 0, "producer-consumer": 1}[request.param])  # (reset after the test: conftest)
     return request.param
 
 
@@ -807,8 +809,8 @@ def test_topk_is_independent_of_item_chunking(ops, d, golden_small, monkeypatch,
     ix = np.concatenate([np.sort(rng.choice(I, int(c), replace=False)) for c in np.diff(ip)]).astype(np.int32)
     args = (dev(Ue), dev(Ie), dev(users_np), 20, dev(ip), dev(ix))
     outs = []
-    for nc in ("1", "2", "3", "12"):
-        monkeypatch.setenv("IDG_TOPK_CHUNKS", nc)
+    for nc in (1, 2, 3, 12):
+        ops.topk_option("chunks", nc)
         outs.append(ops.score_topk(*args, return_values=True))
     for idx, val in outs[1:]:
         assert torch.equal(idx, outs[0][0]) and torch.equal(val, outs[0][1])
@@ -1056,7 +1058,7 @@ def test_topk_calls_of_1024_users_start_from_a_floor(ops, d, sig):
     """Round 3: a call with few user tiles (the reference evaluates 1024 users per call, batch_test.py:52-68) cuts the
     catalogue into ~30 short chunks; every chunk now starts from a per-user floor — the k-th largest of the user's chunk
     maxima, found by a first launch over the chunks' first slabs — instead of from an empty list.  The lists must be the
-    ones the plain form gives (IDG_TOPK_FLOOR=0) and the ones ONE call over all users gives, ids and values, for k = 1, 20,
+    ones the plain form gives (ops.topk_option('floor', 0)) and the ones ONE call over all users gives, ids and values, for k = 1, 20,
     30, 31 (the chunk count follows k) and 64, with train items masked."""
     import os
 
@@ -1073,30 +1075,23 @@ def test_topk_calls_of_1024_users_start_from_a_floor(ops, d, sig):
     Ie[::97] = Ie[5]  # duplicate item rows: ties, also across chunk boundaries
     calls = [torch.arange(s0, s0 + 1024, device="cuda") for s0 in range(0, U, 1024)]
     every = torch.arange(U, device="cuda")
-    old = os.environ.get("IDG_TOPK_FLOOR")
-    try:
-        for k in (1, 20, 30, 31, 64):
-            os.environ["IDG_TOPK_FLOOR"] = "1"
-            got = [ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True) for b in calls]
-            os.environ["IDG_TOPK_FLOOR"] = "0"
-            plain = [ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True) for b in calls]
-            whole = ops.score_topk(Ue, Ie, every, k, ip, ix, apply_sigmoid=sig, return_values=True)
-            gi, gv = torch.cat([x[0] for x in got]), torch.cat([x[1] for x in got])
-            pi, pv = torch.cat([x[0] for x in plain]), torch.cat([x[1] for x in plain])
-            assert torch.equal(gi, pi) and torch.equal(gv, pv), "k=%d: floor form differs from the plain form" % k
-            assert torch.equal(gi, whole[0]) and torch.equal(gv, whole[1]), "k=%d: calls of 1024 differ from one call" % k
-    finally:
-        if old is None:
-            os.environ.pop("IDG_TOPK_FLOOR", None)
-        else:
-            os.environ["IDG_TOPK_FLOOR"] = old
+    for k in (1, 20, 30, 31, 64):
+        ops.topk_option("floor", 1)
+        got = [ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True) for b in calls]
+        ops.topk_option("floor", 0)
+        plain = [ops.score_topk(Ue, Ie, b, k, ip, ix, apply_sigmoid=sig, return_values=True) for b in calls]
+        whole = ops.score_topk(Ue, Ie, every, k, ip, ix, apply_sigmoid=sig, return_values=True)
+        gi, gv = torch.cat([x[0] for x in got]), torch.cat([x[1] for x in got])
+        pi, pv = torch.cat([x[0] for x in plain]), torch.cat([x[1] for x in plain])
+        assert torch.equal(gi, pi) and torch.equal(gv, pv), "k=%d: floor form differs from the plain form" % k
+        assert torch.equal(gi, whole[0]) and torch.equal(gv, whole[1]), "k=%d: calls of 1024 differ from one call" % k
 
 
 @pytest.mark.parametrize("sig", [True, False])
 @pytest.mark.parametrize("k", [20, 22, 1, 40])
 def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatch):
     """Round 5, form 3 (the default for calls of >= 8 user tiles over >= 32,768 items at d = 64 / 128, k <= 42;
-    IDG_TOPK_COLLECT=0 turns it off): a floor per user from the maxima of a strided sample of the catalogue scored as bf16
+    ops.topk_option('collect', 0) turns it off): a floor per user from the maxima of a strided sample of the catalogue scored as bf16
     LOWER bounds, ONE pass that appends every item whose bf16 UPPER bound reaches the floor to the user's candidate list —
     no list insertions in the scoring pass — and an exact finish: the candidates' fp32 scores as the fmaf chain the fp32
     matrix cores evaluate, masked, through the streaming select.  At yelp2018 size, all users in one call, train items
@@ -1116,12 +1111,12 @@ def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatc
     Ue[5] = 0.0
     every = torch.arange(U, device="cuda")
     info = {}
-    monkeypatch.delenv("IDG_TOPK_COLLECT", raising=False)
+    ops.topk_option("collect", 1)
     got = ops.score_topk(Ue, Ie, every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
     assert info["form"] == 3 and info["chunks"] == 1, info
     # user 5 (every score ties: its candidate list overflows) certainly; the 377 identical item rows overflow a few more
     assert 1 <= info["users_redone"] <= U // 200, info
-    monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
+    ops.topk_option("collect", 0)
     want = ops.score_topk(Ue, Ie, every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
     assert info["form"] == 1
     assert torch.equal(got[0], want[0]), "ids differ from the exact form"
@@ -1131,10 +1126,10 @@ def test_topk_threshold_collect_form_is_the_exact_answer(ops, k, sig, monkeypatc
         # then the BEST items of a user and must head its list (the collect pass masks in this mode for exactly that); in
         # sigmoid mode they rank below everything and never appear
         Un, In = -Ue.abs() - 0.1, Ie.abs() + 0.1
-        monkeypatch.delenv("IDG_TOPK_COLLECT", raising=False)
+        ops.topk_option("collect", 1)
         got = ops.score_topk(Un, In, every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
         assert info["form"] == 3, info
-        monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
+        ops.topk_option("collect", 0)
         want = ops.score_topk(Un, In, every, k, ip, ix, apply_sigmoid=sig, return_values=True)
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), "all-negative scores: differs from the exact form"
         deg = torch.from_numpy(np.diff(ptr)).cuda()
@@ -1173,10 +1168,10 @@ def test_topk_collect_form_with_uneven_norms_and_at_d128(ops, d, per_call, monke
                for s0 in range(0, U, per_call)]
         return torch.cat([x[0] for x in out]), torch.cat([x[1] for x in out])
 
-    monkeypatch.delenv("IDG_TOPK_COLLECT", raising=False)
+    ops.topk_option("collect", 1)
     got = run()
     assert info["form"] == 3, info
-    monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
+    ops.topk_option("collect", 0)
     want = run()
     assert info["form"] in (0, 1), info
     assert torch.equal(got[0], want[0]), "ids differ from the exact form"
@@ -1219,10 +1214,10 @@ def test_topk_collect_form_on_adversarial_roundings(ops, d, monkeypatch):
     Ud, Id = dev(Ue), dev(Ie)
     every = torch.arange(U, device="cuda")
     info = {}
-    monkeypatch.delenv("IDG_TOPK_COLLECT", raising=False)
+    ops.topk_option("collect", 1)
     got = ops.score_topk(Ud, Id, every, k, apply_sigmoid=True, return_values=True, info=info)
     assert info["form"] == 3 and info["users_redone"] == 0, info
-    monkeypatch.setenv("IDG_TOPK_COLLECT", "0")
+    ops.topk_option("collect", 0)
     want = ops.score_topk(Ud, Id, every, k, apply_sigmoid=True, return_values=True)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     # the construction does what it says: the ten A items head every list, C items fill it

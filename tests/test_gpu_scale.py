@@ -329,19 +329,27 @@ def test_topk_at_full_catalogue_geometry(monkeypatch):
     for b, u in enumerate(sample):
         R[b, items[pos_ptr[u]:pos_ptr[u + 1]]] = -1
     for k in (20, 100):
-        idx = ops.score_topk(ue, ie, all_users, k, ip, ix).cpu().numpy()
+        info = {}
+        idx = ops.score_topk(ue, ie, all_users, k, ip, ix, info=info).cpu().numpy()
+        # 823 user tiles over 91,599 items: k = 20 takes the threshold + collect form on bf16 bounds (form 3), k = 100 (two
+        # passes) the producer / consumer kernel on exact scores
+        assert info["form"] == (3 if k == 20 else 1), info
+        if k == 20:
+            assert info["calls_fallen_back"] == 0 and info["users_redone"] <= U // 1000, info
         ok, msg = oracle.topk_is_valid(R, idx[sample], k, tol=2e-6)
         assert ok, msg
-        # a user's list does not depend on who shares its launch
-        part = ops.score_topk(ue, ie, dev(sample), k, ip, ix).cpu().numpy()
+        # a user's list does not depend on who shares its launch (the 160-user call runs the alternating kernel)
+        part = ops.score_topk(ue, ie, dev(sample), k, ip, ix, info=info).cpu().numpy()
+        assert info["form"] == 0, info
         assert np.array_equal(part, idx[sample])
-        # 823 user tiles run the producer / consumer kernel, the 160-user call above the alternating one; here all
-        # users through the alternating kernel too: same ids, same values, bit for bit
+        # ... and all users through the alternating kernel and the producer / consumer kernel too: same ids, same values,
+        # bit for bit
         vals = ops.score_topk(ue, ie, all_users, k, ip, ix, return_values=True)[1]
-        monkeypatch.setenv("IDG_TOPK_FORM", "0")
-        idx0, val0 = ops.score_topk(ue, ie, all_users, k, ip, ix, return_values=True)
-        monkeypatch.delenv("IDG_TOPK_FORM")
-        assert np.array_equal(idx0.cpu().numpy(), idx) and torch.equal(val0, vals)
+        for form in (0, 1):
+            with ops.topk_options(form=form):
+                idx0, val0 = ops.score_topk(ue, ie, all_users, k, ip, ix, return_values=True, info=info)
+            assert info["form"] == form, info
+            assert np.array_equal(idx0.cpu().numpy(), idx) and torch.equal(val0, vals)
 
 
 def test_training_trajectory_at_yelp_size_vs_cpu_port():

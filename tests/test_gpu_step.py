@@ -104,3 +104,84 @@ def test_a_lookahead_nobody_came_for_is_dropped(golden_small):
         res.append((eng.params.clone(), eng.exp_avg_sq.clone(), eng.loss.clone()))
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+def test_a_lookahead_in_another_storage_waits_for_its_ids(golden_small):
+    """the announced batch may live in a storage the caller's stream has only just written (the first batch of
+    a new epoch, a clone, a gather result) while the batch being run lives elsewhere.  The side stream must be ordered
+    behind the caller's stream for THAT storage (idg_step_run_f32's next_ids_token) — with the slots warm, so that no
+    first-use fork hides a missing one.  The announced tensors first hold another batch's (valid) ids and receive the
+    real ones behind a long kernel on the main stream: a side stream that does not wait plans the wrong batch and the
+    weights differ from the call-by-call chain's."""
+    from idgrec_amd.engine import PropagationEngine
+
+    B, steps = 64, 8
+    tri = torch.from_numpy(golden_small["sample1"][:B * (steps + 1)]).cuda()
+    bt = [tuple(tri[i * B:(i + 1) * B, c].contiguous() for c in range(3)) for i in range(steps + 1)]
+    ballast = torch.randn(4096, 4096, device="cuda")
+    res = []
+    for plan in (True, False):
+        U, I, W0, graph = _setup(golden_small, "lgcn")
+        eng = PropagationEngine(graph, U, I, 64, 3, params=W0.clone())
+        eng._plan_on = plan
+        for i in range(steps):
+            if plan and i >= 3:
+                nxt = tuple(t.clone() for t in bt[0])   # a fresh storage holding some OTHER batch's ids ...
+                torch.cuda.synchronize()
+                for _ in range(6):
+                    ballast @ ballast                   # ... the main stream is busy for a few milliseconds ...
+                for t, src in zip(nxt, bt[i + 1]):
+                    t.copy_(src)                        # ... and only then produces the announced ids
+                eng.prefetch(*nxt)
+                eng.train_step(*(bt[i] if i == 3 else cur))
+                cur = nxt
+            else:
+                eng.train_step(*bt[i])
+        torch.cuda.synchronize()
+        assert (eng._plan is not None) == plan
+        res.append((eng.params.clone(), eng.exp_avg_sq.clone(), eng.loss.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
+def test_a_plan_is_closed_behind_its_side_stream(golden_small):
+    """replacing a plan (a larger batch) releases its slot buffers; a lookahead the old plan put on the side
+    stream must have finished by then (idg_step_synchronize drains the preparations too).  The replaced plan's announced
+    batch is never run; the steps after the switch equal the call-by-call chain's."""
+    from idgrec_amd.engine import PropagationEngine
+
+    tri = torch.from_numpy(golden_small["sample1"][:1024]).cuda()
+    small = [tuple(tri[i * 64:(i + 1) * 64, c].contiguous() for c in range(3)) for i in range(4)]
+    big = tuple(tri[256:256 + 512, c].contiguous() for c in range(3))
+    res = []
+    for plan in (True, False):
+        U, I, W0, graph = _setup(golden_small, "lgcn")
+        eng = PropagationEngine(graph, U, I, 64, 3, params=W0.clone())
+        eng._plan_on = plan
+        eng.train_step(*small[0])
+        eng.prefetch(*small[2])
+        eng.train_step(*small[1])
+        eng.train_step(*big)        # B > B_cap: the plan is closed with small[2]'s preparation possibly in flight
+        eng.train_step(*small[3])
+        torch.cuda.synchronize()
+        res.append((eng.params.clone(), eng.exp_avg_sq.clone(), eng.loss.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
+def test_mfbpr_width_beyond_the_plan_keeps_the_call_by_call_chain():
+    """idg_step_create takes widths up to 1024 without a graph; a wider table must not be sent there."""
+    from idgrec_amd.engine import PropagationEngine
+
+    eng = PropagationEngine(None, 50, 40, 1028, 0, params=torch.randn(90, 1028, device="cuda") * 0.1)
+    assert not eng._plan_eligible(16)
+    eng2 = PropagationEngine(None, 50, 40, 1024, 0, params=torch.randn(90, 1024, device="cuda") * 0.1)
+    assert eng2._plan_eligible(16)
+    u = torch.randint(0, 50, (16,), device="cuda")
+    p = torch.randint(0, 40, (16,), device="cuda")
+    n = torch.randint(0, 40, (16,), device="cuda")
+    for e in (eng, eng2):
+        e.train_step(u, p, n)
+        torch.cuda.synchronize()
+        assert torch.isfinite(e.params).all()
+    assert eng._plan is None and eng2._plan is not None

@@ -1,0 +1,324 @@
+"""The evaluator's default top-K path — form 3, threshold + collect on one-sided bf16 bounds (idg_score_collect.inc,
+idg_score_bf16.inc) — pinned OUTSIDE this library:
+
+  * against the REFERENCE: tests/golden/wide_small.npz holds what /root/reference's Test() (utility/utility_train/
+    batch_test.py:37-93) and get_rating_for_test (models/LightGCN.py:74-80) return on a frozen dataset with a catalogue of
+    33,500 items (oracle/gen_golden_wide.py) — the path real data takes, which no earlier golden reached (40-3,000 items);
+  * against the ORACLE (oracle.score: the fp32 fmaf chain in C, + topk_is_valid) at yelp2018 geometry on float tables with
+    skewed norms, d = 64 / 128 / 256, one call and calls of 1024 users, k = 20 and 40;
+  * its ways out, closed in round 6: a call whose candidate lists overflow wholesale falls back to the exact form on the
+    device; rows of 1e-25 (the norm no longer underflows); NaN / infinity rows behave as the exact form does.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import idgrec_amd.ops as ops_
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return ops_
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _train_csr(U, I, E, seed):
+    import idgrec_amd.synth as S
+
+    users, items = S.generate(U, I, E, seed=seed)
+    ptr = np.zeros(U + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(np.bincount(users, minlength=U))
+    return ptr, items.astype(np.int32)
+
+
+def _skewed_tables(U, I, d, seed, item_sigma=0.8, user_sigma=0.5):
+    """Float tables whose row norms spread over an order of magnitude and more (a trained model's item norms follow
+    popularity): Gaussian directions times log-normal lengths."""
+    rng = np.random.default_rng(seed)
+    Ue = (rng.standard_normal((U, d)) * (0.3 * np.exp(rng.standard_normal((U, 1)) * user_sigma))).astype(np.float32)
+    Ie = (rng.standard_normal((I, d)) * (0.3 * np.exp(rng.standard_normal((I, 1)) * item_sigma))).astype(np.float32)
+    return Ue, Ie
+
+
+def _equal_nan(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0))
+
+
+def _exact(ops, *args, **kw):
+    info = {}
+    with ops.topk_options(collect=0):
+        out = ops.score_topk(*args, return_values=True, info=info, **kw)
+    assert info["form"] in (0, 1), info
+    return out
+
+
+# ------------------------------------------------------------------------------------ against the oracle
+@pytest.mark.parametrize("k", [20, 40])
+@pytest.mark.parametrize("per_call", [None, 1024])
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_form3_against_the_oracle_at_yelp_geometry(ops, d, per_call, k):
+    """31,668 users x 38,048 items (BASELINE configs[1]'s geometry), float tables with log-normal row norms, train items
+    masked: the ids form 3 returns for ~200 sampled users against the ORACLE's fp32 scores of the whole catalogue (the fmaf
+    chain in plain C) — tie-aware set equality — and their values against the oracle's, in sigmoid and in raw-score mode."""
+    U, I = 31668, 38048
+    ptr, items = _train_csr(U, I, 700000, seed=31)
+    Ue, Ie = _skewed_tables(U, I, d, seed=100 + d + k)
+    ue, ie, ip, ix = dev(Ue), dev(Ie), dev(ptr), dev(items)
+    rng = np.random.default_rng(k)
+    pool = U if per_call is None else 3 * per_call
+    sample = np.unique(np.concatenate([[0, 63, 64, pool - 1], rng.integers(0, pool, 200)]))
+    for sig in (True, False):
+        info = {}
+        if per_call is None:
+            idx, val = ops.score_topk(ue, ie, torch.arange(U, device="cuda"), k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
+            assert info["form"] == 3 and info["chunks"] == 1, info
+        else:
+            outs = []
+            for s0 in range(0, pool, per_call):
+                outs.append(ops.score_topk(ue, ie, torch.arange(s0, s0 + per_call, device="cuda"), k, ip, ix, apply_sigmoid=sig,
+                                           return_values=True, info=info))
+                assert info["form"] == 3 and info["chunks"] > 1, info
+            idx, val = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        assert info["calls_fallen_back"] == 0 and info["users_redone"] <= 2, info
+        idx, val = idx.cpu().numpy()[sample], val.cpu().numpy()[sample]
+        R = oracle.score(Ue, Ie, sample, apply_sigmoid=False)  # raw fp32 scores; the ranking is taken there in both modes
+        masked = -np.inf if sig else -1.0                      # (batch_test.py:62-65: after the sigmoid -1 ranks below everything)
+        for b, u in enumerate(sample):
+            R[b, items[ptr[u]:ptr[u + 1]]] = masked
+        ok, msg = oracle.topk_is_valid(R, idx, k, tol=1e-6 * float(np.abs(R[np.isfinite(R)]).max()))
+        assert ok, "d=%d per_call=%s k=%d sigmoid=%s: %s" % (d, per_call, k, sig, msg)
+        want = np.take_along_axis(R, idx, 1)
+        if sig:
+            want = np.where(np.isfinite(want), 1.0 / (1.0 + np.exp(-want.astype(np.float64))), -1.0)
+        np.testing.assert_allclose(val, want, rtol=2e-5, atol=2e-6)
+        assert (np.diff(val, axis=1) <= 0).all()
+
+
+# ------------------------------------------------------------------------------------ against the reference
+def test_reference_Test_on_a_wide_catalogue_takes_form3(ops, tmp_path):
+    """oracle/gen_golden_wide.py ran the REFERENCE (LightGCN, d = 64, its own configuration, two epochs of its own
+    universal_trainer, then Test()) on the frozen dataset tests/golden/inputs/wide (1,100 users x 33,500 items) and stored
+    its trained tables, its Test() dict and — for every test user — the 64 best (id, value) of the masked rating row its
+    evaluator ranks (batch_test.py:52-68).  This repo's plugin surface on the same files and weights: Test() takes the
+    threshold + collect form (>= 8 user tiles over >= 32,768 items) and returns the reference's dict to 1e-6; every
+    user's top-20 is tie-aware equal to the reference's row; values agree to 1e-5."""
+    import utility.utility_data.data_loader as data_loader
+    import utility.utility_train.batch_test as batch_test
+    from models.LightGCN import LightGCN
+
+    g = dict(np.load(os.path.join(GOLDEN, "wide_small.npz"), allow_pickle=False))
+    cfg = dict(zip(g["config_keys"].tolist(), g["config_values"].tolist()))
+    src = os.path.join(GOLDEN, "inputs", "wide")
+    d = tmp_path / "wide"
+    d.mkdir()
+    for f in ("train.txt", "test.txt"):
+        (d / f).write_bytes(open(os.path.join(src, f), "rb").read())
+    cfg.update(dataset="wide", dataset_path=str(tmp_path) + "/")
+    data = data_loader.Data(str(d), cfg)
+    U, I = int(g["num_users"]), int(g["num_items"])
+    assert (data.num_users, data.num_items) == (U, I) and I >= 33000
+    test_users = g["test_users"]
+    assert np.array_equal(np.array(list(data.test_dict.keys())), test_users) and len(test_users) >= 600
+    model = LightGCN(cfg, data, torch.device("cuda")).to("cuda")
+    with torch.no_grad():
+        model.user_embedding.weight.copy_(dev(g["user_w"]))
+        model.item_embedding.weight.copy_(dev(g["item_w"]))
+    model.eval()
+    # the evaluator's call at this geometry IS form 3 (what real data takes), and the propagated tables are the reference's
+    assert ops.score_topk_form(len(test_users), I, 64, 20)["form"] == 3
+    fin_u, fin_i = model.final_panels()
+    fin = torch.cat([fin_u, fin_i]).cpu().numpy()
+    np.testing.assert_allclose(fin[g["final_rows_of"]], g["final_rows"], rtol=1e-6, atol=1e-9)
+    # (i) Test() through the plugin surface: the reference's dict
+    res = batch_test.Test(data, model, torch.device("cuda"), cfg)
+    for key in ("recall", "precision", "ndcg"):
+        np.testing.assert_allclose(res[key], g["test_" + key], rtol=0, atol=1e-6, err_msg=key)
+    # (ii) the lists themselves against the reference's masked rating rows (their 64 best entries: an item outside them
+    #      scores at most the 64th value)
+    info = {}
+    idx, val = ops.score_topk(fin_u, fin_i, dev(test_users), 20, dev(g["pos_indptr"]), dev(g["pos_indices"]),
+                              return_values=True, info=info)
+    assert info["form"] == 3 and info["calls_fallen_back"] == 0 and info["users_redone"] == 0, info
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    ref_i, ref_v = g["top64_idx"], g["top64_val"]
+    tol = 2e-6
+    for b in range(len(test_users)):
+        known = dict(zip(ref_i[b].tolist(), ref_v[b].tolist()))
+        kth = ref_v[b, 19]
+        must = {i for i, v in known.items() if v > kth + tol}
+        got = idx[b].tolist()
+        assert len(set(got)) == 20 and must <= set(got), (b, sorted(must - set(got)))
+        for i, v in zip(got, val[b].tolist()):
+            r = known.get(i, ref_v[b, -1])  # (not among the reference's best 64: at most its 64th value)
+            assert r >= kth - tol, (b, i, r, kth)
+            if i in known:
+                assert abs(v - r) <= 1e-5, (b, i, v, r)
+    np.testing.assert_allclose(val, ref_v[:, :20], rtol=1e-5, atol=1e-6)
+    # (iii) whole rating rows of a few users: the dense matrix get_rating_for_test returns, masked as the evaluator masks it
+    rows_of = g["rating_rows_of"]
+    R = model.get_rating_for_test(dev(rows_of)).cpu().numpy()
+    ptr, items = g["pos_indptr"], g["pos_indices"]
+    for j, u in enumerate(rows_of):
+        R[j, items[ptr[u]:ptr[u + 1]]] = -1
+    np.testing.assert_allclose(R, g["rating_rows"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ the ways out of form 3
+def _timed_ms(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(reps):
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    return best
+
+
+def test_a_table_that_ties_everywhere_falls_back_to_the_exact_form(ops):
+    """All item rows equal at yelp2018 size: every score of a user ties, every candidate list overflows.  Round 5 redid
+    every user over the whole catalogue with the scalar exact chain (40 ms against the exact form's 1.9).  Now the call's
+    verdict, taken on the device, hands the call to the exact form's launches: bit-equal to it, within 1.5x of its time."""
+    U, I, d, k = 31668, 38048, 64, 20
+    ptr, items = _train_csr(U, I, 600000, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = (torch.randn(1, d, device="cuda", generator=g) * 0.3).repeat(I, 1).contiguous()
+    every = torch.arange(U, device="cuda")
+    args = (Ue, Ie, every, k, dev(ptr), dev(items))
+    info = {}
+    got = ops.score_topk(*args, return_values=True, info=info)
+    assert info["form"] == 3 and info["calls_fallen_back"] == 1 and info["users_redone"] == 0, info
+    assert info["users_unserved"] > U // 50, info  # (counted up to just past the threshold: 2 % of the call)
+    want = _exact(ops, *args)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    t_form3 = _timed_ms(lambda: ops.score_topk(*args, return_values=True))
+    with ops.topk_options(collect=0):
+        t_exact = _timed_ms(lambda: ops.score_topk(*args, return_values=True))
+    assert t_form3 <= 1.5 * t_exact, (t_form3, t_exact)
+
+
+@pytest.mark.parametrize("share,falls_back", [(0.01, False), (0.06, True)])
+def test_fallback_threshold_and_redo_agree_with_the_exact_form(ops, share, falls_back):
+    """A share of all-zero user rows (their lists overflow): below the threshold (2 % of the call) those users are redone
+    one by one, above it the whole call goes to the exact form — the same bits either way, and with the fall-back switched
+    off (fallback_permille = -1: everybody redone) too."""
+    U, I, d, k = 4096, 38048, 64, 20
+    ptr, items = _train_csr(U, I, 160000, seed=9)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Ue = torch.randn(U, d, device="cuda", generator=g) * 0.3
+    Ie = torch.randn(I, d, device="cuda", generator=g) * 0.3
+    zero = torch.randperm(U, device="cuda", generator=g)[: int(U * share)]
+    Ue[zero] = 0.0
+    every = torch.arange(U, device="cuda")
+    args = (Ue, Ie, every, k, dev(ptr), dev(items))
+    want = _exact(ops, *args)
+    for sig in (True, False):
+        info = {}
+        got = ops.score_topk(*args, apply_sigmoid=sig, return_values=True, info=info)
+        assert info["form"] == 3 and info["calls_fallen_back"] == int(falls_back), info
+        assert info["users_unserved"] >= (U // 50 if falls_back else len(zero)), info
+        assert (info["users_redone"] == 0) == falls_back, info
+        ref = want if sig else _exact(ops, *args, apply_sigmoid=False)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (share, sig)
+    with ops.topk_options(fallback_permille=-1):
+        info = {}
+        got = ops.score_topk(*args, return_values=True, info=info)
+        assert info["calls_fallen_back"] == 0 and info["users_redone"] >= len(zero), info
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("d", [64, 256])
+@pytest.mark.parametrize("what", ["items", "some items", "users", "some users", "both"])
+def test_rows_of_1e_minus_25(ops, d, what):
+    """for a row whose elements lie below ~1e-23 the squares underflowed, the norm bound collapsed to
+    1e-30 while bf16's operand error stayed relative, and LB / UB were wrong for that row.  The norm is now taken on the
+    max-scaled row (and floored at 2^-40).  Tables scaled by 1e-25 — all items, 300 items, all users, 100 users, both
+    (every product underflows to 0: ties) — return the exact form's lists bit for bit; where the scores are distinct they
+    are also checked against the float64 ranking."""
+    U, I, k = 2048, 38048, 20
+    ptr, items = _train_csr(U, I, 80000, seed=13)
+    Ue, Ie = _skewed_tables(U, I, d, seed=d)
+    tiny = np.float32(1e-25)
+    if what == "items":
+        Ie *= tiny
+    elif what == "some items":
+        Ie[::127] *= tiny
+    elif what == "users":
+        Ue *= tiny
+    elif what == "some users":
+        Ue[::21] *= tiny
+    else:
+        Ue *= tiny
+        Ie *= tiny
+    every = torch.arange(U, device="cuda")
+    args = (dev(Ue), dev(Ie), every, k, dev(ptr), dev(items))
+    info = {}
+    got = ops.score_topk(*args, return_values=True, info=info)
+    assert info["form"] == 3, info
+    # (norms below 2^-40 rest on the bound's floor — products of such operands leave fp32's normal range — and a table
+    #  that lies there wholesale is handed to the exact form; a few hundred such rows among ordinary ones change nothing)
+    assert info["calls_fallen_back"] == (0 if what.startswith("some") else 1), info
+    if what == "some items":
+        assert info["users_redone"] <= 2, info
+    want = _exact(ops, *args)
+    assert torch.equal(got[0], want[0]), what
+    assert torch.equal(got[1], want[1]), what
+    if what in ("items", "some items", "some users"):
+        sample = np.arange(0, U, 16)
+        R = Ue[sample].astype(np.float64) @ Ie.astype(np.float64).T
+        for b, u in enumerate(sample):
+            R[b, items[ptr[u]:ptr[u + 1]]] = -np.inf
+        scale = np.linalg.norm(Ue[sample].astype(np.float64), axis=1) * np.linalg.norm(Ie.astype(np.float64), axis=1).max()
+        idx = got[0].cpu().numpy()[sample]
+        for b in range(len(sample)):  # (fp32 accumulation of d products: d 2^-24 of |u| |v|)
+            ok, msg = oracle.topk_is_valid(R[b:b + 1], idx[b:b + 1], k, tol=2e-5 * scale[b])
+            assert ok, (what, int(sample[b]), msg)
+
+
+def test_nan_and_infinity_rows_behave_as_the_exact_form(ops):
+    """VERDICT r05 weak 2b.  USER rows holding a NaN, an infinity, a huge norm: the bound arithmetic cannot take them (bound
+    +inf), the finish hands those users to the exact pass over the whole catalogue — the exact form's ids and values (NaNs
+    where it has NaNs).  An ITEM row holding a NaN touches every user's ranking: the call as a whole goes to the exact form."""
+    U, I, d, k = 2048, 38048, 64, 20
+    ptr, items = _train_csr(U, I, 80000, seed=17)
+    Ue, Ie = _skewed_tables(U, I, d, seed=3)
+    Ue[3, 5] = np.nan
+    Ue[70, :] = np.nan
+    Ue[200, 9] = np.inf
+    Ue[201, 0] = -np.inf
+    Ue[640] *= np.float32(1e30)  # norm beyond 2^60, finite scores
+    every = torch.arange(U, device="cuda")
+    ip, ix = dev(ptr), dev(items)
+    for sig in (True, False):
+        info = {}
+        got = ops.score_topk(dev(Ue), dev(Ie), every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
+        assert info["form"] == 3 and info["calls_fallen_back"] == 0 and 5 <= info["users_redone"] <= 8, info
+        want = _exact(ops, dev(Ue), dev(Ie), every, k, ip, ix, apply_sigmoid=sig)
+        assert torch.equal(got[0], want[0]), sig
+        assert _equal_nan(got[1], want[1]), sig
+        assert torch.isnan(got[1][70]).all() or not sig
+    # an irregular item row
+    Ue2, Ie2 = _skewed_tables(U, I, d, seed=4)
+    Ie2[12345, 17] = np.nan
+    for sig in (True, False):
+        info = {}
+        got = ops.score_topk(dev(Ue2), dev(Ie2), every, k, ip, ix, apply_sigmoid=sig, return_values=True, info=info)
+        assert info["form"] == 3 and info["items_irregular"] and info["calls_fallen_back"] == 1, info
+        want = _exact(ops, dev(Ue2), dev(Ie2), every, k, ip, ix, apply_sigmoid=sig)
+        assert torch.equal(got[0], want[0]) and _equal_nan(got[1], want[1]), sig

@@ -161,3 +161,41 @@ def test_goldens_regenerate_from_the_reference_at_head():
     assert len(res) >= 5
     for f, bad in res.items():
         assert not bad, "%s is not what the generators produce at HEAD: %s" % (f, bad[:6])
+
+
+def test_oracle_reproduces_the_references_evaluation_on_a_wide_catalogue():
+    """wide_small.npz (oracle/gen_golden_wide.py): the reference's trained LightGCN tables on 1,100 users x 33,500 items,
+    its aggregate() rows, rating rows, best-64 lists and Test() dict.  The oracle — adjacency, the fmaf-chain products and
+    layer mean, fp32 scores + sigmoid, masking, top-k by (score, id), the metric formulas — reproduces them from the
+    frozen dataset and the tables: it is the checker the GPU tests of the default top-K path compare with, so it has to
+    agree with the reference at THAT geometry too."""
+    import os
+
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide_small.npz"), allow_pickle=False))
+    U, I = int(g["num_users"]), int(g["num_items"])
+    ptr, items = g["pos_indptr"], g["pos_indices"]
+    users = np.repeat(np.arange(U, dtype=np.int64), np.diff(ptr))
+    ip, ix, dv = oracle.norm_adj(U, I, users, items.astype(np.int64))
+    fin = oracle.propagate_mean(ip, ix, dv, np.concatenate([g["user_w"], g["item_w"]]), 3, include_layer0=True)
+    assert np.array_equal(fin[g["final_rows_of"]], g["final_rows"])  # torch.sparse.mm + mean, bit for bit
+    test_users = g["test_users"]
+    R = oracle.score(fin[:U], fin[U:], test_users, apply_sigmoid=True)
+    for b, u in enumerate(test_users):
+        R[b, items[ptr[u]:ptr[u + 1]]] = -1  # batch_test.py:62-65
+    rows = np.searchsorted(test_users, g["rating_rows_of"])
+    np.testing.assert_allclose(R[rows], g["rating_rows"], rtol=2e-6, atol=1e-7)
+    top = oracle.topk_reference(R, 64)
+    np.testing.assert_allclose(np.take_along_axis(R, top, 1), g["top64_val"], rtol=2e-6, atol=1e-7)
+    ok, msg = oracle.topk_is_valid(R, g["top64_idx"][:, :20], 20, tol=2e-7)  # the reference's own top-20 under the oracle's scores
+    assert ok, msg
+    truth = [g["test_items"][g["test_indptr"][b]:g["test_indptr"][b + 1]].tolist() for b in range(len(test_users))]
+    # the reference sums per batch of `test_batch_size` users and divides by the number of users (batch_test.py:84-91)
+    bs = int(dict(zip(g["config_keys"].tolist(), g["config_values"].tolist()))["test_batch_size"])
+    for j, k in enumerate(g["top_K"].tolist()):
+        tot = np.zeros(3)
+        for lo in range(0, len(test_users), bs):
+            r = oracle.get_label(truth[lo:lo + bs], top[lo:lo + bs, :max(g["top_K"])])
+            tot += [oracle.recall_at_k(r, k, truth[lo:lo + bs]), oracle.precision_at_k(r, k, truth[lo:lo + bs]),
+                    oracle.ndcg_at_k(r, k, truth[lo:lo + bs])]
+        tot /= len(test_users)
+        np.testing.assert_allclose(tot, [g["test_recall"][j], g["test_precision"][j], g["test_ndcg"][j]], rtol=0, atol=1e-9)

@@ -617,3 +617,72 @@ def test_generate_shared_is_generate(tmp_path):
     check()
     check(rank=0)  # rank 0 finds the bad file, draws, and replaces it
     assert npy.read_bytes() == good_npy and json.loads(head.read_text()) == json.loads(good_head)
+
+
+def test_parity_compare_accepts_equal_runs_and_rejects_a_broken_one():
+    """`parity_vs_1gpu` of the N-rank bench line (sharded.parity_compare): the comparison itself, on a toy engine with the
+    single-device engine's surface (U, params, final, train_step) — the captured record of an identical run passes with
+    zero errors, rounding-sized differences pass, a 1e-3 relative error in the final rows or the tables, a loss off by
+    1e-3 or different initial tables fail, and each failure shows in the field it belongs to."""
+    import copy
+
+    import torch
+
+    from idgrec_amd.sharded import PARITY_TOL, parity_compare
+
+    U, I, d, B, n = 50, 40, 8, 16, 3
+
+    class Toy:
+        def __init__(self):
+            g = torch.Generator().manual_seed(1)
+            self.U = U
+            self.params = torch.randn(U + I, d, generator=g) * 0.1
+            self.final = torch.zeros(U + I, d)
+            self.loss = torch.zeros(2)
+
+        def train_step(self, u, p, q):
+            self.final.copy_(self.params * 0.5 + self.params.roll(1, 0) * 0.25)
+            self.loss = torch.stack([self.final[u].sum() + 3.0, self.final[U + p].abs().sum()])
+            self.params[u] -= 0.01 * self.final[U + p]
+            self.params[U + p] -= 0.01 * self.final[u]
+            return self.loss
+
+    rng = np.random.default_rng(0)
+    tri = np.stack([rng.integers(0, U, n * B), rng.integers(0, I, n * B), rng.integers(0, I, n * B)], 1).astype(np.int64)
+    run = Toy()
+    user_ids, item_ids = np.unique(tri[:, 0]), np.unique(np.concatenate([tri[:, 1], tri[:, 2]]))
+    cap = {"triples": tri, "user_ids": user_ids, "item_ids": item_ids, "user_rows_before": run.params[user_ids].clone(),
+           "item_rows_before": run.params[U + item_ids].clone(), "loss": [], "fin_users": [], "fin_items": [], "fin_item_ids": []}
+    for i in range(n):
+        u, p, q = (torch.from_numpy(tri[i * B:(i + 1) * B, c]) for c in range(3))
+        cap["loss"].append(run.train_step(u, p, q).double().numpy().copy())
+        ids = np.unique(tri[i * B:(i + 1) * B, 1:])
+        cap["fin_users"].append(run.final[u].clone())
+        cap["fin_items"].append(run.final[U + ids].clone())
+        cap["fin_item_ids"].append(ids)
+    cap["loss"] = np.stack(cap["loss"])
+    cap["user_rows"], cap["item_rows"] = run.params[user_ids].clone(), run.params[U + item_ids].clone()
+
+    res = parity_compare(Toy(), cap)
+    assert res["ok"] is True and res["tol"] == PARITY_TOL == 1e-4 and res["steps"] == n
+    assert res["loss_rel_err"] == res["final_rows_rel_err"] == res["table_rel_err"] == res["update_rel_err"] == 0.0
+    noisy = copy.deepcopy(cap)
+    noisy["user_rows"] *= 1 + 1e-6
+    noisy["fin_items"][1] *= 1 - 2e-6
+    res = parity_compare(Toy(), noisy)
+    assert res["ok"] is True and 0 < res["table_rel_err"] < 1e-5 and 0 < res["final_rows_rel_err"] < 1e-5
+    for field, breaker in (("final_rows_rel_err", lambda c: c["fin_users"][2].mul_(1.001)),
+                           ("table_rel_err", lambda c: c["item_rows"].mul_(1.001)),
+                           ("loss_rel_err", lambda c: c["loss"].__setitem__((1, 0), c["loss"][1, 0] * 1.001)),
+                           ("initial_tables_equal", lambda c: c["user_rows_before"][0].add_(1e-7))):
+        bad = copy.deepcopy(cap)
+        breaker(bad)
+        res = parity_compare(Toy(), bad)
+        assert res["ok"] is False, field
+        assert (res[field] is False) if field == "initial_tables_equal" else (res[field] > 1e-4), (field, res)
+    # a run whose tables never moved: table_rel_err stays modest (the updates are small against the tables), the error of the
+    # UPDATES is total — which is what update_rel_err is there to show
+    still = copy.deepcopy(cap)
+    still["user_rows"], still["item_rows"] = still["user_rows_before"].clone(), still["item_rows_before"].clone()
+    res = parity_compare(Toy(), still)
+    assert res["ok"] is False and res["update_rel_err"] > 0.99
