@@ -92,6 +92,10 @@ __global__ __launch_bounds__(BLOCK) void score_dense_kernel(const float* __restr
 }
 
 // ---- 64-bit keys ------------------------------------------------------------------------
+// Order of the score word: -NaN* < -inf < ... < -0 < +0 < ... < +inf < NaN.  A NaN score (a NaN or an infinity in a row of
+// either table) therefore ranks ABOVE every number, as torch.topk ranks it (batch_test.py:68); every float pre-filter in
+// front of the key compares tests "not below", so that NaNs reach the keys.  (*a NaN with the sign bit set — never what
+// the fmaf chain / the matrix cores make of the default NaN — ranks lowest.)
 __device__ __forceinline__ unsigned long long make_key(float s, uint32_t item) {
   uint32_t u = __float_as_uint(s);
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(BLOCK, 3) void score_topk_fused_kernel(const float*
         const float s0 = s_score[u * FT_LD + lane], s1 = s_score[u * FT_LD + 64 + lane];
         // columns past the chunk hold scores of a clamped item: the exact key test below drops them
         const float floor_ = tau_floor(tau[uu]);  // score of the k-th key (-inf while the list is short)
-        if (__ballot(s0 >= floor_) | __ballot(s1 >= floor_)) {
+        if (__ballot(!(s0 < floor_)) | __ballot(!(s1 < floor_))) {  // ("not below": a NaN score is a candidate, see make_key)
           unsigned long long c0 = in0 ? make_key(s0, (uint32_t)(slab + lane)) : 0ull;
           unsigned long long c1 = in1 ? make_key(s1, (uint32_t)(slab + 64 + lane)) : 0ull;
           if (bound) {
@@ -416,8 +420,10 @@ __device__ __forceinline__ void flag_candidates(const f32x16& acc0, const f32x16
     const float fa[4] = {f0.x, f0.y, f0.z, f0.w}, fb[4] = {f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (acc0[4 * g + c] >= fa[c]) flag[8 * g + 4 * h + c] = 1u;
-      if (acc1[4 * g + c] >= fb[c]) flag[32 + 8 * g + 4 * h + c] = 1u;
+      // ("not below the floor" rather than ">=": a NaN score ranks ABOVE everything — torch.topk's order, make_key — and
+      //  must reach the select; the same instruction count)
+      if (!(acc0[4 * g + c] < fa[c])) flag[8 * g + 4 * h + c] = 1u;
+      if (!(acc1[4 * g + c] < fb[c])) flag[32 + 8 * g + 4 * h + c] = 1u;
     }
   }
 }
@@ -582,8 +588,8 @@ __device__ __forceinline__ void topk_consume(float (*s_buf)[FT_USERS * FT_LD], f
       float fl0 = -__builtin_inff();
       if (floor0) {  // nothing below the user's starting floor can reach the final list (the chunk's list may stay short)
         fl0 = __shfl(my_floor, uu, WAVE);
-        c0 = s0 >= fl0 ? c0 : 0ull;
-        c1 = s1 >= fl0 ? c1 : 0ull;
+        c0 = s0 < fl0 ? 0ull : c0;  // (a NaN stays: it ranks above everything)
+        c1 = s1 < fl0 ? 0ull : c1;
       }
       unsigned long long tk = shfl_u64(best[uu], k - 1);
       const bool ch0 = offer(best[uu], tk, c0);

@@ -248,7 +248,7 @@ def test_fallback_threshold_and_redo_agree_with_the_exact_form(ops, share, falls
 def test_rows_of_1e_minus_25(ops, d, what):
     """for a row whose elements lie below ~1e-23 the squares underflowed, the norm bound collapsed to
     1e-30 while bf16's operand error stayed relative, and LB / UB were wrong for that row.  The norm is now taken on the
-    max-scaled row (and floored at 2^-40).  Tables scaled by 1e-25 — all items, 300 items, all users, 100 users, both
+    max-scaled row (and floored at 2^-40).  Tables scaled by 1e-25 — all items, 300 items, all users, 32 users, both
     (every product underflows to 0: ties) — return the exact form's lists bit for bit; where the scores are distinct they
     are also checked against the float64 ranking."""
     U, I, k = 2048, 38048, 20
@@ -262,7 +262,7 @@ def test_rows_of_1e_minus_25(ops, d, what):
     elif what == "users":
         Ue *= tiny
     elif what == "some users":
-        Ue[::21] *= tiny
+        Ue[::64] *= tiny  # (32 of 2,048: under the 2 % beyond which the whole call goes to the exact form)
     else:
         Ue *= tiny
         Ie *= tiny
@@ -312,7 +312,13 @@ def test_nan_and_infinity_rows_behave_as_the_exact_form(ops):
         want = _exact(ops, dev(Ue), dev(Ie), every, k, ip, ix, apply_sigmoid=sig)
         assert torch.equal(got[0], want[0]), sig
         assert _equal_nan(got[1], want[1]), sig
-        assert torch.isnan(got[1][70]).all() or not sig
+        # a NaN score ranks above every number (torch.topk's order, batch_test.py:68): the all-NaN users get the k lowest
+        # item ids that are not train items (every key ties in the score word), with NaN values
+        for u in (3, 70):
+            free = np.setdiff1d(np.arange(200), items[ptr[u]:ptr[u + 1]])[:k]
+            assert got[0][u].cpu().numpy().tolist() == free.tolist(), (u, got[0][u])
+            assert torch.isnan(got[1][u]).all()
+        assert torch.isfinite(got[1][640]).all() and got[0].max() < I
     # an irregular item row
     Ue2, Ie2 = _skewed_tables(U, I, d, seed=4)
     Ie2[12345, 17] = np.nan
