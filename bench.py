@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BF16_MFMA_PEAK_FLOPS = 2.5e15  # the dense bf16 MFMA peak (the headline 5 PFLOP/s figure includes 2:1 sparsity)
 INFINITY_CACHE_BYTES = 256 << 20
 # MI355X_MICROARCH.md "Indexed rows": chip-wide rates of whole-row gathers by where the rows are served from (GB/s;
 # midpoints of the measured ranges): rows resident in the XCD's L2 16.8-18.8 TB/s; a 38 MB table out of the Infinity
@@ -462,7 +463,8 @@ def supervise_rank(args):
     sys.exit(1)
 
 
-def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None, before_engine=None, parity=None):
+def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edges=None, before_engine=None, parity=None,
+                     big_batch=0):
     """The multi-GPU lines' workload on ONE GPU, unsharded, through the fused single-GPU engine (PropagationEngine): the
     1-GPU point the N-GPU speed-ups are quoted against, measured in the same run.  ~140 GB resident at synth-10M d=256.
     edges: the (users, items) arrays when the caller has drawn the graph already.  before_engine(graph, U, I, n, nnz,
@@ -480,6 +482,9 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
     ip, ix, dv = H.build_norm_adj(U, I, users, items)
     n, nnz, n_edges = U + I, len(ix), len(users)
     tri = torch.from_numpy(S.draw_triples(args.seed, users, items, U, I, (steps + warmup) * B)[0]).cuda()
+    tri_big = None
+    if big_batch:
+        tri_big = torch.from_numpy(S.draw_triples(args.seed + 1, users, items, U, I, 4 * big_batch)[0][: 4 * big_batch]).cuda()
     del users, items
     if before_engine is not None:
         _save_csr(args, workload, ip, ix, dv, U, I, 64)  # (the d=64 HBM-bound leg's graph: for the traffic children)
@@ -529,7 +534,26 @@ def single_gpu_point(args, workload="synth-10M", dim=256, steps=4, warmup=2, edg
                        "(fused single-GPU engine)" % (workload, U, I, n_edges, nnz, K, dim, B),
            "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "triples/s", "steps": steps, "warmup": warmup,
            "loss_last": float(eng.loss.sum().item())}
-    del eng, graph, tri, tu, tp, tn
+    if big_batch and tri_big is not None:
+        # configs[4] reports B = 1024 AND a throughput-oriented B — a step's time is nearly independent of B << nnz
+        # (the products run over the whole graph either way), so triples/s grows with the batch: B = 2^20, same engine
+        try:
+            bu, bp, bn = (tri_big[:, c].contiguous() for c in range(3))
+            n_big = tri_big.shape[0] // big_batch
+            for i in range(n_big):
+                if i == 1:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                sl = slice(i * big_batch, (i + 1) * big_batch)
+                eng.train_step(bu[sl], bp[sl], bn[sl])
+            torch.cuda.synchronize()
+            dt_big = (time.perf_counter() - t0) / (n_big - 1)
+            out["batch_2p20"] = {"batch": big_batch, "ms_per_step": dt_big * 1e3, "value": big_batch / dt_big, "unit": "triples/s",
+                                 "steps": n_big - 1, "warmup": 1, "loss_last": float(eng.loss.sum().item())}
+            del bu, bp, bn
+        except Exception as exc:  # noqa: BLE001 - the B = 1024 point stands without it
+            out["batch_2p20"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    del eng, graph, tri, tu, tp, tn, tri_big
     torch.cuda.empty_cache()
     out["seconds_including_graph_build"] = time.perf_counter() - t_all
     if extra is not None:
@@ -808,7 +832,7 @@ def main():
             out["roofline"]["hbm_bound"] = hbm_bound_leg(args, graph=g, shape=(U_, I_, n_, nnz_, ne_))
 
         try:
-            out["scale_point"] = single_gpu_point(args, before_engine=hook if hbm_leg else None)
+            out["scale_point"] = single_gpu_point(args, before_engine=hook if hbm_leg else None, big_batch=1 << 20)
             err = out["scale_point"].pop("before_engine", None)
             if err and "hbm_bound" not in out["roofline"]:
                 out["roofline"]["hbm_bound"] = err
@@ -835,24 +859,80 @@ def main():
             attach_measured_traffic(args, out)
         except Exception as exc:  # noqa: BLE001 - the file-based traffic figures stay
             out["roofline"]["traffic_in_run_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+    flatten_north_star(out)
     args.emit(out)
+
+
+def flatten_north_star(out):
+    """The figures BASELINE.json's north star is stated on, as TOP-LEVEL scalars of `roofline` (the driver's
+    record keeps top-level scalars only; the nested legs they come from stay where they were):
+      hbm_*             the dense launch where it is HBM-bound (synth-10M, d=64: panel 15 x the Infinity Cache) — fraction
+                        of the 8 TB/s peak by SURVEY 8d's gather bytes and by the bytes measured at the L2s' memory side
+      hbm_reuse_free_*  the same on the regular graph with uniformly scattered neighbours (nothing to reuse: DRAM bytes),
+                        and on its strided twin
+      eval_bf16_mfma_frac  the evaluation's collect pass against the dense bf16 MFMA peak (2.5 PFLOP/s), beside the
+                        fp32-equivalent figure that is a speed-up label, not a roofline fraction"""
+    rf = out.get("roofline")
+    if not isinstance(rf, dict):
+        return
+    hb, free = rf.get("hbm_bound"), rf.get("hbm_reuse_free")
+    if isinstance(hb, dict) and "frac" in hb:
+        rf.update(hbm_frac_gather=hb["frac"], hbm_frac_traffic=hb.get("frac_traffic"), hbm_us_per_launch=hb.get("us_per_launch"),
+                  hbm_traffic_over_bytes_gather=hb.get("traffic_over_bytes_gather"), hbm_l2_hit_rate=hb.get("traffic_l2_hit_rate"),
+                  hbm_workload="synth-10M d=64: 15 M rows, 398 M entries, gathered panel 3.84 GB = 15 x the Infinity Cache")
+    if isinstance(free, dict) and "frac" in free:
+        rf.update(hbm_reuse_free_frac=free["frac"], hbm_reuse_free_frac_traffic=free.get("frac_traffic"),
+                  hbm_reuse_free_us_per_launch=free.get("us_per_launch"), hbm_reuse_free_l2_hit_rate=free.get("traffic_l2_hit_rate"),
+                  hbm_reuse_free_pattern=free.get("access_pattern"))
+        st = free.get("strided")
+        if isinstance(st, dict) and "frac" in st:
+            rf.update(hbm_reuse_free_strided_frac=st["frac"], hbm_reuse_free_strided_us_per_launch=st.get("us_per_launch"))
+    ev = out.get("eval_scale_point")
+    if isinstance(ev, dict) and "bf16_mfma_frac" in ev:
+        rf["eval_bf16_mfma_frac"] = ev["bf16_mfma_frac"]
+        rf["eval_fp32_equivalent_tflops"] = ev.get("fp32_equivalent_tflops")
+    sp = out.get("scale_point")
+    if isinstance(sp, dict) and sp.get("ms_per_step"):
+        out["scale_point_ms_per_step"] = sp["ms_per_step"]
+        if isinstance(sp.get("batch_2p20"), dict) and sp["batch_2p20"].get("value"):
+            out["scale_point_batch_2p20_triples_per_s"] = sp["batch_2p20"]["value"]
+
+def trained_like_tables(users, items, d, seed=0):
+    """Tables with the norm spread of a TRAINED model instead of i.i.d. Gaussians (form 3's candidate count
+    depends on it): item popularity p_i ~ (rank + 1)^-0.8 under a random id permutation (the bench graphs' law), item norms
+    ~ p_i^0.3 (a factor ~40 between the most and the least popular of 5 M items), user norms log-normal (sigma 0.3), and
+    a direction every row shares to a degree (0.3 of its length: popular items score high for everybody)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    common = torch.nn.functional.normalize(torch.randn(1, d, device="cuda", generator=g), dim=1)
+
+    def rows(n, norms):
+        x = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
+        x = torch.nn.functional.normalize(x + 0.3 * common, dim=1)
+        return (x * norms[:, None]).contiguous()
+
+    rank = torch.randperm(items, device="cuda", generator=g).float()
+    pop = (rank + 1.0) ** -0.8
+    item_norm = 0.3 * d ** 0.5 * (pop / pop.mean()) ** 0.3
+    user_norm = 0.3 * d ** 0.5 * torch.exp(0.3 * torch.randn(users, device="cuda", generator=g))
+    return rows(users, user_norm), rows(items, item_norm)
+
 
 def eval_scale_point(users=16384, items=5_000_000, d=256, k=20, degree=50):
     """BASELINE configs[4]'s evaluation (1e7 users x 5e6 items x d = 256: 25.6 PFLOP in fp32 per evaluation), one call of it:
-    `users` test users against the whole catalogue, `degree` train items each masked, random tables (a call's cost does not
-    depend on the values).  The threshold + collect form and, once, the exact producer / consumer form beside it."""
+    `users` test users against the whole catalogue, `degree` train items each masked.  Tables with a trained model's norm
+    spread (trained_like_tables; round 5 ran on Gaussian tables, on which `users_redone: 0` says little) — and, beside
+    them, the Gaussian tables once.  Reports the candidates per user (what the collect pass lets through: the capacity is
+    4096 at this catalogue size), the users redone, whether the call fell back, the exact form once, and the call's rate
+    against the dense bf16 MFMA peak."""
     import idgrec_amd.ops as ops
 
-    g = torch.Generator(device="cuda").manual_seed(0)
-    Ue = torch.randn(users, d, device="cuda", generator=g) * 0.3
-    Ie = torch.randn(items, d, device="cuda", generator=g) * 0.3
     rng = np.random.default_rng(0)
     ix = np.sort(rng.integers(0, items - degree, (users, degree)), axis=1) + np.arange(degree)[None, :]  # ascending, distinct
     ip = torch.arange(0, (users + 1) * degree, degree, dtype=torch.int64, device="cuda")
     ixd = torch.from_numpy(ix.reshape(-1).astype(np.int32)).cuda()
     every = torch.arange(users, device="cuda")
 
-    def timed(reps):
+    def timed(Ue, Ie, reps):
         ops.score_topk(Ue, Ie, every, k, ip, ixd)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -861,17 +941,38 @@ def eval_scale_point(users=16384, items=5_000_000, d=256, k=20, degree=50):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    info = {}
-    ops.score_topk(Ue, Ie, every, k, ip, ixd, info=info)
-    t = timed(3)
+    def leg(Ue, Ie):
+        info = {"candidates": True}
+        ops.score_topk(Ue, Ie, every, k, ip, ixd, info=info)
+        return timed(Ue, Ie, 3), info
+
+    Ue, Ie = trained_like_tables(users, items, d)
+    t, info = leg(Ue, Ie)
     with ops.topk_options(collect=0):
-        t_exact = timed(1)
+        t_exact = timed(Ue, Ie, 1)
+    del Ue, Ie
+    g = torch.Generator(device="cuda").manual_seed(0)
+    Ug, Ig = torch.randn(users, d, device="cuda", generator=g) * 0.3, torch.randn(items, d, device="cuda", generator=g) * 0.3
+    t_gauss, info_gauss = leg(Ug, Ig)
+    del Ug, Ig
+    torch.cuda.empty_cache()
     flop = 2.0 * users * items * d
+    # what the bf16 matrix cores execute in a form-3 call: d data features + the 16-feature bound k-step, the collect pass over
+    # the whole catalogue + the floor pass over about a tenth of it
+    bf16_flop = 2.0 * users * items * (d + 16) * 1.1
     return {"what": "one fused score + mask + top-%d call at configs[4]'s geometry: %d users x %d items x d=%d, %d train items "
-                    "per user masked, random tables" % (k, users, items, d, degree),
-            "ms_per_call": t * 1e3, "fp32_equivalent_tflops": flop / t / 1e12, "form": info.get("form"),
-            "users_redone": info.get("users_redone"),
+                    "per user masked; tables with a trained model's norm spread (item norms ~ popularity^0.3, a shared "
+                    "direction; bench.py trained_like_tables)" % (k, users, items, d, degree),
+            "ms_per_call": t * 1e3, "fp32_equivalent_tflops": flop / t / 1e12,
+            "bf16_mfma_frac": bf16_flop / t / BF16_MFMA_PEAK_FLOPS,
+            "bf16_mfma_frac_what": "bf16 MFMA work of the call (2 x users x items x (d + 16) x 1.1: collect pass + floor pass) / "
+                                   "the whole call's time / the %.1f PFLOP/s dense bf16 peak — the roofline fraction; "
+                                   "fp32_equivalent_tflops is a speed-up label against the exact form's arithmetic" % (BF16_MFMA_PEAK_FLOPS / 1e15),
+            "form": info.get("form"), "users_redone": info.get("users_redone"), "calls_fallen_back": info.get("calls_fallen_back"),
+            "candidates_per_user": info.get("candidates"), "candidate_capacity": 4096 if items >= 1_000_000 else 1024,
             "exact_form_ms_per_call": t_exact * 1e3, "exact_form_tflops": flop / t_exact / 1e12,
+            "gaussian_tables": {"ms_per_call": t_gauss * 1e3, "users_redone": info_gauss.get("users_redone"),
+                                "candidates_per_user": info_gauss.get("candidates")},
             "s_per_evaluation_of_1e7_users": 1e7 / users * t, "exact_form_s_per_evaluation_of_1e7_users": 1e7 / users * t_exact}
 
 
@@ -1009,7 +1110,9 @@ def attach_measured_traffic(args, out):
     finally:
         shutil.rmtree(root, ignore_errors=True)
     took = time.perf_counter() - t_all
-    legs = {"synth-10M": out["roofline"].get("hbm_bound"), "regular-15M": out["roofline"].get("hbm_reuse_free"),
+    free = out["roofline"].get("hbm_reuse_free")
+    legs = {"synth-10M": out["roofline"].get("hbm_bound"), "regular-15M-perm": free,
+            "regular-15M": free.get("strided") if isinstance(free, dict) else None,
             "synth-1M": out["roofline"].get("cache_boundary")}
     legs[args.workload] = out["roofline"]  # (the headline's own graph)
     legs = {k: [v] for k, v in legs.items() if isinstance(v, dict)}
@@ -1046,30 +1149,45 @@ def attach_measured_traffic(args, out):
 
 def reuse_free_leg(args, d=64):
     """The dense launch where NOTHING can be reused (synth-10M's Zipf(0.8) item popularity keeps hub rows in
-    the 256 MiB Infinity Cache, so its bytes at the L2s' memory side are an upper bound of DRAM bytes): a regular
-    bipartite graph — 10 M users x 5 M items, every user exactly 20 items, every item exactly 40 users, neighbours
-    scattered over the whole id range (idgrec_amd.synth.regular_adjacency) — 15 M rows, 4e8 entries, gathered panel
-    3.84 GB = 14 x the Infinity Cache.  Every gathered row comes from DRAM, so here fabric bytes ~ DRAM bytes ~ SURVEY §8d's
-    gather bytes and `frac` is a fraction of the HBM peak in the plain sense."""
+    the 256 MiB Infinity Cache, so its bytes at the L2s' memory side are an upper bound of DRAM bytes): regular bipartite
+    graphs — 10 M users x 5 M items, every user exactly 20 items, every item exactly 40 users — 15 M rows, 4e8 entries,
+    gathered panel 3.84 GB = 14 x the Infinity Cache.  Every gathered row comes from DRAM, so fabric bytes ~ DRAM bytes ~
+    SURVEY 8d's gather bytes and `frac` is a fraction of the HBM peak in the plain sense.  TWO access patterns, side by
+    side: `strided` — idgrec_amd.synth.regular_adjacency: interaction t joins item (t P) mod I, consecutive
+    gathered rows a constant 564,239 rows apart, perfectly even over channels and banks: a strided sweep — and, the
+    figure this leg reports at its top level, `random` — the same graph with both id ranges relabelled by random
+    permutations (regular_adjacency_permuted): same degrees, a user's 20 items uniformly scattered ids."""
     import idgrec_amd.ops as ops
     import idgrec_amd.synth as S
 
     U, I, D = 10_000_000, 5_000_000, 20
-    t0 = time.perf_counter()
-    ip, ix, dv = S.regular_adjacency(U, I, D)
-    t_gen = time.perf_counter() - t0
-    n, nnz = U + I, len(ix)
-    _save_csr(args, "regular-15M", ip, ix, dv, U, I, d)
-    graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
-    del ip, ix, dv
-    r = dense_launch_leg(args, "regular-15M", d=d, K=3, graph=graph, shape=(U, I, n, nnz, nnz // 2), reps=5)
-    r["workload"] = "regular bipartite graph, no reuse: %d users x %d items, every user %d items, every item %d users, neighbours " \
-                    "scattered over the id range; nnz(A)=%d, d=%d (gathered panel %.0f MB = %.1f x the Infinity Cache); drawn in " \
-                    "%.1f s" % (U, I, D, U * D // I, nnz, d, 4 * n * d / 1e6, 4 * n * d / INFINITY_CACHE_BYTES, t_gen)
-    r["bound"] = "hbm (no row is re-read while it could still be cached: fabric bytes ~ DRAM bytes)"
-    del graph
-    torch.cuda.empty_cache()
-    return r
+    n = U + I
+    legs = {}
+    for name, tag, make in (("random", "regular-15M-perm", lambda: S.regular_adjacency_permuted(U, I, D, seed=args.seed)),
+                            ("strided", "regular-15M", lambda: S.regular_adjacency(U, I, D))):
+        t0 = time.perf_counter()
+        ip, ix, dv = make()
+        t_gen = time.perf_counter() - t0
+        nnz = len(ix)
+        if name == "random":
+            _save_csr(args, tag, ip, ix, dv, U, I, d)  # (the traffic children measure the random pattern; the strided one
+            #                                             keeps profiles/r05/traffic_regular-15M_d64.json)
+        graph = ops.Graph(ip, ix, dv, n, n, split_threshold=args.split)
+        del ip, ix, dv
+        r = dense_launch_leg(args, tag, d=d, K=3, graph=graph, shape=(U, I, n, nnz, nnz // 2), reps=5)
+        r["workload"] = "regular bipartite graph, no reuse, %s neighbours: %d users x %d items, every user %d items, every item " \
+                        "%d users; nnz(A)=%d, d=%d (gathered panel %.0f MB = %.1f x the Infinity Cache); drawn in %.1f s" \
+                        % ("uniformly scattered (both id ranges relabelled by random permutations)" if name == "random" else
+                           "in arithmetic progression (item (t P) mod I: a constant stride between consecutive gathered rows)",
+                           U, I, D, U * D // I, nnz, d, 4 * n * d / 1e6, 4 * n * d / INFINITY_CACHE_BYTES, t_gen)
+        r["bound"] = "hbm (no row is re-read while it could still be cached: fabric bytes ~ DRAM bytes)"
+        r["access_pattern"] = name
+        legs[name] = r
+        del graph
+        torch.cuda.empty_cache()
+    out = legs["random"]
+    out["strided"] = legs["strided"]
+    return out
 
 
 def other_configs(args, wl_yelp, cpu_threads):

@@ -1088,6 +1088,19 @@ int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws,
   return IDG_OK;
 }
 
+int idg_score_topk_candidate_counts(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int32_t* out_counts, void* stream) {
+  IDG_REQUIRE(ws && out_counts && Bt > 0 && I > 0 && d > 0 && k >= 1, "idg_score_topk_candidate_counts: bad argument");
+  int nc, form;
+  int64_t ci;
+  fused_geometry(Bt, I, &nc, &ci, &form, k, d);
+  IDG_REQUIRE(form == 3, "idg_score_topk_candidate_counts: a call of this geometry does not take the threshold + collect form");
+  const CollectWs cw = collect_layout(Bt, nc, I);
+  hipLaunchKernelGGL(candidate_counts_kernel, dim3((unsigned)((Bt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(ws) + cw.count), Bt, nc, out_counts);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
+
 // The exact forms (0: every wave alternates between scoring and selecting, 1: producer / consumer waves) in geometry
 // (nc, ci), k of any size.  gate != nullptr (form 3's fall-back, k <= 64): every launch returns at once unless *gate != 0,
 // and there is no floor phase.

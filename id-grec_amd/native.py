@@ -167,6 +167,7 @@ PROTOTYPES = {
     "idg_score_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "idg_score_topk_info": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, C.POINTER(C.c_int64), c_vp]),
     "idg_score_topk_option": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_int64)]),
+    "idg_score_topk_candidate_counts": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp, c_vp]),
     "idg_score_topk_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int,
                                      C.c_int, c_vp, c_vp, c_vp, c_vp]),
     "idg_step_create": (C.c_int, [c_vp, C.POINTER(c_vp)]),

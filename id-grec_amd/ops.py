@@ -1318,6 +1318,7 @@ def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=No
         while per_call * 2 < Bt and int(lib.idg_score_topk_workspace_bytes(per_call * 2, I, d, int(k))) <= budget:
             per_call *= 2
     redone = unserved = fell_back = 0
+    cand_counts = []
     for s0 in range(0, Bt, per_call):
         n = min(per_call, Bt - s0)
         ws = torch.empty(int(lib.idg_score_topk_workspace_bytes(n, I, d, int(k))), dtype=torch.uint8, device=V.device)
@@ -1336,4 +1337,13 @@ def score_topk(user_panel, item_panel, users, k, excl_indptr=None, excl_items=No
             info["users_redone"] = redone if int(out[3]) >= 0 else int(out[3])
             if int(out[3]) >= 0:  # (form 3)
                 info.update(users_unserved=unserved, calls_fallen_back=fell_back, items_irregular=bool(out[6]))
+                if info.get("candidates") is not None and int(out[5]) == 0:  # (asked for: info = {"candidates": True})
+                    cnt = torch.empty(n, dtype=torch.int32, device=V.device)
+                    check(lib.idg_score_topk_candidate_counts(n, I, d, int(k), _ptr(ws), _ptr(cnt), _stream()),
+                          "idg_score_topk_candidate_counts")
+                    cand_counts.append(cnt)
+    if cand_counts:
+        c = torch.cat(cand_counts).float()
+        info["candidates"] = {"mean": float(c.mean()), "p50": float(c.quantile(0.5)) if c.numel() <= 16_000_000 else None,
+                              "p99": float(c.quantile(0.99)) if c.numel() <= 16_000_000 else None, "max": float(c.max())}
     return (idx, val) if return_values else idx

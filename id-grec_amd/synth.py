@@ -129,6 +129,37 @@ def regular_adjacency(num_users, num_items, user_degree, multiplier=None):
     return indptr, indices, values
 
 
+def regular_adjacency_permuted(num_users, num_items, user_degree, seed=0):
+    """regular_adjacency's graph with BOTH id ranges relabelled by random permutations (user u -> sigma[u], item i -> pi[i]).
+    Same degrees — every user `user_degree` items, every item U * user_degree / I users, nothing to reuse — but the rows a
+    wave gathers are no longer an arithmetic progression: in regular_adjacency interaction t joins item (t P) mod I, so
+    consecutive gathered rows lie a constant ~564,239 rows apart, perfectly even over channels and banks (a
+    strided sweep, not a random gather).  Here a user's items are `user_degree` uniformly scattered ids and an item's users
+    likewise.  The relabelling (two gathers and two row sorts over 2e8 ids) runs on the GPU when there is one."""
+    import torch
+
+    U, I, D = int(num_users), int(num_items), int(user_degree)
+    indptr, indices, values = regular_adjacency(U, I, D)
+    Di = U * D // I
+    dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    pi, sigma = torch.randperm(I, device=dev, generator=g), torch.randperm(U, device=dev, generator=g)
+    ix = torch.from_numpy(indices)
+    out = torch.empty_like(ix)
+    # user rows: row sigma[u] = sort(U + pi[items of u]); item rows: row pi[i] = sort(sigma[users of i])
+    rows = (pi[ix[: U * D].to(dev).long() - U] + U).to(torch.int32).view(U, D).sort(dim=1).values
+    moved = torch.empty_like(rows)
+    moved[sigma] = rows
+    out[: U * D] = moved.view(-1).cpu()
+    del rows, moved
+    rows = sigma[ix[U * D:].to(dev).long()].to(torch.int32).view(I, Di).sort(dim=1).values
+    moved = torch.empty_like(rows)
+    moved[pi] = rows
+    out[U * D:] = moved.view(-1).cpu()
+    del rows, moved, pi, sigma
+    return indptr, out.numpy(), values
+
+
 GENERATOR_VERSION = 2  # part of generate_shared's cache file name: bump when generate()'s output changes
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 140 /* 0.5.1: idg_score_topk_option (the top-K knobs: environment read once), idg_score_topk_info fills info[8], form 3's whole-call fall-back; idg_step_run_f32 takes next_ids_token; idg_step_synchronize also drains the side stream's preparations; 0.5.0: idg_step_* (one library call per training step), idg_adam_rows_f32; 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 140 /* 0.5.1: idg_score_topk_candidate_counts, idg_score_topk_option (the top-K knobs: environment read once), idg_score_topk_info fills info[8], form 3's whole-call fall-back; idg_step_run_f32 takes next_ids_token; idg_step_synchronize also drains the side stream's preparations; 0.5.0: idg_step_* (one library call per training step), idg_adam_rows_f32; 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -820,6 +820,11 @@ size_t idg_score_topk_workspace_bytes(int64_t Bt, int64_t I, int64_t d, int k);
  * IDG_TOPK_OPT_FALLBACK_PERMILLE of the users unservable — tables that tie massively — or an irregular ITEM row: decided
  * on the device, no host read; then info[3] = 0), info[6] = 1 when an item row was irregular.  info[7] = 0 (reserved). */
 int idg_score_topk_info(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int64_t info[8], void* stream);
+/* Diagnostics of a form-3 call (info[0] == 3) that has been ENQUEUED on `stream` with workspace `ws` and did not fall back:
+ * out_counts[b] (device, int32 [Bt]) = the number of candidates the collect pass counted for user b — how many items'
+ * upper bounds reached the user's floor (a list beyond its capacity sends the user to the exact pass).  What the
+ * candidate capacity and the fall-back threshold are sized by; depends on the tables' norm spread.  Asynchronous. */
+int idg_score_topk_candidate_counts(int64_t Bt, int64_t I, int64_t d, int k, const void* ws, int32_t* out_counts, void* stream);
 /* Knobs of the form choice, process-wide, for tests and tuning.  Their initial values are read from the environment ONCE,
  * by the first call that needs them (IDG_TOPK_FORM, IDG_TOPK_COLLECT, IDG_TOPK_FLOOR, IDG_TOPK_WGS, IDG_TOPK_CHUNKS,
  * IDG_TOPK_FALLBACK_PERMILLE).  *previous (nullable) receives the old value; value = IDG_TOPK_OPT_KEEP only reads;

@@ -264,3 +264,27 @@ def test_counter_csv_parsing_tells_the_graphs_apart(tmp_path):
                                                 + row(512, "__amd_rocclr_copyBuffer", "FETCH_SIZE", 5.0))
     got = bench.collect_dense_counters(str(tmp_path), {5321 * 256: "yelp2018", 10242 * 256: "amazon-book", 836557 * 256: "synth-10M"}, {})
     assert got == {"yelp2018": {"FETCH_SIZE": [100.0, 102.0]}, "amazon-book": {"FETCH_SIZE": [300.0]}, "synth-10M": {"FETCH_SIZE": [7.0]}}
+
+
+def test_north_star_figures_are_top_level_scalars_of_roofline():
+    """the driver's record keeps top-level scalars of `roofline` only — the HBM fractions the north star is
+    stated on (nested under hbm_bound / hbm_reuse_free) and the evaluation's bf16 MFMA fraction are flattened there."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("idg_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = {"roofline": {"frac": 1.79, "hbm_bound": {"frac": 0.95, "frac_traffic": 0.88, "us_per_launch": 14330.0,
+                                                    "traffic_over_bytes_gather": 0.93, "traffic_l2_hit_rate": 0.11},
+                        "hbm_reuse_free": {"frac": 0.78, "frac_traffic": 0.80, "us_per_launch": 17477.0, "traffic_l2_hit_rate": 0.05,
+                                           "access_pattern": "random", "strided": {"frac": 0.80, "us_per_launch": 17044.0}}},
+           "eval_scale_point": {"bf16_mfma_frac": 0.38, "fp32_equivalent_tflops": 808.0},
+           "scale_point": {"ms_per_step": 209.0, "batch_2p20": {"value": 3.08e6, "ms_per_step": 340.0}}}
+    bench.flatten_north_star(out)
+    rf = out["roofline"]
+    assert (rf["hbm_frac_gather"], rf["hbm_frac_traffic"], rf["hbm_us_per_launch"]) == (0.95, 0.88, 14330.0)
+    assert (rf["hbm_reuse_free_frac"], rf["hbm_reuse_free_frac_traffic"], rf["hbm_reuse_free_pattern"]) == (0.78, 0.80, "random")
+    assert rf["hbm_reuse_free_strided_frac"] == 0.80 and rf["eval_bf16_mfma_frac"] == 0.38 and isinstance(rf["hbm_workload"], str)
+    assert out["scale_point_ms_per_step"] == 209.0 and out["scale_point_batch_2p20_triples_per_s"] == 3.08e6
+    assert all(not isinstance(v, (dict, list)) for k, v in rf.items() if k.startswith(("hbm_frac", "hbm_us", "hbm_reuse_free_", "eval_")))
+    bench.flatten_north_star({"roofline": {"hbm_bound": {"error": "x"}}})  # (legs that failed leave nothing behind)
