@@ -88,6 +88,10 @@ def parse():
                         "BEFORE the warm-up, from the fresh tables, and repeated on ONE device (rank 0, the fused engine) from "
                         "the same tables and batches; the line carries `parity_vs_1gpu` {loss_rel_err, final_rows_rel_err, "
                         "table_rel_err, tol 1e-4, ok} and the run leaves with status 3 when ok is false (0 = no check)")
+    p.add_argument("--panel-bits", type=int, default=32, choices=[32, 24],
+                   help="sharded form: 24 = the panel-sized exchanges travel as 24-bit values (2^-16 relative: inside the 1e-4 "
+                        "bar) through an explicit exchange — pack, all-to-all, this library's rank-ordered sum, all-gather — "
+                        "3/4 of the bytes on the links and bit-reproducible run to run; 32 (default) = RCCL's fp32 collectives")
     p.add_argument("--item-slices", type=int, default=0,
                    help="sharded form: row slices of the item panel whose collectives overlap the following slices' products "
                         "(0 = auto: 8 from four ranks on, 4 below, 1 while the panel is under 256 MB)")

@@ -23,6 +23,10 @@ struct Rccl {
   decltype(&ncclAllReduce) all_reduce = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclReduceScatter) reduce_scatter = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
   decltype(&ncclGetVersion) get_version = nullptr;
 };
@@ -64,7 +68,8 @@ int idg_comm_load(const char* librccl_path) {
   const bool ok = bind(h, "ncclGetUniqueId", r.get_unique_id) && bind(h, "ncclCommInitRank", r.comm_init_rank) &&
                   bind(h, "ncclCommDestroy", r.comm_destroy) && bind(h, "ncclAllReduce", r.all_reduce) &&
                   bind(h, "ncclAllGather", r.all_gather) && bind(h, "ncclReduceScatter", r.reduce_scatter) &&
-                  bind(h, "ncclGetErrorString", r.error_string) &&
+                  bind(h, "ncclSend", r.send) && bind(h, "ncclRecv", r.recv) && bind(h, "ncclGroupStart", r.group_start) &&
+                  bind(h, "ncclGroupEnd", r.group_end) && bind(h, "ncclGetErrorString", r.error_string) &&
                   bind(h, "ncclGetVersion", r.get_version);
   if (!ok) {
     dlclose(h);
@@ -141,6 +146,35 @@ int idg_reduce_scatter_f32(idg_comm* c, const float* in, float* out, int64_t cou
   IDG_REQUIRE(in && out && count >= 0, "idg_reduce_scatter_f32: NULL buffer / negative count");
   if (count == 0) return IDG_OK;
   IDG_RCCL(g_rccl.reduce_scatter(in, out, (size_t)count, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream));
+  return IDG_OK;
+}
+
+// Every rank hands block p of `send` to rank p and receives rank p's block for it into block p of `recv`: one group of
+// point-to-point transfers — on a fully connected xGMI node each of the 7 peers gets its block over its own link (the
+// reduce-scatter half of a DIRECT all-reduce; idg_reduce24_f32 then adds the blocks in rank order).  The own block is a
+// device copy — unless IDG_ALLTOALL_OWN_THROUGH_RCCL is set (tests: the grouped ncclSend / ncclRecv path on ONE device).
+int idg_alltoall_f32(idg_comm* c, const float* send, float* recv, int64_t count, int flags, void* stream) {
+  IDG_REQUIRE(c && c->comm, "idg_alltoall_f32: NULL communicator");
+  IDG_REQUIRE(send && recv && count >= 0, "idg_alltoall_f32: NULL buffer / negative count");
+  IDG_REQUIRE(send != recv, "idg_alltoall_f32: in place is not supported");
+  if (count == 0) return IDG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool own_rccl = (flags & IDG_ALLTOALL_OWN_THROUGH_RCCL) != 0;
+  if (!own_rccl)
+    IDG_HIP(hipMemcpyAsync(recv + (size_t)c->rank * (size_t)count, send + (size_t)c->rank * (size_t)count,
+                           (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (c->world == 1 && !own_rccl) return IDG_OK;
+  IDG_RCCL(g_rccl.group_start());
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank && !own_rccl) continue;
+    ncclResult_t r = g_rccl.send(send + (size_t)p * (size_t)count, (size_t)count, ncclFloat32, p, c->comm, st);
+    if (r == ncclSuccess) r = g_rccl.recv(recv + (size_t)p * (size_t)count, (size_t)count, ncclFloat32, p, c->comm, st);
+    if (r != ncclSuccess) {
+      (void)g_rccl.group_end();
+      return idg::fail(IDG_E_HIP, "idg_alltoall_f32: ncclSend / ncclRecv with rank %d failed: %s", p, g_rccl.error_string(r));
+    }
+  }
+  IDG_RCCL(g_rccl.group_end());
   return IDG_OK;
 }
 

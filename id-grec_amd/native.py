@@ -166,6 +166,10 @@ PROTOTYPES = {
     "idg_score_dense_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp]),
     "idg_score_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "idg_score_topk_info": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, C.POINTER(C.c_int64), c_vp]),
+    "idg_pack24_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp]),
+    "idg_unpack24_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp]),
+    "idg_reduce24_f32": (C.c_int, [c_vp, C.c_int, C.c_int64, c_vp, c_vp, c_vp]),
+    "idg_alltoall_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int, c_vp]),
     "idg_score_topk_option": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_int64)]),
     "idg_score_topk_candidate_counts": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp, c_vp]),
     "idg_score_topk_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int,

@@ -214,6 +214,12 @@ class ShardedEngine:
         self.GF = z((n, dim))   # d loss / d FIN
         self.MU, self.VU = z((self.Ug, dim)), z((self.Ug, dim))        # Adam moments: the owned user rows ...
         self.MI, self.VI = z((max(off, 1), dim)), z((max(off, 1), dim))  # ... and the owned item rows (1/N of the table)
+        # 24-bit panel exchange (Packed24Comm): the replicated item table then holds 24-bit values on EVERY rank (the owner's
+        # copy too: replicas stay bit-identical), so the owner keeps the fp32 MASTER of its rows here — Adam updates the
+        # master, the all-gather sends it packed.  Filled from the table by the first training step.
+        self.packed = bool(getattr(comm, "packed", False))
+        self.MP = z((max(off, 1), dim)) if self.packed else None
+        self._master_ready = False
         self.XU = [z((self.Ug, dim)) for _ in range(max(self.K - 1, 1))]
         self.XI = [z((self.Ip, dim)) for _ in range(self.K)]
         # more than three earlier layers do not fit one epilogue (sum_in .. sum_in3): from K = 4 on the user-side layer sum
@@ -323,7 +329,8 @@ class ShardedEngine:
                    out_rows=None if out_bits is None else k.bits_from(out_bits, r0), x_rows=x_rows)
             if reduce == "all":
                 self.comm.tag, self.comm.slice = tag, j
-                works.append(self.comm.all_reduce_async(y))
+                # (the packed exchange cuts a slice into one block per rank: the padded view — its padding rows are zero)
+                works.append(self.comm.all_reduce_async(self._slice_rows(Y_i, j, padded=True) if self.packed else y))
             elif reduce == "scatter":
                 self.comm.tag, self.comm.slice = tag, j
                 works.append(self.comm.reduce_scatter_async(self._slice_rows(Y_i, j, padded=True)))
@@ -532,7 +539,9 @@ class ShardedEngine:
         if v is None:
             o0, c, off = self.own[j]
             blk = slice(o0, o0 + c)
-            v = self._views[key] = (t_i[blk], self.GF_i[blk], self.G_i[blk], self.P_i[blk], self.MI[off:off + c],
+            # (packed exchange: Adam's parameter rows and the all-gather's source are the fp32 master, not the table's own copy)
+            p_rows = self.MP[off:off + c] if self.packed else self.P_i[blk]
+            v = self._views[key] = (t_i[blk], self.GF_i[blk], self.G_i[blk], p_rows, self.MI[off:off + c],
                                     self.VI[off:off + c], t_i)
         return v
 
@@ -545,6 +554,12 @@ class ShardedEngine:
         """gb: a GlobalBatch from make_batch() — the same global batch on every rank."""
         k = self.k
         Bc = gb.B
+        if self.packed and not self._master_ready:
+            self._wait_item_table()
+            for o0, c, off in self.own:
+                if c > 0:
+                    self.MP[off:off + c][...] = self.P_i[o0:o0 + c]
+            self._master_ready = True
         prep = None
         if self.batch_sparsity:
             prep = self._prepared.pop(gb.key, None)
@@ -705,9 +720,13 @@ class IssueOrder:
 
     def __init__(self):
         self.events, self.n_steps, self.n_slices = [], 0, 1
+        self.packed_violations = None
 
     def attach(self, eng):
         self.n_slices = len(eng.slices)
+        # the 24-bit panel exchange keeps its own record of the order of its halves (Packed24Comm.order_violations):
+        # slice j + 1's all-to-all queued before slice j's sum and all-gather
+        self.packed_violations = getattr(eng.comm, "order_violations", None)
         names = {id(eng.G_ui): ("user",)}
         names.update({id(sl[0]): ("item", j) for j, sl in enumerate(eng.slices)})
         if isinstance(eng.comm, TimelineComm):
@@ -784,6 +803,8 @@ class IssueOrder:
                                "products" % (si, n_before, S))
                 elif w[-1] > first_user:
                     bad.append("step %d: a user-side product (reads the item table) launched before the table was whole" % si)
+        if self.packed_violations is not None:
+            bad += ["24-bit exchange: " + v for v in self.packed_violations()]
         return bad
 
     def summary(self):
@@ -876,14 +897,19 @@ class TimelineComm:
         self.tl.records.append([self.tag, kind, nbytes, e0, e1])
         return (work, None, self.tag, self.slice)
 
+    def _bytes(self, numel):
+        # (a packed exchange puts 3 bytes per value on the wire: Packed24Comm.wire_bytes)
+        f = getattr(self.inner, "wire_bytes", None)
+        return f(numel) if f is not None else numel * 4
+
     def all_reduce_async(self, t, average=False):
-        return self._issue("all_reduce", t.numel() * 4, lambda: self.inner.all_reduce_async(t, average))
+        return self._issue("all_reduce", self._bytes(t.numel()), lambda: self.inner.all_reduce_async(t, average))
 
     def all_gather_async(self, out, t):
-        return self._issue("all_gather", out.numel() * 4, lambda: self.inner.all_gather_async(out, t))
+        return self._issue("all_gather", self._bytes(out.numel()), lambda: self.inner.all_gather_async(out, t))
 
     def reduce_scatter_async(self, t):
-        return self._issue("reduce_scatter", t.numel() * 4, lambda: self.inner.reduce_scatter_async(t))
+        return self._issue("reduce_scatter", self._bytes(t.numel()), lambda: self.inner.reduce_scatter_async(t))
 
     def wait(self, handle):
         if handle is None:
@@ -960,6 +986,40 @@ class HipKernels:
                                        None if x_rows is None else x_rows.data_ptr(), ws[1], self.ops._stream())
         if rc:
             self.check(rc, "idg_spmm_epi_f32")
+
+    # ---- 24-bit panels (Packed24Comm): values in, 3/4 as many 32-bit words out (buffers are fp32-typed: what the comms move)
+    def pack24(self, src, dst, n):
+        rc = self.lib.idg_pack24_f32(src.data_ptr(), dst.data_ptr(), n, self.ops._stream())
+        if rc:
+            self.check(rc, "idg_pack24_f32")
+
+    def unpack24(self, src, dst, n):
+        rc = self.lib.idg_unpack24_f32(src.data_ptr(), dst.data_ptr(), n, self.ops._stream())
+        if rc:
+            self.check(rc, "idg_unpack24_f32")
+
+    def reduce24(self, blocks, n_blocks, n, out_packed=None, out_f32=None):
+        rc = self.lib.idg_reduce24_f32(blocks.data_ptr(), n_blocks, n, None if out_packed is None else out_packed.data_ptr(),
+                                       None if out_f32 is None else out_f32.data_ptr(), self.ops._stream())
+        if rc:
+            self.check(rc, "idg_reduce24_f32")
+
+    def exchange_stream(self):
+        """Context manager: what is launched (and what collective is issued) inside goes to the exchange's own stream —
+        NOT ordered behind the step's stream: the caller orders it by waiting for the collectives it consumes."""
+        if getattr(self, "_xchg", None) is None:
+            self._xchg = self.torch.cuda.Stream()
+        return self.torch.cuda.stream(self._xchg)
+
+    def record_event(self):
+        """An event on the current stream (inside exchange_stream(): the exchange's), for wait_event()."""
+        ev = self.torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def wait_event(self, ev):
+        if ev is not None:
+            self.torch.cuda.current_stream().wait_event(ev)
 
     def bits_from(self, bits, row0):
         """The bitmap of rows row0, row0 + 1, ... (row0 a multiple of 32)."""
@@ -1243,6 +1303,27 @@ class TorchComm:
         work = self.dist.reduce_scatter_tensor(out, flat, async_op=True)
         return ("copy_after", work, own, out)
 
+    def all_to_all_async(self, recv, send):
+        """Block p of `send` (world equal blocks) goes to rank p; block p of `recv` receives rank p's block for this rank."""
+        import torch
+
+        if isinstance(send, np.ndarray):
+            send, recv = torch.from_numpy(send), torch.from_numpy(recv)
+        if self.backend == "gloo":
+            # (the rehearsal backend has no all-to-all: point-to-point pairs on host copies, completed inside the call)
+            s, r = send.detach().cpu().view(self.world, -1), torch.empty(recv.shape, dtype=recv.dtype).view(self.world, -1)
+            r[self.rank] = s[self.rank]
+            reqs = []
+            for p in range(self.world):
+                if p != self.rank:
+                    reqs.append(self.dist.isend(s[p].contiguous(), p))
+                    reqs.append(self.dist.irecv(r[p], p))
+            for q in reqs:
+                q.wait()
+            recv.view(self.world, -1).copy_(r)
+            return None
+        return self.dist.all_to_all_single(recv.view(-1), send.view(-1), async_op=True)
+
     def wait(self, work):
         if isinstance(work, tuple):  # reduce_scatter_async: the reduced block goes to its place once the collective is done
             _, inner, own, out = work
@@ -1395,6 +1476,21 @@ class NativeComm:
         self.check(self.lib.idg_reduce_scatter_f32(self.handle, base, own, c, self._stream()), "idg_reduce_scatter_f32")
         return None
 
+    def all_to_all_async(self, recv, send):
+        """Block p of `send` goes to rank p; block p of `recv` receives rank p's block for this rank (idg_alltoall_f32:
+        grouped ncclSend / ncclRecv)."""
+        c = send.numel() // self.world
+        assert c * self.world == send.numel() == recv.numel(), "all-to-all of %d floats over %d ranks" % (send.numel(), self.world)
+        flags = 1 if self._force else 0  # (tests at world size 1: the own block through ncclSend / ncclRecv too)
+        if send.numel() * 4 >= self.overlap_bytes and not (self.world == 1 and not self._force):
+            stream, done = self._fork()
+            self.check(self.lib.idg_alltoall_f32(self.handle, self._f32(send), self._f32(recv), c, flags, stream), "idg_alltoall_f32")
+            done.record(self._own)
+            return done
+        self.check(self.lib.idg_alltoall_f32(self.handle, self._f32(send), self._f32(recv), c, flags, self._stream()),
+                   "idg_alltoall_f32")
+        return None
+
     def wait(self, work):
         if work is not None:
             self.torch.cuda.current_stream().wait_event(work)
@@ -1509,8 +1605,213 @@ class NoComm:
     def reduce_scatter_async(self, t):
         return None
 
+    def all_to_all_async(self, recv, send):
+        recv[...] = send
+        return None
+
     def wait(self, work):
         pass
+
+
+# --------------------------------------------------------------------------- the panel exchanges as 24-bit rows (opt-in)
+class Packed24Comm:
+    """A comm wrapper (around NativeComm / TorchComm / NoComm / the tests' comms): the step's LARGE exchanges — the two
+    [I, d] all-reduces, the reduce-scatter of the last backward product, the all-gather of the updated item rows, the
+    touched-item row sets — travel as 24-bit values (idg_pack24_f32: sign, exponent, 15 mantissa bits, rounded to nearest;
+    2^-16 = 1.5e-5 relative, inside the north star's 1e-4) and are summed by this library's own kernel IN RANK ORDER:
+
+        all-reduce      pack -> all-to-all (block p to rank p) -> reduce24 (q0 + q1 + ... in rank order, packed again)
+                        -> all-gather of the packed sums -> unpack (EVERY rank, the owner included, holds the same bits)
+        reduce-scatter  pack -> all-to-all -> reduce24 into the own fp32 block
+        all-gather      pack the own block -> all-gather -> unpack (the own block too: replicas stay bit-identical)
+
+    3/4 of the fp32 exchange's bytes on the links (what lowers the link rate >= 6x at 8 GPUs needs from 88 %
+    to 66 % of the xGMI peak), and a k-GPU run is bit-reproducible run to run whatever algorithm RCCL would pick
+    (SURVEY.md 8e).  Collectives below `min_bytes` (the batch's guest rows, whose exchange must stay exact: x + 0 + ...)
+    or whose length does not divide by 4 x world stay with the inner comm, in fp32.
+
+    Streams (kernels.exchange_stream): pack runs on the step's stream right behind the product; the all-to-all is issued
+    from there; the second half — wait for the all-to-all, reduce24, all-gather, unpack — runs on the exchange's own
+    stream, and is issued only AFTER the next slice's first half (slice j + 1's all-to-all is queued before slice j's
+    all-gather, so the links are not idle while slice j is being summed).  wait() joins the step's stream.
+    `log` records the order of the halves (IssueOrder checks it); `stats()` the bytes put on the wire."""
+
+    packed = True
+    averages = False
+
+    def __init__(self, inner, kernels, min_bytes=4 << 20):
+        self.inner, self.k = inner, kernels
+        self.world, self.rank = int(inner.world), int(inner.rank)
+        self.min_bytes = int(min_bytes)
+        self._free = {}        # words -> [(snd, rcv), ...] buffers not in flight
+        self._pending = []     # exchanges whose second half has not been issued yet, oldest first
+        self._seq = 0
+        self.log = []          # ("first" | "second" | "wait", seq, kind)
+        self.wire = {"packed_bytes_sent": 0, "fp32_bytes_it_replaces": 0, "exchanges": 0, "fp32_collectives": 0}
+
+    # ---- helpers
+    @staticmethod
+    def _n(t):
+        return int(t.size) if isinstance(t, np.ndarray) else int(t.numel())
+
+    @staticmethod
+    def _flat(t):
+        return t.reshape(-1)
+
+    def _eligible(self, n):
+        return n * 4 >= self.min_bytes and n % (4 * self.world) == 0
+
+    def _buffers(self, words):
+        pool = self._free.setdefault(words, [])
+        if pool:
+            return pool.pop()
+        return (self.k.zeros((words,)), self.k.zeros((words,)))
+
+    def _count(self, n_values, phases):
+        # a rank sends (N - 1) / N of the buffer in each phase (all-to-all, all-gather)
+        share = (self.world - 1) / self.world
+        self.wire["packed_bytes_sent"] += int(phases * share * n_values * 3)
+        self.wire["fp32_bytes_it_replaces"] += int(phases * share * n_values * 4)
+        self.wire["exchanges"] += 1
+
+    class _X:
+        __slots__ = ("seq", "kind", "t", "n", "snd", "rcv", "work", "done", "second", "own")
+
+    def _first_half(self, kind, t, n):
+        """pack + all-to-all of t's n values (kind "ar" / "rs"), on the current (the step's) stream."""
+        words = n // 4 * 3
+        x = self._X()
+        x.seq, x.kind, x.t, x.n, x.second, x.done, x.own = self._seq, kind, t, n, False, None, None
+        self._seq += 1
+        x.snd, x.rcv = self._buffers(words)
+        self.k.pack24(self._flat(t), x.snd, n)
+        x.work = self.inner.all_to_all_async(x.rcv, x.snd)
+        self.log.append(("first", x.seq, kind))
+        # the exchange before this one may now go on: its sum and its all-gather queue BEHIND this all-to-all
+        self._flush(keep=x)
+        self._pending.append(x)
+        return x
+
+    def _second_half(self, x):
+        k, N = self.k, self.world
+        blk_words, blk_n = x.n // 4 * 3 // N, x.n // N
+        with k.exchange_stream():
+            self.inner.wait(x.work)
+            if x.kind == "rs":
+                own = self._flat(x.t)[self.rank * blk_n:(self.rank + 1) * blk_n]
+                k.reduce24(x.rcv, N, blk_n, out_f32=own)
+            else:
+                own = x.snd[self.rank * blk_words:(self.rank + 1) * blk_words]
+                k.reduce24(x.rcv, N, blk_n, out_packed=own)
+                self.inner.wait(self.inner.all_gather_async(x.snd, own))
+                k.unpack24(x.snd, self._flat(x.t), x.n)
+            x.done = k.record_event()
+        x.second = True
+        self.log.append(("second", x.seq, x.kind))
+
+    def _flush(self, keep=None):
+        while self._pending and self._pending[0] is not keep:
+            self._second_half(self._pending.pop(0))
+
+    # ---- the comm interface
+    def all_reduce_async(self, t, average=False):
+        n = self._n(t)
+        if not self._eligible(n):
+            self.wire["fp32_collectives"] += 1
+            return ("inner", self.inner.all_reduce_async(t, average))
+        assert not average, "Packed24Comm sums"
+        self._count(n, 2)
+        return ("packed", self._first_half("ar", t, n))
+
+    def reduce_scatter_async(self, t):
+        n = self._n(t)
+        if not self._eligible(n):
+            self.wire["fp32_collectives"] += 1
+            return ("inner", self.inner.reduce_scatter_async(t))
+        self._count(n, 1)
+        return ("packed", self._first_half("rs", t, n))
+
+    def all_gather_async(self, out, t):
+        n, nb = self._n(out), self._n(t)
+        if not self._eligible(n) or nb * self.world != n:
+            self.wire["fp32_collectives"] += 1
+            return ("inner", self.inner.all_gather_async(out, t))
+        self._count(n, 1)
+        self._flush()  # (an all-gather has no first half to hide a sum behind: whatever is pending goes first)
+        words, blk_words = n // 4 * 3, nb // 4 * 3
+        x = self._X()
+        x.seq, x.kind, x.t, x.n, x.second = self._seq, "ag", out, n, True
+        self._seq += 1
+        x.snd, x.rcv = self._buffers(words)
+        own = x.snd[self.rank * blk_words:(self.rank + 1) * blk_words]
+        self.k.pack24(self._flat(t), own, nb)
+        x.work = self.inner.all_gather_async(x.snd, own)
+        self.log.append(("first", x.seq, "ag"))
+        with self.k.exchange_stream():
+            self.inner.wait(x.work)
+            self.k.unpack24(x.snd, self._flat(out), n)
+            x.done = self.k.record_event()
+        self.log.append(("second", x.seq, "ag"))
+        return ("packed", x)
+
+    def all_to_all_async(self, recv, send):
+        return ("inner", self.inner.all_to_all_async(recv, send))
+
+    def wire_bytes(self, numel):
+        """Bytes a collective over `numel` values moves per unit of buffer (TimelineComm's bus-rate arithmetic)."""
+        return numel * (3 if self._eligible(numel) else 4)
+
+    def timed_stream(self, nbytes):
+        return None  # (a compound exchange: TimelineComm brackets it on the step's stream, issue to wait)
+
+    def wait(self, handle):
+        if handle is None:
+            return
+        kind, x = handle
+        if kind == "inner":
+            self.inner.wait(x)
+            return
+        if not x.second:  # nobody issued a later exchange behind it: its second half goes out now (and all before it)
+            while self._pending:
+                y = self._pending.pop(0)
+                self._second_half(y)
+                if y is x:
+                    break
+        self.k.wait_event(x.done)
+        self.log.append(("wait", x.seq, x.kind))
+        self._free.setdefault(x.n // 4 * 3, []).append((x.snd, x.rcv))
+        x.snd = x.rcv = x.t = None
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    # ---- evidence
+    def order_violations(self):
+        """The halves' issue order against the pipeline this class promises: every first half is followed by its second
+        half exactly once and waited for after it; the second half of exchange i is never issued before the first half
+        of exchange i + 1 when that one was issued before i was waited for (its all-to-all is in the queue first)."""
+        bad, pos = [], {}
+        for i, (what, seq, kind) in enumerate(self.log):
+            pos.setdefault(seq, {})[what] = i
+        for seq, p in sorted(pos.items()):
+            if "first" in p and "second" not in p and "wait" in p:
+                bad.append("exchange %d waited for without its second half" % seq)
+            if "second" in p and "first" in p and not p["first"] < p["second"]:
+                bad.append("exchange %d: second half before the first" % seq)
+            if "wait" in p and "second" in p and not p["second"] < p["wait"]:
+                bad.append("exchange %d: waited for before its second half was issued" % seq)
+            nxt = pos.get(seq + 1)
+            # (an all-gather has no all-to-all to queue ahead: it flushes what is pending and is not part of this rule)
+            if nxt and "first" in nxt and "wait" in p and nxt["first"] < p["wait"] and p.get("second", 0) < nxt["first"] \
+                    and self.log[p["first"]][2] != "ag" and self.log[nxt["first"]][2] != "ag":
+                bad.append("exchange %d: its sum / all-gather was issued before exchange %d's all-to-all (no overlap)" % (seq, seq + 1))
+        return bad
+
+    def stats(self):
+        w = dict(self.wire)
+        w["ratio"] = (w["packed_bytes_sent"] / w["fp32_bytes_it_replaces"]) if w["fp32_bytes_it_replaces"] else None
+        w["order_violations"] = self.order_violations()
+        return w
 
 
 # --------------------------------------------------------------------------- bench driver
@@ -1657,6 +1958,11 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     del users, items
     phase("engine")
     kern = HipKernels()
+    panel_bits = int(getattr(args, "panel_bits", 32) or 32)
+    if panel_bits == 24:
+        # opt-in: the panel-sized exchanges as 24-bit rows, summed in rank order by idg_reduce24_f32 (Packed24Comm)
+        comm = Packed24Comm(comm, kern)
+        comm_name += " + 24-bit panel exchange (pack -> all-to-all -> rank-ordered sum -> all-gather)"
     # global_user_degree: the touched-item exchanges are sized by a host-side bound — no host synchronisation in the step
     eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
                         n_slices=n_slices, item_cuts=cuts, store_grad=False, global_user_degree=user_degree)
@@ -1694,10 +2000,12 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     dist.barrier()
     torch.cuda.synchronize()
     phase("timed")
+    wire0 = dict(comm.wire) if panel_bits == 24 else None
     t0 = time.perf_counter()
     for i in range(first + args.warmup, first + args.warmup + args.steps):
         step(i)
     t_enqueue = time.perf_counter() - t0  # host time to issue the steps (== wall time when the host is the bottleneck)
+    wire1 = dict(comm.wire) if panel_bits == 24 else None
     eng._wait_item_table()                # (the last step's all-gathers of the updated item rows belong to it)
     torch.cuda.synchronize()
     dist.barrier()
@@ -1815,6 +2123,22 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
                 "exchange_rows": {"touched_items": n_touched, "items": I},
             },
         }
+        # bytes one rank puts on the wire per step (SURVEY.md 8e / DESIGN.md 7: what the 1 -> 8 speed-up hangs on)
+        fp32_wire = out["roofline"]["exchange_bytes_per_step_per_rank"]
+        out["panel_exchange"] = {"bits": panel_bits, "bytes_on_the_wire_per_step_per_rank": fp32_wire,
+                                 "reduction_order": "RCCL's (ring / tree by its own choice)"}
+        if panel_bits == 24:
+            sent = (wire1["packed_bytes_sent"] - wire0["packed_bytes_sent"]) / args.steps
+            repl = (wire1["fp32_bytes_it_replaces"] - wire0["fp32_bytes_it_replaces"]) / args.steps
+            out["panel_exchange"].update(
+                bytes_on_the_wire_per_step_per_rank=int(fp32_wire - repl + sent), packed_bytes_per_step_per_rank=int(sent),
+                fp32_bytes_they_replace=int(repl), ratio=(sent / repl) if repl else None,
+                exchanges_per_step=(wire1["exchanges"] - wire0["exchanges"]) / args.steps,
+                reduction_order="rank order (idg_reduce24_f32: q0 + q1 + ... one fp32 add per rank and element): bit-reproducible "
+                                "run to run", order_violations=comm.order_violations(),
+                what="the [I, d] all-reduces, the last backward product's reduce-scatter, the all-gather of the updated item rows "
+                     "and the touched-item row sets travel as 24-bit values (2^-16 relative), 3 bytes per value; the batch's guest "
+                     "rows and other small collectives stay fp32")
     kern.close()
     del eng, batches, kern
     torch.cuda.empty_cache()

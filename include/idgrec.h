@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IDG_VERSION 140 /* 0.5.1: idg_score_topk_candidate_counts, idg_score_topk_option (the top-K knobs: environment read once), idg_score_topk_info fills info[8], form 3's whole-call fall-back; idg_step_run_f32 takes next_ids_token; idg_step_synchronize also drains the side stream's preparations; 0.5.0: idg_step_* (one library call per training step), idg_adam_rows_f32; 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
+#define IDG_VERSION 140 /* 0.5.1: idg_pack24_f32 / idg_unpack24_f32 / idg_reduce24_f32 / idg_alltoall_f32 (24-bit panel exchange, rank-ordered sum), idg_score_topk_candidate_counts, idg_score_topk_option (the top-K knobs: environment read once), idg_score_topk_info fills info[8], form 3's whole-call fall-back; idg_step_run_f32 takes next_ids_token; idg_step_synchronize also drains the side stream's preparations; 0.5.0: idg_step_* (one library call per training step), idg_adam_rows_f32; 0.4.4: IDG_ADAM_DISCARD_GRAD; 0.4.3: idg_event_synchronize; 0.4.2: idg_infonce_plan / IDG_SSL_PLANNED / idg_infonce_cross_ex_f32 (InfoNCE id lists a batch ahead); 0.4.1: idg_ngcf_layer_fwd_f32 / idg_ngcf_layer_bwd_f32 (one kernel per NGCF layer and direction); 0.4.0: idg_rows_layer_mean_n_f32 (any number of layers), idg_flags_compact_f32 (the touched-item
                            agreement without a host read-back), idg_shard_prepare validates its geometry.
                            133 / 0.3.0: process-wide live-unit registry + idg_graph_live_units_check; idg_spmm_epi_f32 (every
                            epilogue option; out_rows and x_rows combined); round-3 sharded step: idg_rows_gather2 / _scatter /
@@ -887,6 +887,27 @@ int idg_allgather_f32(idg_comm* comm, const float* in, float* out, int64_t count
  * step ends its last backward exchange with this: each rank finishes the gradient and applies Adam for the item rows it
  * owns, and the updated rows go round by idg_allgather_f32. */
 int idg_reduce_scatter_f32(idg_comm* comm, const float* in, float* out, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * MULTI-GPU, opt-in: the step's panel-sized exchanges as 24-bit rows with a rank-ordered sum (id-grec_amd/sharded.py
+ * Packed24Comm; SURVEY.md 8e "fix the reduction order (rank order) so k-GPU runs are reproducible run to run").
+ * An fp32 value travels as its upper 24 bits (sign, exponent, 15 mantissa bits; the dropped byte rounded to nearest even:
+ * 2^-16 relative), four values in three 32-bit words — 3/4 of the bytes of the fp32 exchange.  An all-reduce becomes
+ * pack -> idg_alltoall_f32 (block p to rank p) -> idg_reduce24_f32 (the N blocks added in rank order, packed again) ->
+ * idg_allgather_f32 of the packed result -> unpack; a reduce-scatter stops after the sum (fp32 out).  Counts `n` are fp32
+ * VALUES (multiples of 4); a packed array of n values has 3n/4 words.  Buffers 16-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int idg_pack24_f32(const float* src, uint32_t* dst, int64_t n, void* stream);
+int idg_unpack24_f32(const uint32_t* src, float* dst, int64_t n, void* stream);
+/* out <- blocks[0] + blocks[1] + ... + blocks[n_blocks - 1] in THAT order (block b: the 3n/4 words at blocks + b * 3n/4), as
+ * fp32 (out_f32, nullable) and / or packed (out_packed, nullable; may be one of the input blocks' own words: each thread
+ * reads its four values of every block before it writes). */
+int idg_reduce24_f32(const uint32_t* blocks, int n_blocks, int64_t n, uint32_t* out_packed, float* out_f32, void* stream);
+/* Block p (count floats) of `send` goes to rank p; block p of `recv` receives rank p's block for this rank (grouped
+ * ncclSend / ncclRecv: on a fully connected node every peer's block travels over its own link).  Not in place.  The own
+ * block is a device copy; flags = IDG_ALLTOALL_OWN_THROUGH_RCCL sends it through RCCL as well (tests on one device). */
+#define IDG_ALLTOALL_OWN_THROUGH_RCCL 1
+int idg_alltoall_f32(idg_comm* comm, const float* send, float* recv, int64_t count, int flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -241,3 +241,39 @@ def topk_is_valid(ref_rating, idx, k, tol=0.0):
         if worst < kth - tol:
             return False, "row %d: returned score %g below k-th %g" % (b, worst, kth)
     return True, ""
+
+
+# ---- 24-bit panels of the sharded step's opt-in exchange (id-grec_amd/csrc/idg_shard.hip: pack24 / unpack24 / reduce24).
+# No reference counterpart (the reference trains on one device, utility/utility_train/trainer.py:8-74): these restate the
+# library's own published format so that the CPU tests of sharded.Packed24Comm run the same arithmetic.
+def top24(x):
+    """Upper 24 bits of each fp32 word, the dropped byte rounded to nearest even (a uint32 array of 24-bit values)."""
+    b = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((b + 0x7F + ((b >> 8) & 1)) >> 8).astype(np.uint32)
+
+
+def pack24(x):
+    """fp32 values (a multiple of 4 of them) -> 3 words per 4 values: A | B << 24, B >> 8 | C << 16, C >> 16 | D << 8."""
+    t = top24(np.asarray(x).reshape(-1)).reshape(-1, 4)
+    a, b, c, d = (t[:, j] for j in range(4))
+    w = np.stack([a | (b << np.uint32(24)), (b >> np.uint32(8)) | (c << np.uint32(16)), (c >> np.uint32(16)) | (d << np.uint32(8))], 1)
+    return w.astype(np.uint32).reshape(-1)
+
+
+def unpack24(w):
+    w = np.ascontiguousarray(w, dtype=np.uint32).reshape(-1, 3)
+    w0, w1, w2 = w[:, 0], w[:, 1], w[:, 2]
+    a = w0 & np.uint32(0xFFFFFF)
+    b = (w0 >> np.uint32(24)) | ((w1 & np.uint32(0xFFFF)) << np.uint32(8))
+    c = (w1 >> np.uint32(16)) | ((w2 & np.uint32(0xFF)) << np.uint32(16))
+    d = w2 >> np.uint32(8)
+    return (np.stack([a, b, c, d], 1).astype(np.uint32) << np.uint32(8)).reshape(-1).view(np.float32)
+
+
+def reduce24(blocks):
+    """Sum of packed blocks IN THE ORDER GIVEN, one fp32 add per block and element (the rank-ordered sum)."""
+    acc = unpack24(blocks[0]).copy()
+    with np.errstate(invalid="ignore", over="ignore"):
+        for b in blocks[1:]:
+            acc = (acc + unpack24(b)).astype(np.float32)
+    return acc

@@ -195,6 +195,33 @@ class OracleKernels:
     def adam(self, p, g, m, v, lr, step):
         self.o.adam(p, np.ascontiguousarray(g), m, v, lr, step)
 
+    # ---- 24-bit panels (sharded.Packed24Comm): packed buffers are fp32-typed arrays holding the words
+    def pack24(self, src, dst, n):
+        dst.view(np.uint32)[: n // 4 * 3] = self.o.pack24(src.reshape(-1)[:n])
+
+    def unpack24(self, src, dst, n):
+        dst.reshape(-1)[:n] = self.o.unpack24(src.view(np.uint32)[: n // 4 * 3])
+
+    def reduce24(self, blocks, n_blocks, n, out_packed=None, out_f32=None):
+        w = n // 4 * 3
+        words = blocks.view(np.uint32)
+        acc = self.o.reduce24([words[b * w:(b + 1) * w] for b in range(n_blocks)])
+        if out_f32 is not None:
+            out_f32.reshape(-1)[:n] = acc
+        if out_packed is not None:
+            out_packed.view(np.uint32)[:w] = self.o.pack24(acc)
+
+    def exchange_stream(self):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def record_event(self):
+        return None
+
+    def wait_event(self, ev):
+        pass
+
 
 class DeferredComm:
     """TorchComm whose asynchronous collectives do NOTHING until wait(): the engine sees un-reduced partials if it reads a
@@ -216,6 +243,9 @@ class DeferredComm:
     def reduce_scatter_async(self, t):
         return ("rs", t)
 
+    def all_to_all_async(self, recv, send):
+        return ("a2a", recv, send)
+
     def wait(self, work):
         if work is None:
             return
@@ -224,6 +254,8 @@ class DeferredComm:
             self.inner.wait(self.inner.all_reduce_async(work[1], work[2]))
         elif kind == "ag":
             self.inner.wait(self.inner.all_gather_async(work[1], work[2]))
+        elif kind == "a2a":
+            self.inner.wait(self.inner.all_to_all_async(work[1], work[2]))
         else:
             self.inner.wait(self.inner.reduce_scatter_async(work[1]))
 
@@ -269,6 +301,21 @@ class SideStreamComm:
     def reduce_scatter_async(self, t):
         return self.all_reduce_async(t)
 
+    def all_to_all_async(self, recv, send):
+        def fn():
+            W = self.world
+            s, r = send.cpu().view(W, -1), self.torch.empty(recv.shape, dtype=recv.dtype).view(W, -1)
+            r[self.rank] = s[self.rank]
+            reqs = []
+            for p in range(W):
+                if p != self.rank:
+                    reqs.append(self.dist.isend(s[p].contiguous(), p))
+                    reqs.append(self.dist.irecv(r[p], p))
+            for q in reqs:
+                q.wait()
+            recv.view(W, -1).copy_(r)
+        return self._run(fn)
+
     def wait(self, work):
         if work is not None:
             self.torch.cuda.current_stream().wait_event(work)
@@ -279,6 +326,8 @@ def run(rank, world, port, mode, path, steps):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    packed = mode.endswith("+p24")  # the panel exchanges as 24-bit rows with the rank-ordered sum (sharded.Packed24Comm)
+    mode = mode[:-4] if packed else mode
     rccl = mode.startswith("nccl")  # "nccl-native" / "nccl-torch": one DEVICE per rank, RCCL between them (needs >= world GPUs)
     if rccl:
         torch.cuda.set_device(rank)
@@ -312,6 +361,8 @@ def run(rank, world, port, mode, path, steps):
         if mode == "nccl-native":
             comm.overlap_bytes = 1 << 16  # the second-stream route (>= 64 MB in production) on this small problem too
             comm._force = True            # at world size 1 a collective is the identity and would not be enqueued: go through RCCL
+    if packed:
+        comm = sh.Packed24Comm(comm, kern, min_bytes=int(z["p24_min_bytes"]) if "p24_min_bytes" in z.files else 0)
     eng = sh.ShardedEngine(kern, comm, ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
                            batch_sparsity=mode not in ("gpu-dense", "cpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
                            live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None,
@@ -370,6 +421,11 @@ def run(rank, world, port, mode, path, steps):
                touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1],
                n_slices=len(eng.slices), order_violations=np.array("\n".join(order.violations())),
                order_events=np.array(repr(order.steps()[-1])))
+    if packed:
+        import json
+
+        out["packed_stats"] = np.array(json.dumps(comm.stats()))
+        out["master_rows"] = to_np(eng.MP)
     if tl is not None:
         import json
 

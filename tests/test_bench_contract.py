@@ -154,6 +154,29 @@ def test_eight_rank_line():
 
 
 @pytest.mark.gpu
+def test_eight_rank_line_with_the_24_bit_exchange():
+    """--panel-bits 24 (opt-in): the eight-rank rehearsal with the panel exchanges as 24-bit rows summed in rank
+    order — 3/4 of the fp32 exchange's bytes on the wire in the line, the halves of every exchange issued in the pipelined
+    order, and the run's own parity check against the single-GPU result inside 1e-4."""
+    env = dict(_env(), IDG_BENCH_TIMEOUT="900")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--parallel", "shard", "--workload",
+                        "synth-1M", "--dim", "64", "--item-slices", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--scale-point", "on", "--panel-bits", "24"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["item_table_coherent"] is True and "24-bit panel exchange" in d["config"]["comm"]
+    px = d["panel_exchange"]
+    assert px["bits"] == 24 and abs(px["ratio"] - 0.75) < 1e-9 and px["order_violations"] == [] and px["exchanges_per_step"] >= 4 * 8
+    assert px["packed_bytes_per_step_per_rank"] > 0.9 * 0.75 * px["fp32_bytes_they_replace"]
+    assert px["bytes_on_the_wire_per_step_per_rank"] < 0.8 * d["roofline"]["exchange_bytes_per_step_per_rank"]
+    assert "rank order" in px["reduction_order"]
+    t = d["timeline"]
+    assert t["issue_order"]["violations"] == [] and t["issue_order"]["ranks_with_violations"] == 0
+    par = d["parity_vs_1gpu"]
+    assert par["ok"] is True and 0 < par["table_rel_err"] <= 1e-4 and 0 < par["final_rows_rel_err"] <= 1e-4 and par["loss_rel_err"] <= 1e-4, par
+
+
+@pytest.mark.gpu
 def test_a_wrong_multi_rank_result_fails_the_run():
     """`parity_vs_1gpu.ok` false: the line is printed WITH an "error" field and the launcher leaves with status 3 — no
     retry (a wrong result is not a hang).  IDG_BENCH_TEST_BREAK_PARITY stands in for a broken exchange: rank 1 scales the

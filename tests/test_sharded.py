@@ -686,3 +686,199 @@ def test_parity_compare_accepts_equal_runs_and_rejects_a_broken_one():
     still["user_rows"], still["item_rows"] = still["user_rows_before"].clone(), still["item_rows_before"].clone()
     res = parity_compare(Toy(), still)
     assert res["ok"] is False and res["update_rel_err"] > 0.99
+
+
+# ------------------------------------------------------------------------------------ 24-bit panel exchange (opt-in)
+def test_pack24_format_and_rank_ordered_sum():
+    """idg_pack24_f32's published format, restated in oracle.pack24 / unpack24 / reduce24 (what the CPU ranks below run; the
+    HIP kernels are compared with it bit for bit in test_gpu_parity.py): upper 24 bits of the fp32 word, the dropped byte
+    rounded to nearest even — at most 2^-16 relative, idempotent, sign / zeros / infinities kept — four values in three
+    words; the sum over blocks is one fp32 add per block IN THE ORDER GIVEN (another order gives other bits)."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(1 << 14) * 10.0 ** rng.uniform(-25, 25, 1 << 14)).astype(np.float32)
+    w = oracle.pack24(x)
+    assert w.dtype == np.uint32 and w.size == x.size // 4 * 3
+    y = oracle.unpack24(w)
+    assert (np.abs(y.astype(np.float64) - x) <= np.abs(x.astype(np.float64)) * 2.0 ** -16).all()
+    assert (y.view(np.uint32) & 0xFF == 0).all() and np.array_equal(oracle.unpack24(oracle.pack24(y)), y)
+    # ties go to even: 1 + 2^-16 lies exactly between the 24-bit neighbours 1 and 1 + 2^-15
+    tie = np.array([1 + 2.0 ** -16, 1 + 3 * 2.0 ** -16, -1 - 2.0 ** -16, 0.0], dtype=np.float32)
+    assert oracle.unpack24(oracle.pack24(tie)).tolist() == [1.0, 1 + 2.0 ** -14, -1.0, 0.0]
+    z = np.array([0.0, -0.0, np.inf, -np.inf], dtype=np.float32)
+    assert np.array_equal(oracle.unpack24(oracle.pack24(z)).view(np.uint32), z.view(np.uint32))
+    blocks = [oracle.pack24((rng.standard_normal(4096) * 10.0 ** r).astype(np.float32)) for r in (0, 3, -3, 3, 0, -2, 1, 2)]
+    want = oracle.unpack24(blocks[0]).copy()
+    for b in blocks[1:]:
+        want = (want + oracle.unpack24(b)).astype(np.float32)
+    assert np.array_equal(oracle.reduce24(blocks), want)
+    assert not np.array_equal(oracle.reduce24(blocks[::-1]), want)  # (fp32 addition is not associative: the ORDER is the contract)
+
+
+def _check_packed(p, outs, steps):
+    """A run with the 24-bit exchange against the single-device oracle: losses, FIN at the batch's rows, gradients of the
+    owned rows and the tables within 1e-4 (relative Frobenius norms: single elements of a gradient that cancels to ~0 carry
+    the quantisation of the terms they cancel from); the replicated item table bit-identical on every rank; the owners'
+    fp32 master rows within 2^-16 of the 24-bit table rows every rank computes with."""
+    import json
+
+    W, fin, grad, losses = _single_device_reference(p, steps)
+    U = p["U"]
+
+    def rel(a, b):
+        return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-300))
+
+    for o in outs:
+        assert str(o["order_violations"]) == "", str(o["order_violations"])
+        st = json.loads(str(o["packed_stats"]))
+        assert st["order_violations"] == [] and st["exchanges"] > 0 and abs(st["ratio"] - 0.75) < 1e-9, st
+        lo, hi = int(o["lo"]), int(o["hi"])
+        np.testing.assert_allclose(o["losses"], losses, rtol=1e-4)
+        rows, it, own = o["fin_rows"], o["fin_items"], o["own_items"]
+        assert rel(o["FIN"][: hi - lo][rows], fin[lo:hi][rows]) <= 1e-4
+        assert rel(o["FIN"][hi - lo:][it], fin[U:][it]) <= 1e-4
+        assert rel(o["G"][: hi - lo], grad[lo:hi]) <= 1e-4 and rel(o["G"][hi - lo:][own], grad[U:][own]) <= 1e-4
+        assert rel(o["P"][: hi - lo], W[lo:hi]) <= 1e-4 and rel(o["P"][hi - lo:], W[U:]) <= 1e-4
+        # the table rows a rank owns: its fp32 master against the 24-bit copy every rank (this one too) computes with
+        master = o["master_rows"][: len(own)]
+        table = o["P"][hi - lo:][own]
+        assert (table.view(np.uint32) & 0xFF == 0).all()
+        assert (np.abs(master.astype(np.float64) - table) <= np.abs(master.astype(np.float64)) * 2.0 ** -16 + 1e-45).all()
+        assert rel(master, W[U:][own]) <= 1e-4
+    a = outs[0]
+    for b in outs[1:]:
+        assert np.array_equal(a["P"][int(a["hi"]) - int(a["lo"]):], b["P"][int(b["hi"]) - int(b["lo"]):])
+        assert np.array_equal(a["losses"], b["losses"])
+
+
+@pytest.mark.parametrize("world,mode,thin,K,include0", [(2, "cpu+p24", False, 3, True), (4, "cpu-deferred+p24", True, 3, True),
+                                                       (8, "cpu+p24", False, 3, True), (8, "cpu-deferred+p24", True, 2, False),
+                                                       (4, "cpu+p24", False, 4, True)])
+def test_packed_exchange_matches_single_device_and_is_reproducible(world, mode, thin, K, include0, tmp_path):
+    """the two [I, d] all-reduces, the reduce-scatter / owner tail / all-gather of the last backward product
+    and the touched-item row sets as an explicit exchange of 24-bit rows summed IN RANK ORDER (sharded.Packed24Comm) — world
+    2, 4 and 8 with eight item slices over gloo, plain and with the communicator whose collectives take effect only in
+    wait() (a second half issued before its all-to-all has landed, or a buffer reused in flight, shows): within 1e-4 of
+    the single-device oracle, the replicas bit-identical, 3/4 of the fp32 bytes on the wire — and the SAME BITS when the
+    run is repeated."""
+    steps = 3
+    p = _wide_problem(K, include0, B=24 if thin else 96, steps=steps, thin=thin)
+    if thin:
+        p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch(mode, path, steps, world=world)
+    assert all(int(o["n_slices"]) == 8 for o in outs)
+    _check_packed(p, outs, steps)
+    again = _launch(mode, path, steps, world=world)
+    for a, b in zip(outs, again):
+        for key in ("P", "FIN", "G", "losses", "master_rows"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+
+
+def test_packed_exchange_order_checker_flags_a_serialised_pipeline():
+    """Packed24Comm.order_violations on hand-made logs: the pipelined order passes; a sum / all-gather issued before the
+    next slice's all-to-all (no overlap), a wait before the second half, a second half without a first are flagged."""
+    import idgrec_amd.sharded as sh
+
+    c = sh.Packed24Comm(sh.NoComm(), None)
+    c.log = [("first", 0, "ar"), ("first", 1, "ar"), ("second", 0, "ar"), ("first", 2, "rs"), ("second", 1, "ar"), ("wait", 0, "ar"),
+             ("second", 2, "rs"), ("wait", 1, "ar"), ("wait", 2, "rs"), ("first", 3, "ag"), ("second", 3, "ag"), ("wait", 3, "ag")]
+    assert c.order_violations() == []
+    c.log = [("first", 0, "ar"), ("second", 0, "ar"), ("first", 1, "ar"), ("wait", 0, "ar"), ("second", 1, "ar"), ("wait", 1, "ar")]
+    assert any("no overlap" in v for v in c.order_violations())
+    c.log = [("first", 0, "ar"), ("wait", 0, "ar"), ("second", 0, "ar")]
+    assert any("before its second half" in v for v in c.order_violations())
+    c.log = [("first", 0, "rs"), ("wait", 0, "rs")]
+    assert any("without its second half" in v for v in c.order_violations())
+
+
+@pytest.mark.gpu
+def test_pack24_kernels_equal_the_published_format():
+    """idg_pack24_f32 / idg_unpack24_f32 / idg_reduce24_f32 against the oracle's restatement, bit for bit: ragged lengths
+    (the < 16 values at the end go four at a time), special values, eight blocks in rank order, the packed result written
+    over one of the input blocks."""
+    import torch
+
+    import idgrec_amd.sharded as sh
+
+    k = sh.HipKernels()
+    rng = np.random.default_rng(1)
+    for n in (4, 16, 20, 64 * 1000 + 12, 1 << 20):
+        x = (rng.standard_normal(n) * 10.0 ** rng.uniform(-30, 30, n)).astype(np.float32)
+        x[: min(n, 4)] = np.array([0.0, -0.0, np.inf, -np.inf], dtype=np.float32)[: min(n, 4)]
+        src = torch.from_numpy(x).cuda()
+        dst = torch.zeros(n // 4 * 3, dtype=torch.float32, device="cuda")
+        k.pack24(src, dst, n)
+        w = dst.cpu().numpy().view(np.uint32)
+        assert np.array_equal(w, oracle.pack24(x)), n
+        back = torch.zeros(n, dtype=torch.float32, device="cuda")
+        k.unpack24(dst, back, n)
+        assert np.array_equal(back.cpu().numpy().view(np.uint32), oracle.unpack24(w).view(np.uint32)), n
+    n, N = 64 * 513 + 8, 8
+    parts = [(rng.standard_normal(n) * 10.0 ** r).astype(np.float32) for r in (0, 3, -3, 3, 0, -2, 1, 2)]
+    blocks = np.concatenate([oracle.pack24(p) for p in parts])
+    want = oracle.reduce24([blocks[b * (n // 4 * 3):(b + 1) * (n // 4 * 3)] for b in range(N)])
+    buf = torch.from_numpy(blocks.view(np.float32).copy()).cuda()
+    out_f = torch.zeros(n, dtype=torch.float32, device="cuda")
+    k.reduce24(buf, N, n, out_packed=buf[3 * (n // 4 * 3): 4 * (n // 4 * 3)], out_f32=out_f)  # (packed result over block 3)
+    assert np.array_equal(out_f.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32)[3 * (n // 4 * 3): 4 * (n // 4 * 3)], oracle.pack24(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,K,include0,d,thin", [("gpu+p24", 3, True, 64, False), ("gpu-async+p24", 3, True, 256, True),
+                                                    ("gpu+p24", 2, False, 64, True), ("gpu-async+p24", 4, True, 64, False)])
+def test_packed_exchange_hip_kernels(mode, K, include0, d, thin, tmp_path, golden_small):
+    """The 24-bit exchange on the HIP kernels, two ranks on cuda:0 over gloo — plain, and under the communicator that works on
+    a side stream joined only by wait() (the exchange's own stream then waits for the all-to-all before it sums, and the
+    step's stream for the unpacked panel: a missing dependency races): against the single-device oracle within 1e-4,
+    replicas bit-identical, the same bits when repeated."""
+    steps = 4
+    p = _sparse_problem(K, include0, B=6, steps=steps, d=d) if thin else _problem(golden_small, K, include0, B=160, steps=steps, d=d, n_slices=3)
+    if thin:
+        p["degree_bound"] = 1
+    p.pop("test_users", None)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch(mode, path, steps)
+    _check_packed(p, outs, steps)
+    again = _launch(mode, path, steps)
+    for a, b in zip(outs, again):
+        for key in ("P", "losses", "master_rows"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["native", "torch"])
+def test_packed_exchange_over_rccl_at_world_one(kind, tmp_path, golden_small):
+    """The exchange's RCCL calls on the one device there is: backend nccl at world size 1 through both communicators —
+    libidgrec's (idg_alltoall_f32 with the own block sent through the grouped ncclSend / ncclRecv, the second-stream route,
+    the in-place all-gather of the packed sums) and torch.distributed's (all_to_all_single, all_gather_into_tensor)."""
+    steps = 4
+    p = _problem(golden_small, 3, True, B=160, steps=steps, d=64, n_slices=3)
+    p.pop("test_users", None)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("nccl-%s+p24" % kind, path, steps, world=1)
+    assert bool(outs[0]["coherent"])
+    _check_packed(p, outs, steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["native", "torch"])
+def test_packed_exchange_between_devices_over_rccl(kind, tmp_path, golden_small):
+    """RCCL BETWEEN DEVICES for the 24-bit exchange (grouped ncclSend / ncclRecv all-to-all, rank-ordered sum, all-gather of
+    the packed sums): needs at least two GPUs — skipped on this pool's 1-GPU boxes, the first thing to run on a real node."""
+    import torch
+
+    world = min(torch.cuda.device_count(), 4)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL between distinct devices)")
+    steps = 4
+    p = _problem(golden_small, 3, True, B=160, steps=steps, d=64, n_slices=3)
+    p.pop("test_users", None)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch("nccl-%s+p24" % kind, path, steps, world=world)
+    assert all(bool(o["coherent"]) for o in outs)
+    _check_packed(p, outs, steps)
