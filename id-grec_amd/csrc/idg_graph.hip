@@ -125,9 +125,14 @@ struct Epilogue {
   float adam_w1, adam_beta2, adam_w2, adam_step_size, adam_bc2_sqrt, adam_eps;
   int adam_discard;     // the finished gradient feeds the update and is NOT written to sum_out (4 B / element less)
   // EPI_ACT: applied to t = A.X (+ addend) of rows r < act_rows (0: every row), before Y / sum_out see it
-  int act;              // 0 none, 1 t = tanh(t), 2 t = t * (1 - act_src[r]^2)
+  int act;              // 0 none, 1 t = tanh(t), 2 t = t * (1 - act_src[r]^2), 3 none — but the EPI_ACT instantiation (y24)
   const float* act_src; // act 2: the SAVED tanh output of the forward layer (same layout as Y)
   int64_t act_rows;
+  // the finished row ALSO (or only: Y may be NULL) as 24-bit values, three words per four values at y24 + (r ldy + off) / 4 * 3
+  // (idg_pack24_f32's format: what the sharded step's packed exchange sends — the product writes its partial straight into
+  // the send buffer).  Lives in the EPI_ACT instantiations (act = 3 when no activation is asked for): the plain kernels'
+  // code and register budget are untouched.
+  uint32_t* y24;
 };
 
 }  // namespace
@@ -330,6 +335,15 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& ep, int64_t r, in
     }
   }
   if (ep.Y) *reinterpret_cast<float4*>(ep.Y + o) = acc;
+  if (EPI == EPI_ACT && ep.y24) {
+    auto top24 = [](float x) {
+      const uint32_t b = __float_as_uint(x);
+      return (b + 0x7Fu + ((b >> 8) & 1u)) >> 8;  // (round to nearest even: idg_shard.hip top24)
+    };
+    const uint32_t a = top24(acc.x), b = top24(acc.y), c = top24(acc.z), e = top24(acc.w);
+    uint32_t* q = ep.y24 + (o >> 2) * 3;
+    q[0] = a | (b << 24), q[1] = (b >> 8) | (c << 16), q[2] = (c >> 16) | (e << 8);
+  }
   if (ep.sum_out) {
     float4 s = acc;
     if (ep.sum_in && live) {
@@ -2553,7 +2567,7 @@ static void adam_constants(Epilogue& ep, float* p, float* m, float* v, double lr
 
 int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d, const idg_epilogue* e,
                      const uint32_t* out_rows, const uint32_t* x_rows, void* ws, void* stream) {
-  IDG_REQUIRE(g && X && e && (e->Y || e->sum_out), "idg_spmm_epi_f32: NULL argument");
+  IDG_REQUIRE(g && X && e && (e->Y || e->sum_out || e->y24), "idg_spmm_epi_f32: NULL argument");
   IDG_REQUIRE(d > 0 && ldx >= d && e->ldy >= d, "idg_spmm_epi_f32: bad d/ldx/ldy (%lld,%lld,%lld)", (long long)d,
               (long long)ldx, (long long)e->ldy);
   IDG_REQUIRE(e->div != 0.0f, "idg_spmm_epi_f32: div must be non-zero");
@@ -2574,6 +2588,13 @@ int idg_spmm_epi_f32(const idg_graph* g, const float* X, int64_t ldx, int64_t d,
     IDG_REQUIRE(e->act_rows >= 0 && !e->adam_param, "idg_spmm_epi_f32: act_rows >= 0; an activation and Adam do not share a launch");
     IDG_REQUIRE(!(out_rows && x_rows), "idg_spmm_epi_f32: an activation with out_rows AND x_rows is not built");
     ep.act = e->act, ep.act_src = e->act_src, ep.act_rows = e->act_rows;
+  }
+  if (e->y24) {
+    IDG_REQUIRE(!e->adam_param && !out_rows, "idg_spmm_epi_f32: the packed output lives in dense launches without the Adam epilogue");
+    IDG_REQUIRE(e->ldy % 4 == 0 && ldx % 4 == 0 && (uintptr_t)X % 16 == 0 && (d == 32 || d == 64 || d == 128 || d == 256 || d == 512),
+                "idg_spmm_epi_f32: the packed output needs a tiled width (32 .. 512) and 16-byte aligned panels");
+    ep.y24 = e->y24;
+    if (!ep.act) ep.act = 3;  // (no activation: the EPI_ACT instantiation is selected for its packed store)
   }
   if (e->adam_param) {
     IDG_REQUIRE(e->sum_out && e->adam_exp_avg && e->adam_exp_avg_sq && e->adam_step >= 1,

@@ -226,7 +226,7 @@ class Epilogue(C.Structure):
                 ("adam_param", c_vp), ("adam_exp_avg", c_vp), ("adam_exp_avg_sq", c_vp),
                 ("adam_lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
                 ("adam_step", C.c_int64), ("adam_discard_grad", C.c_int),
-                ("act", C.c_int), ("act_src", c_vp), ("act_rows", C.c_int64)]
+                ("act", C.c_int), ("act_src", c_vp), ("act_rows", C.c_int64), ("y24", c_vp)]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -322,11 +322,16 @@ class ShardedEngine:
         (this rank keeps its own block of the slice), None = no exchange (the caller moves rows).  Returns the works."""
         k, works = self.k, []
         add = addend if self.rank == 0 else None
+        # packed exchange: a slice whose partial goes straight into an all-reduce / reduce-scatter is written PACKED by the
+        # product itself, into the exchange's send buffer (nobody reads the fp32 partial: the sum overwrites it)
+        target = getattr(self.comm, "packed_target", None) if (self.packed and reduce in ("all", "scatter") and out_bits is None) else None
         for j, (g, r0, r1, r1p) in enumerate(self.slices):
             y = self._slice_rows(Y_i, j)
-            k.spmm(g, X_u, Y=y, addend=None if add is None else self._slice_rows(add, j),
+            y24 = target(self._slice_rows(Y_i, j, padded=True), (r1 - r0) * self.d) if target is not None else None
+            k.spmm(g, X_u, Y=None if y24 is not None else y, addend=None if add is None else self._slice_rows(add, j),
                    mask=None if (add is None or mask is None) else k.bits_from(mask, r0),
-                   out_rows=None if out_bits is None else k.bits_from(out_bits, r0), x_rows=x_rows)
+                   out_rows=None if out_bits is None else k.bits_from(out_bits, r0), x_rows=x_rows,
+                   **({"Y24": y24} if y24 is not None else {}))
             if reduce == "all":
                 self.comm.tag, self.comm.slice = tag, j
                 # (the packed exchange cuts a slice into one block per rank: the padded view — its padding rows are zero)
@@ -965,8 +970,9 @@ class HipKernels:
                               build_transpose=False)
 
     def spmm(self, graph, X, Y=None, addend=None, sums=(), sum_out=None, div=1.0, accumulate=False, mask=None, adam=None,
-             out_rows=None, x_rows=None, discard_grad=False):
-        """idg_spmm_epi_f32 (include/idgrec.h): the product with the whole epilogue."""
+             out_rows=None, x_rows=None, discard_grad=False, Y24=None):
+        """idg_spmm_epi_f32 (include/idgrec.h): the product with the whole epilogue.  Y24: the finished rows as 24-bit values
+        (a packed exchange's send buffer) instead of / beside Y."""
         d = X.shape[1]
         n_s = len(sums)
         e = self.Epilogue(None if Y is None else Y.data_ptr(), None if addend is None else addend.data_ptr(),
@@ -978,6 +984,8 @@ class HipKernels:
             e.adam_param, e.adam_exp_avg, e.adam_exp_avg_sq = p.data_ptr(), m.data_ptr(), v.data_ptr()
             e.adam_lr, e.adam_beta1, e.adam_beta2, e.adam_eps, e.adam_step = lr, 0.9, 0.999, 1e-8, step
             e.adam_discard_grad = 1 if discard_grad else 0
+        if Y24 is not None:
+            e.y24 = Y24.data_ptr()
         key = (id(graph), d)
         ws = self._ws.get(key)
         if ws is None:
@@ -1647,7 +1655,9 @@ class Packed24Comm:
         self._pending = []     # exchanges whose second half has not been issued yet, oldest first
         self._seq = 0
         self.log = []          # ("first" | "second" | "wait", seq, kind)
-        self.wire = {"packed_bytes_sent": 0, "fp32_bytes_it_replaces": 0, "exchanges": 0, "fp32_collectives": 0}
+        self._pre = {}         # (address, length) of a tensor -> (snd, rcv) its producer is writing packed values into
+        self.wire = {"packed_bytes_sent": 0, "fp32_bytes_it_replaces": 0, "exchanges": 0, "fp32_collectives": 0,
+                     "packed_by_producer": 0}
 
     # ---- helpers
     @staticmethod
@@ -1683,8 +1693,13 @@ class Packed24Comm:
         x = self._X()
         x.seq, x.kind, x.t, x.n, x.second, x.done, x.own = self._seq, kind, t, n, False, None, None
         self._seq += 1
-        x.snd, x.rcv = self._buffers(words)
-        self.k.pack24(self._flat(t), x.snd, n)
+        pre = self._pre.pop(self._key(t), None)
+        if pre is not None:   # the producer has written the packed values itself (packed_target)
+            x.snd, x.rcv = pre
+            self.wire["packed_by_producer"] += 1
+        else:
+            x.snd, x.rcv = self._buffers(words)
+            self.k.pack24(self._flat(t), x.snd, n)
         x.work = self.inner.all_to_all_async(x.rcv, x.snd)
         self.log.append(("first", x.seq, kind))
         # the exchange before this one may now go on: its sum and its all-gather queue BEHIND this all-to-all
@@ -1712,6 +1727,24 @@ class Packed24Comm:
     def _flush(self, keep=None):
         while self._pending and self._pending[0] is not keep:
             self._second_half(self._pending.pop(0))
+
+    @staticmethod
+    def _key(t):
+        return (t.ctypes.data, t.size) if isinstance(t, np.ndarray) else (t.data_ptr(), t.numel())
+
+    def packed_target(self, t, n_valid=None):
+        """The send buffer of the NEXT all_reduce_async / reduce_scatter_async of `t`, for a producer that writes its result
+        packed by itself (the item-side product's y24 epilogue: no fp32 write of the partial, no pack pass) — or None when
+        that collective would not travel packed.  n_valid: the values the producer will write (the rest of t is zero:
+        a slice's padding rows)."""
+        n = self._n(t)
+        if not self._eligible(n):
+            return None
+        snd, rcv = self._buffers(n // 4 * 3)
+        if n_valid is not None and n_valid < n:
+            snd[n_valid // 4 * 3:] = 0
+        self._pre[self._key(t)] = (snd, rcv)
+        return snd
 
     # ---- the comm interface
     def all_reduce_async(self, t, average=False):

@@ -316,6 +316,11 @@ typedef struct idg_epilogue {
   int act;
   const float* act_src;
   int64_t act_rows;
+  /* The finished row t (after addend / activation) ALSO — or only: Y may then be NULL — as 24-bit values in idg_pack24_f32's
+   * format, three words per four values at y24 + (r * ldy + f) / 4 * 3: the sharded step's packed exchange lets the product
+   * write its partial straight into the send buffer (one fp32 write and one pack pass less per exchanged panel).  Dense
+   * launches (x_rows allowed, out_rows not), tiled widths, not with Adam. */
+  uint32_t* y24;
 } idg_epilogue;
 #define IDG_ACT_TANH 1
 #define IDG_ACT_TANH_BWD 2

@@ -134,7 +134,7 @@ class OracleKernels:
         return self.o.topk_reference(R, k)
 
     def spmm(self, graph, X, Y=None, addend=None, sums=(), sum_out=None, div=1.0, accumulate=False, mask=None, adam=None,
-             out_rows=None, x_rows=None, discard_grad=False):
+             out_rows=None, x_rows=None, discard_grad=False, Y24=None):
         ptr, idx, val, n_rows, n_cols = graph
         Xe = np.ascontiguousarray(X[:n_cols])
         if x_rows is not None:  # rows outside the live set are zero by agreement and must not be read
@@ -148,6 +148,9 @@ class OracleKernels:
             if Y is not None:
                 Y[:n_rows][rows] = t[rows]
                 Y[:n_rows][~rows] = np.nan
+            if Y24 is not None:  # the finished rows as 24-bit values (the packed exchange's send buffer), dense launches only
+                assert out_rows is None
+                Y24.view(np.uint32)[: t.size // 4 * 3] = self.o.pack24(t.reshape(-1))
             if sum_out is not None:
                 s = t
                 if len(sums):

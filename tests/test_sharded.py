@@ -730,7 +730,9 @@ def _check_packed(p, outs, steps):
     for o in outs:
         assert str(o["order_violations"]) == "", str(o["order_violations"])
         st = json.loads(str(o["packed_stats"]))
-        assert st["order_violations"] == [] and st["exchanges"] > 0 and abs(st["ratio"] - 0.75) < 1e-9, st
+        assert st["order_violations"] == [] and st["exchanges"] > 0, st
+        assert st["ratio"] is None if len(outs) == 1 else abs(st["ratio"] - 0.75) < 1e-9, st  # (one rank sends nothing)
+        assert st["packed_by_producer"] > 0, st  # the item-side products wrote their partials packed (y24 epilogue)
         lo, hi = int(o["lo"]), int(o["hi"])
         np.testing.assert_allclose(o["losses"], losses, rtol=1e-4)
         rows, it, own = o["fin_rows"], o["fin_items"], o["own_items"]
