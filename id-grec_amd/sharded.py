@@ -1672,10 +1672,13 @@ class Packed24Comm:
         return n * 4 >= self.min_bytes and n % (4 * self.world) == 0
 
     def _buffers(self, words):
-        pool = self._free.setdefault(words, [])
-        if pool:
-            return pool.pop()
-        return (self.k.zeros((words,)), self.k.zeros((words,)))
+        """(send, receive) buffers of `words` 32-bit words: views of buffers kept per SIZE CLASS (the next power of two —
+        the touched-item exchanges come in a different length for nearly every batch: one pool entry per length would
+        grow without bound over a training run)."""
+        cls = 1 << max(int(words) - 1, 0).bit_length()
+        pool = self._free.setdefault(cls, [])
+        snd, rcv = pool.pop() if pool else (self.k.zeros((cls,)), self.k.zeros((cls,)))
+        return snd[:words], rcv[:words], (cls, snd, rcv)
 
     def _count(self, n_values, phases):
         # a rank sends (N - 1) / N of the buffer in each phase (all-to-all, all-gather)
@@ -1685,7 +1688,7 @@ class Packed24Comm:
         self.wire["exchanges"] += 1
 
     class _X:
-        __slots__ = ("seq", "kind", "t", "n", "snd", "rcv", "work", "done", "second", "own")
+        __slots__ = ("seq", "kind", "t", "n", "snd", "rcv", "home", "work", "done", "second", "own")
 
     def _first_half(self, kind, t, n):
         """pack + all-to-all of t's n values (kind "ar" / "rs"), on the current (the step's) stream."""
@@ -1695,10 +1698,10 @@ class Packed24Comm:
         self._seq += 1
         pre = self._pre.pop(self._key(t), None)
         if pre is not None:   # the producer has written the packed values itself (packed_target)
-            x.snd, x.rcv = pre
+            x.snd, x.rcv, x.home = pre
             self.wire["packed_by_producer"] += 1
         else:
-            x.snd, x.rcv = self._buffers(words)
+            x.snd, x.rcv, x.home = self._buffers(words)
             self.k.pack24(self._flat(t), x.snd, n)
         x.work = self.inner.all_to_all_async(x.rcv, x.snd)
         self.log.append(("first", x.seq, kind))
@@ -1740,10 +1743,13 @@ class Packed24Comm:
         n = self._n(t)
         if not self._eligible(n):
             return None
-        snd, rcv = self._buffers(n // 4 * 3)
+        snd, rcv, home = self._buffers(n // 4 * 3)
         if n_valid is not None and n_valid < n:
             snd[n_valid // 4 * 3:] = 0
-        self._pre[self._key(t)] = (snd, rcv)
+        old = self._pre.pop(self._key(t), None)
+        if old is not None:  # (a target nobody came for: its buffers go back)
+            self._free[old[2][0]].append(old[2][1:])
+        self._pre[self._key(t)] = (snd, rcv, home)
         return snd
 
     # ---- the comm interface
@@ -1775,7 +1781,7 @@ class Packed24Comm:
         x = self._X()
         x.seq, x.kind, x.t, x.n, x.second = self._seq, "ag", out, n, True
         self._seq += 1
-        x.snd, x.rcv = self._buffers(words)
+        x.snd, x.rcv, x.home = self._buffers(words)
         own = x.snd[self.rank * blk_words:(self.rank + 1) * blk_words]
         self.k.pack24(self._flat(t), own, nb)
         x.work = self.inner.all_gather_async(x.snd, own)
@@ -1812,8 +1818,8 @@ class Packed24Comm:
                     break
         self.k.wait_event(x.done)
         self.log.append(("wait", x.seq, x.kind))
-        self._free.setdefault(x.n // 4 * 3, []).append((x.snd, x.rcv))
-        x.snd = x.rcv = x.t = None
+        self._free[x.home[0]].append(x.home[1:])
+        x.snd = x.rcv = x.t = x.home = None
 
     def __getattr__(self, name):
         return getattr(self.inner, name)
