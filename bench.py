@@ -92,6 +92,10 @@ def parse():
                    help="sharded form: 24 = the panel-sized exchanges travel as 24-bit values (2^-16 relative: inside the 1e-4 "
                         "bar) through an explicit exchange — pack, all-to-all, this library's rank-ordered sum, all-gather — "
                         "3/4 of the bytes on the links and bit-reproducible run to run; 32 (default) = RCCL's fp32 collectives")
+    p.add_argument("--reduce-order", default="rccl", choices=["rccl", "rank"],
+                   help="sharded form: rank = the panel-sized reductions as an explicit exchange (all-to-all, this library's sum "
+                        "over the ranks IN RANK ORDER, all-gather) instead of RCCL's all-reduce / reduce-scatter: the same fp32 "
+                        "bytes on the links, bit-reproducible run to run (SURVEY 8e); implied by --panel-bits 24")
     p.add_argument("--item-slices", type=int, default=0,
                    help="sharded form: row slices of the item panel whose collectives overlap the following slices' products "
                         "(0 = auto: 8 from four ranks on, 4 below, 1 while the panel is under 256 MB)")

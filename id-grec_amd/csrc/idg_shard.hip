@@ -326,9 +326,35 @@ __global__ __launch_bounds__(BLOCK) void reduce24_kernel(const uint32_t* __restr
   if (out_packed) pack4(acc, out_packed[3 * g], out_packed[3 * g + 1], out_packed[3 * g + 2]);
 }
 
+// out = blocks[0] + blocks[1] + ... IN THAT ORDER, fp32 blocks of n values (the rank-ordered sum without the 24-bit packing:
+// sharded.RankOrderComm with 32 bits — the same bytes on the links as RCCL's all-reduce, but one fixed sequence of adds)
+__global__ __launch_bounds__(BLOCK) void reduce_blocks_kernel(const float* __restrict__ blocks, int n_blocks, int64_t n,
+                                                             float* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (4 * g >= n) return;
+  const float4* p = reinterpret_cast<const float4*>(blocks) + g;
+  float4 acc = *p;
+  for (int b = 1; b < n_blocks; ++b) {
+    p += n / 4;
+    const float4 v = *p;
+    acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[g] = acc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int idg_reduce_blocks_f32(const float* blocks, int n_blocks, int64_t n, float* out, void* stream) {
+  IDG_REQUIRE(blocks && out && n_blocks >= 1 && n >= 0 && n % 4 == 0, "idg_reduce_blocks_f32: NULL buffer, no block, or a count that is not a multiple of 4");
+  IDG_REQUIRE(((uintptr_t)blocks | (uintptr_t)out) % 16 == 0, "idg_reduce_blocks_f32: buffers must be 16-byte aligned");
+  if (n == 0) return IDG_OK;
+  hipLaunchKernelGGL(reduce_blocks_kernel, dim3((unsigned)((n / 4 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, blocks,
+                     n_blocks, n, out);
+  IDG_HIP(hipGetLastError());
+  return IDG_OK;
+}
 
 int idg_pack24_f32(const float* src, uint32_t* dst, int64_t n, void* stream) {
   IDG_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "idg_pack24_f32: NULL buffer, or a count that is not a multiple of 4");

@@ -170,6 +170,7 @@ PROTOTYPES = {
     "idg_unpack24_f32": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp]),
     "idg_reduce24_f32": (C.c_int, [c_vp, C.c_int, C.c_int64, c_vp, c_vp, c_vp]),
     "idg_alltoall_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int, c_vp]),
+    "idg_reduce_blocks_f32": (C.c_int, [c_vp, C.c_int, C.c_int64, c_vp, c_vp]),
     "idg_score_topk_option": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_int64)]),
     "idg_score_topk_candidate_counts": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, c_vp, c_vp, c_vp]),
     "idg_score_topk_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, c_vp, c_vp, C.c_int,

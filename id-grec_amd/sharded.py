@@ -218,6 +218,7 @@ class ShardedEngine:
         # copy too: replicas stay bit-identical), so the owner keeps the fp32 MASTER of its rows here — Adam updates the
         # master, the all-gather sends it packed.  Filled from the table by the first training step.
         self.packed = bool(getattr(comm, "packed", False))
+        self.by_blocks = bool(getattr(comm, "by_blocks", False))  # (an explicit exchange, packed or not: slices by rank blocks)
         self.MP = z((max(off, 1), dim)) if self.packed else None
         self._master_ready = False
         self.XU = [z((self.Ug, dim)) for _ in range(max(self.K - 1, 1))]
@@ -335,7 +336,7 @@ class ShardedEngine:
             if reduce == "all":
                 self.comm.tag, self.comm.slice = tag, j
                 # (the packed exchange cuts a slice into one block per rank: the padded view — its padding rows are zero)
-                works.append(self.comm.all_reduce_async(self._slice_rows(Y_i, j, padded=True) if self.packed else y))
+                works.append(self.comm.all_reduce_async(self._slice_rows(Y_i, j, padded=True) if self.by_blocks else y))
             elif reduce == "scatter":
                 self.comm.tag, self.comm.slice = tag, j
                 works.append(self.comm.reduce_scatter_async(self._slice_rows(Y_i, j, padded=True)))
@@ -1012,6 +1013,11 @@ class HipKernels:
         if rc:
             self.check(rc, "idg_reduce24_f32")
 
+    def reduce_blocks(self, blocks, n_blocks, n, out):
+        rc = self.lib.idg_reduce_blocks_f32(blocks.data_ptr(), n_blocks, n, out.data_ptr(), self.ops._stream())
+        if rc:
+            self.check(rc, "idg_reduce_blocks_f32")
+
     def exchange_stream(self):
         """Context manager: what is launched (and what collective is issued) inside goes to the exchange's own stream —
         NOT ordered behind the step's stream: the caller orders it by waiting for the collectives it consumes."""
@@ -1644,12 +1650,16 @@ class Packed24Comm:
     all-gather, so the links are not idle while slice j is being summed).  wait() joins the step's stream.
     `log` records the order of the halves (IssueOrder checks it); `stats()` the bytes put on the wire."""
 
-    packed = True
     averages = False
+    by_blocks = True   # (the engine hands over slices that divide into one block per rank: the padded views)
 
-    def __init__(self, inner, kernels, min_bytes=4 << 20):
+    def __init__(self, inner, kernels, min_bytes=4 << 20, bits=24):
+        """bits = 32: the same explicit exchange on fp32 values — no packing, RCCL's bytes on the links, the rank-ordered sum
+        (idg_reduce_blocks_f32): reproducible without the 2^-16 quantisation (`bench.py --reduce-order rank`)."""
+        assert bits in (24, 32)
         self.inner, self.k = inner, kernels
         self.world, self.rank = int(inner.world), int(inner.rank)
+        self.bits, self.packed = int(bits), bits == 24
         self.min_bytes = int(min_bytes)
         self._free = {}        # words -> [(snd, rcv), ...] buffers not in flight
         self._pending = []     # exchanges whose second half has not been issued yet, oldest first
@@ -1677,13 +1687,17 @@ class Packed24Comm:
         grow without bound over a training run)."""
         cls = 1 << max(int(words) - 1, 0).bit_length()
         pool = self._free.setdefault(cls, [])
-        snd, rcv = pool.pop() if pool else (self.k.zeros((cls,)), self.k.zeros((cls,)))
+        # (fp32 blocks: the tensor itself is the send buffer — only the receive side needs one)
+        snd, rcv = pool.pop() if pool else (self.k.zeros((cls if self.packed else 1,)), self.k.zeros((cls,)))
         return snd[:words], rcv[:words], (cls, snd, rcv)
+
+    def _words(self, n):
+        return n // 4 * 3 if self.packed else n
 
     def _count(self, n_values, phases):
         # a rank sends (N - 1) / N of the buffer in each phase (all-to-all, all-gather)
         share = (self.world - 1) / self.world
-        self.wire["packed_bytes_sent"] += int(phases * share * n_values * 3)
+        self.wire["packed_bytes_sent"] += int(phases * share * n_values * (3 if self.packed else 4))
         self.wire["fp32_bytes_it_replaces"] += int(phases * share * n_values * 4)
         self.wire["exchanges"] += 1
 
@@ -1692,7 +1706,7 @@ class Packed24Comm:
 
     def _first_half(self, kind, t, n):
         """pack + all-to-all of t's n values (kind "ar" / "rs"), on the current (the step's) stream."""
-        words = n // 4 * 3
+        words = self._words(n)
         x = self._X()
         x.seq, x.kind, x.t, x.n, x.second, x.done, x.own = self._seq, kind, t, n, False, None, None
         self._seq += 1
@@ -1700,9 +1714,12 @@ class Packed24Comm:
         if pre is not None:   # the producer has written the packed values itself (packed_target)
             x.snd, x.rcv, x.home = pre
             self.wire["packed_by_producer"] += 1
-        else:
+        elif self.packed:
             x.snd, x.rcv, x.home = self._buffers(words)
             self.k.pack24(self._flat(t), x.snd, n)
+        else:                 # fp32 blocks: the tensor itself is the send buffer
+            _, x.rcv, x.home = self._buffers(words)
+            x.snd = self._flat(t)
         x.work = self.inner.all_to_all_async(x.rcv, x.snd)
         self.log.append(("first", x.seq, kind))
         # the exchange before this one may now go on: its sum and its all-gather queue BEHIND this all-to-all
@@ -1712,10 +1729,15 @@ class Packed24Comm:
 
     def _second_half(self, x):
         k, N = self.k, self.world
-        blk_words, blk_n = x.n // 4 * 3 // N, x.n // N
+        blk_words, blk_n = self._words(x.n) // N, x.n // N
         with k.exchange_stream():
             self.inner.wait(x.work)
-            if x.kind == "rs":
+            if not self.packed:
+                own = x.snd[self.rank * blk_n:(self.rank + 1) * blk_n]   # (x.snd is the tensor itself)
+                k.reduce_blocks(x.rcv, N, blk_n, own)
+                if x.kind == "ar":
+                    self.inner.wait(self.inner.all_gather_async(x.snd, own))
+            elif x.kind == "rs":
                 own = self._flat(x.t)[self.rank * blk_n:(self.rank + 1) * blk_n]
                 k.reduce24(x.rcv, N, blk_n, out_f32=own)
             else:
@@ -1741,7 +1763,7 @@ class Packed24Comm:
         that collective would not travel packed.  n_valid: the values the producer will write (the rest of t is zero:
         a slice's padding rows)."""
         n = self._n(t)
-        if not self._eligible(n):
+        if not self.packed or not self._eligible(n):
             return None
         snd, rcv, home = self._buffers(n // 4 * 3)
         if n_valid is not None and n_valid < n:
@@ -1772,8 +1794,10 @@ class Packed24Comm:
 
     def all_gather_async(self, out, t):
         n, nb = self._n(out), self._n(t)
-        if not self._eligible(n) or nb * self.world != n:
+        if not self.packed or not self._eligible(n) or nb * self.world != n:
             self.wire["fp32_collectives"] += 1
+            if self._pending:
+                self._flush()  # (collectives go out in program order on every rank)
             return ("inner", self.inner.all_gather_async(out, t))
         self._count(n, 1)
         self._flush()  # (an all-gather has no first half to hide a sum behind: whatever is pending goes first)
@@ -1798,7 +1822,7 @@ class Packed24Comm:
 
     def wire_bytes(self, numel):
         """Bytes a collective over `numel` values moves per unit of buffer (TimelineComm's bus-rate arithmetic)."""
-        return numel * (3 if self._eligible(numel) else 4)
+        return numel * (3 if (self.packed and self._eligible(numel)) else 4)
 
     def timed_stream(self, nbytes):
         return None  # (a compound exchange: TimelineComm brackets it on the step's stream, issue to wait)
@@ -1851,6 +1875,9 @@ class Packed24Comm:
         w["ratio"] = (w["packed_bytes_sent"] / w["fp32_bytes_it_replaces"]) if w["fp32_bytes_it_replaces"] else None
         w["order_violations"] = self.order_violations()
         return w
+
+
+RankOrderComm = Packed24Comm  # (bits = 32: the explicit exchange and the rank-ordered sum on fp32 values)
 
 
 # --------------------------------------------------------------------------- bench driver
@@ -1998,10 +2025,13 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     phase("engine")
     kern = HipKernels()
     panel_bits = int(getattr(args, "panel_bits", 32) or 32)
-    if panel_bits == 24:
-        # opt-in: the panel-sized exchanges as 24-bit rows, summed in rank order by idg_reduce24_f32 (Packed24Comm)
-        comm = Packed24Comm(comm, kern)
-        comm_name += " + 24-bit panel exchange (pack -> all-to-all -> rank-ordered sum -> all-gather)"
+    rank_order = panel_bits == 24 or getattr(args, "reduce_order", "rccl") == "rank"
+    if rank_order:
+        # opt-in: the panel-sized exchanges as an explicit exchange summed in rank order by this library's own kernel —
+        # 24-bit rows (idg_reduce24_f32) or fp32 blocks (idg_reduce_blocks_f32)
+        comm = Packed24Comm(comm, kern, bits=panel_bits)
+        comm_name += (" + 24-bit panel exchange (pack -> all-to-all -> rank-ordered sum -> all-gather)" if panel_bits == 24 else
+                      " + explicit fp32 panel exchange (all-to-all -> rank-ordered sum -> all-gather)")
     # global_user_degree: the touched-item exchanges are sized by a host-side bound — no host synchronisation in the step
     eng = ShardedEngine(kern, comm, ui, iu, hi - lo, I, d, K, True, 1e-4, 1e-3, batch_size=B, user_lo=lo,
                         n_slices=n_slices, item_cuts=cuts, store_grad=False, global_user_degree=user_degree)
@@ -2039,12 +2069,12 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
     dist.barrier()
     torch.cuda.synchronize()
     phase("timed")
-    wire0 = dict(comm.wire) if panel_bits == 24 else None
+    wire0 = dict(comm.wire) if rank_order else None
     t0 = time.perf_counter()
     for i in range(first + args.warmup, first + args.warmup + args.steps):
         step(i)
     t_enqueue = time.perf_counter() - t0  # host time to issue the steps (== wall time when the host is the bottleneck)
-    wire1 = dict(comm.wire) if panel_bits == 24 else None
+    wire1 = dict(comm.wire) if rank_order else None
     eng._wait_item_table()                # (the last step's all-gathers of the updated item rows belong to it)
     torch.cuda.synchronize()
     dist.barrier()
@@ -2166,18 +2196,21 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
         fp32_wire = out["roofline"]["exchange_bytes_per_step_per_rank"]
         out["panel_exchange"] = {"bits": panel_bits, "bytes_on_the_wire_per_step_per_rank": fp32_wire,
                                  "reduction_order": "RCCL's (ring / tree by its own choice)"}
-        if panel_bits == 24:
+        if rank_order:
             sent = (wire1["packed_bytes_sent"] - wire0["packed_bytes_sent"]) / args.steps
             repl = (wire1["fp32_bytes_it_replaces"] - wire0["fp32_bytes_it_replaces"]) / args.steps
             out["panel_exchange"].update(
                 bytes_on_the_wire_per_step_per_rank=int(fp32_wire - repl + sent), packed_bytes_per_step_per_rank=int(sent),
                 fp32_bytes_they_replace=int(repl), ratio=(sent / repl) if repl else None,
                 exchanges_per_step=(wire1["exchanges"] - wire0["exchanges"]) / args.steps,
-                reduction_order="rank order (idg_reduce24_f32: q0 + q1 + ... one fp32 add per rank and element): bit-reproducible "
-                                "run to run", order_violations=comm.order_violations(),
-                what="the [I, d] all-reduces, the last backward product's reduce-scatter, the all-gather of the updated item rows "
-                     "and the touched-item row sets travel as 24-bit values (2^-16 relative), 3 bytes per value; the batch's guest "
-                     "rows and other small collectives stay fp32")
+                reduction_order="rank order (%s: q0 + q1 + ... one fp32 add per rank and element): bit-reproducible run to run"
+                                % ("idg_reduce24_f32" if panel_bits == 24 else "idg_reduce_blocks_f32"),
+                order_violations=comm.order_violations(),
+                what=("the [I, d] all-reduces, the last backward product's reduce-scatter, the all-gather of the updated item rows "
+                      "and the touched-item row sets travel as 24-bit values (2^-16 relative), 3 bytes per value; the batch's guest "
+                      "rows and other small collectives stay fp32") if panel_bits == 24 else
+                     ("the [I, d] all-reduces, the last backward product's reduce-scatter and the touched-item row sets as an explicit "
+                      "exchange of fp32 blocks (all-to-all, this library's rank-ordered sum, all-gather): RCCL's bytes, a fixed order"))
     kern.close()
     del eng, batches, kern
     torch.cuda.empty_cache()

@@ -908,6 +908,9 @@ int idg_unpack24_f32(const uint32_t* src, float* dst, int64_t n, void* stream);
  * fp32 (out_f32, nullable) and / or packed (out_packed, nullable; may be one of the input blocks' own words: each thread
  * reads its four values of every block before it writes). */
 int idg_reduce24_f32(const uint32_t* blocks, int n_blocks, int64_t n, uint32_t* out_packed, float* out_f32, void* stream);
+/* The same rank-ordered sum on fp32 blocks of n values each (no packing: `bench.py --reduce-order rank` with 32-bit panels —
+ * RCCL's bytes on the links, one fixed sequence of adds).  out may be one of the blocks. */
+int idg_reduce_blocks_f32(const float* blocks, int n_blocks, int64_t n, float* out, void* stream);
 /* Block p (count floats) of `send` goes to rank p; block p of `recv` receives rank p's block for this rank (grouped
  * ncclSend / ncclRecv: on a fully connected node every peer's block travels over its own link).  Not in place.  The own
  * block is a device copy; flags = IDG_ALLTOALL_OWN_THROUGH_RCCL sends it through RCCL as well (tests on one device). */

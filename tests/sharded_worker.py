@@ -214,6 +214,12 @@ class OracleKernels:
         if out_packed is not None:
             out_packed.view(np.uint32)[:w] = self.o.pack24(acc)
 
+    def reduce_blocks(self, blocks, n_blocks, n, out):
+        acc = blocks[:n].copy()
+        for b in range(1, n_blocks):
+            acc = (acc + blocks[b * n:(b + 1) * n]).astype(np.float32)
+        out.reshape(-1)[:n] = acc
+
     def exchange_stream(self):
         import contextlib
 
@@ -330,7 +336,8 @@ def run(rank, world, port, mode, path, steps):
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     packed = mode.endswith("+p24")  # the panel exchanges as 24-bit rows with the rank-ordered sum (sharded.Packed24Comm)
-    mode = mode[:-4] if packed else mode
+    ranked = mode.endswith("+r32")  # ... or as fp32 blocks with the rank-ordered sum (the same class, bits = 32)
+    mode = mode[:-4] if (packed or ranked) else mode
     rccl = mode.startswith("nccl")  # "nccl-native" / "nccl-torch": one DEVICE per rank, RCCL between them (needs >= world GPUs)
     if rccl:
         torch.cuda.set_device(rank)
@@ -364,8 +371,9 @@ def run(rank, world, port, mode, path, steps):
         if mode == "nccl-native":
             comm.overlap_bytes = 1 << 16  # the second-stream route (>= 64 MB in production) on this small problem too
             comm._force = True            # at world size 1 a collective is the identity and would not be enqueued: go through RCCL
-    if packed:
-        comm = sh.Packed24Comm(comm, kern, min_bytes=int(z["p24_min_bytes"]) if "p24_min_bytes" in z.files else 0)
+    if packed or ranked:
+        comm = sh.Packed24Comm(comm, kern, min_bytes=int(z["p24_min_bytes"]) if "p24_min_bytes" in z.files else 0,
+                               bits=24 if packed else 32)
     eng = sh.ShardedEngine(kern, comm, ui, iu, hi - lo, I, W0.shape[1], K, bool(z["include0"]), 1e-4, 1e-3,
                            batch_sparsity=mode not in ("gpu-dense", "cpu-dense"), batch_size=B, user_lo=lo, n_slices=n_slices,
                            live_rows_cap=int(z["live_cap"]) if "live_cap" in z.files else None,
@@ -424,10 +432,11 @@ def run(rank, world, port, mode, path, steps):
                touched_n=-1 if getattr(eng, "touched_items", None) is None else eng.touched_items[1],
                n_slices=len(eng.slices), order_violations=np.array("\n".join(order.violations())),
                order_events=np.array(repr(order.steps()[-1])))
-    if packed:
+    if packed or ranked:
         import json
 
         out["packed_stats"] = np.array(json.dumps(comm.stats()))
+    if packed:
         out["master_rows"] = to_np(eng.MP)
     if tl is not None:
         import json

@@ -177,6 +177,21 @@ def test_eight_rank_line_with_the_24_bit_exchange():
 
 
 @pytest.mark.gpu
+def test_two_rank_line_with_the_rank_ordered_fp32_exchange():
+    """--reduce-order rank: the panel reductions as an explicit fp32 exchange summed in rank order (no packing): the bytes of
+    the RCCL form on the wire, the parity check at fp32 rounding."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--parallel", "shard", "--workload",
+                        "synth-1M", "--dim", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--scale-point", "on",
+                        "--reduce-order", "rank"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    px = d["panel_exchange"]
+    assert px["bits"] == 32 and abs(px["ratio"] - 1.0) < 1e-9 and px["order_violations"] == [] and "idg_reduce_blocks_f32" in px["reduction_order"]
+    assert "explicit fp32 panel exchange" in d["config"]["comm"] and d["item_table_coherent"] is True
+    _assert_parity(d)
+
+
+@pytest.mark.gpu
 def test_a_wrong_multi_rank_result_fails_the_run():
     """`parity_vs_1gpu.ok` false: the line is printed WITH an "error" field and the launcher leaves with status 3 — no
     retry (a wrong result is not a hang).  IDG_BENCH_TEST_BREAK_PARITY stands in for a broken exchange: rank 1 scales the

@@ -884,3 +884,40 @@ def test_packed_exchange_between_devices_over_rccl(kind, tmp_path, golden_small)
     outs = _launch("nccl-%s+p24" % kind, path, steps, world=world)
     assert all(bool(o["coherent"]) for o in outs)
     _check_packed(p, outs, steps)
+
+
+@pytest.mark.parametrize("world,mode,thin,K", [(2, "cpu+r32", False, 3), (8, "cpu-deferred+r32", True, 3), (4, "cpu+r32", False, 4)])
+def test_rank_ordered_fp32_exchange(world, mode, thin, K, tmp_path):
+    """`--reduce-order rank` without the packing (RankOrderComm, bits = 32): the panel reductions as all-to-all + this
+    library's sum in rank order + all-gather on fp32 blocks — RCCL's bytes on the links, no quantisation: the ordinary
+    fp32 tolerances against the single-device oracle hold (_check), the exchange's halves are pipelined, and a repeated run
+    gives the same bits (a fixed reduction order makes k-GPU runs reproducible)."""
+    import json
+
+    steps = 3
+    p = _wide_problem(K, True, B=24 if thin else 96, steps=steps, thin=thin)
+    if thin:
+        p["degree_bound"] = 1
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch(mode, path, steps, world=world)
+    _check(p, outs, steps, rtol=1e-4, atol=2e-7)
+    for o in outs:
+        st = json.loads(str(o["packed_stats"]))
+        assert st["order_violations"] == [] and st["exchanges"] > 0 and abs(st["ratio"] - 1.0) < 1e-9 and st["packed_by_producer"] == 0, st
+    again = _launch(mode, path, steps, world=world)
+    for a, b in zip(outs, again):
+        for key in ("P", "FIN", "G", "losses"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["gpu+r32", "gpu-async+r32"])
+def test_rank_ordered_fp32_exchange_hip_kernels(mode, tmp_path, golden_small):
+    """The same on the HIP kernels (idg_reduce_blocks_f32), two ranks on cuda:0, plain and under the side-stream communicator."""
+    steps = 4
+    p = _problem(golden_small, 3, True, B=160, steps=steps, d=64, n_slices=3)
+    path = str(tmp_path / "prob.npz")
+    np.savez(path, **p)
+    outs = _launch(mode, path, steps)
+    _check(p, outs, steps, rtol=1e-4, atol=2e-7, sparse=True)
