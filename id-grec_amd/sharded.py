@@ -1938,8 +1938,8 @@ def parity_compare(single, captured, tol=PARITY_TOL):
     """The 1-GPU half: `single` = a freshly initialised PropagationEngine on the WHOLE graph with the same initial tables;
     runs the captured batches through it and returns the `parity_vs_1gpu` object of the bench line — relative errors
     (Frobenius norms over the compared rows; the loss: largest over steps and terms) of the N-rank run against this one,
-    and `ok` = all three within tol.  `update_rel_err` (informational) measures the same table rows as UPDATES since the
-    initial tables: an N-rank step that left the tables alone would show there."""
+    and `ok` = all three within tol and `update_rel_err` — the same table rows as UPDATES since the initial tables: an
+    N-rank step that left the tables alone would show there — within 100 x tol."""
     import torch
 
     tri = torch.from_numpy(captured["triples"]).to(single.params.device)
@@ -1970,7 +1970,10 @@ def parity_compare(single, captured, tol=PARITY_TOL):
     after_n = torch.cat([captured["user_rows"], captured["item_rows"]])
     table_err = rel(after_n, after_1)
     upd_err = rel(after_n - init_n, after_1 - before)
-    ok = bool(init_equal and loss_err <= tol and fin_err <= tol and table_err <= tol)
+    # (the first steps of a run start at loss ~ ln 2 whatever the tables hold, and the tables move by ~lr per step against
+    #  values of ~1e-2: the UPDATES are the sensitive quantity — a loose bound on them is part of the verdict)
+    tol_update = 100 * tol
+    ok = bool(init_equal and loss_err <= tol and fin_err <= tol and table_err <= tol and upd_err <= tol_update)
     return {"what": "%d training steps from the same initial tables and the same global batches on the N ranks and on ONE "
                     "device (the fused single-GPU engine, rank 0, same run): N-rank result against the 1-GPU result — loss: "
                     "largest relative error over steps and terms; final_rows: FIN at every batch's user and item rows; table: "
@@ -1980,7 +1983,7 @@ def parity_compare(single, captured, tol=PARITY_TOL):
             "steps": len(loss_1), "loss_rel_err": loss_err, "final_rows_rel_err": fin_err, "table_rel_err": table_err,
             "update_rel_err": upd_err, "table_max_abs_err": float((after_n - after_1).abs().max()),
             "initial_tables_equal": init_equal, "loss_n_ranks": [[float(x) for x in row] for row in captured["loss"]],
-            "loss_1_gpu": [[float(x) for x in row] for row in loss_1], "tol": tol, "ok": ok}
+            "loss_1_gpu": [[float(x) for x in row] for row in loss_1], "tol": tol, "tol_update": tol_update, "ok": ok}
 
 
 def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_reference=None):

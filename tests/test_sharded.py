@@ -686,6 +686,12 @@ def test_parity_compare_accepts_equal_runs_and_rejects_a_broken_one():
     still["user_rows"], still["item_rows"] = still["user_rows_before"].clone(), still["item_rows_before"].clone()
     res = parity_compare(Toy(), still)
     assert res["ok"] is False and res["update_rel_err"] > 0.99
+    # ... and it is part of the verdict on its own: updates off by 5 % move the tables by far less than tol
+    half = copy.deepcopy(cap)
+    half["user_rows"] = half["user_rows_before"] + (half["user_rows"] - half["user_rows_before"]) * 0.95
+    half["item_rows"] = half["item_rows_before"] + (half["item_rows"] - half["item_rows_before"]) * 0.95
+    res = parity_compare(Toy(), half)
+    assert res["update_rel_err"] > res["tol_update"] == 1e-2 and res["ok"] is False
 
 
 # ------------------------------------------------------------------------------------ 24-bit panel exchange (opt-in)
