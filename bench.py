@@ -901,9 +901,10 @@ def flatten_north_star(out):
         rf["eval_fp32_equivalent_tflops"] = ev.get("fp32_equivalent_tflops")
     sp = out.get("scale_point")
     if isinstance(sp, dict) and sp.get("ms_per_step"):
-        out["scale_point_ms_per_step"] = sp["ms_per_step"]
+        # (also inside `roofline`: the one nested object whose scalars the driver's record is known to keep)
+        out["scale_point_ms_per_step"] = rf["scale_point_ms_per_step"] = sp["ms_per_step"]
         if isinstance(sp.get("batch_2p20"), dict) and sp["batch_2p20"].get("value"):
-            out["scale_point_batch_2p20_triples_per_s"] = sp["batch_2p20"]["value"]
+            out["scale_point_batch_2p20_triples_per_s"] = rf["scale_point_batch_2p20_triples_per_s"] = sp["batch_2p20"]["value"]
 
 def trained_like_tables(users, items, d, seed=0):
     """Tables with the norm spread of a TRAINED model instead of i.i.d. Gaussians (form 3's candidate count
