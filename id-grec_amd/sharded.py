@@ -1870,6 +1870,13 @@ class Packed24Comm:
                 bad.append("exchange %d: its sum / all-gather was issued before exchange %d's all-to-all (no overlap)" % (seq, seq + 1))
         return bad
 
+    def release_buffers(self):
+        """Drop the pooled send / receive buffers (nothing may be in flight): the bench frees them before rank 0 builds the
+        single-GPU reference."""
+        assert not self._pending, "an exchange is still in flight"
+        self._free.clear()
+        self._pre.clear()
+
     def stats(self):
         w = dict(self.wire)
         w["ratio"] = (w["packed_bytes_sent"] / w["fp32_bytes_it_replaces"]) if w["fp32_bytes_it_replaces"] else None
@@ -2215,6 +2222,8 @@ def run_sharded_bench(args, rank, world, dist, comm, comm_name, single_gpu_refer
                      ("the [I, d] all-reduces, the last backward product's reduce-scatter and the touched-item row sets as an explicit "
                       "exchange of fp32 blocks (all-to-all, this library's rank-ordered sum, all-gather): RCCL's bytes, a fixed order"))
     kern.close()
+    if rank_order:
+        comm.release_buffers()
     del eng, batches, kern
     torch.cuda.empty_cache()
     phase("single_gpu_reference")
