@@ -7,7 +7,11 @@ import sys
 line, rnd = json.load(open(sys.argv[1])), sys.argv[2]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", rnd)
 r = line["roofline"]
-legs = {"synth-10M": r.get("hbm_bound"), "regular-15M": r.get("hbm_reuse_free"), "synth-1M": r.get("cache_boundary")}
+free = r.get("hbm_reuse_free")
+if isinstance(free, dict) and free.get("access_pattern") == "random":  # (round 6: the permuted graph at the top level, the strided twin inside)
+    legs = {"synth-10M": r.get("hbm_bound"), "regular-15M-perm": free, "regular-15M": free.get("strided"), "synth-1M": r.get("cache_boundary")}
+else:
+    legs = {"synth-10M": r.get("hbm_bound"), "regular-15M": free, "synth-1M": r.get("cache_boundary")}
 legs = {k: v for k, v in legs.items() if isinstance(v, dict)}
 legs[line["config"]["workload"].split("-shape")[0].split(":")[0].split(" ")[0]] = r  # the headline's own graph
 for c in line.get("configs") or []:
